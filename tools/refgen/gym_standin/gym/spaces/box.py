@@ -1,0 +1,1 @@
+from . import Box  # noqa: F401

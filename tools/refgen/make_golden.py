@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at /root/reference).
+
+Build-container only: /root/reference does not exist on the GPU box, and nothing in tests/,
+bench.py or the package reads it at run time.  The reference's `import gym` is satisfied by the
+numerics-free stand-in in tools/refgen/gym_standin (gym is not installed and there is no network).
+Only DATA is written: inputs (actions, noise, initial inventories) and the reference's outputs.
+
+Noise injection: each reference process only ever calls `rng.uniform(size=...)` /
+`rng.normal(size=...)` (arrival_models.py:55,122; fill_probability_models.py:33;
+midprice_models.py:64,143), so replacing `process.rng` by a replay object feeds it pre-drawn,
+float32-representable noise.  Some draws are placed exactly on / next to the decision thresholds to
+pin the strict `<` comparisons in float64.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/refgen/make_golden.py
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "gym_standin"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+from mbt_gym.gym.ModelDynamics import LimitAndMarketOrderModelDynamics, LimitOrderModelDynamics  # noqa: E402
+from mbt_gym.gym.TradingEnvironment import TradingEnvironment  # noqa: E402
+from mbt_gym.rewards.RewardFunctions import CjMmCriterion, PnL, RunningInventoryPenalty  # noqa: E402
+from mbt_gym.stochastic_processes.arrival_models import HawkesArrivalModel, PoissonArrivalModel  # noqa: E402
+from mbt_gym.stochastic_processes.fill_probability_models import ExponentialFillFunction  # noqa: E402
+from mbt_gym.stochastic_processes.midprice_models import BrownianMotionMidpriceModel, OuMidpriceModel  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+class Replay:
+    """Stands in for a numpy Generator inside one reference process."""
+
+    def __init__(self, uniforms=None, normals=None):
+        self.uniforms, self.normals, self.ku, self.kn = uniforms, normals, 0, 0
+
+    def uniform(self, size=None):
+        out = self.uniforms[self.ku].astype(np.float64)
+        assert out.shape == tuple(size)
+        self.ku += 1
+        return out
+
+    def normal(self, size=None):
+        out = self.normals[self.kn].astype(np.float64).reshape(size)
+        self.kn += 1
+        return out
+
+
+def f32_neighbours(x):
+    """float32 values just below / nearest / just above a float64 array."""
+    c = np.float32(x)
+    return np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))
+
+
+def draw_noise(rng, k, n):
+    u_arr = (rng.integers(0, 1 << 24, size=(k, n, 2)) / float(1 << 24)).astype(np.float32)
+    u_fill = (rng.integers(0, 1 << 24, size=(k, n, 2)) / float(1 << 24)).astype(np.float32)
+    z = rng.normal(size=(k, n)).astype(np.float32)
+    return u_arr, u_fill, z
+
+
+def draw_actions(rng, k, n, a_dim, max_depth, normalised):
+    if normalised:
+        act = rng.uniform(-1, 1, size=(k, n, a_dim))
+    else:
+        act = rng.uniform(0, 0.8 * max_depth, size=(k, n, a_dim))
+        act[rng.uniform(size=act.shape) < 0.02] = 0.0
+        act[rng.uniform(size=act.shape) < 0.02] = max_depth
+        if a_dim == 4:
+            mo = rng.choice([0.0, 1.0, 0.5, 0.50000006, 0.3], p=[0.86, 0.1, 0.015, 0.015, 0.01], size=(k, n, 2))
+            act[:, :, 2:4] = mo
+    return act.astype(np.float32)
+
+
+def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None):
+    rng = np.random.default_rng(1000 + seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = build_env()
+    md = env.model_dynamics
+    max_depth = md.max_depth
+    u_arr, u_fill, z = draw_noise(rng, k_steps, n)
+    actions = draw_actions(rng, k_steps, n, a_dim, max_depth, normalised)
+    # threshold-adjacent draws (strict '<' in float64): arrivals on lanes 0..2, fills on lanes 3..5
+    if poisson_thr is not None:
+        lo, c, hi = f32_neighbours(np.float64(poisson_thr))
+        for j, v in enumerate((lo, c, hi)):
+            u_arr[::3, j % n, :] = v
+    if not normalised:
+        p = np.exp(-kappa * actions[:, :, 0:2].astype(np.float64))
+        lo, c, hi = f32_neighbours(p)
+        for j, v in enumerate((lo, c, hi)):
+            u_fill[1::4, (3 + j) % n, :] = v[1::4, (3 + j) % n, :]
+    md.midprice_model.rng = Replay(normals=z)
+    md.arrival_model.rng = Replay(uniforms=u_arr)
+    md.fill_probability_model.rng = Replay(uniforms=u_fill)
+
+    rec = {"arr": [], "fill": []}
+    orig_af = md.get_arrivals_and_fills
+    orig_mask = env._remove_max_inventory_fills
+
+    def spy_af(action):
+        a, f = orig_af(action)
+        rec["arr"].append(np.array(a, dtype=np.uint8))
+        return a, f
+
+    def spy_mask(fills):
+        out = orig_mask(fills)
+        rec["fill"].append(np.array(out, dtype=np.uint8))
+        return out
+
+    md.get_arrivals_and_fills = spy_af
+    env._remove_max_inventory_fills = spy_mask
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        obs0 = env.reset()
+        q0 = env.model_dynamics.state[:, 1].copy()
+        t0 = float(env.model_dynamics.state[0, 2])
+        obs, rew, done = [], [], []
+        for k in range(k_steps):
+            o, r, d, _ = env.step(actions[k].astype(np.float64))
+            obs.append(np.array(o, dtype=np.float64))
+            rew.append(np.array(r, dtype=np.float64))
+            done.append(bool(d[0]))
+    assert done[-1] and not any(done[:-1]), (name, done)
+    lo = env.original_observation_space.low if normalised else env.observation_space.low
+    hi = env.original_observation_space.high if normalised else env.observation_space.high
+    alo = env.original_action_space.low if env.normalise_action_space_ else env.action_space.low
+    ahi = env.original_action_space.high if env.normalise_action_space_ else env.action_space.high
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        u_arr=u_arr, u_fill=u_fill, z=z, actions=actions, q0=q0, t0=t0,
+        obs0=np.array(obs0, dtype=np.float64), obs=np.stack(obs), rewards=np.stack(rew), done=np.array(done),
+        arrivals=np.stack(rec["arr"]), fills=np.stack(rec["fill"]),
+        obs_lo=lo, obs_hi=hi, act_lo=np.float32(alo), act_hi=np.float32(ahi), max_cash=float(env.max_cash),
+        process_indices=np.array([v for v in env.stochastic_process_indices.values()]),
+        config_json=json.dumps(dict(cfg, num_trajectories=n)),
+    )
+    fills_total = int(np.sum(np.stack(rec["arr"]) * np.stack(rec["fill"])))
+    print(f"{name}: N={n} steps={k_steps} D={obs[0].shape[1]} trades={fills_total} "
+          f"clip_q={int(np.sum(np.abs(np.stack(obs)[:, :, 1]) >= env.max_inventory)) if not normalised else '-'}")
+
+
+def lo_dynamics(n, dt, T, mid, arr, kappa=1.5, cls=LimitOrderModelDynamics, **kw):
+    fill = ExponentialFillFunction(fill_exponent=kappa, step_size=dt, num_trajectories=n)
+    return cls(midprice_model=mid, arrival_model=arr, fill_probability_model=fill, num_trajectories=n, **kw)
+
+
+def main():
+    # A. Avellaneda-Stoikov configuration of notebooks/Test_1 (BASELINE config 0), noise injected
+    n, ns = 48, 200
+    run_case(
+        "as_limit_pnl",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=50, initial_inventory=0, max_inventory=ns,
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(initial_price=100, volatility=2.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([140, 140]), step_size=1 / ns, num_trajectories=n)),
+            normalise_action_space=False, normalise_observation_space=False, num_trajectories=n),
+        ns, n, 2, 50,
+        dict(n_steps=ns, terminal_time=1.0, midprice='bm', volatility=2.0, initial_price=100.0, arrival='poisson',
+             intensity=[140.0, 140.0], fill_exponent=1.5, dynamics='limit', reward='pnl', initial_inventory=0,
+             max_inventory=ns, seed=50, normalise_action_space=False, normalise_observation_space=False),
+        poisson_thr=140 * (1 / ns))
+
+    # B. CJP-2015 style rewards, tight inventory limit, random integer initial inventories
+    n, ns = 40, 100
+    for tag, rew, t0 in (("cjp_running", RunningInventoryPenalty(0.01, 0.001), 0.0),
+                         ("cjp_cjmm", CjMmCriterion(0.01, 0.001, terminal_time=1.0), 0.25)):
+        steps = ns - int(round(t0 * ns))
+        run_case(
+            tag,
+            lambda: TradingEnvironment(
+                terminal_time=1.0, n_steps=ns, seed=410, initial_inventory=(-3, 4), max_inventory=3, start_time=t0,
+                reward_function=rew,
+                model_dynamics=lo_dynamics(
+                    n, 1 / ns, 1.0,
+                    BrownianMotionMidpriceModel(drift=0.05, initial_price=100, volatility=2.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                    PoissonArrivalModel(intensity=np.array([140, 90]), step_size=1 / ns, num_trajectories=n)),
+                normalise_action_space=False, normalise_observation_space=False, num_trajectories=n),
+            steps, n, 2, 410 + len(tag),
+            dict(n_steps=ns, terminal_time=1.0, midprice='bm', drift=0.05, volatility=2.0, initial_price=100.0,
+                 arrival='poisson', intensity=[140.0, 90.0], fill_exponent=1.5, dynamics='limit',
+                 reward='running' if tag == 'cjp_running' else 'cjmm', phi=0.01, alpha=0.001, inventory_exponent=2.0,
+                 initial_inventory=[-3, 4], max_inventory=3, start_time=t0, seed=410,
+                 normalise_action_space=False, normalise_observation_space=False),
+            poisson_thr=90 * (1 / ns))
+
+    # C. Hawkes arrivals + OU midprice (D = 6)
+    n, ns = 40, 150
+    run_case(
+        "hawkes_ou",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=7, initial_inventory=0, max_inventory=50,
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                OuMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.02, volatility=2.0, initial_price=100.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                HawkesArrivalModel(baseline_arrival_rate=np.array([[10.0, 10.0]]), step_size=1 / ns, jump_size=40.0, mean_reversion_speed=60.0, terminal_time=1.0, num_trajectories=n)),
+            normalise_action_space=False, normalise_observation_space=False, num_trajectories=n),
+        ns, n, 2, 7,
+        dict(n_steps=ns, terminal_time=1.0, midprice='ou', ou_level=100.0, ou_speed=0.02, volatility=2.0,
+             initial_price=100.0, arrival='hawkes', intensity=[10.0, 10.0], hawkes_jump=40.0, hawkes_speed=60.0,
+             fill_exponent=1.5, dynamics='limit', reward='pnl', initial_inventory=0, max_inventory=50, seed=7,
+             normalise_action_space=False, normalise_observation_space=False))
+
+    # D. limit + market orders (A = 4), inventory clip after market orders, terminal penalty
+    n, ns = 40, 120
+    run_case(
+        "limit_and_market",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=11, initial_inventory=10, max_inventory=12,
+            reward_function=RunningInventoryPenalty(0.01, 0.5),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(initial_price=100, volatility=2.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([100, 100]), step_size=1 / ns, num_trajectories=n),
+                cls=LimitAndMarketOrderModelDynamics, fixed_market_half_spread=0.5),
+            normalise_action_space=False, normalise_observation_space=False, num_trajectories=n),
+        ns, n, 4, 11,
+        dict(n_steps=ns, terminal_time=1.0, midprice='bm', volatility=2.0, initial_price=100.0, arrival='poisson',
+             intensity=[100.0, 100.0], fill_exponent=1.5, dynamics='limit_and_market', market_half_spread=0.5,
+             reward='running', phi=0.01, alpha=0.5, inventory_exponent=2.0, initial_inventory=10, max_inventory=12,
+             seed=11, normalise_action_space=False, normalise_observation_space=False),
+        poisson_thr=100 * (1 / ns))
+
+    # E. the reference's DEFAULT environment: normalised observations and actions (TE:42-63)
+    n, ns = 24, 200
+    run_case(
+        "default_normalised",
+        lambda: TradingEnvironment(num_trajectories=n, seed=3),
+        ns, n, 2, 3,
+        dict(n_steps=ns, terminal_time=1.0, midprice='bm', volatility=2.0, initial_price=100.0, arrival='poisson',
+             intensity=[100.0, 100.0], fill_exponent=1.5, dynamics='limit', reward='pnl', initial_inventory=0,
+             max_inventory=10_000, seed=3, normalise_action_space=True, normalise_observation_space=True),
+        normalised=True)
+
+    # F. cash clipping (small max_cash) together with a tight inventory limit
+    n, ns = 16, 50
+    run_case(
+        "clip_cash",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=5, initial_inventory=0, max_inventory=2, max_cash=150.0,
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(initial_price=100, volatility=2.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([40, 40]), step_size=1 / ns, num_trajectories=n)),
+            normalise_action_space=False, normalise_observation_space=False, num_trajectories=n),
+        ns, n, 2, 5,
+        dict(n_steps=ns, terminal_time=1.0, midprice='bm', volatility=2.0, initial_price=100.0, arrival='poisson',
+             intensity=[40.0, 40.0], fill_exponent=1.5, dynamics='limit', reward='pnl', initial_inventory=0,
+             max_inventory=2, max_cash=150.0, seed=5, normalise_action_space=False, normalise_observation_space=False),
+        poisson_thr=40 * (1 / ns))
+
+
+if __name__ == "__main__":
+    main()
