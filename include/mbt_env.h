@@ -1,0 +1,186 @@
+/*
+ * mbt_env.h - C ABI of libmbtenv: the MI355X-native (gfx950) TradingEnvironment.step() hot path.
+ *
+ * The reference (JJJerome/mbt_gym) is pure Python/NumPy and has no FFI; the boundary it offers is the
+ * Python duck type gym.Env / StochasticProcessModel / RewardFunction.  This header is the C boundary a
+ * maintainer would bind (ctypes) underneath those Python classes.  Every entry point
+ * names the reference code it replaces (paths relative to /root/reference/mbt_gym):
+ *   TE   gym/TradingEnvironment.py      MD   gym/ModelDynamics.py     RW  rewards/RewardFunctions.py
+ *   MID  stochastic_processes/midprice_models.py    ARR  stochastic_processes/arrival_models.py
+ *   FILL stochastic_processes/fill_probability_models.py   SP  stochastic_processes/StochasticProcessModel.py
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; every call returns 0 or a negative
+ *     mbt_status and leaves a message for mbt_last_error() (thread local).
+ *   - the library owns all device memory of an environment; callers own every pointer they pass.
+ *   - "*_host" entry points take pageable host pointers and are synchronous (NumPy semantics);
+ *     "*_device" entry points take device pointers (or NULL = the library's own buffers), only enqueue
+ *     work on the environment's HIP stream and return immediately.
+ *   - one host thread per environment handle at a time.
+ *   - state rows are float32 [cash, inventory, time, midprice] (index_names.py:1-4); a Hawkes arrival
+ *     model adds [bid intensity, ask intensity] (TE:311-318).  Side 0 = bid, 1 = ask (index_names.py:6-7).
+ *   - there is NO CPU fallback: without a gfx950 device mbt_env_create fails with MBT_ERR_NO_DEVICE.
+ */
+#ifndef MBT_ENV_H
+#define MBT_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBT_ABI_VERSION 1u
+
+typedef enum mbt_status {
+  MBT_OK = 0,
+  MBT_ERR_INVALID = -1,     /* bad argument / unsupported plugin combination */
+  MBT_ERR_NO_DEVICE = -2,   /* no HIP device, or device is not gfx950 */
+  MBT_ERR_HIP = -3,         /* a HIP runtime call failed */
+  MBT_ERR_STATE = -4,       /* call order violated (e.g. step before reset, noise not set) */
+  MBT_ERR_ABI = -5          /* mbt_config.abi_version mismatch */
+} mbt_status;
+
+/* plugin kinds: the reference classes that have a device implementation */
+enum { MBT_MID_BROWNIAN = 0 /* MID:36-68 */, MBT_MID_OU = 1 /* MID:114-146 */ };
+enum { MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */ };
+enum { MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */ };
+enum { MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */ };
+enum { MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */ };
+enum {
+  MBT_NOISE_PHILOX = 0,   /* counter-based Philox4x32-10 drawn inside the kernel (production) */
+  MBT_NOISE_INJECTED = 1  /* noise supplied by mbt_env_set_noise_* (parity tests vs. the reference) */
+};
+
+/* Everything the constructors of TradingEnvironment (TE:27-94), the ModelDynamics (MD:18-40) and the plugin
+ * classes hold, flattened.  Plain data; versioned by abi_version. */
+typedef struct mbt_config {
+  uint32_t abi_version;        /* MBT_ABI_VERSION */
+  int32_t device;              /* HIP device ordinal */
+  uint64_t num_trajectories;   /* lanes owned by this handle (TE:41) */
+  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; must be even */
+  uint32_t n_steps;            /* TE:30 */
+  uint32_t reserved0;
+  double terminal_time;        /* TE:29; step_size = terminal_time / n_steps (TE:49) */
+
+  int32_t midprice_kind;
+  int32_t arrival_kind;
+  int32_t fill_kind;
+  int32_t dynamics_kind;
+  int32_t reward_kind;
+  int32_t noise_mode;
+
+  double drift, volatility, initial_price;   /* MID:39-41 / MID:117-120 */
+  double ou_level, ou_speed;                 /* MID:117-118 (speed is NOT multiplied by dt, MID:140-143) */
+  double intensity[2];                       /* Poisson rate (ARR:35) or Hawkes baseline (ARR:89), bid/ask */
+  double hawkes_jump, hawkes_speed;          /* ARR:91-92 */
+  double fill_exponent;                      /* FILL:44 */
+  double market_half_spread;                 /* MD:189 */
+  double phi, alpha, inventory_exponent;     /* RW:119-122 / RW:83-86 */
+  double initial_cash;                       /* TE:33 */
+  double initial_inventory;                  /* TE:34, used by reset when no per-lane array is given */
+  double max_inventory;                      /* TE:36 */
+  double max_cash;                           /* TE:37, TE:229-230 */
+  double reward_scale;                       /* TE:128-129; 1.0 when rewards are not normalised */
+
+  uint64_t seed;                             /* Philox key */
+  int32_t normalise_observation;             /* TE:44, TE:112-118 */
+  int32_t normalise_action;                  /* TE:43, TE:120-126 */
+  float obs_lo[8], obs_hi[8];                /* float32 Box bounds (TE:232-241) */
+  float act_lo[4], act_hi[4];                /* float32 Box bounds (MD:118-121, MD:224-231) */
+} mbt_config;
+
+typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
+
+/* ---- library ---------------------------------------------------------------------------------- */
+uint32_t mbt_abi_version(void);
+size_t mbt_config_sizeof(void); /* sizeof(mbt_config) as compiled, for binding self-checks */
+const char* mbt_last_error(void);
+int mbt_device_count(void);
+/* Writes the device name ("gfx950...") into buf; returns MBT_OK or an error. */
+int mbt_device_name(int device, char* buf, size_t buf_len);
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+/* Replaces TradingEnvironment.__init__ (TE:27-94) for the numeric part: validates the plugin combination,
+ * allocates the (N, D) state and the output buffers in HBM, creates the stream. */
+int mbt_env_create(const mbt_config* cfg, mbt_env** out);
+void mbt_env_destroy(mbt_env* env);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the environment's own. */
+int mbt_env_set_stream(mbt_env* env, void* hip_stream);
+int mbt_env_synchronize(mbt_env* env);
+
+/* ---- seeding (TE:345-348, SP:37-39) ----------------------------------------------------------- */
+/* Re-keys the Philox generator and restarts its step counter.  Like the reference, reset() does not reseed:
+ * successive episodes continue the stream. */
+int mbt_env_seed(mbt_env* env, uint64_t seed);
+
+/* ---- reset (TE:96-101, TE:131-140, TE:257-281, RW:111-113) ------------------------------------ */
+/* start_time must already be quantised to a step multiple (TE:266-268).  q0 is an optional per-lane initial
+ * inventory array (N floats, host memory) - NULL means cfg.initial_inventory for every lane. */
+int mbt_env_reset(mbt_env* env, double start_time, const float* q0_host);
+/* Same, then copies the (normalised) observation (N, D) row-major into obs_host (may be NULL). */
+int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, float* obs_host);
+
+/* ---- step (TE:103-110 and everything it calls: MD:108-131, MD:208-240, ARR:54-56, ARR:110-123,
+ *      FILL:28-34, FILL:57-58, TE:198-220, TE:283-289, TE:323-327, MID:60-65, MID:140-143, RW:23-33,
+ *      RW:96-109, RW:128-138, TE:112-129) --------------------------------------------------------- */
+/* action: (N, A) float32 row-major, A = 2 (limit) or 4 (limit + market).  Outputs: obs (N, D), reward (N),
+ * done (scalar; lane-invariant, TE:218-220).  Any output pointer may be NULL. */
+int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);
+/* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
+int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);
+
+/* ---- injected noise (parity mode; replaces the three numpy Generators of SP:27) ---------------- */
+/* u_arr, u_fill: (N, 2) float32 in [0, 1); z: (N) float32.  Consumed by the next step. */
+int mbt_env_set_noise_host(mbt_env* env, const float* u_arr, const float* u_fill, const float* z);
+
+/* ---- device buffers (zero-copy consumers) ------------------------------------------------------ */
+float* mbt_env_action_ptr(mbt_env* env);   /* (N, A) staging buffer a device policy may write */
+float* mbt_env_obs_ptr(mbt_env* env);      /* (N, D) observation of the last reset/step; D = 4: this IS the state */
+float* mbt_env_reward_ptr(mbt_env* env);   /* (N) rewards of the last step */
+int mbt_env_obs_dim(mbt_env* env);
+int mbt_env_action_dim(mbt_env* env);
+
+/* ---- state access / checkpoint (TE:142-144 `state`) -------------------------------------------- */
+/* Un-normalised state (N, D) row-major float32. */
+int mbt_env_get_state_host(mbt_env* env, float* state_host);
+/* Observation of the last reset/step as the API returns it ((N, D), normalised when configured, TE:112-118). */
+int mbt_env_get_obs_host(mbt_env* env, float* obs_host);
+/* Upload (N, A) actions into the buffer of mbt_env_action_ptr() (e.g. a fixed quote for step_device loops). */
+int mbt_env_set_action_host(mbt_env* env, const float* action_host);
+int mbt_env_set_state_host(mbt_env* env, const float* state_host, double time, uint32_t philox_step);
+int mbt_env_get_clock(mbt_env* env, double* time, uint32_t* episode_step, uint32_t* philox_step);
+
+/* ---- diagnostics ------------------------------------------------------------------------------- */
+/* When enabled the step kernel also writes one byte per lane: bit0/1 arrival bid/ask (ARR:56), bit2/3 fill
+ * bid/ask after the max-inventory mask (TE:323-327), bit4/5 market buy/sell (MD:209-210), bit6 inventory
+ * clipped, bit7 cash clipped (TE:283-289). */
+int mbt_env_record_events(mbt_env* env, int enabled);
+int mbt_env_get_events_host(mbt_env* env, uint8_t* events_host);
+/* Number of lane-steps on which the clip of TE:283-289 changed a value since create (the reference prints). */
+int mbt_env_clip_count(mbt_env* env, uint64_t* count);
+
+/* ---- episode-return statistics (the quantity SB3's VecMonitor / plotting.py:96-108 report) ------ */
+/* sums[0] = sum over lanes of the rewards since the last reset, sums[1] = sum of squared per-lane returns
+ * (NaN unless per-lane tracking is on), sums[2] = number of lanes.  These three doubles are what the
+ * multi-GPU all-reduce carries. */
+int mbt_env_track_lane_returns(mbt_env* env, int enabled);
+int mbt_env_return_sums(mbt_env* env, double sums[3]);
+
+/* ---- the generator itself (so tests can pin it) ------------------------------------------------ */
+/* Writes the noise lane ids [trajectory_offset, trajectory_offset + n) would draw at philox step `step`
+ * under `seed` into host arrays (any may be NULL): u_arr (n,2), u_fill (n,2), z (n). */
+int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n,
+                      float* u_arr, float* u_fill, float* z);
+/* Raw Philox4x32-10 block function on the device: out[4] = philox(ctr[4], key[2]) (known-answer tests). */
+int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* ---- timing on the environment's stream (HIP events) ------------------------------------------- */
+int mbt_env_timer_begin(mbt_env* env);
+int mbt_env_timer_end(mbt_env* env, float* elapsed_ms); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBT_ENV_H */

@@ -1,0 +1,179 @@
+"""ctypes binding of include/mbt_env.h (libmbtenv.so).  This is the only module that touches the C ABI.
+
+There is deliberately no alternative implementation behind it: if the shared library is missing or no gfx950
+device is visible, environment construction raises - it never degrades to a CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
+ABI_VERSION = 1
+
+MID_BROWNIAN, MID_OU = 0, 1
+ARR_POISSON, ARR_HAWKES = 0, 1
+FILL_EXPONENTIAL = 0
+DYN_LIMIT, DYN_LIMIT_AND_MARKET = 0, 1
+REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM = 0, 1, 2
+NOISE_PHILOX, NOISE_INJECTED = 0, 1
+
+
+class MbtConfig(C.Structure):
+    """struct mbt_config (include/mbt_env.h) - field order and types must match the header."""
+
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device", C.c_int32),
+        ("num_trajectories", C.c_uint64), ("trajectory_offset", C.c_uint64),
+        ("n_steps", C.c_uint32), ("reserved0", C.c_uint32),
+        ("terminal_time", C.c_double),
+        ("midprice_kind", C.c_int32), ("arrival_kind", C.c_int32), ("fill_kind", C.c_int32),
+        ("dynamics_kind", C.c_int32), ("reward_kind", C.c_int32), ("noise_mode", C.c_int32),
+        ("drift", C.c_double), ("volatility", C.c_double), ("initial_price", C.c_double),
+        ("ou_level", C.c_double), ("ou_speed", C.c_double),
+        ("intensity", C.c_double * 2),
+        ("hawkes_jump", C.c_double), ("hawkes_speed", C.c_double),
+        ("fill_exponent", C.c_double), ("market_half_spread", C.c_double),
+        ("phi", C.c_double), ("alpha", C.c_double), ("inventory_exponent", C.c_double),
+        ("initial_cash", C.c_double), ("initial_inventory", C.c_double),
+        ("max_inventory", C.c_double), ("max_cash", C.c_double), ("reward_scale", C.c_double),
+        ("seed", C.c_uint64),
+        ("normalise_observation", C.c_int32), ("normalise_action", C.c_int32),
+        ("obs_lo", C.c_float * 8), ("obs_hi", C.c_float * 8),
+        ("act_lo", C.c_float * 4), ("act_hi", C.c_float * 4),
+    ]
+
+
+class NativeError(RuntimeError):
+    """A libmbtenv call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libmbtenv error {code}: {message}")
+        self.code = code
+
+
+_F = C.POINTER(C.c_float)
+_ENV = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/mbt_env.h
+SIGNATURES = {
+    "mbt_abi_version": (C.c_uint32, []),
+    "mbt_config_sizeof": (C.c_size_t, []),
+    "mbt_last_error": (C.c_char_p, []),
+    "mbt_device_count": (C.c_int, []),
+    "mbt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "mbt_env_create": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(_ENV)]),
+    "mbt_env_destroy": (None, [_ENV]),
+    "mbt_env_set_stream": (C.c_int, [_ENV, C.c_void_p]),
+    "mbt_env_synchronize": (C.c_int, [_ENV]),
+    "mbt_env_seed": (C.c_int, [_ENV, C.c_uint64]),
+    "mbt_env_reset": (C.c_int, [_ENV, C.c_double, _F]),
+    "mbt_env_reset_host": (C.c_int, [_ENV, C.c_double, _F, _F]),
+    "mbt_env_step_host": (C.c_int, [_ENV, _F, _F, _F, C.POINTER(C.c_int32)]),
+    "mbt_env_step_device": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_int32)]),
+    "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),
+    "mbt_env_action_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_obs_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_reward_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_obs_dim": (C.c_int, [_ENV]),
+    "mbt_env_action_dim": (C.c_int, [_ENV]),
+    "mbt_env_get_state_host": (C.c_int, [_ENV, _F]),
+    "mbt_env_get_obs_host": (C.c_int, [_ENV, _F]),
+    "mbt_env_set_action_host": (C.c_int, [_ENV, _F]),
+    "mbt_env_set_state_host": (C.c_int, [_ENV, _F, C.c_double, C.c_uint32]),
+    "mbt_env_get_clock": (C.c_int, [_ENV, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mbt_env_record_events": (C.c_int, [_ENV, C.c_int]),
+    "mbt_env_get_events_host": (C.c_int, [_ENV, C.POINTER(C.c_uint8)]),
+    "mbt_env_clip_count": (C.c_int, [_ENV, C.POINTER(C.c_uint64)]),
+    "mbt_env_track_lane_returns": (C.c_int, [_ENV, C.c_int]),
+    "mbt_env_return_sums": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
+    "mbt_rng_fill_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F, _F, _F]),
+    "mbt_philox4x32_10_host": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mbt_env_timer_begin": (C.c_int, [_ENV]),
+    "mbt_env_timer_end": (C.c_int, [_ENV, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmbtenv.so and bind every symbol of the header.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m mbt_gym_amd.build). "
+            "mbt_gym_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mbt_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmbtenv ABI {lib.mbt_abi_version()} != binding {ABI_VERSION}")
+    if lib.mbt_config_sizeof() != C.sizeof(MbtConfig):
+        raise RuntimeError(f"struct mbt_config is {lib.mbt_config_sizeof()} bytes in the library, {C.sizeof(MbtConfig)} in the binding")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code < 0:
+        raise NativeError(code, load_library().mbt_last_error().decode("utf-8", "replace"))
+    return code
+
+
+def fptr(array):
+    """float32 C-contiguous numpy array -> float*; None -> NULL."""
+    if array is None:
+        return None
+    assert array.dtype == np.float32 and array.flags["C_CONTIGUOUS"]
+    return array.ctypes.data_as(_F)
+
+
+def as_f32(a, shape=None):
+    out = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and out.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {out.shape}")
+    return out
+
+
+class DeviceView:
+    """A borrowed (N, D) / (N,) float32 device buffer owned by libmbtenv, exposed through
+    `__cuda_array_interface__` so that `torch.as_tensor(view, device="cuda")` wraps it without a copy."""
+
+    def __init__(self, ptr, shape, owner):
+        self.ptr, self.shape, self._owner = int(ptr), tuple(shape), owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
+
+
+def device_count():
+    return int(load_library().mbt_device_count())
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(64)
+    check(load_library().mbt_device_name(device, buf, 64))
+    return buf.value.decode()
+
+
+def philox4x32_10(ctr, key, device=0):
+    lib = load_library()
+    c = (C.c_uint32 * 4)(*[int(x) for x in ctr])
+    k = (C.c_uint32 * 2)(*[int(x) for x in key])
+    out = (C.c_uint32 * 4)()
+    check(lib.mbt_philox4x32_10_host(device, c, k, out))
+    return [int(x) for x in out]
+
+
+def rng_fill(seed, trajectory_offset, step, n, device=0):
+    """The production generator's draws for lanes [offset, offset+n) at one step: (u_arr, u_fill, z)."""
+    lib = load_library()
+    u_arr, u_fill, z = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32), np.empty((n,), np.float32)
+    check(lib.mbt_rng_fill_host(device, int(seed), int(trajectory_offset), int(step), int(n), fptr(u_arr), fptr(u_fill), fptr(z)))
+    return u_arr, u_fill, z

@@ -1,0 +1,53 @@
+"""Closed-form baseline policies (reference: mbt_gym/agents/BaselineAgents.py).  Policies are CALLERS of the hot
+path: they map the observation matrix to an action matrix on the host, once per step."""
+import warnings
+
+import numpy as np
+
+from mbt_gym_amd.agents.Agent import Agent
+from mbt_gym_amd.gym.index_names import INVENTORY_INDEX, TIME_INDEX
+
+
+class FixedActionAgent(Agent):
+    def __init__(self, fixed_action: np.ndarray, env):
+        self.fixed_action = np.asarray(fixed_action, dtype=np.float32)
+        self.env = env
+
+    def get_action(self, state: np.ndarray) -> np.ndarray:
+        return np.repeat(self.fixed_action.reshape(1, -1), self.env.num_trajectories, axis=0)
+
+
+class FixedSpreadAgent(Agent):
+    """Quotes half_spread -/+ offset on bid/ask (AG:34-42)."""
+
+    def __init__(self, env, half_spread: float = 1.0, offset: float = 0.0):
+        self.half_spread, self.offset, self.env = half_spread, offset, env
+
+    def get_action(self, state: np.ndarray) -> np.ndarray:
+        quote = np.array([[self.half_spread - self.offset, self.half_spread + self.offset]], dtype=np.float32)
+        return np.repeat(quote, self.env.num_trajectories, axis=0)
+
+
+class AvellanedaStoikovAgent(Agent):
+    """The Avellaneda-Stoikov (2008) quotes: reservation-price shift q gamma sigma^2 (T-t) around a spread of
+    gamma sigma^2 (T-t) + (2/gamma) ln(1 + gamma/kappa) (AG:52-83).  Expects un-normalised observations."""
+
+    def __init__(self, risk_aversion: float = 0.1, env=None):
+        assert env is not None
+        self.risk_aversion = risk_aversion
+        self.env = env
+        self.terminal_time = env.terminal_time
+        self.volatility = env.model_dynamics.midprice_model.volatility
+        self.rate_of_arrival = env.model_dynamics.arrival_model.intensity
+        self.fill_exponent = env.model_dynamics.fill_probability_model.fill_exponent
+
+    def get_action(self, state: np.ndarray) -> np.ndarray:
+        q = state[:, INVENTORY_INDEX].astype(np.float64)
+        tau = self.terminal_time - state[:, TIME_INDEX].astype(np.float64)
+        g, s2, k = self.risk_aversion, self.volatility**2, self.fill_exponent
+        shift = q * g * s2 * tau
+        spread = 2 / k if g == 0 else g * s2 * tau + 2 / g * np.log(1 + g / k)
+        action = np.stack((shift + spread / 2, -shift + spread / 2), axis=1)
+        if action.min() < 0:
+            warnings.warn("Avellaneda-Stoikov agent is quoting a negative spread")
+        return action.astype(np.float32)

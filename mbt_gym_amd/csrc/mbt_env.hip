@@ -1,0 +1,593 @@
+// libmbtenv: host side of the C ABI declared in include/mbt_env.h.
+//
+// Owns the HBM-resident environment (ping-pong state, action/reward/noise buffers), the host clock that the
+// reference keeps in state[0, TIME] (TradingEnvironment.py:216-220), and the launch of the fused step kernel.
+// No CPU fallback exists in this file or anywhere in the product path: without a gfx950 device every entry
+// point that needs one fails with MBT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/mbt_env.h"
+#include "step_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(MBT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                                \
+  } while (0)
+
+int check_device(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(MBT_ERR_NO_DEVICE, "no HIP device visible: libmbtenv has no CPU path");
+  if (device < 0 || device >= count) return fail(MBT_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MBT_ERR_NO_DEVICE, "device %d is %s; libmbtenv is built for gfx950 only", device, prop.gcnArchName);
+  return MBT_OK;
+}
+
+// smallest float32 >= x: for float32 u, (u < x in double) <=> (u < round_up_f32(x))
+float round_up_f32(double x) {
+  float f = static_cast<float>(x);
+  if (static_cast<double>(f) < x) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+
+using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
+
+template <int MID, int ARR, int DYN>
+StepKernel pick_noise(bool inject) {
+  return inject ? mbt::step_kernel<MID, ARR, DYN, true> : mbt::step_kernel<MID, ARR, DYN, false>;
+}
+template <int MID, int ARR>
+StepKernel pick_dyn(int dyn, bool inject) {
+  return dyn == MBT_DYN_LIMIT ? pick_noise<MID, ARR, mbt::kDynLimit>(inject)
+                              : pick_noise<MID, ARR, mbt::kDynLimitAndMarket>(inject);
+}
+template <int MID>
+StepKernel pick_arr(int arr, int dyn, bool inject) {
+  return arr == MBT_ARR_POISSON ? pick_dyn<MID, mbt::kArrPoisson>(dyn, inject)
+                                : pick_dyn<MID, mbt::kArrHawkes>(dyn, inject);
+}
+StepKernel pick_kernel(int mid, int arr, int dyn, bool inject) {
+  return mid == MBT_MID_BROWNIAN ? pick_arr<mbt::kMidBrownian>(arr, dyn, inject)
+                                 : pick_arr<mbt::kMidOu>(arr, dyn, inject);
+}
+
+}  // namespace
+
+struct mbt_env {
+  mbt_config cfg;
+  int dim = 4, act_dim = 2;
+  uint32_t n = 0, n_pad = 0, n_pairs = 0, n_blocks = 0, n_waves = 0;
+  double dt = 0.0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  // device buffers
+  float* state[2] = {nullptr, nullptr};
+  int cur = 0;  // state[cur] holds the current state
+  float* obs = nullptr;
+  float* action = nullptr;
+  float* reward = nullptr;
+  float* u_arr = nullptr;
+  float* u_fill = nullptr;
+  float* z = nullptr;
+  float* q_init = nullptr;
+  uint8_t* events = nullptr;
+  float* lane_returns = nullptr;
+  double* wave_sums = nullptr;
+  unsigned long long* clip_count = nullptr;
+  double* reduce_out = nullptr;
+  // host clock (the reference keeps it in state[:, TIME])
+  double time = 0.0, start_time = 0.0;
+  uint32_t episode_step = 0, philox_step = 0;
+  uint64_t seed = 0;
+  bool was_reset = false, noise_ready = false, q_init_per_lane = false;
+  bool record_events = false, track_returns = false;
+  StepKernel kernel = nullptr;
+  mbt::StepParams params;
+};
+
+namespace {
+
+void fill_static_params(mbt_env* e) {
+  const mbt_config& c = e->cfg;
+  mbt::StepParams& P = e->params;
+  std::memset(&P, 0, sizeof P);
+  P.n = e->n;
+  P.n_pairs = e->n_pairs;
+  P.pair_offset = c.trajectory_offset >> 1;
+  P.dt = static_cast<float>(e->dt);
+  P.drift_dt = static_cast<float>(c.drift * e->dt);
+  P.vol_sqrt_dt = static_cast<float>(c.volatility * std::sqrt(e->dt));
+  P.ou_speed = static_cast<float>(c.ou_speed);
+  P.ou_level = static_cast<float>(c.ou_level);
+  P.arr_thr_bid = round_up_f32(c.intensity[0] * e->dt);
+  P.arr_thr_ask = round_up_f32(c.intensity[1] * e->dt);
+  P.dt_f64 = e->dt;
+  P.hawkes_base_bid = static_cast<float>(c.intensity[0]);
+  P.hawkes_base_ask = static_cast<float>(c.intensity[1]);
+  P.hawkes_speed = static_cast<float>(c.hawkes_speed);
+  P.hawkes_jump = static_cast<float>(c.hawkes_jump);
+  P.kappa = static_cast<float>(c.fill_exponent);
+  P.kappa_f64 = c.fill_exponent;
+  P.half_spread = static_cast<float>(c.market_half_spread);
+  P.q_max = static_cast<float>(c.max_inventory);
+  P.c_max = static_cast<float>(c.max_cash);
+  P.reward_kind = c.reward_kind;
+  P.exponent_is_two = c.inventory_exponent == 2.0 ? 1 : 0;
+  P.phi = static_cast<float>(c.phi);
+  P.alpha = static_cast<float>(c.alpha);
+  P.exponent = static_cast<float>(c.inventory_exponent);
+  P.reward_scale = static_cast<float>(c.reward_scale);
+  P.norm_act = c.normalise_action;
+  P.norm_obs = c.normalise_observation;
+  for (int j = 0; j < 4; ++j) {
+    P.act_lo[j] = c.act_lo[j];
+    P.act_grad[j] = (c.act_hi[j] - c.act_lo[j]) / 2.0f;  // float32 arithmetic, as TE:193 does on the Box bounds
+  }
+  for (int j = 0; j < 6; ++j) {
+    P.obs_lo[j] = c.obs_lo[j];
+    P.obs_grad[j] = (c.obs_hi[j] - c.obs_lo[j]) / 2.0f;  // TE:185
+  }
+}
+
+void key_from_seed(mbt_env* e) {
+  e->params.key0 = static_cast<uint32_t>(e->seed);
+  e->params.key1 = static_cast<uint32_t>(e->seed >> 32);
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+  return MBT_OK;
+}
+
+int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
+  if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
+  const bool inject = e->cfg.noise_mode == MBT_NOISE_INJECTED;
+  if (inject && !e->noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: set_noise() must precede every step()");
+  // host clock: t += dt (TE:216); done = t >= T - dt/2 (TE:218-220)
+  e->time += e->dt;
+  const bool terminal = e->time >= e->cfg.terminal_time - e->dt / 2;
+  mbt::StepParams& P = e->params;
+  P.philox_step = e->philox_step;
+  P.is_terminal = terminal ? 1 : 0;
+  P.t_next = static_cast<float>(e->time);
+
+  mbt::StepBuffers B;
+  B.state_in = e->state[e->cur];
+  B.state_out = e->state[e->cur ^ 1];
+  B.action = action_dev != nullptr ? action_dev : e->action;
+  B.reward = e->reward;
+  B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
+  B.u_arr = e->u_arr;
+  B.u_fill = e->u_fill;
+  B.z = e->z;
+  B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.events = e->record_events ? e->events : nullptr;
+  B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
+  B.wave_sums = e->wave_sums;
+  B.clip_count = e->clip_count;
+  hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P);
+  HIP_TRY(hipGetLastError());
+  e->cur ^= 1;
+  e->philox_step += 1;
+  e->episode_step += 1;
+  e->noise_ready = false;
+  if (done != nullptr) *done = terminal ? 1 : 0;
+  return MBT_OK;
+}
+
+int do_reset(mbt_env* e, double start_time, const float* q0_host) {
+  const mbt_config& c = e->cfg;
+  if (!(start_time >= 0.0 && start_time < c.terminal_time))
+    return fail(MBT_ERR_INVALID, "start time %g is not within [0, terminal_time)", start_time);  // TE:267
+  e->q_init_per_lane = false;
+  if (q0_host != nullptr) {
+    HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM;
+  }
+  e->time = e->start_time = start_time;
+  e->episode_step = 0;
+  e->cur = 0;
+  mbt::StepParams& P = e->params;
+  P.q_init_scalar = static_cast<float>(c.initial_inventory);
+  P.dt_over_episode = static_cast<float>(e->dt / (c.terminal_time - start_time));  // RW:106, RW:113
+  const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
+  hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
+                     c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
+                     q0_host != nullptr ? e->q_init : nullptr, static_cast<float>(c.initial_inventory),
+                     static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
+                     static_cast<float>(c.intensity[0]), static_cast<float>(c.intensity[1]), e->n_pad, e->n_waves, e->dim, P);
+  HIP_TRY(hipGetLastError());
+  if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
+  e->was_reset = true;
+  return MBT_OK;
+}
+
+float* current_obs(mbt_env* e) { return e->cfg.normalise_observation ? e->obs : e->state[e->cur]; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mbt_abi_version(void) { return MBT_ABI_VERSION; }
+size_t mbt_config_sizeof(void) { return sizeof(mbt_config); }
+const char* mbt_last_error(void) { return g_error.c_str(); }
+
+int mbt_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+int mbt_device_name(int device, char* buf, size_t buf_len) {
+  if (buf == nullptr || buf_len == 0) return fail(MBT_ERR_INVALID, "null buffer");
+  int count = mbt_device_count();
+  if (device < 0 || device >= count) return fail(MBT_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  std::snprintf(buf, buf_len, "%s", prop.gcnArchName);
+  return MBT_OK;
+}
+
+int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
+  if (cfg == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != MBT_ABI_VERSION)
+    return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
+  if (cfg->num_trajectories == 0 || cfg->num_trajectories > 0x7FFFFFF0ull)
+    return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
+  if (cfg->trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even (noise is drawn per pair)");
+  if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
+  if (cfg->midprice_kind != MBT_MID_BROWNIAN && cfg->midprice_kind != MBT_MID_OU)
+    return fail(MBT_ERR_INVALID, "midprice kind %d has no device implementation", cfg->midprice_kind);
+  if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES)
+    return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation", cfg->arrival_kind);
+  if (cfg->fill_kind != MBT_FILL_EXPONENTIAL) return fail(MBT_ERR_INVALID, "fill kind %d has no device implementation", cfg->fill_kind);
+  if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET)
+    return fail(MBT_ERR_INVALID, "dynamics kind %d has no device implementation", cfg->dynamics_kind);
+  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_CJ_MM)
+    return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", cfg->reward_kind);
+  if (cfg->noise_mode != MBT_NOISE_PHILOX && cfg->noise_mode != MBT_NOISE_INJECTED)
+    return fail(MBT_ERR_INVALID, "unknown noise mode %d", cfg->noise_mode);
+  int rc = check_device(cfg->device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  mbt_env* e = new (std::nothrow) mbt_env();
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "out of host memory");
+  e->cfg = *cfg;
+  e->dim = cfg->arrival_kind == MBT_ARR_HAWKES ? 6 : 4;
+  e->act_dim = cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2;
+  e->n = static_cast<uint32_t>(cfg->num_trajectories);
+  e->n_pad = (e->n + 1u) & ~1u;
+  e->n_pairs = e->n_pad / 2;
+  e->n_blocks = (e->n_pairs + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
+  e->n_waves = e->n_blocks * (mbt::kBlockThreads / 64);
+  e->dt = cfg->terminal_time / cfg->n_steps;  // TE:49
+  e->seed = cfg->seed;
+  e->kernel = pick_kernel(cfg->midprice_kind, cfg->arrival_kind, cfg->dynamics_kind, cfg->noise_mode == MBT_NOISE_INJECTED);
+  fill_static_params(e);
+  key_from_seed(e);
+
+#define ENV_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != MBT_OK) {       \
+      mbt_env_destroy(e);      \
+      return rc_;              \
+    }                          \
+  } while (0)
+  hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (he != hipSuccess) {
+    delete e;
+    return fail(MBT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+  }
+  e->own_stream = true;
+  if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess) {
+    mbt_env_destroy(e);
+    return fail(MBT_ERR_HIP, "hipEventCreate failed");
+  }
+  const size_t np = e->n_pad;
+  ENV_TRY(dev_alloc(&e->state[0], np * e->dim));
+  ENV_TRY(dev_alloc(&e->state[1], np * e->dim));
+  if (cfg->normalise_observation) ENV_TRY(dev_alloc(&e->obs, np * e->dim));
+  ENV_TRY(dev_alloc(&e->action, np * e->act_dim));
+  ENV_TRY(dev_alloc(&e->reward, np));
+  if (cfg->noise_mode == MBT_NOISE_INJECTED) {
+    ENV_TRY(dev_alloc(&e->u_arr, np * 2));
+    ENV_TRY(dev_alloc(&e->u_fill, np * 2));
+    ENV_TRY(dev_alloc(&e->z, np));
+  }
+  ENV_TRY(dev_alloc(&e->q_init, np));
+  ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves));
+  ENV_TRY(dev_alloc(&e->clip_count, 1));
+  ENV_TRY(dev_alloc(&e->reduce_out, 2));
+#undef ENV_TRY
+  *out = e;
+  return MBT_OK;
+}
+
+void mbt_env_destroy(mbt_env* e) {
+  if (e == nullptr) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
+  void* bufs[] = {e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
+                  e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out};
+  for (void* b : bufs)
+    if (b != nullptr) (void)hipFree(b);
+  if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);
+  if (e->ev_end != nullptr) (void)hipEventDestroy(e->ev_end);
+  if (e->own_stream && e->stream != nullptr) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mbt_env_set_stream(mbt_env* e, void* hip_stream) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->own_stream && e->stream != nullptr) (void)hipStreamDestroy(e->stream);
+  e->stream = static_cast<hipStream_t>(hip_stream);
+  e->own_stream = false;
+  return MBT_OK;
+}
+
+int mbt_env_synchronize(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_seed(mbt_env* e, uint64_t seed) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  e->seed = seed;
+  e->philox_step = 0;
+  key_from_seed(e);
+  return MBT_OK;
+}
+
+int mbt_env_reset(mbt_env* e, double start_time, const float* q0_host) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  return do_reset(e, start_time, q0_host);
+}
+
+int mbt_env_reset_host(mbt_env* e, double start_time, const float* q0_host, float* obs_host) {
+  int rc = mbt_env_reset(e, start_time, q0_host);
+  if (rc != MBT_OK) return rc;
+  if (obs_host != nullptr)
+    HIP_TRY(hipMemcpyAsync(obs_host, current_obs(e), size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, float* reward_host, int32_t* done) {
+  if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  int rc = launch_step(e, nullptr, done);
+  if (rc != MBT_OK) return rc;
+  if (obs_host != nullptr)
+    HIP_TRY(hipMemcpyAsync(obs_host, current_obs(e), size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (reward_host != nullptr)
+    HIP_TRY(hipMemcpyAsync(reward_host, e->reward, size_t(e->n) * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (action_device != nullptr && (e->n & 1u)) {
+    // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
+    HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    action_device = nullptr;
+  }
+  return launch_step(e, action_device, done);
+}
+
+int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, const float* z) {
+  if (e == nullptr || u_arr == nullptr || u_fill == nullptr || z == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->u_arr, u_arr, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->u_fill, u_fill, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->z, z, size_t(e->n) * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->noise_ready = true;
+  return MBT_OK;
+}
+
+float* mbt_env_action_ptr(mbt_env* e) { return e != nullptr ? e->action : nullptr; }
+float* mbt_env_obs_ptr(mbt_env* e) { return e != nullptr ? current_obs(e) : nullptr; }
+float* mbt_env_reward_ptr(mbt_env* e) { return e != nullptr ? e->reward : nullptr; }
+int mbt_env_obs_dim(mbt_env* e) { return e != nullptr ? e->dim : 0; }
+int mbt_env_action_dim(mbt_env* e) { return e != nullptr ? e->act_dim : 0; }
+
+int mbt_env_get_state_host(mbt_env* e, float* state_host) {
+  if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(state_host, e->state[e->cur], size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_get_obs_host(mbt_env* e, float* obs_host) {
+  if (e == nullptr || obs_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(obs_host, current_obs(e), size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_set_action_host(mbt_env* e, const float* action_host) {
+  if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uint32_t philox_step) {
+  if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->state[e->cur], state_host, size_t(e->n) * e->dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (e->cfg.normalise_observation) {
+    const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
+    hipLaunchKernelGGL(mbt::normalise_rows_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->state[e->cur], e->obs,
+                       e->n_pad, e->dim, e->params);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->time = time;
+  e->philox_step = philox_step;
+  e->episode_step = static_cast<uint32_t>(std::llround((time - e->start_time) / e->dt));
+  e->was_reset = true;
+  return MBT_OK;
+}
+
+int mbt_env_get_clock(mbt_env* e, double* time, uint32_t* episode_step, uint32_t* philox_step) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (time != nullptr) *time = e->time;
+  if (episode_step != nullptr) *episode_step = e->episode_step;
+  if (philox_step != nullptr) *philox_step = e->philox_step;
+  return MBT_OK;
+}
+
+int mbt_env_record_events(mbt_env* e, int enabled) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (enabled && e->events == nullptr) {
+    int rc = dev_alloc(&e->events, size_t(e->n_pad));
+    if (rc != MBT_OK) return rc;
+  }
+  e->record_events = enabled != 0;
+  return MBT_OK;
+}
+
+int mbt_env_get_events_host(mbt_env* e, uint8_t* events_host) {
+  if (e == nullptr || events_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!e->record_events) return fail(MBT_ERR_STATE, "event recording is off");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(events_host, e->events, size_t(e->n), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_clip_count(mbt_env* e, uint64_t* count) {
+  if (e == nullptr || count == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, e->clip_count, sizeof v, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *count = v;
+  return MBT_OK;
+}
+
+int mbt_env_track_lane_returns(mbt_env* e, int enabled) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (enabled && e->lane_returns == nullptr) {
+    int rc = dev_alloc(&e->lane_returns, size_t(e->n_pad));
+    if (rc != MBT_OK) return rc;
+  }
+  e->track_returns = enabled != 0;
+  return MBT_OK;
+}
+
+int mbt_env_return_sums(mbt_env* e, double sums[3]) {
+  if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(mbt::reduce_returns_kernel, dim3(1), dim3(256), 0, e->stream, e->wave_sums, e->n_waves,
+                     e->track_returns ? e->lane_returns : nullptr, e->n, e->reduce_out);
+  HIP_TRY(hipGetLastError());
+  double host[2] = {0.0, 0.0};
+  HIP_TRY(hipMemcpyAsync(host, e->reduce_out, sizeof host, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  sums[0] = host[0];
+  sums[1] = e->track_returns ? host[1] : NAN;
+  sums[2] = static_cast<double>(e->n);
+  return MBT_OK;
+}
+
+int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* u_arr,
+                      float* u_fill, float* z) {
+  if (trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even");
+  if (n == 0 || n > 0x7FFFFFF0ull) return fail(MBT_ERR_INVALID, "n out of range");
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t n_pad = (static_cast<uint32_t>(n) + 1u) & ~1u, n_pairs = n_pad / 2;
+  float *d_ua = nullptr, *d_uf = nullptr, *d_z = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ua), size_t(n_pad) * 2 * sizeof(float)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_uf), size_t(n_pad) * 2 * sizeof(float)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_z), size_t(n_pad) * sizeof(float)));
+  hipLaunchKernelGGL(mbt::rng_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, nullptr, trajectory_offset >> 1, step,
+                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), n_pairs, d_ua, d_uf, d_z);
+  HIP_TRY(hipGetLastError());
+  if (u_arr != nullptr) HIP_TRY(hipMemcpy(u_arr, d_ua, size_t(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  if (u_fill != nullptr) HIP_TRY(hipMemcpy(u_fill, d_uf, size_t(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  if (z != nullptr) HIP_TRY(hipMemcpy(z, d_z, size_t(n) * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(d_ua);
+  (void)hipFree(d_uf);
+  (void)hipFree(d_z);
+  return MBT_OK;
+}
+
+int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  if (ctr == nullptr || key == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  uint32_t* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 10 * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(d, ctr, 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d + 4, key, 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mbt::philox_kat_kernel, dim3(1), dim3(1), 0, nullptr, d, d + 4, d + 6);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d + 6, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return MBT_OK;
+}
+
+int mbt_env_timer_begin(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_timer_end(mbt_env* e, float* elapsed_ms) {
+  if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipEventRecord(e->ev_end, e->stream));
+  HIP_TRY(hipEventSynchronize(e->ev_end));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev_begin, e->ev_end));
+  return MBT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Counter-based Philox4x32-10 (Salmon et al., SC'11) for gfx950, and the noise layout of the step kernel.
+//
+// The reference draws from three numpy PCG64 generators (StochasticProcessModel.py:27); a device kernel
+// cannot reproduce that stream, so production noise is defined here instead - as a pure function of
+// (seed, global trajectory id, philox step).  It costs zero bytes of HBM traffic, is restart-safe and is
+// independent of how the trajectory axis is sharded over GPUs.
+//
+// Stream layout.  Trajectories are grouped in PAIRS p = gid >> 1 (one GPU thread owns one pair, so all
+// twelve words of its three blocks are used):
+//   block 0: ctr = (p.lo, p.hi, step, 0)  -> lane 2p   : u_arr_bid, u_arr_ask, u_fill_bid, u_fill_ask
+//   block 1: ctr = (p.lo, p.hi, step, 1)  -> lane 2p+1 : same four
+//   block 2: ctr = (p.lo, p.hi, step, 2)  -> words 0,1 feed one Box-Muller transform:
+//                                            z(2p) = r cos(theta), z(2p+1) = r sin(theta); words 2,3 unused
+//   key = (seed.lo, seed.hi)
+// Uniforms are u = (w >> 8) * 2^-24 in [0,1): exactly representable in float32, which is what lets the
+// Bernoulli decisions of the step be bit-exact against a float64 evaluation of the same draws.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbt {
+
+struct PhiloxWords {
+  uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ PhiloxWords philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                     uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;  // round multipliers
+  constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;  // Weyl key increments
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = static_cast<uint64_t>(M0) * c0;  // one v_mad_u64_u32 yields hi and lo
+    const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;  // v_xor3_b32
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    c1 = static_cast<uint32_t>(p1);
+    c3 = static_cast<uint32_t>(p0);
+    c0 = n0;
+    c2 = n2;
+    k0 += W0;  // keys are wave-uniform: this runs on the scalar unit
+    k1 += W1;
+  }
+  return PhiloxWords{c0, c1, c2, c3};
+}
+
+// [0,1) on the 2^-24 grid - exact in float32.
+__device__ __forceinline__ float uniform24(uint32_t w) { return static_cast<float>(w >> 8) * 0x1.0p-24f; }
+
+// Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (which take
+// their argument in revolutions, so the 32-bit word maps straight onto the angle).
+__device__ __forceinline__ void box_muller(uint32_t wr, uint32_t wt, float& z_cos, float& z_sin) {
+  const float u1 = (static_cast<float>(wr >> 8) + 0.5f) * 0x1.0p-24f;  // (0,1): log never sees 0
+  const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+  const float rev = static_cast<float>(wt >> 8) * 0x1.0p-24f;  // angle in revolutions, [0,1)
+  z_cos = r * __builtin_amdgcn_cosf(rev);
+  z_sin = r * __builtin_amdgcn_sinf(rev);
+}
+
+struct LaneNoise {
+  float ua_bid, ua_ask, uf_bid, uf_ask, z;
+};
+
+// Noise of the pair `pair` (global pair index) at `step`: lane 0 = trajectory 2*pair, lane 1 = 2*pair+1.
+__device__ __forceinline__ void philox_pair_noise(uint64_t pair, uint32_t step, uint32_t k0, uint32_t k1,
+                                                  LaneNoise& a, LaneNoise& b) {
+  const uint32_t plo = static_cast<uint32_t>(pair), phi = static_cast<uint32_t>(pair >> 32);
+  const PhiloxWords wa = philox4x32_10(plo, phi, step, 0u, k0, k1);
+  const PhiloxWords wb = philox4x32_10(plo, phi, step, 1u, k0, k1);
+  const PhiloxWords wn = philox4x32_10(plo, phi, step, 2u, k0, k1);
+  a.ua_bid = uniform24(wa.w0); a.ua_ask = uniform24(wa.w1); a.uf_bid = uniform24(wa.w2); a.uf_ask = uniform24(wa.w3);
+  b.ua_bid = uniform24(wb.w0); b.ua_ask = uniform24(wb.w1); b.uf_bid = uniform24(wb.w2); b.uf_ask = uniform24(wb.w3);
+  box_muller(wn.w0, wn.w1, a.z, b.z);
+}
+
+}  // namespace mbt

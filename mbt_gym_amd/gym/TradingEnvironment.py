@@ -1,0 +1,525 @@
+"""TradingEnvironment: the gym.Env face of the HIP step kernel
+(reference: mbt_gym/gym/TradingEnvironment.py:24-348).
+
+Same constructor arguments, attributes and old-gym 4-tuple `step()` as the reference, so existing agents,
+`generate_trajectory` and the Stable-Baselines3 adapter work unchanged - but the (N, D) state matrix lives in
+HBM and every `step()` is ONE launch of the fused kernel in csrc/step_kernel.hpp through the C ABI of
+include/mbt_env.h.  This module holds host logic only (argument handling, spaces, seeding protocol, clock);
+no numerics of the step are evaluated here, and there is no CPU fallback.
+
+Extra keyword arguments (after the reference's): `device`, `trajectory_offset` (global id of lane 0 when the
+trajectory axis is sharded over GPUs), `noise` ("philox" | "injected").
+Extra methods: `step_device()` / `obs_device` / `reward_device` (zero-copy, asynchronous), `set_noise()`,
+`record_events()`, `episode_return_sums()`.
+
+Differences from the reference, all deliberate:
+  * outputs are float32 (the dtype of the observation Box), not float64;
+  * randomness comes from Philox4x32-10 keyed by `seed` instead of three numpy PCG64 generators, so a seed
+    reproduces OUR stream, not numpy's; "injected" noise mode exists to compare against the reference bit for bit;
+  * clipping of cash/inventory is counted on the device (`clip_count`) instead of printing whole arrays.
+"""
+import ctypes as C
+from collections import OrderedDict
+from typing import Callable, Tuple, Union
+
+import numpy as np
+
+from mbt_gym_amd import _native
+from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics, ModelDynamics
+from mbt_gym_amd.gym.index_names import INVENTORY_INDEX
+from mbt_gym_amd.rewards.RewardFunctions import PnL, RewardFunction
+from mbt_gym_amd.spaces import Box
+from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+
+try:  # pragma: no cover - gym is not installed in the build image
+    import gym as _gym
+
+    _EnvBase = _gym.Env
+except Exception:  # noqa: BLE001
+    _EnvBase = object
+
+PROCESS_ORDER = ("midprice_model", "arrival_model", "fill_probability_model", "price_impact_model")  # TE:305
+
+
+class UnsupportedOnDevice(NotImplementedError):
+    """The requested plugin combination has no HIP implementation (and there is no CPU path to fall back to)."""
+
+
+class TradingEnvironment(_EnvBase):
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(
+        self,
+        terminal_time: float = 1.0,
+        n_steps: int = 20 * 10,
+        reward_function: RewardFunction = None,
+        model_dynamics: ModelDynamics = None,
+        initial_cash: float = 0.0,
+        initial_inventory: Union[int, Tuple[float, float]] = 0,
+        max_inventory: int = 10_000,
+        max_cash: float = None,
+        max_stock_price: float = None,
+        start_time: Union[float, int, Callable] = 0.0,
+        info_calculator=None,
+        seed: int = None,
+        num_trajectories: int = 1,
+        normalise_action_space: bool = True,
+        normalise_observation_space: bool = True,
+        normalise_rewards: bool = False,
+        *,
+        device: int = 0,
+        trajectory_offset: int = 0,
+        noise: str = "philox",
+    ):
+        if _EnvBase is not object:
+            super().__init__()
+        self._handle = None
+        self.terminal_time = terminal_time
+        self.n_steps = n_steps
+        self._step_size = self.terminal_time / self.n_steps
+        self.reward_function = reward_function or PnL()
+        if model_dynamics is None:  # the reference's default market (TE:51-63)
+            dt = self._step_size
+            model_dynamics = LimitOrderModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(step_size=dt, num_trajectories=num_trajectories, seed=seed),
+                arrival_model=PoissonArrivalModel(
+                    intensity=np.array([100, 100]), step_size=dt, num_trajectories=num_trajectories, seed=seed
+                ),
+                fill_probability_model=ExponentialFillFunction(step_size=dt, num_trajectories=num_trajectories, seed=seed),
+                num_trajectories=num_trajectories,
+                seed=seed,
+            )
+        self.model_dynamics = model_dynamics
+        self.model_dynamics._env = self
+        self.stochastic_processes = self._get_stochastic_processes()
+        self.stochastic_process_indices = self._get_stochastic_process_indices()
+        for name, proc in self.stochastic_processes.items():
+            proc._attach(self, *self.stochastic_process_indices[name])
+        self._num_trajectories = num_trajectories
+        for proc in self.stochastic_processes.values():
+            proc.num_trajectories = num_trajectories
+        self.initial_cash = initial_cash
+        self.initial_inventory = initial_inventory
+        self.max_inventory = max_inventory
+        self.device = device
+        self.trajectory_offset = trajectory_offset
+        self.noise = noise
+        # Seeding protocol of the reference: `if seed:` - seed=0 or None leaves the processes unseeded (TE:70);
+        # the environment-level generator (initial inventories) is always default_rng(seed) (TE:72).
+        self.seed_ = seed
+        self._philox_key = int(seed) if seed else int(np.random.SeedSequence().entropy) & (2**64 - 1)
+        if seed:
+            for i, proc in enumerate(self.stochastic_processes.values()):
+                proc.seed(seed + i + 1)
+        self.rng = np.random.default_rng(seed)
+        self.start_time = start_time
+        self.max_stock_price = max_stock_price or self.model_dynamics.midprice_model.max_value[0, 0]
+        self.max_cash = max_cash or self._get_max_cash()
+        if info_calculator is not None:
+            raise UnsupportedOnDevice("info_calculator is not supported (it is broken in the reference, TE:224)")
+        self.info_calculator = None
+        self._empty_infos = None
+        self.observation_space = self._get_observation_space()
+        self.action_space = self.model_dynamics.get_action_space()
+        self.normalise_action_space_ = normalise_action_space
+        self.normalise_observation_space_ = normalise_observation_space
+        self.normalise_rewards_ = normalise_rewards
+        self.original_observation_space = self.observation_space
+        self.original_action_space = self.action_space
+        if normalise_observation_space:
+            self.observation_space = _unit_box(self.original_observation_space)
+        if normalise_action_space:
+            self.action_space = _unit_box(self.original_action_space)
+        self.reward_scaling = 1.0
+        if normalise_rewards:
+            assert isinstance(self.model_dynamics.arrival_model, PoissonArrivalModel) and isinstance(
+                self.model_dynamics.fill_probability_model, ExponentialFillFunction
+            ), "Arrival model must be Poisson and fill probability model must be exponential to scale rewards"
+            self.reward_scaling = 1 / self._get_inventory_neutral_rewards()
+        self._handle = self._create_handle(num_trajectories, self.reward_scaling)
+        self._events_on = False
+        self._last_events = None
+        # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
+        # environment generator when initial inventories are random; keep the stream aligned
+        self._reset_device()
+
+    # ---------------------------------------------------------------------------------------------------
+    # construction helpers
+    # ---------------------------------------------------------------------------------------------------
+    def _device_config(self, num_trajectories: int, reward_scale: float, trajectory_offset=None) -> _native.MbtConfig:
+        md = self.model_dynamics
+        parts = [md, md.midprice_model, md.arrival_model, md.fill_probability_model, self.reward_function]
+        for part in parts:
+            if part is None or getattr(part, "device_kind", None) is None:
+                raise UnsupportedOnDevice(
+                    f"{type(part).__name__} has no HIP implementation; supported: BrownianMotion/Ou midprice, "
+                    "Poisson/Hawkes arrivals, exponential fills, limit / limit+market dynamics, PnL / "
+                    "RunningInventoryPenalty / CjMmCriterion rewards.  There is no CPU fallback."
+                )
+        if md.price_impact_model is not None:
+            raise UnsupportedOnDevice("price impact models have no HIP implementation yet")
+        fields = {}
+        for part in parts:
+            fields.update(part.device_params())
+        cfg = _native.MbtConfig()
+        cfg.abi_version = _native.ABI_VERSION
+        cfg.device = self.device
+        cfg.num_trajectories = num_trajectories
+        cfg.trajectory_offset = self.trajectory_offset if trajectory_offset is None else trajectory_offset
+        cfg.n_steps = self.n_steps
+        cfg.terminal_time = self.terminal_time
+        cfg.noise_mode = {"philox": _native.NOISE_PHILOX, "injected": _native.NOISE_INJECTED}[self.noise]
+        cfg.inventory_exponent = 2.0
+        for key, value in fields.items():
+            if key == "intensity":
+                cfg.intensity[0], cfg.intensity[1] = value
+            else:
+                setattr(cfg, key, value)
+        cfg.initial_cash = self.initial_cash
+        cfg.initial_inventory = float(self.initial_inventory) if isinstance(self.initial_inventory, (int, float)) else 0.0
+        cfg.max_inventory = self.max_inventory
+        cfg.max_cash = self.max_cash
+        cfg.reward_scale = reward_scale
+        cfg.seed = self._philox_key
+        cfg.normalise_observation = int(self.normalise_observation_space_)
+        cfg.normalise_action = int(self.normalise_action_space_)
+        lo, hi = self.original_observation_space.low, self.original_observation_space.high
+        for j in range(len(lo)):
+            cfg.obs_lo[j], cfg.obs_hi[j] = float(lo[j]), float(hi[j])
+        alo, ahi = self.original_action_space.low, self.original_action_space.high
+        for j in range(len(alo)):
+            cfg.act_lo[j], cfg.act_hi[j] = float(alo[j]), float(ahi[j])
+        return cfg
+
+    def _create_handle(self, num_trajectories: int, reward_scale: float, trajectory_offset=None):
+        lib = _native.load_library()
+        cfg = self._device_config(num_trajectories, reward_scale, trajectory_offset)
+        handle = C.c_void_p()
+        _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        return handle
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            _native.load_library().mbt_env_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---------------------------------------------------------------------------------------------------
+    # gym API
+    # ---------------------------------------------------------------------------------------------------
+    def reset(self):
+        """Re-initialise every lane (TE:96-101) and return the (N, D) float32 observation."""
+        obs = np.empty((self.num_trajectories, self.observation_dim), dtype=np.float32)
+        self._reset_device(obs)
+        return obs
+
+    def step(self, action: np.ndarray):
+        """One environment step for all lanes: ONE kernel launch.  Returns (obs, rewards, dones, infos) with the
+        reference's shapes (TE:103-110): (N, D) float32, (N,) float32, (N,) bool, list of N dicts."""
+        n = self.num_trajectories
+        act = _native.as_f32(action, (n, self.action_dim))
+        obs = np.empty((n, self.observation_dim), dtype=np.float32)
+        rewards = np.empty((n,), dtype=np.float32)
+        done = C.c_int32(0)
+        lib = _native.load_library()
+        _native.check(lib.mbt_env_step_host(self._handle, _native.fptr(act), _native.fptr(obs), _native.fptr(rewards), C.byref(done)))
+        if self._events_on:
+            ev = np.empty((n,), dtype=np.uint8)
+            _native.check(lib.mbt_env_get_events_host(self._handle, ev.ctypes.data_as(C.POINTER(C.c_uint8))))
+            self._last_events = ev
+        dones = np.full((n,), bool(done.value), dtype=bool)
+        return obs, rewards, dones, self._infos()
+
+    def seed(self, seed: int = None):
+        """Re-key the generators (TE:345-348): environment generator <- default_rng(seed), Philox key <- seed,
+        process i remembers seed + i + 1."""
+        self.rng = np.random.default_rng(seed)
+        for i, proc in enumerate(self.stochastic_processes.values()):
+            proc.seed(seed + i + 1)
+        self.seed_ = seed
+        self._philox_key = int(seed) & (2**64 - 1)
+        _native.check(_native.load_library().mbt_env_seed(self._handle, self._philox_key))
+
+    # ---------------------------------------------------------------------------------------------------
+    # zero-copy / asynchronous path
+    # ---------------------------------------------------------------------------------------------------
+    def step_device(self, action_ptr: int = None) -> bool:
+        """Enqueue one step on the environment's stream without any host transfer.  `action_ptr` is a device
+        pointer to (N, A) float32 (default: `action_device`).  Results stay in HBM (`obs_device`,
+        `reward_device`).  Returns the (host-side) done flag."""
+        done = C.c_int32(0)
+        _native.check(_native.load_library().mbt_env_step_device(self._handle, action_ptr, C.byref(done)))
+        return bool(done.value)
+
+    @property
+    def action_device(self):
+        ptr = _native.load_library().mbt_env_action_ptr(self._handle)
+        return _native.DeviceView(ptr, (self.num_trajectories, self.action_dim), self)
+
+    @property
+    def obs_device(self):
+        """Observation of the last reset/step.  Valid until the step after next (ping-pong buffers)."""
+        ptr = _native.load_library().mbt_env_obs_ptr(self._handle)
+        return _native.DeviceView(ptr, (self.num_trajectories, self.observation_dim), self)
+
+    @property
+    def reward_device(self):
+        ptr = _native.load_library().mbt_env_reward_ptr(self._handle)
+        return _native.DeviceView(ptr, (self.num_trajectories,), self)
+
+    def set_stream(self, hip_stream: int):
+        _native.check(_native.load_library().mbt_env_set_stream(self._handle, hip_stream))
+
+    def synchronize(self):
+        _native.check(_native.load_library().mbt_env_synchronize(self._handle))
+
+    def set_action_host(self, action: np.ndarray):
+        """Upload an action once (e.g. a fixed quote) for repeated `step_device()` calls."""
+        act = _native.as_f32(action, (self.num_trajectories, self.action_dim))
+        _native.check(_native.load_library().mbt_env_set_action_host(self._handle, _native.fptr(act)))
+
+    def observation_host(self) -> np.ndarray:
+        """Host copy of the observation of the last reset/step (what `step()` returned, or would have)."""
+        obs = np.empty((self.num_trajectories, self.observation_dim), dtype=np.float32)
+        _native.check(_native.load_library().mbt_env_get_obs_host(self._handle, _native.fptr(obs)))
+        return obs
+
+    # ---------------------------------------------------------------------------------------------------
+    # parity / diagnostics
+    # ---------------------------------------------------------------------------------------------------
+    def set_noise(self, u_arr: np.ndarray, u_fill: np.ndarray, z: np.ndarray):
+        """Injected-noise mode: the uniforms/normal the next step consumes in place of the three numpy
+        generators of the reference (arrival_models.py:55, fill_probability_models.py:33, midprice_models.py:64)."""
+        n = self.num_trajectories
+        ua, uf = _native.as_f32(u_arr, (n, 2)), _native.as_f32(u_fill, (n, 2))
+        zz = _native.as_f32(np.asarray(z).reshape(-1), (n,))
+        _native.check(_native.load_library().mbt_env_set_noise_host(self._handle, _native.fptr(ua), _native.fptr(uf), _native.fptr(zz)))
+
+    def record_events(self, enabled: bool = True):
+        _native.check(_native.load_library().mbt_env_record_events(self._handle, int(enabled)))
+        self._events_on = bool(enabled)
+
+    @property
+    def last_arrivals(self) -> np.ndarray:
+        """(N, 2) bool arrivals of the last step (needs record_events)."""
+        ev = self._last_events
+        return np.stack(((ev & 1) != 0, (ev & 2) != 0), axis=1)
+
+    @property
+    def last_fills(self) -> np.ndarray:
+        """(N, 2) fills of the last step after the max-inventory mask (TE:323-327)."""
+        ev = self._last_events
+        return np.stack(((ev & 4) != 0, (ev & 8) != 0), axis=1)
+
+    @property
+    def last_events(self) -> np.ndarray:
+        return self._last_events
+
+    @property
+    def clip_count(self) -> int:
+        out = C.c_uint64(0)
+        _native.check(_native.load_library().mbt_env_clip_count(self._handle, C.byref(out)))
+        return int(out.value)
+
+    def track_lane_returns(self, enabled: bool = True):
+        _native.check(_native.load_library().mbt_env_track_lane_returns(self._handle, int(enabled)))
+
+    def episode_return_sums(self) -> np.ndarray:
+        """[sum of rewards since reset over all lanes, sum of squared per-lane returns (NaN unless tracked),
+        lane count] - the three doubles a multi-GPU run all-reduces for the mean episode return."""
+        out = (C.c_double * 3)()
+        _native.check(_native.load_library().mbt_env_return_sums(self._handle, out))
+        return np.array(out[:], dtype=np.float64)
+
+    # ---------------------------------------------------------------------------------------------------
+    # state / normalisation helpers with the reference's names
+    # ---------------------------------------------------------------------------------------------------
+    @property
+    def has_device_state(self) -> bool:
+        return getattr(self, "_handle", None) is not None
+
+    @property
+    def state(self) -> np.ndarray:
+        """Host copy of the un-normalised (N, D) state (TE:142-144)."""
+        out = np.empty((self.num_trajectories, self.observation_dim), dtype=np.float32)
+        _native.check(_native.load_library().mbt_env_get_state_host(self._handle, _native.fptr(out)))
+        return out
+
+    def set_state(self, state: np.ndarray, time: float = None, philox_step: int = None):
+        st = _native.as_f32(state, (self.num_trajectories, self.observation_dim))
+        t_now, _, ph = self.clock
+        _native.check(_native.load_library().mbt_env_set_state_host(
+            self._handle, _native.fptr(st), float(st[0, 2]) if time is None else time, ph if philox_step is None else philox_step))
+
+    @property
+    def clock(self):
+        """(time, episode step, philox step) kept on the host."""
+        t, k, p = C.c_double(0), C.c_uint32(0), C.c_uint32(0)
+        _native.check(_native.load_library().mbt_env_get_clock(self._handle, C.byref(t), C.byref(k), C.byref(p)))
+        return t.value, k.value, p.value
+
+    def normalise_observation(self, obs: np.ndarray, inverse: bool = False):
+        if not self.normalise_observation_space_:
+            return obs
+        lo, grad = self._intercept_obs_norm, self._gradient_obs_norm
+        return (obs + 1) * grad + lo if inverse else (obs - lo) / grad - 1
+
+    def normalise_action(self, action: np.ndarray, inverse: bool = False):
+        if not self.normalise_action_space_:
+            return action
+        lo, grad = self._intercept_action_norm, self._gradient_action_norm
+        return (action + 1) * grad + lo if inverse else (action - lo) / grad - 1
+
+    def normalise_rewards(self, rewards: np.ndarray):
+        return self.reward_scaling * rewards if self.normalise_rewards_ else rewards
+
+    @property
+    def _intercept_obs_norm(self):
+        return self.original_observation_space.low
+
+    @property
+    def _gradient_obs_norm(self):
+        return (self.original_observation_space.high - self.original_observation_space.low) / 2
+
+    @property
+    def _intercept_action_norm(self):
+        return self.original_action_space.low
+
+    @property
+    def _gradient_action_norm(self):
+        return (self.original_action_space.high - self.original_action_space.low) / 2
+
+    @property
+    def is_at_max_inventory(self):
+        return self.state[:, INVENTORY_INDEX] >= self.max_inventory
+
+    @property
+    def is_at_min_inventory(self):
+        return self.state[:, INVENTORY_INDEX] <= -self.max_inventory
+
+    @property
+    def step_size(self):
+        return self._step_size
+
+    @property
+    def num_trajectories(self):
+        return self._num_trajectories
+
+    @property
+    def observation_dim(self) -> int:
+        return int(self.original_observation_space.shape[0])
+
+    @property
+    def action_dim(self) -> int:
+        return int(self.original_action_space.shape[0])
+
+    # ---------------------------------------------------------------------------------------------------
+    # host logic behind reset (TE:257-281)
+    # ---------------------------------------------------------------------------------------------------
+    def _get_start_time(self) -> float:
+        if isinstance(self.start_time, (float, int)):
+            start = self.start_time
+        elif isinstance(self.start_time, Callable):
+            start = self.start_time()
+        else:
+            raise NotImplementedError
+        return self._quantise_time_to_step(start)
+
+    def _quantise_time_to_step(self, time: float) -> float:
+        assert (time >= 0.0) and (time < self.terminal_time), "Start time is not within (0, env.terminal_time)."
+        return float(np.round(time / self.step_size) * self.step_size)
+
+    def _get_initial_inventories(self):
+        """None = the scalar `initial_inventory` for every lane; otherwise a per-lane float32 array."""
+        q0 = self.initial_inventory
+        if isinstance(q0, tuple) and len(q0) == 2:
+            return self.rng.integers(*q0, size=self.num_trajectories).astype(np.float32)
+        if isinstance(q0, int):
+            return None
+        if isinstance(q0, Callable):
+            value = q0()
+            if self.model_dynamics.round_initial_inventory:
+                value = int(np.round(value))
+            return np.full((self.num_trajectories,), value, dtype=np.float32)
+        raise Exception("Initial inventory must be a tuple of length 2 or an int.")
+
+    def _reset_device(self, obs_out: np.ndarray = None):
+        """start time and initial inventories are host decisions (TE:257-281); the rows are written on the device.
+        The initial inventory and episode length CjMmCriterion captures at reset (RW:111-113) go with them."""
+        start = self._get_start_time()
+        q0 = self._get_initial_inventories()
+        _native.check(_native.load_library().mbt_env_reset_host(self._handle, start, _native.fptr(q0), _native.fptr(obs_out)))
+
+    def _infos(self):
+        if self._empty_infos is None:  # TE:320-321: one shared list of dicts, reused every step
+            n = self.num_trajectories
+            self._empty_infos = [{} for _ in range(n)] if n > 1 else {}
+        return self._empty_infos
+
+    def _get_max_cash(self) -> float:
+        return self.n_steps * self.max_stock_price  # TE:229-230
+
+    def _get_observation_space(self):
+        """[cash, inventory, time] bounds followed by each process's bounds, as float32 (TE:232-241)."""
+        low = [-self.max_cash, -self.max_inventory, 0]
+        high = [self.max_cash, self.max_inventory, self.terminal_time]
+        for proc in self.stochastic_processes.values():
+            low.extend(np.asarray(proc.min_value).reshape(-1))
+            high.extend(np.asarray(proc.max_value).reshape(-1))
+        return Box(low=np.float32(np.array(low, dtype=np.float64)), high=np.float32(np.array(high, dtype=np.float64)))
+
+    def _get_stochastic_processes(self):
+        found = OrderedDict()
+        for name in PROCESS_ORDER:
+            proc = getattr(self.model_dynamics, name)
+            if proc is not None:
+                found[name] = proc
+        return found
+
+    def _get_stochastic_process_indices(self):
+        """Column ranges of each process in the state matrix, after [cash, inventory, time] (TE:311-318)."""
+        spans, col = OrderedDict(), 3
+        for name, proc in self.stochastic_processes.items():
+            spans[name] = (col, col + proc.state_dim)
+            col += proc.state_dim
+        return spans
+
+    def _get_inventory_neutral_rewards(self, num_total_trajectories=100_000):
+        """Mean episode return of the constant quote 1/kappa from t=0 over 100k lanes (TE:329-343), rolled out on
+        the device with a throw-away handle."""
+        lib = _native.load_library()
+        saved = (self.start_time, self.normalise_action_space_, self.normalise_observation_space_)
+        self.normalise_action_space_, self.normalise_observation_space_ = False, False
+        n = num_total_trajectories
+        try:
+            cfg = self._device_config(n, 1.0, trajectory_offset=0)
+        finally:
+            self.start_time, self.normalise_action_space_, self.normalise_observation_space_ = saved
+        handle = C.c_void_p()
+        _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        try:
+            _native.check(lib.mbt_env_reset(handle, 0.0, None))
+            quote = 1.0 / self.model_dynamics.fill_probability_model.fill_exponent
+            act = np.full((n, self.original_action_space.shape[0]), 0.0, dtype=np.float32)
+            act[:, 0:2] = quote
+            done = C.c_int32(0)
+            _native.check(lib.mbt_env_step_host(handle, _native.fptr(act), None, None, C.byref(done)))
+            while not done.value:
+                _native.check(lib.mbt_env_step_device(handle, None, C.byref(done)))
+            sums = (C.c_double * 3)()
+            _native.check(lib.mbt_env_return_sums(handle, sums))
+        finally:
+            lib.mbt_env_destroy(handle)
+        return sums[0] / n
+
+
+def _unit_box(space):
+    """[-1, 1]^n box with the shape of `space` (TE:243-255)."""
+    return Box(low=-np.ones_like(space.low, dtype=np.float32), high=np.ones_like(space.high, dtype=np.float32))
