@@ -58,23 +58,37 @@ float round_up_f32(double x) {
 
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 
+// 2 x 2 x 2 x 3 x 2 x 2 = 96 instantiations: one lean kernel per plugin combination.
+template <int MID, int ARR, int DYN, int REW>
+StepKernel pick_flags(bool norm, bool inject) {
+  if (norm) return inject ? mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, true, true>>
+                          : mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, true, false>>;
+  return inject ? mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, false, true>>
+                : mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, false, false>>;
+}
 template <int MID, int ARR, int DYN>
-StepKernel pick_noise(bool inject) {
-  return inject ? mbt::step_kernel<MID, ARR, DYN, true> : mbt::step_kernel<MID, ARR, DYN, false>;
+StepKernel pick_rew(int rew, bool norm, bool inject) {
+  switch (rew) {
+    case MBT_REW_PNL: return pick_flags<MID, ARR, DYN, mbt::kRewPnl>(norm, inject);
+    case MBT_REW_RUNNING_PENALTY: return pick_flags<MID, ARR, DYN, mbt::kRewRunning>(norm, inject);
+    default: return pick_flags<MID, ARR, DYN, mbt::kRewCjMm>(norm, inject);
+  }
 }
 template <int MID, int ARR>
-StepKernel pick_dyn(int dyn, bool inject) {
-  return dyn == MBT_DYN_LIMIT ? pick_noise<MID, ARR, mbt::kDynLimit>(inject)
-                              : pick_noise<MID, ARR, mbt::kDynLimitAndMarket>(inject);
+StepKernel pick_dyn(int dyn, int rew, bool norm, bool inject) {
+  return dyn == MBT_DYN_LIMIT ? pick_rew<MID, ARR, mbt::kDynLimit>(rew, norm, inject)
+                              : pick_rew<MID, ARR, mbt::kDynLimitAndMarket>(rew, norm, inject);
 }
 template <int MID>
-StepKernel pick_arr(int arr, int dyn, bool inject) {
-  return arr == MBT_ARR_POISSON ? pick_dyn<MID, mbt::kArrPoisson>(dyn, inject)
-                                : pick_dyn<MID, mbt::kArrHawkes>(dyn, inject);
+StepKernel pick_arr(int arr, int dyn, int rew, bool norm, bool inject) {
+  return arr == MBT_ARR_POISSON ? pick_dyn<MID, mbt::kArrPoisson>(dyn, rew, norm, inject)
+                                : pick_dyn<MID, mbt::kArrHawkes>(dyn, rew, norm, inject);
 }
-StepKernel pick_kernel(int mid, int arr, int dyn, bool inject) {
-  return mid == MBT_MID_BROWNIAN ? pick_arr<mbt::kMidBrownian>(arr, dyn, inject)
-                                 : pick_arr<mbt::kMidOu>(arr, dyn, inject);
+StepKernel pick_kernel(const mbt_config& c) {
+  const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
+  const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
+  return c.midprice_kind == MBT_MID_BROWNIAN ? pick_arr<mbt::kMidBrownian>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm, inject)
+                                             : pick_arr<mbt::kMidOu>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm, inject);
 }
 
 }  // namespace
@@ -138,7 +152,6 @@ void fill_static_params(mbt_env* e) {
   P.half_spread = static_cast<float>(c.market_half_spread);
   P.q_max = static_cast<float>(c.max_inventory);
   P.c_max = static_cast<float>(c.max_cash);
-  P.reward_kind = c.reward_kind;
   P.exponent_is_two = c.inventory_exponent == 2.0 ? 1 : 0;
   P.phi = static_cast<float>(c.phi);
   P.alpha = static_cast<float>(c.alpha);
@@ -293,7 +306,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->n_waves = e->n_blocks * (mbt::kBlockThreads / 64);
   e->dt = cfg->terminal_time / cfg->n_steps;  // TE:49
   e->seed = cfg->seed;
-  e->kernel = pick_kernel(cfg->midprice_kind, cfg->arrival_kind, cfg->dynamics_kind, cfg->noise_mode == MBT_NOISE_INJECTED);
+  e->kernel = pick_kernel(*cfg);
   fill_static_params(e);
   key_from_seed(e);
 

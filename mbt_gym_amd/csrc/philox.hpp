@@ -18,6 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MBT_PHILOX_ROUNDS
+#define MBT_PHILOX_ROUNDS 10  // the standard Philox4x32-10; fewer rounds are for sensitivity experiments only
+#endif
+
 namespace mbt {
 
 struct PhiloxWords {
@@ -29,7 +33,7 @@ __device__ __forceinline__ PhiloxWords philox4x32_10(uint32_t c0, uint32_t c1, u
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;  // round multipliers
   constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;  // Weyl key increments
 #pragma unroll
-  for (int round = 0; round < 10; ++round) {
+  for (int round = 0; round < MBT_PHILOX_ROUNDS; ++round) {
     const uint64_t p0 = static_cast<uint64_t>(M0) * c0;  // one v_mad_u64_u32 yields hi and lo
     const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
     const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;  // v_xor3_b32

@@ -11,6 +11,10 @@
 // Nothing else touches HBM: `dones` is a host scalar (TE:218-220), time is a kernel argument, the generator is
 // stateless.  Algorithmic traffic per env-step: 4*(D + A + D + 1) bytes = 44 B for D=4, A=2.
 //
+// Schedule inside a wave: all loads are issued first; the Philox rounds (which depend on nothing in memory) run
+// while they are in flight; an empty asm ties the loaded registers to the finished noise so the compiler cannot
+// pull a consumer of the loads (and its s_waitcnt) above the generator.
+//
 // Numerics contract (checked by tests/ against oracle/ and the golden fixtures):
 //   * arrivals, fills, market-order flags, inventory: BIT-EXACT against the float64 reference on the same
 //     float32-representable draws.  Decisions are taken on exact thresholds: Poisson thresholds arrive rounded
@@ -29,12 +33,25 @@
 
 namespace mbt {
 
-constexpr int kBlockThreads = 256;  // 4 wave64 per workgroup
+#ifndef MBT_BLOCK_THREADS
+#define MBT_BLOCK_THREADS 256
+#endif
+constexpr int kBlockThreads = MBT_BLOCK_THREADS;  // wave64 x 4 per workgroup by default
 
 enum : int { kMidBrownian = 0, kMidOu = 1 };
 enum : int { kArrPoisson = 0, kArrHawkes = 1 };
 enum : int { kDynLimit = 0, kDynLimitAndMarket = 1 };
 enum : int { kRewPnl = 0, kRewRunning = 1, kRewCjMm = 2 };
+
+// Compile-time shape of one kernel instantiation.
+template <int MID_, int ARR_, int DYN_, int REW_, bool NORM_, bool INJECT_>
+struct Variant {
+  static constexpr int MID = MID_, ARR = ARR_, DYN = DYN_, REW = REW_;
+  static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
+  static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
+  static constexpr int DIM = (ARR_ == kArrHawkes) ? 6 : 4;
+  static constexpr int VEC_PER_PAIR = DIM / 2;  // float4 per pair of state rows
+};
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
 struct StepParams {
@@ -61,7 +78,6 @@ struct StepParams {
   float half_spread;
   float q_max, c_max;
   // reward
-  int32_t reward_kind;
   int32_t exponent_is_two;
   float phi, alpha, exponent;
   float dt_over_episode;  // CjMm: dt / (T - t_start)    (RW:106)
@@ -89,21 +105,42 @@ struct StepBuffers {
   unsigned long long* clip_count;
 };
 
-__device__ __forceinline__ float pow_inventory(float q, const StepParams& P) {
-  // numpy `q ** p` (RW:101-104, RW:133-137): p == 2 is the case every reference config uses
-  return P.exponent_is_two ? q * q : powf(q, P.exponent);
-}
+// ---- fill decisions --------------------------------------------------------------------------------------
+// float32 exponential fill test (FILL:34, FILL:57-58) that is exact against float64: v_exp_f32 decides unless the
+// draw lies inside its error band (plus the rounding of a normalised depth); `near` flags that case and ONE cold
+// block per pair re-decides the flagged entries in double.
+struct FillTest {
+  bool fill;  // u < exp(-kappa * depth), fast evaluation
+  bool near;  // the fast evaluation cannot be trusted
+};
 
-// float32 exponential fill test, exact against float64 (FILL:34, FILL:57-58).
-__device__ __forceinline__ bool fill_decision(float u, float depth_f32, double depth_f64, const StepParams& P) {
-  const float x = P.kappa * depth_f32;
+__device__ __forceinline__ FillTest fill_test(float u, float depth, const StepParams& P) {
+  const float x = P.kappa * depth;
   const float p = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
   const float band = p * (4e-6f + 4e-7f * __builtin_fabsf(x)) + 1e-30f;
   const float d = u - p;
-  if (__builtin_expect(__builtin_fabsf(d) <= band, 0)) {
-    return static_cast<double>(u) < exp(-P.kappa_f64 * depth_f64);
+  return FillTest{d < 0.0f, __builtin_fabsf(d) <= band};
+}
+
+__device__ __forceinline__ float depth_of(float a, int side, bool norm, const StepParams& P) {
+  return norm ? static_cast<float>((static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side]) : a;  // TE:124
+}
+
+// cold: exact re-decision of the flagged entries of a pair (about 4e-6 of draws get here)
+__device__ __attribute__((cold)) void refine_fills_f64(const float (&u)[4], const float (&a)[4], bool norm, const StepParams& P,
+                                                       bool (&fill)[4], const bool (&near)[4]) {
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    if (!near[k]) continue;
+    double depth = a[k];
+    if (norm) depth = (static_cast<double>(a[k]) + 1.0) * P.act_grad[k & 1] + P.act_lo[k & 1];
+    fill[k] = static_cast<double>(u[k]) < exp(-P.kappa_f64 * depth);
   }
-  return d < 0.0f;
+}
+
+// numpy `q ** p` (RW:101-104, RW:133-137); p == 2 in every reference configuration
+__device__ __forceinline__ float pow_inventory(float q, const StepParams& P) {
+  return __builtin_expect(P.exponent_is_two, 1) ? q * q : powf(q, P.exponent);
 }
 
 struct LaneResult {
@@ -113,25 +150,15 @@ struct LaneResult {
   uint32_t events;
 };
 
-template <int MID, int ARR, int DYN>
-__device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 lam, const float a0, const float a1,
-                                                const float a2, const float a3, const LaneNoise nz,
-                                                const float q_init, const StepParams& P) {
+template <class V>
+__device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 lam, const float4 act, const float d_bid,
+                                                const float d_ask, const bool raw_fill_bid, const bool raw_fill_ask,
+                                                const LaneNoise nz, const float q_init, const StepParams& P) {
   const float cash = core.x, q = core.y, mid = core.w;
-
-  // -- action (TE:104, TE:120-126): depths in float32 for the arithmetic, in double for exact decisions
-  float d_bid = a0, d_ask = a1;
-  double d_bid64 = a0, d_ask64 = a1;
-  if (P.norm_act) {
-    d_bid64 = (static_cast<double>(a0) + 1.0) * P.act_grad[0] + P.act_lo[0];
-    d_ask64 = (static_cast<double>(a1) + 1.0) * P.act_grad[1] + P.act_lo[1];
-    d_bid = static_cast<float>(d_bid64);
-    d_ask = static_cast<float>(d_ask64);
-  }
 
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
   bool arr_bid, arr_ask;
-  if (ARR == kArrPoisson) {
+  if (V::ARR == kArrPoisson) {
     arr_bid = nz.ua_bid < P.arr_thr_bid;
     arr_ask = nz.ua_ask < P.arr_thr_ask;
   } else {
@@ -140,8 +167,8 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
   }
 
   // -- fills (FILL:28-34, FILL:57-58) masked by the PRE-update inventory (TE:323-327)
-  const bool fill_bid = fill_decision(nz.uf_bid, d_bid, d_bid64, P) && !(q >= P.q_max);
-  const bool fill_ask = fill_decision(nz.uf_ask, d_ask, d_ask64, P) && !(q <= -P.q_max);
+  const bool fill_bid = raw_fill_bid && !(q >= P.q_max);
+  const bool fill_ask = raw_fill_ask && !(q <= -P.q_max);
   const float n_bid = (arr_bid && fill_bid) ? 1.0f : 0.0f;
   const float n_ask = (arr_ask && fill_ask) ? 1.0f : 0.0f;
 
@@ -149,14 +176,14 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
   //    fills (MD:108-116 / MD:215-222)
   float q_new = q, cash_new = cash, gain = 0.0f;
   uint32_t ev = (arr_bid ? 1u : 0u) | (arr_ask ? 2u : 0u) | (fill_bid ? 4u : 0u) | (fill_ask ? 8u : 0u);
-  if (DYN == kDynLimitAndMarket) {
+  if (V::DYN == kDynLimitAndMarket) {
     bool mo_buy, mo_sell;
-    if (P.norm_act) {
-      mo_buy = (static_cast<double>(a2) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
-      mo_sell = (static_cast<double>(a3) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
+    if (V::NORM && P.norm_act) {
+      mo_buy = (static_cast<double>(act.z) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
+      mo_sell = (static_cast<double>(act.w) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
     } else {
-      mo_buy = a2 > 0.5f;
-      mo_sell = a3 > 0.5f;
+      mo_buy = act.z > 0.5f;
+      mo_sell = act.w > 0.5f;
     }
     const float mb = mo_buy ? 1.0f : 0.0f, ms = mo_sell ? 1.0f : 0.0f;
     cash_new += ms * (mid - P.half_spread) - mb * (mid + P.half_spread);
@@ -177,7 +204,7 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
 
   // -- midprice (MID:60-65 / MID:140-143: the OU pull is not scaled by dt in the reference)
   float d_mid;
-  if (MID == kMidBrownian) {
+  if (V::MID == kMidBrownian) {
     d_mid = P.drift_dt + P.vol_sqrt_dt * nz.z;
   } else {
     d_mid = -P.ou_speed * (mid - P.ou_level) + P.vol_sqrt_dt * nz.z;
@@ -186,17 +213,17 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
 
   // -- Hawkes intensities jump on arrivals, not on fills (ARR:110-119)
   float2 lam_new = lam;
-  if (ARR == kArrHawkes) {
+  if (V::ARR == kArrHawkes) {
     lam_new.x = (lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.dt) + (arr_bid ? P.hawkes_jump : 0.0f);
     lam_new.y = (lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.dt) + (arr_ask ? P.hawkes_jump : 0.0f);
   }
 
   // -- reward (RW:23-33, RW:96-109, RW:128-138): incremental mark-to-market, see the header comment
   float reward = gain + q_clip * d_mid + dq_clip * mid + dc_clip;
-  if (P.reward_kind != kRewPnl) {
+  if (V::REW != kRewPnl) {
     const float qp = pow_inventory(q_clip, P);
     reward -= P.dt * P.phi * qp;
-    if (P.reward_kind == kRewRunning) {
+    if (V::REW == kRewRunning) {
       reward -= P.is_terminal ? P.alpha * qp : 0.0f;
     } else {
       reward -= P.alpha * ((qp - pow_inventory(q, P)) + P.dt_over_episode * pow_inventory(q_init, P));
@@ -233,89 +260,142 @@ __device__ __forceinline__ void write_obs_row(float* obs, uint32_t lane, int dim
   }
 }
 
-template <int MID, int ARR, int DYN, bool INJECT>
+// Everything one pair of trajectories reads from HBM.
+template <class V>
+struct PairLoads {
+  float4 s0, s1, s2;  // D/2 float4 of state (s2: Hawkes only)
+  float4 a0, a1;      // actions (a1: limit+market only)
+  float4 ua, uf;      // injected noise
+  float2 zz;
+  float2 qi;          // CjMm per-lane initial inventories
+};
+
+template <class V>
+__device__ __forceinline__ PairLoads<V> load_pair(const StepBuffers& B, const StepParams& P, uint32_t pair) {
+  PairLoads<V> L;
+  const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
+  L.s0 = src[0];
+  L.s1 = src[1];
+  if (V::ARR == kArrHawkes) L.s2 = src[2];
+  if (V::DYN == kDynLimit) {
+    L.a0 = reinterpret_cast<const float4*>(B.action)[pair];
+  } else {
+    L.a0 = reinterpret_cast<const float4*>(B.action)[2 * pair];
+    L.a1 = reinterpret_cast<const float4*>(B.action)[2 * pair + 1];
+  }
+  if (V::INJECT) {
+    L.ua = reinterpret_cast<const float4*>(B.u_arr)[pair];
+    L.uf = reinterpret_cast<const float4*>(B.u_fill)[pair];
+    L.zz = reinterpret_cast<const float2*>(B.z)[pair];
+  }
+  L.qi = make_float2(P.q_init_scalar, P.q_init_scalar);
+  if (V::REW == kRewCjMm && B.q_init != nullptr) L.qi = reinterpret_cast<const float2*>(B.q_init)[pair];
+  return L;
+}
+
+// Orders the schedule: every operand is an in/out of one empty asm, so the noise is complete before, and every
+// consumer of the loaded state/action after, this point.  Costs no instruction.
+template <class V>
+__device__ __forceinline__ void tie_loads_to_noise(PairLoads<V>& L, LaneNoise& a, LaneNoise& b) {
+  asm volatile("; loads are first consumed below this line"
+               : "+v"(L.s0.x), "+v"(L.s0.y), "+v"(L.s0.z), "+v"(L.s0.w), "+v"(L.s1.x), "+v"(L.s1.y), "+v"(L.s1.z), "+v"(L.s1.w),
+                 "+v"(L.a0.x), "+v"(L.a0.y), "+v"(L.a0.z), "+v"(L.a0.w), "+v"(a.ua_bid), "+v"(a.ua_ask), "+v"(a.uf_bid), "+v"(a.uf_ask), "+v"(a.z),
+                 "+v"(b.ua_bid), "+v"(b.ua_ask), "+v"(b.uf_bid), "+v"(b.uf_ask), "+v"(b.z));
+}
+
+// Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
+template <class V>
+__device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
+                                             const LaneNoise& nz0, const LaneNoise& nz1) {
+  const uint32_t lane0 = 2u * pair;
+  float4 core0 = L.s0, core1 = L.s1;
+  float2 lam0 = make_float2(0.f, 0.f), lam1 = lam0;
+  if (V::ARR == kArrHawkes) {  // rows of 6: [c q t S | lb la c q | t S lb la]
+    lam0 = make_float2(L.s1.x, L.s1.y);
+    core1 = make_float4(L.s1.z, L.s1.w, L.s2.x, L.s2.y);
+    lam1 = make_float2(L.s2.z, L.s2.w);
+  }
+  float4 act0, act1;
+  if (V::DYN == kDynLimit) {
+    act0 = make_float4(L.a0.x, L.a0.y, 0.f, 0.f);
+    act1 = make_float4(L.a0.z, L.a0.w, 0.f, 0.f);
+  } else {
+    act0 = L.a0;
+    act1 = L.a1;
+  }
+
+  // -- fill tests of the four quotes of the pair (TE:104 de-normalisation first)
+  const bool norm_act = V::NORM && P.norm_act;
+  const float a[4] = {act0.x, act0.y, act1.x, act1.y};
+  const float u[4] = {nz0.uf_bid, nz0.uf_ask, nz1.uf_bid, nz1.uf_ask};
+  float depth[4];
+  bool fill[4], near[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    depth[k] = depth_of(a[k], k & 1, norm_act, P);
+    const FillTest t = fill_test(u[k], depth[k], P);
+    fill[k] = t.fill;
+    near[k] = t.near;
+  }
+  if (__builtin_expect(near[0] | near[1] | near[2] | near[3], 0)) refine_fills_f64(u, a, norm_act, P, fill, near);
+
+  const LaneResult r0 = step_lane<V>(core0, lam0, act0, depth[0], depth[1], fill[0], fill[1], nz0, L.qi.x, P);
+  const LaneResult r1 = step_lane<V>(core1, lam1, act1, depth[2], depth[3], fill[2], fill[3], nz1, L.qi.y, P);
+
+  float4* dst = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
+  if (V::ARR == kArrHawkes) {
+    dst[0] = r0.core;
+    dst[1] = make_float4(r0.lam.x, r0.lam.y, r1.core.x, r1.core.y);
+    dst[2] = make_float4(r1.core.z, r1.core.w, r1.lam.x, r1.lam.y);
+  } else {
+    dst[0] = r0.core;
+    dst[1] = r1.core;
+  }
+  reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
+
+  const bool second = lane0 + 1 < P.n;  // the pad lane of an odd shard is computed but never reported
+
+  // -- optional outputs (wave-uniform branches)
+  if (V::NORM && B.obs != nullptr) {
+    write_obs_row(B.obs, lane0, V::DIM, r0.core, r0.lam, P);
+    write_obs_row(B.obs, lane0 + 1, V::DIM, r1.core, r1.lam, P);
+  }
+  if (B.events != nullptr) {
+    reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
+  }
+  if (B.lane_returns != nullptr) {
+    float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
+    acc.x += r0.reward;
+    acc.y += r1.reward;
+    reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
+  }
+  const uint32_t clipped = ((r0.events >> 6) != 0u ? 1u : 0u) + ((second && (r1.events >> 6) != 0u) ? 1u : 0u);
+  if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+  return r0.reward + (second ? r1.reward : 0.0f);
+}
+
+template <class V>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
   const uint32_t pair = blockIdx.x * kBlockThreads + threadIdx.x;
   float r_sum = 0.0f;
   if (pair < P.n_pairs) {
-    const uint32_t lane0 = 2u * pair;
-    constexpr int kVecPerPair = (ARR == kArrHawkes) ? 3 : 2;  // float4 per pair of rows
-    const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(pair) * kVecPerPair;
-    const float4 v0 = src[0], v1 = src[1];
-    float4 core0 = v0, core1 = v1;
-    float2 lam0 = make_float2(0.f, 0.f), lam1 = lam0;
-    if (ARR == kArrHawkes) {  // rows of 6: [c q t S | lb la c q | t S lb la]
-      const float4 v2 = src[2];
-      lam0 = make_float2(v1.x, v1.y);
-      core1 = make_float4(v1.z, v1.w, v2.x, v2.y);
-      lam1 = make_float2(v2.z, v2.w);
-    }
-    float4 act0, act1;
-    if (DYN == kDynLimit) {
-      const float4 a = reinterpret_cast<const float4*>(B.action)[pair];
-      act0 = make_float4(a.x, a.y, 0.f, 0.f);
-      act1 = make_float4(a.z, a.w, 0.f, 0.f);
-    } else {
-      act0 = reinterpret_cast<const float4*>(B.action)[lane0];
-      act1 = reinterpret_cast<const float4*>(B.action)[lane0 + 1];
-    }
+    PairLoads<V> L = load_pair<V>(B, P, pair);  // issue every load ...
     LaneNoise nz0, nz1;
-    if (INJECT) {
-      const float4 ua = reinterpret_cast<const float4*>(B.u_arr)[pair];
-      const float4 uf = reinterpret_cast<const float4*>(B.u_fill)[pair];
-      const float2 zz = reinterpret_cast<const float2*>(B.z)[pair];
-      nz0 = LaneNoise{ua.x, ua.y, uf.x, uf.y, zz.x};
-      nz1 = LaneNoise{ua.z, ua.w, uf.z, uf.w, zz.y};
+    if (V::INJECT) {
+      nz0 = LaneNoise{L.ua.x, L.ua.y, L.uf.x, L.uf.y, L.zz.x};
+      nz1 = LaneNoise{L.ua.z, L.ua.w, L.uf.z, L.uf.w, L.zz.y};
     } else {
-      philox_pair_noise(P.pair_offset + pair, P.philox_step, P.key0, P.key1, nz0, nz1);
+      philox_pair_noise(P.pair_offset + pair, P.philox_step, P.key0, P.key1, nz0, nz1);  // ... draw while they fly
+      tie_loads_to_noise<V>(L, nz0, nz1);
     }
-    float qi0 = P.q_init_scalar, qi1 = P.q_init_scalar;
-    if (B.q_init != nullptr) {
-      const float2 qi = reinterpret_cast<const float2*>(B.q_init)[pair];
-      qi0 = qi.x;
-      qi1 = qi.y;
-    }
-
-    const LaneResult r0 = step_lane<MID, ARR, DYN>(core0, lam0, act0.x, act0.y, act0.z, act0.w, nz0, qi0, P);
-    const LaneResult r1 = step_lane<MID, ARR, DYN>(core1, lam1, act1.x, act1.y, act1.z, act1.w, nz1, qi1, P);
-
-    float4* dst = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(pair) * kVecPerPair;
-    if (ARR == kArrHawkes) {
-      dst[0] = r0.core;
-      dst[1] = make_float4(r0.lam.x, r0.lam.y, r1.core.x, r1.core.y);
-      dst[2] = make_float4(r1.core.z, r1.core.w, r1.lam.x, r1.lam.y);
-    } else {
-      dst[0] = r0.core;
-      dst[1] = r1.core;
-    }
-    reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
-
-    const bool second = lane0 + 1 < P.n;  // the pad lane of an odd shard is computed but never reported
-    r_sum = r0.reward + (second ? r1.reward : 0.0f);
-
-    // -- optional outputs (wave-uniform branches)
-    if (B.obs != nullptr) {
-      constexpr int dim = (ARR == kArrHawkes) ? 6 : 4;
-      write_obs_row(B.obs, lane0, dim, r0.core, r0.lam, P);
-      write_obs_row(B.obs, lane0 + 1, dim, r1.core, r1.lam, P);
-    }
-    if (B.events != nullptr) {
-      reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
-    }
-    if (B.lane_returns != nullptr) {
-      float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
-      acc.x += r0.reward;
-      acc.y += r1.reward;
-      reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
-    }
-    const uint32_t clipped = ((r0.events >> 6) != 0u ? 1u : 0u) + ((second && (r1.events >> 6) != 0u) ? 1u : 0u);
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+    r_sum = finish_pair<V>(B, P, pair, L, nz0, nz1);
   }
-  // -- per-wave running sum of rewards: the numerator of the mean episode return
+  // -- per-wave running sum of rewards (numerator of the mean episode return): one slot per wave, one
+  //    fire-and-forget hardware fp64 atomic per wave, no contention
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
-    B.wave_sums[wave] += static_cast<double>(total);
+    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
   }
 }
 

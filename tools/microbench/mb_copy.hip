@@ -1,0 +1,100 @@
+// Memory-floor experiments for the step's access pattern (GPU box only): block size, lane->row mapping,
+// non-temporal hints.  Every kernel moves 44 B per trajectory: 16 B state in, 8 B action in, 16 B state out, 4 B reward.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// pair per thread, adjacent rows (the production mapping)
+template <int BLOCK, bool NT>
+__global__ __launch_bounds__(BLOCK) void copy_pair(const float4* s_in, float4* s_out, const float4* act, float2* rew, uint32_t n_pairs) {
+  const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n_pairs) return;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v4 a, b, c;
+  const v4* in = reinterpret_cast<const v4*>(s_in);
+  v4* out = reinterpret_cast<v4*>(s_out);
+  if (NT) { a = __builtin_nontemporal_load(&in[2 * p]); b = __builtin_nontemporal_load(&in[2 * p + 1]); c = __builtin_nontemporal_load(reinterpret_cast<const v4*>(act) + p); }
+  else { a = in[2 * p]; b = in[2 * p + 1]; c = reinterpret_cast<const v4*>(act)[p]; }
+  a.x += c.x; b.x += c.z;
+  v2 r = {c.y, c.w};
+  if (NT) { __builtin_nontemporal_store(a, &out[2 * p]); __builtin_nontemporal_store(b, &out[2 * p + 1]); __builtin_nontemporal_store(r, reinterpret_cast<v2*>(rew) + p); }
+  else { out[2 * p] = a; out[2 * p + 1] = b; reinterpret_cast<v2*>(rew)[p] = r; }
+}
+
+// one row per thread: perfectly coalesced 16 B / lane
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void copy_row(const float4* s_in, float4* s_out, const float2* act, float* rew, uint32_t n) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 a = s_in[i];
+  const float2 c = act[i];
+  a.x += c.x;
+  s_out[i] = a;
+  rew[i] = c.y;
+}
+
+// pair per thread, rows t and t + BLOCK of the block's 2*BLOCK-row tile: every instruction is fully coalesced
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void copy_split(const float4* s_in, float4* s_out, const float2* act, float* rew, uint32_t n) {
+  const uint32_t i = blockIdx.x * (2 * BLOCK) + threadIdx.x;
+  if (i + BLOCK >= n) return;
+  float4 a = s_in[i], b = s_in[i + BLOCK];
+  const float2 c = act[i], d = act[i + BLOCK];
+  a.x += c.x; b.x += d.x;
+  s_out[i] = a; s_out[i + BLOCK] = b;
+  rew[i] = c.y; rew[i + BLOCK] = d.y;
+}
+
+__global__ void empty_kernel(uint32_t n) {}
+
+template <typename F>
+float time_it(F launch, int iters) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 20; ++i) launch(i);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) launch(i);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+  const uint32_t n = argc > 1 ? (1u << atoi(argv[1])) : (1u << 20);
+  const uint32_t n_pairs = n / 2;
+  float *s0, *s1, *act, *rew;
+  CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
+  CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(s1, 0, n * 16)); CK(hipMemset(act, 0, n * 8));
+  float* st[2] = {s0, s1};
+  const int iters = 500;
+  const double bytes = 44.0 * n;
+  float t;
+#define REPORT(LABEL) printf("%-34s %8.2f us  %7.0f GB/s\n", LABEL, t, bytes / t * 1e-3)
+  t = time_it([&](int i) { hipLaunchKernelGGL(empty_kernel, dim3(2048), dim3(256), 0, 0, n); }, iters);
+  printf("%-34s %8.2f us\n", "empty 2048x256", t);
+  t = time_it([&](int i) { hipLaunchKernelGGL(empty_kernel, dim3(512), dim3(1024), 0, 0, n); }, iters);
+  printf("%-34s %8.2f us\n", "empty 512x1024", t);
+#define PAIR(BLOCK, NT, LABEL) \
+  t = time_it([&](int i) { hipLaunchKernelGGL((copy_pair<BLOCK, NT>), dim3((n_pairs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float4*)act, (float2*)rew, n_pairs); }, iters); REPORT(LABEL);
+  PAIR(64, false, "pair/thread block 64")
+  PAIR(128, false, "pair/thread block 128")
+  PAIR(256, false, "pair/thread block 256")
+  PAIR(512, false, "pair/thread block 512")
+  PAIR(1024, false, "pair/thread block 1024")
+  PAIR(256, true, "pair/thread block 256 nontemporal")
+#define ROW(BLOCK, LABEL) \
+  t = time_it([&](int i) { hipLaunchKernelGGL((copy_row<BLOCK>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float2*)act, rew, n); }, iters); REPORT(LABEL);
+  ROW(256, "row/thread block 256")
+  ROW(512, "row/thread block 512")
+  ROW(1024, "row/thread block 1024")
+#define SPLIT(BLOCK, LABEL) \
+  t = time_it([&](int i) { hipLaunchKernelGGL((copy_split<BLOCK>), dim3((n + 2 * BLOCK - 1) / (2 * BLOCK)), dim3(BLOCK), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float2*)act, rew, n); }, iters); REPORT(LABEL);
+  SPLIT(256, "2 rows/thread coalesced block 256")
+  SPLIT(512, "2 rows/thread coalesced block 512")
+  return 0;
+}

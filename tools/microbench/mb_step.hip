@@ -1,0 +1,86 @@
+// Micro-benchmarks behind the kernel design decisions in DESIGN.md (GPU box only):
+//   copy44      - a kernel that moves exactly the step's algorithmic traffic (2 float4 + 1 float4 in, 2 float4 +
+//                 float2 out per pair) and does nothing else: the memory floor for this access pattern
+//   philox3     - the three Philox blocks + Box-Muller of a pair with no memory traffic: the RNG floor
+//   step(philox)- the production kernel;  step(inject) - the same arithmetic with noise loaded from HBM
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../../mbt_gym_amd/csrc/step_kernel.hpp"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ __launch_bounds__(mbt::kBlockThreads) void copy44(const float4* s_in, float4* s_out, const float4* act, float2* rew, uint32_t n_pairs) {
+  const uint32_t p = blockIdx.x * mbt::kBlockThreads + threadIdx.x;
+  if (p >= n_pairs) return;
+  const float4 a = s_in[2 * p], b = s_in[2 * p + 1], c = act[p];
+  s_out[2 * p] = make_float4(a.x + c.x, a.y, a.z, a.w);
+  s_out[2 * p + 1] = make_float4(b.x + c.z, b.y, b.z, b.w);
+  rew[p] = make_float2(c.y, c.w);
+}
+
+__global__ __launch_bounds__(mbt::kBlockThreads) void philox3(float* sink, uint32_t n_pairs, uint32_t step, uint32_t k0, uint32_t k1) {
+  const uint32_t p = blockIdx.x * mbt::kBlockThreads + threadIdx.x;
+  mbt::LaneNoise a, b;
+  mbt::philox_pair_noise(p, step, k0, k1, a, b);
+  const float s = a.ua_bid + a.ua_ask + a.uf_bid + a.uf_ask + a.z + b.ua_bid + b.ua_ask + b.uf_bid + b.uf_ask + b.z;
+  if (s == 12345.678f) sink[p] = s;  // never true: keeps the work alive without a store
+}
+
+template <typename F>
+float time_it(F launch, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 20; ++i) launch(i);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) launch(i);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+  const uint32_t n = argc > 1 ? (1u << atoi(argv[1])) : (1u << 20);
+  const uint32_t n_pairs = n / 2, blocks = (n_pairs + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
+  float *s0, *s1, *act, *rew, *ua, *uf, *z; double* ws; unsigned long long* clip;
+  CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
+  CK(hipMalloc(&ua, n * 8)); CK(hipMalloc(&uf, n * 8)); CK(hipMalloc(&z, n * 4));
+  CK(hipMalloc(&ws, blocks * 4 * 8)); CK(hipMalloc(&clip, 8));
+  CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(act, 0, n * 8)); CK(hipMemset(ws, 0, blocks * 32)); CK(hipMemset(clip, 0, 8));
+  CK(hipMemset(ua, 0, n * 8)); CK(hipMemset(uf, 0, n * 8)); CK(hipMemset(z, 0, n * 4));
+  std::vector<float> h(n * 4);
+  for (uint32_t i = 0; i < n; ++i) { h[4 * i] = 0; h[4 * i + 1] = 0; h[4 * i + 2] = 0; h[4 * i + 3] = 100.f; }
+  CK(hipMemcpy(s0, h.data(), n * 16, hipMemcpyHostToDevice));
+  std::vector<float> ha(n * 2, 0.7f);
+  CK(hipMemcpy(act, ha.data(), n * 8, hipMemcpyHostToDevice));
+
+  mbt::StepParams P{};
+  P.n = n; P.n_pairs = n_pairs; P.key0 = 50; P.dt = 1e-3f; P.vol_sqrt_dt = 2.f * sqrtf(1e-3f);
+  P.arr_thr_bid = P.arr_thr_ask = 0.14f; P.dt_f64 = 1e-3; P.kappa = 1.5f; P.kappa_f64 = 1.5; P.q_max = 1000.f; P.c_max = 1e8f;
+  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f;
+  mbt::StepBuffers B{};
+  B.action = act; B.reward = rew; B.u_arr = ua; B.u_fill = uf; B.z = z; B.wave_sums = ws; B.clip_count = clip;
+  float* st[2] = {s0, s1};
+  const int iters = 500;
+  const double bytes = 44.0 * n;
+
+  float t = time_it([&](int i) { hipLaunchKernelGGL(copy44, dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float4*)act, (float2*)rew, n_pairs); }, iters);
+  printf("copy44        %8.2f us  %7.0f GB/s\n", t, bytes / t * 1e-3);
+  t = time_it([&](int i) { hipLaunchKernelGGL(philox3, dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, rew, n_pairs, (uint32_t)i, 50u, 0u); }, iters);
+  printf("philox3       %8.2f us\n", t);
+#define RUN(VARIANT, LABEL, BYTES)                                                                                  \
+  t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
+                           hipLaunchKernelGGL((mbt::step_kernel<VARIANT>), dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
+  printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, BYTES * n / t * 1e-3);
+  using AS = mbt::Variant<0, 0, 0, 0, false, false>;
+  using ASI = mbt::Variant<0, 0, 0, 0, false, true>;
+  using CJ = mbt::Variant<0, 0, 0, 2, false, false>;
+  RUN(AS, "step AS philox (44 B)", 44.0)
+  RUN(CJ, "step CjMm philox (44 B)", 44.0)
+  RUN(ASI, "step AS inject (64 B)", 64.0)
+  return 0;
+}
