@@ -1,0 +1,81 @@
+"""The C-ABI shared library: builds for gfx950, loads, exports every symbol include/mbt_env.h declares, agrees
+with the ctypes binding on the config struct, and refuses to run without a gfx950 device.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from mbt_gym_amd import _native
+from mbt_gym_amd.build import LIB_PATH, build_native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mbt_env.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_native()
+    return _native.load_library()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds():
+    assert set(declared_functions()) == set(_native.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = C.CDLL(LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(raw, name), f"{name} is declared in include/mbt_env.h but not exported"
+    assert lib.mbt_abi_version() == _native.ABI_VERSION
+
+
+def test_config_struct_layout_matches_a_c_compiler(lib, tmp_path):
+    """sizeof/offsetof from gcc on the header == ctypes binding == the hipcc-built library."""
+    src = tmp_path / "layout.c"
+    fields = ["abi_version", "num_trajectories", "n_steps", "terminal_time", "midprice_kind", "noise_mode", "drift",
+              "intensity", "fill_exponent", "inventory_exponent", "initial_inventory", "reward_scale", "seed",
+              "normalise_observation", "obs_lo", "act_hi"]
+    body = "\n".join(f'  printf("{f} %zu\\n", offsetof(mbt_config, {f}));' for f in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(void) {{\n'
+                   f'  printf("sizeof %zu\\n", sizeof(mbt_config));\n{body}\n  return 0; }}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out.pop("sizeof")) == C.sizeof(_native.MbtConfig) == lib.mbt_config_sizeof()
+    for name, offset in out.items():
+        assert getattr(_native.MbtConfig, name).offset == int(offset), name
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "c89.c"
+    src.write_text(f'#include "{HEADER}"\nint main(void) {{ return (int)MBT_ABI_VERSION - 1; }}\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-c", str(src), "-o", str(tmp_path / "c89.o")], check=True)
+
+
+def test_no_cpu_fallback_without_a_device(lib):
+    if lib.mbt_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    cfg = _native.MbtConfig()
+    cfg.abi_version = _native.ABI_VERSION
+    cfg.num_trajectories, cfg.n_steps, cfg.terminal_time = 4, 10, 1.0
+    handle = C.c_void_p()
+    rc = lib.mbt_env_create(C.byref(cfg), C.byref(handle))
+    assert rc == -2 and not handle.value  # MBT_ERR_NO_DEVICE
+    assert b"no CPU path" in lib.mbt_last_error()
+    with pytest.raises(_native.NativeError):
+        _native.philox4x32_10([0, 0, 0, 0], [0, 0])
+
+
+def test_abi_version_mismatch_is_rejected(lib):
+    cfg = _native.MbtConfig()
+    cfg.abi_version = 999
+    handle = C.c_void_p()
+    assert lib.mbt_env_create(C.byref(cfg), C.byref(handle)) == -5  # MBT_ERR_ABI

@@ -1,0 +1,178 @@
+"""Host-side logic of the Python layer, without a GPU: spaces and bounds, column registry, seeding protocol,
+start-time quantisation, initial-inventory protocol, the mbt_config the kernel will receive, the SB3 adapter's
+auto-reset semantics, and the refusal to run unsupported plugins on the CPU.
+
+The device handle is replaced by a stub (`_create_handle` / `_reset_device`), so no numerics are exercised here;
+expected values come from the golden fixtures (= the reference's own bounds and draws)."""
+import numpy as np
+import pytest
+
+from mbt_gym_amd import _native
+from mbt_gym_amd.gym import TradingEnvironment as te_module
+from mbt_gym_amd.gym.StableBaselinesTradingEnvironment import StableBaselinesTradingEnvironment
+from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment, UnsupportedOnDevice
+from mbt_gym_amd.stochastic_processes.StochasticProcessModel import DeviceResidentError, StochasticProcessModel
+from tests.env_factory import make_env
+from tests.golden_io import CASES, load_case
+
+
+@pytest.fixture()
+def no_device(monkeypatch):
+    resets = []
+    monkeypatch.setattr(TradingEnvironment, "_create_handle", lambda self, n, scale, offset=None: None)
+
+    def fake_reset(self, obs_out=None):
+        resets.append((self._get_start_time(), self._get_initial_inventories()))
+
+    monkeypatch.setattr(TradingEnvironment, "_reset_device", fake_reset)
+    monkeypatch.setattr(TradingEnvironment, "close", lambda self: None)
+    return resets
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_spaces_bounds_and_columns_match_the_reference(name, no_device):
+    cfg, g = load_case(name)
+    env = make_env(cfg)
+    np.testing.assert_array_equal(env.original_observation_space.low, g["obs_lo"])
+    np.testing.assert_array_equal(env.original_observation_space.high, g["obs_hi"])
+    np.testing.assert_array_equal(env.original_action_space.low, g["act_lo"])
+    np.testing.assert_array_equal(env.original_action_space.high, g["act_hi"])
+    assert env.max_cash == float(g["max_cash"])
+    assert env.original_observation_space.low.dtype == np.float32
+    np.testing.assert_array_equal(np.array(list(env.stochastic_process_indices.values())), g["process_indices"])
+    if cfg.normalise_observation_space:
+        assert np.all(env.observation_space.low == -1) and np.all(env.observation_space.high == 1)
+    assert env.observation_space.shape == (g["obs"].shape[2],)
+    assert env.action_space.shape == (g["actions"].shape[2],)
+
+
+@pytest.mark.parametrize("name", ["cjp_running", "cjp_cjmm"])
+def test_random_initial_inventories_follow_the_reference_protocol(name, no_device):
+    """tuple (a, b) -> default_rng(seed).integers(a, b, N); one draw in the constructor, one per reset (TE:72-74,
+    TE:271-272).  The fixture holds what the reference drew at its first reset."""
+    cfg, g = load_case(name)
+    env = make_env(cfg)
+    env._reset_device()
+    start, q0 = no_device[-1]
+    np.testing.assert_array_equal(q0, g["q0"].astype(np.float32))
+    assert start == float(g["t0"])
+
+
+def test_seeding_protocol(no_device):
+    cfg, _ = load_case("as_limit_pnl")
+    env = make_env(cfg)  # seed 50
+    md = env.model_dynamics
+    assert (md.midprice_model.seed_, md.arrival_model.seed_, md.fill_probability_model.seed_) == (51, 52, 53)  # TE:345-348
+    assert env._philox_key == 50
+    cfg.seed = 0  # `if seed:` (TE:70): zero behaves like None - processes stay unseeded, key from entropy
+    env0 = make_env(cfg)
+    assert env0.model_dynamics.midprice_model.seed_ is None
+    assert env0._philox_key != make_env(cfg)._philox_key
+
+
+def test_start_time_is_quantised_to_a_step(no_device):
+    cfg, _ = load_case("as_limit_pnl")
+    env = make_env(cfg, start_time=0.3333)
+    assert env._get_start_time() == pytest.approx(round(0.3333 * 200) / 200)
+    env.start_time = lambda: 0.5
+    assert env._get_start_time() == 0.5
+    env.start_time = 1.0
+    with pytest.raises(AssertionError):
+        env._get_start_time()
+
+
+def test_device_config_carries_every_plugin_parameter(no_device):
+    cfg, _ = load_case("limit_and_market")
+    c = make_env(cfg)._device_config(cfg.num_trajectories, 1.0)
+    assert (c.midprice_kind, c.arrival_kind, c.dynamics_kind, c.reward_kind) == (
+        _native.MID_BROWNIAN, _native.ARR_POISSON, _native.DYN_LIMIT_AND_MARKET, _native.REW_RUNNING_PENALTY)
+    assert (c.volatility, c.initial_price, c.fill_exponent, c.market_half_spread) == (2.0, 100.0, 1.5, 0.5)
+    assert tuple(c.intensity) == (100.0, 100.0) and (c.phi, c.alpha, c.inventory_exponent) == (0.01, 0.5, 2.0)
+    assert (c.max_inventory, c.initial_inventory, c.n_steps, c.num_trajectories) == (12, 10, 120, 40)
+    assert c.seed == 11 and c.noise_mode == _native.NOISE_PHILOX and not c.normalise_action
+    cfg, _ = load_case("hawkes_ou")
+    c = make_env(cfg, noise="injected")._device_config(8, 1.0, trajectory_offset=16)
+    assert (c.midprice_kind, c.arrival_kind, c.noise_mode) == (_native.MID_OU, _native.ARR_HAWKES, _native.NOISE_INJECTED)
+    assert (c.ou_level, c.ou_speed, c.hawkes_jump, c.hawkes_speed) == (100.0, 0.02, 40.0, 60.0)
+    assert c.trajectory_offset == 16 and c.num_trajectories == 8
+
+
+def test_unsupported_plugins_raise_instead_of_falling_back(no_device):
+    class GeometricBrownianMotionMidpriceModel(StochasticProcessModel):
+        def __init__(self):
+            one = np.array([[100.0]])
+            super().__init__(one, one, 0.01, 1.0, one)
+
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+
+    md = LimitOrderModelDynamics(midprice_model=GeometricBrownianMotionMidpriceModel(), arrival_model=PoissonArrivalModel(),
+                                 fill_probability_model=ExponentialFillFunction())
+    env = TradingEnvironment(model_dynamics=md)
+    with pytest.raises(UnsupportedOnDevice):
+        env._device_config(1, 1.0)
+    with pytest.raises(DeviceResidentError):
+        md.arrival_model.get_arrivals()
+    with pytest.raises(DeviceResidentError):
+        md.midprice_model.update(None, None, None)
+    with pytest.raises(AssertionError):  # MD:79-80
+        LimitOrderModelDynamics(midprice_model=GeometricBrownianMotionMidpriceModel())
+
+
+def test_environment_creation_needs_the_hip_device():
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_native.NativeError):
+        TradingEnvironment(num_trajectories=4)
+
+
+class _ScriptedEnv:
+    """Stands in for a TradingEnvironment: 3-step episodes, observations tagged by (episode, step)."""
+
+    def __init__(self, n=3):
+        from mbt_gym_amd.spaces import Box
+
+        self.num_trajectories, self.n_steps = n, 3
+        self.observation_space = Box(low=-np.ones(4, np.float32), high=np.ones(4, np.float32))
+        self.action_space = Box(low=-np.ones(2, np.float32), high=np.ones(2, np.float32))
+        self.episode, self.k, self.infos = 0, 0, [{} for _ in range(n)]
+
+    def reset(self):
+        self.episode, self.k = self.episode + 1, 0
+        return np.full((self.num_trajectories, 4), 100.0 * self.episode, np.float32)
+
+    def step(self, action):
+        self.k += 1
+        obs = np.full((self.num_trajectories, 4), 100.0 * self.episode + self.k, np.float32)
+        done = self.k == self.n_steps
+        return obs, np.full(self.num_trajectories, float(self.k), np.float32), np.full(self.num_trajectories, done), self.infos
+
+    def seed(self, seed=None):
+        self.seeded = seed
+
+    def close(self):
+        pass
+
+
+def test_sb3_adapter_auto_reset_and_terminal_observation():
+    """SBE:28-37: on the terminal step return the RESET observation, keep the terminal step's rewards/dones and put
+    each lane's last observation in infos[i]['terminal_observation']."""
+    inner = _ScriptedEnv()
+    venv = StableBaselinesTradingEnvironment(inner)
+    assert venv.num_envs == 3 and venv.num_trajectories == 3 and venv.n_steps == 3
+    first = venv.reset()
+    assert first[0, 0] == 100.0
+    act = np.zeros((3, 2), np.float32)
+    for k in (1, 2):
+        venv.step_async(act)
+        obs, rew, dones, infos = venv.step_wait()
+        assert obs[0, 0] == 100.0 + k and not dones.any() and "terminal_observation" not in infos[0]
+    venv.step_async(act)
+    obs, rew, dones, infos = venv.step_wait()
+    assert dones.all() and rew[0] == 3.0
+    assert obs[0, 0] == 200.0  # observation of the automatic reset
+    assert all(info["terminal_observation"][0] == 103.0 for info in infos)
+    assert venv.env_is_wrapped(object) == [False, False, False]
+    venv.seed(7)
+    assert inner.seeded == 7
