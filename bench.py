@@ -70,14 +70,28 @@ def build_env(n, rank, device):
     )
 
 
-def run_steps(env, k):
-    """k env.step() launches, restarting the episode when it ends.  Returns the number of finished episodes."""
-    finished = 0
+def run_steps(env, k, device, returns):
+    """k env.step() launches.  When an episode ends: all-reduce its [sum R, sum R^2, count] across ranks (the only
+    collective on the path, 3 doubles over RCCL) and restart it (reset kernel), like a VecEnv consumer would."""
+    from mbt_gym_amd.distributed import allreduce_return_sums
+
     for _ in range(k):
         if env.step_device():
-            finished += 1
+            returns.append(allreduce_return_sums(env.episode_return_sums(), device=device))
             env._reset_device()
-    return finished
+
+
+def pmc_traffic(n):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/r01_pmc_summary.json, produced by tools/pmc_summary.py for this workload at 2^20 lanes); None for
+    other sizes.  Counters cannot be read from inside the benchmark process, so this is the profiled value."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if n != LANES_PER_GPU or not os.path.exists(path):
+        return None
+    for name, row in json.load(open(path)).items():
+        if "Variant<0, 0, 0, 0, false, false>" in name:
+            return row["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(budget_s=12.0):
@@ -128,6 +142,9 @@ def main():
     torch.cuda.set_device(local_rank)
 
     n = args.lanes
+    from mbt_gym_amd.distributed import shard_bounds
+    offset, count = shard_bounds(n * world, rank, world)
+    assert count == n and offset == rank * n
     env = build_env(n, rank, local_rank)
     env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
     env.reset()
@@ -138,7 +155,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    run_steps(env, args.warmup)
+    from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics
+
+    device = torch.device("cuda", local_rank)
+    episode_returns = []
+    run_steps(env, args.warmup, device, episode_returns)
     barrier()
     from mbt_gym_amd import _native
     import ctypes as C
@@ -146,7 +167,9 @@ def main():
     lib = _native.load_library()
     _native.check(lib.mbt_env_timer_begin(env._handle))
     t0 = time.perf_counter()
-    episodes = run_steps(env, args.steps)
+    episode_returns.clear()
+    run_steps(env, args.steps, device, episode_returns)
+    episodes = len(episode_returns)
     ms = C.c_float(0)
     _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))  # HIP events on the kernel's stream
     env.synchronize()
@@ -160,12 +183,8 @@ def main():
     else:
         event_s = ms.value / 1e3
 
-    # episode-return mean across all shards: the only collective on this path (3 doubles over RCCL)
-    sums = env.episode_return_sums()
-    if dist is not None:
-        st = torch.tensor([sums[0], 0.0, sums[2]], dtype=torch.float64, device="cuda")
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        sums = st.cpu().numpy()
+    # mean return of the last finished episode over ALL shards (or of the partial episode if none finished)
+    sums = episode_returns[-1] if episode_returns else allreduce_return_sums(env.episode_return_sums(), device=device)
 
     if rank == 0:
         total_lanes = n * world
@@ -186,11 +205,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "bytes_per_env_step": BYTES_PER_ENV_STEP, "avg_launch_us": launch_us,
+                "traffic": pmc_traffic(n), "bytes_per_env_step": BYTES_PER_ENV_STEP, "avg_launch_us": launch_us,
                 "note": "algorithmic bytes (44 B/env-step x lanes per launch) / mean launch-to-launch time from HIP "
                         "events on the kernel's stream; at 2^20 lanes the 44 MB working set is Infinity-Cache resident",
             },
-            "mean_episode_return_so_far": float(sums[0] / sums[2]),
+            "mean_episode_return": return_statistics(sums)[0],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

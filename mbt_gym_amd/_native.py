@@ -96,6 +96,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two copies of the HIP
+    runtime in one process cannot share the GPU ("No HIP GPUs are available" in whichever initialises second), so
+    when torch is installed its copy is loaded first and libmbtenv.so binds to it - regardless of import order.
+    torch itself is not imported."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(bundled):
+        return None
+    return C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """dlopen libmbtenv.so and bind every symbol of the header.  Raises if the extension is not built."""
     global _lib
@@ -106,6 +125,7 @@ def load_library():
             f"{LIB_PATH} is missing: build the HIP extension first (python -m mbt_gym_amd.build). "
             "mbt_gym_amd has no CPU fallback."
         )
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

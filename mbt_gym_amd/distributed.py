@@ -1,0 +1,47 @@
+"""Sharding of the trajectory axis over the GPUs of one node, and the only collective on the path.
+
+Trajectories are independent (no operation of the step mixes lanes; the reference's only cross-lane reads are the
+lane-invariant time and done flag, TradingEnvironment.py:218-220), so each rank owns a contiguous range of GLOBAL
+lane ids and steps it with no communication at all.  Noise is a function of the global lane id, so results do
+not depend on the number of ranks.  What a run reports - the mean (and spread) of the episode return - needs three
+doubles per rank, [sum R, sum R^2, count]: ONE all-reduce over RCCL/xGMI per episode, 24 bytes, latency bound
+(never inside the step loop).  `torch.distributed` is the transport (backend "nccl" = RCCL on ROCm, "gloo" on CPU).
+"""
+from typing import Tuple
+
+import numpy as np
+
+
+def shard_bounds(total_lanes: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """(offset, count) of rank's contiguous lane range.  Offsets are even because noise is drawn per pair of lanes."""
+    assert 0 <= rank < world_size
+    per = -(-total_lanes // world_size)
+    per += per & 1
+    offset = min(rank * per, total_lanes)
+    return offset, max(0, min(per, total_lanes - offset))
+
+
+def allreduce_return_sums(sums, device=None) -> np.ndarray:
+    """Sum the per-rank [sum R, sum R^2, count] over the default process group (no-op without one)."""
+    import torch
+    import torch.distributed as dist
+
+    local = np.asarray(sums, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    t = torch.tensor(np.nan_to_num(local, nan=0.0), dtype=torch.float64, device=device or "cpu")
+    flag = torch.tensor([float(np.isnan(local[1]))], dtype=torch.float64, device=t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    out = t.cpu().numpy()
+    if flag.item() > 0:  # some rank did not track per-lane returns: the second moment is unknown
+        out[1] = np.nan
+    return out
+
+
+def return_statistics(sums) -> Tuple[float, float]:
+    """(mean, population std) of the episode return from [sum R, sum R^2, count] (plotting.py:104-105)."""
+    total, total_sq, count = (float(x) for x in sums)
+    mean = total / count
+    var = total_sq / count - mean * mean
+    return mean, float(np.sqrt(max(var, 0.0))) if not np.isnan(var) else float("nan")

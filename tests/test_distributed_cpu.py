@@ -1,0 +1,82 @@
+"""The multi-GPU path, on CPU: two `gloo` ranks shard the trajectory axis, each steps its shard (here with the
+oracle standing in for the kernel, drawing the same Philox stream keyed on GLOBAL lane ids), and the three-double
+all-reduce reproduces the single-rank statistics exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics, shard_bounds
+from oracle.mbt_oracle import OracleConfig, OracleEnv
+from oracle.philox_ref import PhiloxNoise
+
+N, STEPS, SEED = 1000, 12, 31
+
+
+def _cfg(n):
+    return OracleConfig(num_trajectories=n, n_steps=50, midprice="bm", arrival="poisson", intensity=(140.0, 140.0),
+                        max_inventory=50, seed=SEED, normalise_action_space=False, normalise_observation_space=False)
+
+
+def _returns(offset, count):
+    env = OracleEnv(_cfg(count), PhiloxNoise(SEED, offset))
+    env.reset()
+    action = np.tile(np.array([[0.7, 0.7]]), (count, 1))
+    total = np.zeros(count)
+    for _ in range(STEPS):
+        _, r, _ = env.step(action)
+        total += r
+    return total
+
+
+def test_shard_bounds_cover_the_axis_with_even_offsets():
+    for total, world in [(1000, 2), (1 << 24, 8), (7, 4), (1 << 20, 1), (1001, 3)]:
+        spans = [shard_bounds(total, r, world) for r in range(world)]
+        assert all(off % 2 == 0 for off, _ in spans)
+        assert sum(c for _, c in spans) == total
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1) if spans[i + 1][1] > 0)
+
+
+def _worker(rank, world, port, queue):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    offset, count = shard_bounds(N, rank, world)
+    r = _returns(offset, count)
+    sums = allreduce_return_sums(np.array([r.sum(), (r * r).sum(), count]))
+    queue.put((rank, sums.tolist(), r.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allreduce_matches_single_rank():
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(rank, 2, port, queue)) for rank in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(queue.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = _returns(0, N)
+    np.testing.assert_array_equal(np.concatenate([np.array(g[2]) for g in got]), whole)  # shard-invariant lanes
+    want = np.array([whole.sum(), (whole * whole).sum(), N])
+    for _, sums, _ in got:
+        np.testing.assert_allclose(sums, want, rtol=1e-12)
+    mean, std = return_statistics(got[0][1])
+    assert mean == pytest.approx(whole.mean()) and std == pytest.approx(whole.std())
+
+
+def test_allreduce_without_a_process_group_is_identity():
+    sums = np.array([3.0, np.nan, 2.0])
+    out = allreduce_return_sums(sums)
+    assert out[0] == 3.0 and np.isnan(out[1]) and out[2] == 2.0

@@ -1,0 +1,39 @@
+"""The device-resident interface: torch wraps the library's buffers without a copy (__cuda_array_interface__),
+an on-GPU policy writes actions in place, the environment runs on torch's stream."""
+import numpy as np
+import pytest
+
+from tests.env_factory import make_env
+from tests.golden_io import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_torch_wraps_device_buffers_without_copies():
+    torch = pytest.importorskip("torch")
+    cfg, _ = load_case("as_limit_pnl")
+    cfg.num_trajectories, cfg.seed = 2048, 77
+    env = make_env(cfg)
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    host_obs = env.reset()
+    obs = torch.as_tensor(env.obs_device, device="cuda")
+    assert obs.data_ptr() == env.obs_device.ptr and obs.shape == (2048, 4) and obs.dtype == torch.float32
+    np.testing.assert_array_equal(obs.cpu().numpy(), host_obs)
+    act = torch.as_tensor(env.action_device, device="cuda")
+    act[:, 0] = 0.5
+    act[:, 1] = 0.9  # an "on-GPU policy" writing its action in place, ordered before the step on the same stream
+    env.step_device()
+    rew = torch.as_tensor(env.reward_device, device="cuda")
+    obs1 = torch.as_tensor(env.obs_device, device="cuda")
+    torch.cuda.synchronize()
+    # the same step through the host path on a twin environment
+    twin = make_env(cfg)
+    twin.reset()
+    o, r, _, _ = twin.step(np.tile(np.array([[0.5, 0.9]], np.float32), (2048, 1)))
+    np.testing.assert_array_equal(obs1.cpu().numpy(), o)
+    np.testing.assert_array_equal(rew.cpu().numpy(), r)
+    # ping-pong: the previous observation buffer is still intact after one more step
+    assert obs1.data_ptr() != obs.data_ptr()
+    np.testing.assert_array_equal(obs.cpu().numpy(), host_obs)
+    env.close()
+    twin.close()
