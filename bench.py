@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--lanes", type=int, default=LANES_PER_GPU, help="trajectories per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for testing)")
+    ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,16 +138,20 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    gpu = 0 if args.single_device else local_rank
+    torch.cuda.set_device(gpu)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
 
     n = args.lanes
     from mbt_gym_amd.distributed import shard_bounds
     offset, count = shard_bounds(n * world, rank, world)
     assert count == n and offset == rank * n
-    env = build_env(n, rank, local_rank)
+    env = build_env(n, rank, gpu)
     env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
     env.reset()
 
@@ -157,7 +163,7 @@ def main():
 
     from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics
 
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", gpu) if args.backend == "nccl" else torch.device("cpu")
     episode_returns = []
     run_steps(env, args.warmup, device, episode_returns)
     barrier()
@@ -177,7 +183,7 @@ def main():
     wall = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([wall, ms.value / 1e3], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, ms.value / 1e3], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, event_s = float(t[0]), float(t[1])
     else:

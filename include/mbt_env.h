@@ -131,6 +131,31 @@ int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, f
 /* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
 int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);
 
+/* ---- fused rollout: many steps in one launch with an on-device closed-form policy ---------------
+ * Replaces the caller's per-time-step loop (gym/helpers/generate_trajectory.py:21-34) for policies that are closed
+ * forms of the observation.  Bit-identical to the equivalent sequence of mbt_env_step_* calls (same Philox
+ * counters).  Runs until the episode ends or max_steps, whichever comes first.
+ * Trajectory buffers are optional (NULL = not recorded) and TIME-MAJOR so that device stores coalesce:
+ *   obs_traj (steps+1, N, D) with row 0 = the observation before the first step, act_traj (steps, N, A),
+ *   rew_traj (steps, N).  generate_trajectory's (N, D, steps+1) layout (GT:11-15) is the transpose (2,0,1)... i.e.
+ *   np.transpose(obs_traj, (1, 2, 0)); the Python layer returns that view. */
+enum {
+  MBT_POLICY_FIXED = 0,               /* params[0..A) = the action every lane takes every step (agents/BaselineAgents.py:25-42) */
+  MBT_POLICY_AVELLANEDA_STOIKOV = 1   /* params[0] = risk aversion gamma (agents/BaselineAgents.py:52-83); needs un-normalised actions */
+};
+typedef struct mbt_policy {
+  int32_t kind;
+  int32_t reserved;
+  double params[8];
+} mbt_policy;
+/* Device variant: trajectory pointers are device memory sized for the PADDED lane count mbt_env_padded_lanes(). */
+int mbt_env_rollout_device(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
+                           float* rew_traj, uint32_t* steps_done, int32_t* done);
+/* Host variant: trajectory pointers are host memory with exactly N lanes per time slice; synchronous. */
+int mbt_env_rollout_host(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
+                         float* rew_traj, uint32_t* steps_done, int32_t* done);
+uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to even: lanes per time slice of device trajectories */
+
 /* ---- injected noise (parity mode; replaces the three numpy Generators of SP:27) ---------------- */
 /* u_arr, u_fill: (N, 2) float32 in [0, 1); z: (N) float32.  Consumed by the next step. */
 int mbt_env_set_noise_host(mbt_env* env, const float* u_arr, const float* u_fill, const float* z);

@@ -44,6 +44,15 @@ class MbtConfig(C.Structure):
     ]
 
 
+POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV = 0, 1
+
+
+class MbtPolicy(C.Structure):
+    """struct mbt_policy (include/mbt_env.h)."""
+
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_double * 8)]
+
+
 class NativeError(RuntimeError):
     """A libmbtenv call returned a negative status."""
 
@@ -71,6 +80,10 @@ SIGNATURES = {
     "mbt_env_reset_host": (C.c_int, [_ENV, C.c_double, _F, _F]),
     "mbt_env_step_host": (C.c_int, [_ENV, _F, _F, _F, C.POINTER(C.c_int32)]),
     "mbt_env_step_device": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_int32)]),
+    "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "mbt_env_rollout_host": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, _F, _F, _F, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "mbt_env_padded_lanes": (C.c_uint64, [_ENV]),
     "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),
     "mbt_env_action_ptr": (C.c_void_p, [_ENV]),
     "mbt_env_obs_ptr": (C.c_void_p, [_ENV]),

@@ -4,6 +4,7 @@ import warnings
 
 import numpy as np
 
+from mbt_gym_amd import _native
 from mbt_gym_amd.agents.Agent import Agent
 from mbt_gym_amd.gym.index_names import INVENTORY_INDEX, TIME_INDEX
 
@@ -16,6 +17,13 @@ class FixedActionAgent(Agent):
     def get_action(self, state: np.ndarray) -> np.ndarray:
         return np.repeat(self.fixed_action.reshape(1, -1), self.env.num_trajectories, axis=0)
 
+    def device_policy(self) -> _native.MbtPolicy:
+        """The same policy as a descriptor the fused rollout kernel evaluates on the device."""
+        pol = _native.MbtPolicy(kind=_native.POLICY_FIXED)
+        for j, value in enumerate(self.fixed_action.reshape(-1)):
+            pol.params[j] = float(value)
+        return pol
+
 
 class FixedSpreadAgent(Agent):
     """Quotes half_spread -/+ offset on bid/ask (AG:34-42)."""
@@ -26,6 +34,11 @@ class FixedSpreadAgent(Agent):
     def get_action(self, state: np.ndarray) -> np.ndarray:
         quote = np.array([[self.half_spread - self.offset, self.half_spread + self.offset]], dtype=np.float32)
         return np.repeat(quote, self.env.num_trajectories, axis=0)
+
+    def device_policy(self) -> _native.MbtPolicy:
+        pol = _native.MbtPolicy(kind=_native.POLICY_FIXED)
+        pol.params[0], pol.params[1] = self.half_spread - self.offset, self.half_spread + self.offset
+        return pol
 
 
 class AvellanedaStoikovAgent(Agent):
@@ -51,3 +64,8 @@ class AvellanedaStoikovAgent(Agent):
         if action.min() < 0:
             warnings.warn("Avellaneda-Stoikov agent is quoting a negative spread")
         return action.astype(np.float32)
+
+    def device_policy(self) -> _native.MbtPolicy:
+        pol = _native.MbtPolicy(kind=_native.POLICY_AVELLANEDA_STOIKOV)
+        pol.params[0] = self.risk_aversion
+        return pol

@@ -8,7 +8,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmbtenv.so")
 SOURCES = ["mbt_env.hip"]
 HEADERS = ["step_kernel.hpp", "philox.hpp", os.path.join("..", "..", "include", "mbt_env.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+# -ffp-contract=off: the step kernel and the fused rollout kernel inline the same arithmetic and must agree bit for bit;
+# letting the compiler pick FMA contractions per kernel breaks that (1-ulp reward differences were observed).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
 def _stale() -> bool:

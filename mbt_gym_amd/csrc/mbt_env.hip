@@ -91,6 +91,35 @@ StepKernel pick_kernel(const mbt_config& c) {
                                              : pick_arr<mbt::kMidOu>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm, inject);
 }
 
+using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
+
+template <int MID, int ARR, int DYN, int REW>
+RolloutKernel rpick_flags(bool norm) {
+  return norm ? mbt::rollout_kernel<mbt::Variant<MID, ARR, DYN, REW, true, false>>
+              : mbt::rollout_kernel<mbt::Variant<MID, ARR, DYN, REW, false, false>>;
+}
+template <int MID, int ARR, int DYN>
+RolloutKernel rpick_rew(int rew, bool norm) {
+  switch (rew) {
+    case MBT_REW_PNL: return rpick_flags<MID, ARR, DYN, mbt::kRewPnl>(norm);
+    case MBT_REW_RUNNING_PENALTY: return rpick_flags<MID, ARR, DYN, mbt::kRewRunning>(norm);
+    default: return rpick_flags<MID, ARR, DYN, mbt::kRewCjMm>(norm);
+  }
+}
+template <int MID, int ARR>
+RolloutKernel rpick_dyn(int dyn, int rew, bool norm) {
+  return dyn == MBT_DYN_LIMIT ? rpick_rew<MID, ARR, mbt::kDynLimit>(rew, norm) : rpick_rew<MID, ARR, mbt::kDynLimitAndMarket>(rew, norm);
+}
+template <int MID>
+RolloutKernel rpick_arr(int arr, int dyn, int rew, bool norm) {
+  return arr == MBT_ARR_POISSON ? rpick_dyn<MID, mbt::kArrPoisson>(dyn, rew, norm) : rpick_dyn<MID, mbt::kArrHawkes>(dyn, rew, norm);
+}
+RolloutKernel pick_rollout_kernel(const mbt_config& c) {
+  const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
+  return c.midprice_kind == MBT_MID_BROWNIAN ? rpick_arr<mbt::kMidBrownian>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm)
+                                             : rpick_arr<mbt::kMidOu>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm);
+}
+
 }  // namespace
 
 struct mbt_env {
@@ -123,6 +152,7 @@ struct mbt_env {
   bool was_reset = false, noise_ready = false, q_init_per_lane = false;
   bool record_events = false, track_returns = false;
   StepKernel kernel = nullptr;
+  RolloutKernel rollout = nullptr;
   mbt::StepParams params;
 };
 
@@ -217,6 +247,70 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   return MBT_OK;
 }
 
+// Enqueue one fused rollout from the current state; trajectory pointers are device memory (or nullptr).
+int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj, float* rew_traj,
+                   uint32_t* steps_done, int32_t* done) {
+  if (!e->was_reset) return fail(MBT_ERR_STATE, "rollout() before reset()");
+  if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "rollouts draw Philox noise; this environment is in injected-noise mode");
+  if (policy == nullptr) return fail(MBT_ERR_INVALID, "null policy");
+  mbt::RolloutParams R;
+  std::memset(&R, 0, sizeof R);
+  if (policy->kind == MBT_POLICY_FIXED) {
+    R.policy = mbt::kPolicyFixed;
+    for (int j = 0; j < e->act_dim; ++j) R.action[j] = static_cast<float>(policy->params[j]);
+  } else if (policy->kind == MBT_POLICY_AVELLANEDA_STOIKOV) {
+    if (e->cfg.normalise_action) return fail(MBT_ERR_INVALID, "the Avellaneda-Stoikov policy needs normalise_action_space=False");
+    if (e->cfg.dynamics_kind != MBT_DYN_LIMIT) return fail(MBT_ERR_INVALID, "the Avellaneda-Stoikov policy quotes two depths (limit-order dynamics)");
+    const double g = policy->params[0], s2 = e->cfg.volatility * e->cfg.volatility, k = e->cfg.fill_exponent;
+    R.policy = mbt::kPolicyAvellanedaStoikov;
+    R.as_c1 = static_cast<float>(g * s2);
+    R.as_c2 = static_cast<float>(g == 0.0 ? 2.0 / k : 2.0 / g * std::log(1.0 + g / k));  // BaselineAgents.py:74-79
+  } else {
+    return fail(MBT_ERR_INVALID, "unknown policy kind %d", policy->kind);
+  }
+  // how many steps until the episode ends, on the host clock (t += dt; done = t >= T - dt/2: TE:216-220)
+  double t = e->time;
+  uint32_t steps = 0;
+  bool terminal = false;
+  while (steps < max_steps && !terminal) {
+    t += e->dt;
+    ++steps;
+    terminal = t >= e->cfg.terminal_time - e->dt / 2;
+  }
+  if (steps == 0) return fail(MBT_ERR_INVALID, "max_steps must be positive");
+  R.n_steps = steps;
+  R.last_is_terminal = terminal ? 1 : 0;
+  R.t_start = e->time;
+  R.dt_f64 = e->dt;
+  R.terminal_time = e->cfg.terminal_time;
+  R.obs_traj = obs_traj;
+  R.act_traj = act_traj;
+  R.rew_traj = rew_traj;
+
+  mbt::StepParams& P = e->params;
+  P.philox_step = e->philox_step;
+  mbt::StepBuffers B;
+  std::memset(&B, 0, sizeof B);
+  B.state_in = e->state[e->cur];
+  B.state_out = e->state[e->cur ^ 1];
+  B.reward = e->reward;
+  B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
+  B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.events = e->record_events ? e->events : nullptr;
+  B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
+  B.wave_sums = e->wave_sums;
+  B.clip_count = e->clip_count;
+  hipLaunchKernelGGL(e->rollout, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R);
+  HIP_TRY(hipGetLastError());
+  e->cur ^= 1;
+  e->time = t;
+  e->philox_step += steps;
+  e->episode_step += steps;
+  if (steps_done != nullptr) *steps_done = steps;
+  if (done != nullptr) *done = terminal ? 1 : 0;
+  return MBT_OK;
+}
+
 int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   const mbt_config& c = e->cfg;
   if (!(start_time >= 0.0 && start_time < c.terminal_time))
@@ -307,6 +401,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->dt = cfg->terminal_time / cfg->n_steps;  // TE:49
   e->seed = cfg->seed;
   e->kernel = pick_kernel(*cfg);
+  e->rollout = pick_rollout_kernel(*cfg);
   fill_static_params(e);
   key_from_seed(e);
 
@@ -422,6 +517,52 @@ int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
     action_device = nullptr;
   }
   return launch_step(e, action_device, done);
+}
+
+uint64_t mbt_env_padded_lanes(mbt_env* e) { return e != nullptr ? e->n_pad : 0; }
+
+int mbt_env_rollout_device(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
+                           float* rew_traj, uint32_t* steps_done, int32_t* done) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  return launch_rollout(e, policy, max_steps, obs_traj, act_traj, rew_traj, steps_done, done);
+}
+
+int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
+                         float* rew_traj, uint32_t* steps_done, int32_t* done) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends)
+  const uint32_t remaining = static_cast<uint32_t>(std::ceil((e->cfg.terminal_time - e->time) / e->dt)) + 1;
+  const size_t k_max = max_steps < remaining ? max_steps : remaining;
+  const size_t np = e->n_pad;
+  float *d_obs = nullptr, *d_act = nullptr, *d_rew = nullptr;
+  int rc = MBT_OK;
+  if (obs_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_obs), (k_max + 1) * np * e->dim * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
+  if (rc == MBT_OK && act_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_act), k_max * np * e->act_dim * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
+  if (rc == MBT_OK && rew_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_rew), k_max * np * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
+  uint32_t steps = 0;
+  if (rc != MBT_OK) {
+    fail(MBT_ERR_HIP, "out of device memory for the trajectory staging buffers");
+  } else {
+    rc = launch_rollout(e, policy, max_steps, d_obs, d_act, d_rew, &steps, done);
+  }
+  if (rc == MBT_OK) {
+    // compact the padded time slices (n_pad lanes) into the caller's (n lanes) with strided copies
+    const size_t n = e->n;
+    hipError_t he = hipSuccess;
+    if (d_obs != nullptr) he = hipMemcpy2DAsync(obs_traj, n * e->dim * sizeof(float), d_obs, np * e->dim * sizeof(float), n * e->dim * sizeof(float), steps + 1, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess && d_act != nullptr) he = hipMemcpy2DAsync(act_traj, n * e->act_dim * sizeof(float), d_act, np * e->act_dim * sizeof(float), n * e->act_dim * sizeof(float), steps, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess && d_rew != nullptr) he = hipMemcpy2DAsync(rew_traj, n * sizeof(float), d_rew, np * sizeof(float), n * sizeof(float), steps, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) rc = fail(MBT_ERR_HIP, "trajectory copy failed: %s", hipGetErrorString(he));
+  }
+  (void)hipStreamSynchronize(e->stream);
+  if (d_obs != nullptr) (void)hipFree(d_obs);
+  if (d_act != nullptr) (void)hipFree(d_act);
+  if (d_rew != nullptr) (void)hipFree(d_rew);
+  if (steps_done != nullptr) *steps_done = steps;
+  return rc;
 }
 
 int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, const float* z) {

@@ -153,7 +153,8 @@ struct LaneResult {
 template <class V>
 __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 lam, const float4 act, const float d_bid,
                                                 const float d_ask, const bool raw_fill_bid, const bool raw_fill_ask,
-                                                const LaneNoise nz, const float q_init, const StepParams& P) {
+                                                const LaneNoise nz, const float q_init, const float t_next,
+                                                const bool is_terminal, const StepParams& P) {
   const float cash = core.x, q = core.y, mid = core.w;
 
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
@@ -224,7 +225,7 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
     const float qp = pow_inventory(q_clip, P);
     reward -= P.dt * P.phi * qp;
     if (V::REW == kRewRunning) {
-      reward -= P.is_terminal ? P.alpha * qp : 0.0f;
+      reward -= is_terminal ? P.alpha * qp : 0.0f;
     } else {
       reward -= P.alpha * ((qp - pow_inventory(q, P)) + P.dt_over_episode * pow_inventory(q_init, P));
     }
@@ -232,7 +233,7 @@ __device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 
   reward *= P.reward_scale;
 
   LaneResult r;
-  r.core = make_float4(c_clip, q_clip, P.t_next, mid_new);
+  r.core = make_float4(c_clip, q_clip, t_next, mid_new);
   r.lam = lam_new;
   r.reward = reward;
   r.events = ev;
@@ -303,28 +304,13 @@ __device__ __forceinline__ void tie_loads_to_noise(PairLoads<V>& L, LaneNoise& a
                  "+v"(b.ua_bid), "+v"(b.ua_ask), "+v"(b.uf_bid), "+v"(b.uf_ask), "+v"(b.z));
 }
 
-// Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
+// One env-step of a pair of lanes held in registers: fill tests of the four quotes (TE:104 de-normalisation
+// first), then the per-lane dynamics.
 template <class V>
-__device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
-                                             const LaneNoise& nz0, const LaneNoise& nz1) {
-  const uint32_t lane0 = 2u * pair;
-  float4 core0 = L.s0, core1 = L.s1;
-  float2 lam0 = make_float2(0.f, 0.f), lam1 = lam0;
-  if (V::ARR == kArrHawkes) {  // rows of 6: [c q t S | lb la c q | t S lb la]
-    lam0 = make_float2(L.s1.x, L.s1.y);
-    core1 = make_float4(L.s1.z, L.s1.w, L.s2.x, L.s2.y);
-    lam1 = make_float2(L.s2.z, L.s2.w);
-  }
-  float4 act0, act1;
-  if (V::DYN == kDynLimit) {
-    act0 = make_float4(L.a0.x, L.a0.y, 0.f, 0.f);
-    act1 = make_float4(L.a0.z, L.a0.w, 0.f, 0.f);
-  } else {
-    act0 = L.a0;
-    act1 = L.a1;
-  }
-
-  // -- fill tests of the four quotes of the pair (TE:104 de-normalisation first)
+__device__ __forceinline__ void advance_pair(const float4 core0, const float2 lam0, const float4 core1, const float2 lam1,
+                                             const float4 act0, const float4 act1, const LaneNoise& nz0, const LaneNoise& nz1,
+                                             const float2 q_init, const float t_next, const bool is_terminal,
+                                             const StepParams& P, LaneResult& r0, LaneResult& r1) {
   const bool norm_act = V::NORM && P.norm_act;
   const float a[4] = {act0.x, act0.y, act1.x, act1.y};
   const float u[4] = {nz0.uf_bid, nz0.uf_ask, nz1.uf_bid, nz1.uf_ask};
@@ -338,19 +324,59 @@ __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepPar
     near[k] = t.near;
   }
   if (__builtin_expect(near[0] | near[1] | near[2] | near[3], 0)) refine_fills_f64(u, a, norm_act, P, fill, near);
+  r0 = step_lane<V>(core0, lam0, act0, depth[0], depth[1], fill[0], fill[1], nz0, q_init.x, t_next, is_terminal, P);
+  r1 = step_lane<V>(core1, lam1, act1, depth[2], depth[3], fill[2], fill[3], nz1, q_init.y, t_next, is_terminal, P);
+}
 
-  const LaneResult r0 = step_lane<V>(core0, lam0, act0, depth[0], depth[1], fill[0], fill[1], nz0, L.qi.x, P);
-  const LaneResult r1 = step_lane<V>(core1, lam1, act1, depth[2], depth[3], fill[2], fill[3], nz1, L.qi.y, P);
-
-  float4* dst = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
+// rows of 6 are packed [c q t S | lb la c q | t S lb la] in three float4
+template <class V>
+__device__ __forceinline__ void unpack_rows(const float4 s0, const float4 s1, const float4 s2, float4& core0, float2& lam0,
+                                            float4& core1, float2& lam1) {
+  core0 = s0;
+  core1 = s1;
+  lam0 = lam1 = make_float2(0.f, 0.f);
   if (V::ARR == kArrHawkes) {
-    dst[0] = r0.core;
-    dst[1] = make_float4(r0.lam.x, r0.lam.y, r1.core.x, r1.core.y);
-    dst[2] = make_float4(r1.core.z, r1.core.w, r1.lam.x, r1.lam.y);
-  } else {
-    dst[0] = r0.core;
-    dst[1] = r1.core;
+    lam0 = make_float2(s1.x, s1.y);
+    core1 = make_float4(s1.z, s1.w, s2.x, s2.y);
+    lam1 = make_float2(s2.z, s2.w);
   }
+}
+
+template <class V>
+__device__ __forceinline__ void store_rows(float* base, uint32_t pair, const float4 core0, const float2 lam0, const float4 core1,
+                                           const float2 lam1) {
+  float4* dst = reinterpret_cast<float4*>(base) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
+  if (V::ARR == kArrHawkes) {
+    dst[0] = core0;
+    dst[1] = make_float4(lam0.x, lam0.y, core1.x, core1.y);
+    dst[2] = make_float4(core1.z, core1.w, lam1.x, lam1.y);
+  } else {
+    dst[0] = core0;
+    dst[1] = core1;
+  }
+}
+
+// Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
+template <class V>
+__device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
+                                             const LaneNoise& nz0, const LaneNoise& nz1) {
+  const uint32_t lane0 = 2u * pair;
+  float4 core0, core1;
+  float2 lam0, lam1;
+  unpack_rows<V>(L.s0, L.s1, L.s2, core0, lam0, core1, lam1);
+  float4 act0, act1;
+  if (V::DYN == kDynLimit) {
+    act0 = make_float4(L.a0.x, L.a0.y, 0.f, 0.f);
+    act1 = make_float4(L.a0.z, L.a0.w, 0.f, 0.f);
+  } else {
+    act0 = L.a0;
+    act1 = L.a1;
+  }
+
+  LaneResult r0, r1;
+  advance_pair<V>(core0, lam0, core1, lam1, act0, act1, nz0, nz1, L.qi, P.t_next, P.is_terminal != 0, P, r0, r1);
+
+  store_rows<V>(B.state_out, pair, r0.core, r0.lam, r1.core, r1.lam);
   reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
 
   const bool second = lane0 + 1 < P.n;  // the pad lane of an odd shard is computed but never reported
@@ -393,6 +419,118 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
   // -- per-wave running sum of rewards (numerator of the mean episode return): one slot per wave, one
   //    fire-and-forget hardware fp64 atomic per wave, no contention
   const float total = wave_sum(r_sum);
+  if ((threadIdx.x & 63u) == 0u) {
+    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
+  }
+}
+
+// ---- fused rollout -----------------------------------------------------------------------
+// Many consecutive env-steps in ONE launch with an on-device closed-form policy: the pair's state stays in
+// registers, noise comes from the same Philox stream the step kernel would draw (philox step = first + k), so a
+// rollout is bit-identical to the equivalent sequence of step() calls.  The caller's per-time-step Python loop
+// (generate_trajectory.py:21-34) disappears; HBM is touched only to record the trajectory (optional, time-major
+// so that every store is a coalesced float4) and once at the end for the final state.
+enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1 };
+
+struct RolloutParams {
+  uint32_t n_steps;        // env-steps to run in this launch
+  int32_t last_is_terminal;  // the final one ends the episode (TE:218-220), decided on the host
+  double t_start, dt_f64, terminal_time;  // the clock, advanced exactly like the host does (t += dt, TE:216)
+  int32_t policy;
+  float action[4];         // kPolicyFixed: the constant action (FixedActionAgent / FixedSpreadAgent, AG:25-42)
+  float as_c1, as_c2;      // kPolicyAvellanedaStoikov: gamma sigma^2 and (2/gamma) ln(1 + gamma/kappa) (AG:70-83)
+  float* obs_traj;         // (n_steps + 1, n_pad, D) or nullptr; row 0 is the observation before the first step
+  float* act_traj;         // (n_steps, n_pad, A) or nullptr
+  float* rew_traj;         // (n_steps, n_pad) or nullptr
+};
+
+template <class V>
+__global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
+  static_assert(!V::INJECT, "rollouts draw their own noise");
+  constexpr int A = (V::DYN == kDynLimitAndMarket) ? 4 : 2;
+  const uint32_t pair = blockIdx.x * kBlockThreads + threadIdx.x;
+  float ret_sum = 0.0f;
+  if (pair < P.n_pairs) {
+    const uint32_t lane0 = 2u * pair;
+    const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
+    const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
+    float4 core0, core1;
+    float2 lam0, lam1;
+    unpack_rows<V>(src[0], src[1], V::ARR == kArrHawkes ? src[2] : make_float4(0.f, 0.f, 0.f, 0.f), core0, lam0, core1, lam1);
+    float2 qi = make_float2(P.q_init_scalar, P.q_init_scalar);
+    if (V::REW == kRewCjMm && B.q_init != nullptr) qi = reinterpret_cast<const float2*>(B.q_init)[pair];
+    float ret0 = 0.0f, ret1 = 0.0f;
+    uint32_t clipped = 0;
+    double t = R.t_start;
+    if (R.obs_traj != nullptr) {
+      if (V::NORM) {
+        write_obs_row(R.obs_traj, lane0, V::DIM, core0, lam0, P);
+        write_obs_row(R.obs_traj, lane0 + 1, V::DIM, core1, lam1, P);
+      } else {
+        store_rows<V>(R.obs_traj, pair, core0, lam0, core1, lam1);
+      }
+    }
+    for (uint32_t k = 0; k < R.n_steps; ++k) {
+      LaneNoise nz0, nz1;
+      philox_pair_noise(P.pair_offset + pair, P.philox_step + k, P.key0, P.key1, nz0, nz1);
+      float4 act0, act1;
+      if (R.policy == kPolicyFixed) {
+        act0 = act1 = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
+      } else {  // Avellaneda-Stoikov quotes from (inventory, time) of the current observation
+        const float tau = static_cast<float>(R.terminal_time - t);
+        const float half = 0.5f * (R.as_c1 * tau + R.as_c2);
+        const float s0 = core0.y * R.as_c1 * tau, s1 = core1.y * R.as_c1 * tau;
+        act0 = make_float4(s0 + half, -s0 + half, 0.f, 0.f);
+        act1 = make_float4(s1 + half, -s1 + half, 0.f, 0.f);
+      }
+      t += R.dt_f64;
+      const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
+      LaneResult r0, r1;
+      advance_pair<V>(core0, lam0, core1, lam1, act0, act1, nz0, nz1, qi, static_cast<float>(t), terminal, P, r0, r1);
+      core0 = r0.core; lam0 = r0.lam; core1 = r1.core; lam1 = r1.lam;
+      ret0 += r0.reward;
+      ret1 += r1.reward;
+      clipped += ((r0.events >> 6) != 0u ? 1u : 0u) + ((r1.events >> 6) != 0u && lane0 + 1 < P.n ? 1u : 0u);
+      if (R.obs_traj != nullptr) {
+        float* dst = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
+        if (V::NORM) {
+          write_obs_row(dst, lane0, V::DIM, core0, lam0, P);
+          write_obs_row(dst, lane0 + 1, V::DIM, core1, lam1, P);
+        } else {
+          store_rows<V>(dst, pair, core0, lam0, core1, lam1);
+        }
+      }
+      if (R.act_traj != nullptr) {
+        float* dst = R.act_traj + static_cast<size_t>(k) * n_pad * A;
+        if (A == 2) {
+          reinterpret_cast<float4*>(dst)[pair] = make_float4(act0.x, act0.y, act1.x, act1.y);
+        } else {
+          reinterpret_cast<float4*>(dst)[2 * pair] = act0;
+          reinterpret_cast<float4*>(dst)[2 * pair + 1] = act1;
+        }
+      }
+      if (R.rew_traj != nullptr) reinterpret_cast<float2*>(R.rew_traj + static_cast<size_t>(k) * n_pad)[pair] = make_float2(r0.reward, r1.reward);
+      if (k + 1 == R.n_steps) {  // what step() leaves behind: last rewards (and events) of the final step
+        reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
+        if (B.events != nullptr) reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
+      }
+    }
+    store_rows<V>(B.state_out, pair, core0, lam0, core1, lam1);
+    if (V::NORM && B.obs != nullptr) {
+      write_obs_row(B.obs, lane0, V::DIM, core0, lam0, P);
+      write_obs_row(B.obs, lane0 + 1, V::DIM, core1, lam1, P);
+    }
+    if (B.lane_returns != nullptr) {
+      float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
+      acc.x += ret0;
+      acc.y += ret1;
+      reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
+    }
+    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+    ret_sum = ret0 + (lane0 + 1 < P.n ? ret1 : 0.0f);
+  }
+  const float total = wave_sum(ret_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));

@@ -292,6 +292,44 @@ class TradingEnvironment(_EnvBase):
         return obs
 
     # ---------------------------------------------------------------------------------------------------
+    # fused rollout: the caller's per-step loop moved onto the device for closed-form policies
+    # ---------------------------------------------------------------------------------------------------
+    def rollout(self, policy, max_steps: int = None, record: bool = True):
+        """Run from the current state until the episode ends (or `max_steps`) in ONE kernel launch, with the
+        on-device `policy` (an `mbt_gym_amd._native.MbtPolicy`, or an agent exposing `device_policy()`).
+        Bit-identical to the same number of `step()` calls.  Returns (obs, actions, rewards, steps, done) with
+        TIME-MAJOR float32 arrays obs (steps+1, N, D), actions (steps, N, A), rewards (steps, N) - or Nones when
+        `record` is False (then nothing but the final state touches HBM)."""
+        pol = policy.device_policy() if hasattr(policy, "device_policy") else policy
+        k = self.n_steps if max_steps is None else int(max_steps)
+        n = self.num_trajectories
+        obs = act = rew = None
+        if record:
+            obs = np.zeros((k + 1, n, self.observation_dim), dtype=np.float32)
+            act = np.zeros((k, n, self.action_dim), dtype=np.float32)
+            rew = np.zeros((k, n), dtype=np.float32)
+        steps, done = C.c_uint32(0), C.c_int32(0)
+        _native.check(_native.load_library().mbt_env_rollout_host(
+            self._handle, C.byref(pol), k, _native.fptr(obs), _native.fptr(act), _native.fptr(rew), C.byref(steps), C.byref(done)))
+        if record:
+            obs, act, rew = obs[: steps.value + 1], act[: steps.value], rew[: steps.value]
+        return obs, act, rew, int(steps.value), bool(done.value)
+
+    def rollout_device(self, policy, max_steps: int = None, obs_ptr: int = None, act_ptr: int = None, rew_ptr: int = None):
+        """Asynchronous variant: optional device pointers to time-major trajectory buffers sized for
+        `padded_lanes` lanes per time slice.  Returns (steps, done)."""
+        pol = policy.device_policy() if hasattr(policy, "device_policy") else policy
+        k = self.n_steps if max_steps is None else int(max_steps)
+        steps, done = C.c_uint32(0), C.c_int32(0)
+        _native.check(_native.load_library().mbt_env_rollout_device(
+            self._handle, C.byref(pol), k, obs_ptr, act_ptr, rew_ptr, C.byref(steps), C.byref(done)))
+        return int(steps.value), bool(done.value)
+
+    @property
+    def padded_lanes(self) -> int:
+        return int(_native.load_library().mbt_env_padded_lanes(self._handle))
+
+    # ---------------------------------------------------------------------------------------------------
     # parity / diagnostics
     # ---------------------------------------------------------------------------------------------------
     def set_noise(self, u_arr: np.ndarray, u_fill: np.ndarray, z: np.ndarray):
