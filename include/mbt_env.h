@@ -193,6 +193,14 @@ int mbt_env_clip_count(mbt_env* env, uint64_t* count);
 int mbt_env_track_lane_returns(mbt_env* env, int enabled);
 int mbt_env_return_sums(mbt_env* env, double sums[3]);
 
+/* ---- RewardFunction.calculate on caller-supplied matrices (RW:23-33, RW:96-109, RW:128-138) ---------------------
+ * cur, nxt: (n, dim) row-major float64 state matrices; q_init, episode_length: (n) float64, only for MBT_REW_CJ_MM
+ * (what CjMmCriterion.reset captured, RW:111-113); out: (n) float64.  Evaluated on the device in double, in the
+ * reference's order of operations. */
+int mbt_reward_calculate_host(int device, int reward_kind, double phi, double alpha, double inventory_exponent,
+                              const double* cur, const double* nxt, int dim, uint64_t n, int is_terminal,
+                              const double* q_init, const double* episode_length, double* out);
+
 /* ---- the generator itself (so tests can pin it) ------------------------------------------------ */
 /* Writes the noise lane ids [trajectory_offset, trajectory_offset + n) would draw at philox step `step`
  * under `seed` into host arrays (any may be NULL): u_arr (n,2), u_fill (n,2), z (n). */

@@ -100,6 +100,9 @@ SIGNATURES = {
     "mbt_env_clip_count": (C.c_int, [_ENV, C.POINTER(C.c_uint64)]),
     "mbt_env_track_lane_returns": (C.c_int, [_ENV, C.c_int]),
     "mbt_env_return_sums": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
+    "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mbt_rng_fill_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F, _F, _F]),
     "mbt_philox4x32_10_host": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_timer_begin": (C.c_int, [_ENV]),
@@ -183,6 +186,21 @@ class DeviceView:
     @property
     def __cuda_array_interface__(self):
         return {"shape": self.shape, "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
+
+
+def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_terminal, q_init=None, episode_length=None, device=0):
+    """RewardFunction.calculate on float64 state matrices, evaluated on the device (mbt_reward_calculate_host)."""
+    cur = np.ascontiguousarray(current_state, dtype=np.float64)
+    nxt = np.ascontiguousarray(next_state, dtype=np.float64)
+    assert cur.ndim == 2 and cur.shape == nxt.shape, "Reward functions must be calculated on state matrices."
+    n, dim = cur.shape
+    out = np.empty((n,), dtype=np.float64)
+    dptr = lambda a: None if a is None else np.ascontiguousarray(np.broadcast_to(a, (n,)), dtype=np.float64)  # noqa: E731
+    qi, ln = dptr(q_init), dptr(episode_length)
+    as_p = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    check(load_library().mbt_reward_calculate_host(device, kind, float(phi), float(alpha), float(exponent), as_p(cur), as_p(nxt),
+                                                   dim, n, int(bool(is_terminal)), as_p(qi), as_p(ln), as_p(out)))
+    return out
 
 
 def device_count():

@@ -689,6 +689,35 @@ int mbt_env_return_sums(mbt_env* e, double sums[3]) {
   return MBT_OK;
 }
 
+int mbt_reward_calculate_host(int device, int reward_kind, double phi, double alpha, double inventory_exponent, const double* cur,
+                              const double* nxt, int dim, uint64_t n, int is_terminal, const double* q_init,
+                              const double* episode_length, double* out) {
+  if (cur == nullptr || nxt == nullptr || out == nullptr || n == 0 || dim < 4) return fail(MBT_ERR_INVALID, "bad argument");
+  if (reward_kind < MBT_REW_PNL || reward_kind > MBT_REW_CJ_MM) return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", reward_kind);
+  if (reward_kind == MBT_REW_CJ_MM && (q_init == nullptr || episode_length == nullptr))
+    return fail(MBT_ERR_STATE, "CjMmCriterion.calculate before reset(): initial inventory / episode length unknown");
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  const size_t mat = n * dim * sizeof(double), vec = n * sizeof(double);
+  double* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 2 * mat + 3 * vec));
+  double *d_cur = d, *d_nxt = d + n * dim, *d_qi = d_nxt + n * dim, *d_len = d_qi + n, *d_out = d_len + n;
+  hipError_t he = hipMemcpy(d_cur, cur, mat, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(d_nxt, nxt, mat, hipMemcpyHostToDevice);
+  if (he == hipSuccess && q_init != nullptr) he = hipMemcpy(d_qi, q_init, vec, hipMemcpyHostToDevice);
+  if (he == hipSuccess && episode_length != nullptr) he = hipMemcpy(d_len, episode_length, vec, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(mbt::reward_calculate_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, reward_kind, d_cur, d_nxt, dim,
+                       static_cast<uint32_t>(n), is_terminal, phi, alpha, inventory_exponent, d_qi, d_len, d_out);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipMemcpy(out, d_out, vec, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (he != hipSuccess) return fail(MBT_ERR_HIP, "reward_calculate failed: %s", hipGetErrorString(he));
+  return MBT_OK;
+}
+
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* u_arr,
                       float* u_fill, float* z) {
   if (trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even");

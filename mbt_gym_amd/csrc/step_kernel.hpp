@@ -589,6 +589,33 @@ __global__ void reduce_returns_kernel(const double* wave_sums, uint32_t n_waves,
   }
 }
 
+// RewardFunction.calculate on caller-supplied state matrices (RW:23-33, RW:96-109, RW:128-138), in DOUBLE and in
+// the reference's order of operations, so host code that calls `calculate()` on stored trajectories (and the
+// reference's own unit tests) gets the reference's float64 values without a CPU implementation.
+__global__ void reward_calculate_kernel(int kind, const double* cur, const double* nxt, int dim, uint32_t n, int is_terminal,
+                                        double phi, double alpha, double p, const double* q_init, const double* episode_length,
+                                        double* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* c = cur + static_cast<size_t>(i) * dim;
+  const double* x = nxt + static_cast<size_t>(i) * dim;
+  const double pnl = (x[0] + x[1] * x[3]) - (c[0] + c[1] * c[3]);
+  double r = pnl;
+  if (kind != kRewPnl) {
+    const double dt = x[2] - c[2];
+    const double qp = (p == 2.0) ? x[1] * x[1] : pow(x[1], p);
+    r = pnl - dt * phi * qp;
+    if (kind == kRewRunning) {
+      r = r - alpha * static_cast<double>(is_terminal) * qp;
+    } else {
+      const double q0p = (p == 2.0) ? c[1] * c[1] : pow(c[1], p);
+      const double qip = (p == 2.0) ? q_init[i] * q_init[i] : pow(q_init[i], p);
+      r = r - alpha * (qp - q0p + dt / episode_length[i] * qip);
+    }
+  }
+  out[i] = r;
+}
+
 // The production noise, written out (tests pin the generator and tie Philox mode to injected mode with it).
 __global__ void rng_fill_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0, uint32_t k1, uint32_t n_pairs,
                                 float* u_arr, float* u_fill, float* z) {

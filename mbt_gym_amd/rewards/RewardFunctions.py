@@ -4,10 +4,10 @@ PnL                     (RW:20-36)    r = (c' + q' S') - (c + q S)
 RunningInventoryPenalty (RW:116-143)  r = PnL - dt phi q'^p - alpha [terminal] q'^p         (alias CjCriterion, RW:146)
 CjMmCriterion           (RW:77-113)   r = PnL - dt phi q'^p - alpha (q'^p - q^p + dt/L q0^p),  L = T - t0, q0 = q(reset)
 
-The reward is evaluated inside the fused step kernel (csrc/step_kernel.hpp), from the step's increments rather
-than from two large mark-to-market values.  `calculate()` below evaluates the same formulas for host arrays
-the caller already holds (reward shaping of stored trajectories, the reference's unit tests); the
-environment never calls it.
+Inside `TradingEnvironment.step()` the reward is part of the fused step kernel (csrc/step_kernel.hpp), computed in
+float32 from the step's increments.  `calculate()` - the reference's public method, which its unit tests and
+reward-shaping code call on stored state matrices - is evaluated on the device too (reward_calculate_kernel, in
+double and in the reference's order of operations): there is no NumPy implementation of the formulas in this package.
 """
 import abc
 from typing import Union
@@ -15,15 +15,24 @@ from typing import Union
 import numpy as np
 
 from mbt_gym_amd import _native
-from mbt_gym_amd.gym.index_names import ASSET_PRICE_INDEX, CASH_INDEX, INVENTORY_INDEX, TIME_INDEX
+from mbt_gym_amd.gym.index_names import INVENTORY_INDEX, TIME_INDEX
 
 
 class RewardFunction(metaclass=abc.ABCMeta):
     device_kind = None
+    per_step_inventory_aversion = 0.0
+    terminal_inventory_aversion = 0.0
+    inventory_exponent = 2.0
 
-    @abc.abstractmethod
     def calculate(self, current_state, action, next_state, is_terminal_step: bool = False) -> Union[float, np.ndarray]:
-        pass
+        assert len(np.shape(current_state)) > 1, "Reward functions must be calculated on state matrices."
+        return _native.reward_calculate(
+            self.device_kind, self.per_step_inventory_aversion, self.terminal_inventory_aversion, self.inventory_exponent,
+            current_state, next_state, np.all(is_terminal_step), *self._episode_constants(),
+        )
+
+    def _episode_constants(self):
+        return None, None
 
     @abc.abstractmethod
     def reset(self, initial_state: np.ndarray):
@@ -33,18 +42,10 @@ class RewardFunction(metaclass=abc.ABCMeta):
         return dict(reward_kind=self.device_kind)
 
 
-def _mark_to_market(state: np.ndarray) -> np.ndarray:
-    return state[:, CASH_INDEX] + state[:, INVENTORY_INDEX] * state[:, ASSET_PRICE_INDEX]
-
-
 class PnL(RewardFunction):
     """Change of the mark-to-market value of the agent's portfolio."""
 
     device_kind = _native.REW_PNL
-
-    def calculate(self, current_state, action, next_state, is_terminal_step=False):
-        assert len(current_state.shape) > 1, "Reward functions must be calculated on state matrices."
-        return _mark_to_market(next_state) - _mark_to_market(current_state)
 
     def reset(self, initial_state):
         pass
@@ -56,11 +57,6 @@ class _InventoryAverse(RewardFunction):
         self.terminal_inventory_aversion = terminal_inventory_aversion
         self.inventory_exponent = inventory_exponent
         self.pnl = PnL()
-
-    def _running_part(self, current_state, action, next_state):
-        dt = next_state[:, TIME_INDEX] - current_state[:, TIME_INDEX]
-        penalty = dt * self.per_step_inventory_aversion * next_state[:, INVENTORY_INDEX] ** self.inventory_exponent
-        return self.pnl.calculate(current_state, action, next_state) - penalty, dt
 
     def device_params(self):
         return dict(
@@ -79,11 +75,6 @@ class RunningInventoryPenalty(_InventoryAverse):
         inventory_exponent: float = 2.0,
     ):
         super().__init__(per_step_inventory_aversion, terminal_inventory_aversion, inventory_exponent)
-
-    def calculate(self, current_state, action, next_state, is_terminal_step=False):
-        running, _ = self._running_part(current_state, action, next_state)
-        at_end = self.terminal_inventory_aversion * int(is_terminal_step)
-        return running - at_end * next_state[:, INVENTORY_INDEX] ** self.inventory_exponent
 
     def reset(self, initial_state):
         pass
@@ -109,16 +100,11 @@ class CjMmCriterion(_InventoryAverse):
         self.initial_inventory = None
         self.episode_length = None
 
-    def calculate(self, current_state, action, next_state, is_terminal_step=False):
-        running, dt = self._running_part(current_state, action, next_state)
-        p = self.inventory_exponent
-        spread_terminal = (
-            next_state[:, INVENTORY_INDEX] ** p
-            - current_state[:, INVENTORY_INDEX] ** p
-            + dt / self.episode_length * self.initial_inventory**p
-        )
-        return running - self.terminal_inventory_aversion * spread_terminal
+    def _episode_constants(self):
+        return self.initial_inventory, self.episode_length
 
     def reset(self, initial_state):
-        self.initial_inventory = initial_state[:, INVENTORY_INDEX]
-        self.episode_length = self.terminal_time - initial_state[:, TIME_INDEX]
+        """Capture the initial inventory and the episode length (RW:111-113)."""
+        state = np.asarray(initial_state, dtype=np.float64)
+        self.initial_inventory = state[:, INVENTORY_INDEX].copy()
+        self.episode_length = self.terminal_time - state[:, TIME_INDEX]
