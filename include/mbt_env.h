@@ -141,12 +141,20 @@ int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done)
  *   np.transpose(obs_traj, (1, 2, 0)); the Python layer returns that view. */
 enum {
   MBT_POLICY_FIXED = 0,               /* params[0..A) = the action every lane takes every step (agents/BaselineAgents.py:25-42) */
-  MBT_POLICY_AVELLANEDA_STOIKOV = 1   /* params[0] = risk aversion gamma (agents/BaselineAgents.py:52-83); needs un-normalised actions */
+  MBT_POLICY_AVELLANEDA_STOIKOV = 1,  /* params[0] = risk aversion gamma (agents/BaselineAgents.py:52-83); needs un-normalised actions */
+  MBT_POLICY_TIME_INVENTORY_TABLE = 2 /* (bid, ask) depths looked up by (time step, inventory): any policy that is a function
+                                         of (t, q) tabulated by the host, e.g. the Cartea-Jaimungal optimal quotes
+                                         (agents/BaselineAgents.py:86-170).  table[(row * table_cols + col) * 2 + side], host
+                                         memory, row = round(t / dt), col = clamp(q + table_q_offset, 0, table_cols - 1) */
 };
 typedef struct mbt_policy {
   int32_t kind;
   int32_t reserved;
   double params[8];
+  const float* table;      /* MBT_POLICY_TIME_INVENTORY_TABLE only */
+  uint32_t table_rows, table_cols;
+  int32_t table_q_offset;
+  int32_t reserved1;
 } mbt_policy;
 /* Device variant: trajectory pointers are device memory sized for the PADDED lane count mbt_env_padded_lanes(). */
 int mbt_env_rollout_device(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,

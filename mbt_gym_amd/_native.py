@@ -44,13 +44,25 @@ class MbtConfig(C.Structure):
     ]
 
 
-POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV = 0, 1
+POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE = 0, 1, 2
 
 
 class MbtPolicy(C.Structure):
     """struct mbt_policy (include/mbt_env.h)."""
 
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_double * 8)]
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_double * 8),
+                ("table", C.POINTER(C.c_float)), ("table_rows", C.c_uint32), ("table_cols", C.c_uint32),
+                ("table_q_offset", C.c_int32), ("reserved1", C.c_int32)]
+
+
+def table_policy(table: np.ndarray, q_offset: int) -> MbtPolicy:
+    """(rows = time steps, cols = inventory levels, 2) float32 depths -> policy descriptor (keeps the array alive)."""
+    arr = np.ascontiguousarray(table, dtype=np.float32)
+    assert arr.ndim == 3 and arr.shape[2] == 2
+    pol = MbtPolicy(kind=POLICY_TIME_INVENTORY_TABLE, table=arr.ctypes.data_as(C.POINTER(C.c_float)),
+                    table_rows=arr.shape[0], table_cols=arr.shape[1], table_q_offset=int(q_offset))
+    pol._keepalive = arr
+    return pol
 
 
 class NativeError(RuntimeError):

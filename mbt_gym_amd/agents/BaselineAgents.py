@@ -6,7 +6,7 @@ import numpy as np
 
 from mbt_gym_amd import _native
 from mbt_gym_amd.agents.Agent import Agent
-from mbt_gym_amd.gym.index_names import INVENTORY_INDEX, TIME_INDEX
+from mbt_gym_amd.gym.index_names import ASSET_PRICE_INDEX, CASH_INDEX, INVENTORY_INDEX, TIME_INDEX
 
 
 class FixedActionAgent(Agent):
@@ -69,3 +69,101 @@ class AvellanedaStoikovAgent(Agent):
         pol = _native.MbtPolicy(kind=_native.POLICY_AVELLANEDA_STOIKOV)
         pol.params[0] = self.risk_aversion
         return pol
+
+
+class CarteaJaimungalMmAgent(Agent):
+    """Optimal market-making quotes of Cartea, Jaimungal & Penalva (2015), section 10.2, for the running-inventory
+    criterion: omega(t) = exp(A (T - t)) z with A tridiagonal over the inventory grid -Q..Q, h = ln(omega) / kappa,
+    depth_bid(q) = 1/kappa - h(q+1) + h(q), depth_ask(q) = 1/kappa - h(q-1) + h(q) (reference:
+    agents/BaselineAgents.py:86-170).  At the inventory limits the blocked side quotes a very large depth.
+
+    The whole (time step, inventory) table is built once - one matrix exponential for the step dt, then n_steps
+    mat-vecs backwards from T - instead of one 201x201 expm per get_action call; `device_policy()` hands the same
+    table to the fused rollout kernel."""
+
+    large_depth = 10_000
+
+    def __init__(self, env=None, max_inventory: int = None):
+        from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+        from mbt_gym_amd.rewards.RewardFunctions import CjMmCriterion, PnL
+
+        assert env is not None
+        assert isinstance(env.model_dynamics, LimitOrderModelDynamics), "Trader must be type LimitOrderTrader"
+        assert isinstance(env.reward_function, (CjMmCriterion, PnL)), "Reward function for CjMmAgent is incorrect."
+        self.env = env
+        self.kappa = env.model_dynamics.fill_probability_model.fill_exponent
+        self.num_trajectories = env.num_trajectories
+        self.inventory_neutral = isinstance(env.reward_function, PnL)
+        if self.inventory_neutral:
+            self.risk_neutral_action = np.full((env.num_trajectories, env.action_space.shape[0]), 1 / self.kappa, dtype=np.float32)
+            return
+        self.phi = env.reward_function.per_step_inventory_aversion
+        self.alpha = env.reward_function.terminal_inventory_aversion
+        assert env.reward_function.inventory_exponent == 2.0, "Inventory exponent must be = 2."
+        self.terminal_time = env.terminal_time
+        self.lambdas = np.asarray(env.model_dynamics.arrival_model.intensity, dtype=np.float64).reshape(-1)
+        self.max_inventory = int(env.max_inventory if max_inventory is None else max_inventory)
+        self.a_matrix, self.z_vector = self._calculate_a_and_z()
+        self._h = None  # (n_steps + 1, 2Q + 1): h at t_k = k dt
+
+    def _calculate_a_and_z(self):
+        size = 2 * self.max_inventory + 1
+        q = self.max_inventory - np.arange(size)  # row i holds inventory Q - i (descending, as in the reference)
+        a = np.diag(-self.phi * self.kappa * q.astype(np.float64) ** 2)
+        a += np.diag(np.full(size - 1, self.lambdas[0] * np.exp(-1)), k=1)
+        a += np.diag(np.full(size - 1, self.lambdas[1] * np.exp(-1)), k=-1)
+        z = np.exp(-self.alpha * self.kappa * q.astype(np.float64) ** 2).reshape(-1, 1)
+        return a, z
+
+    def _calculate_omega(self, current_time: float) -> np.ndarray:
+        """Equation (10.11) of [CJP15] at an arbitrary time."""
+        from scipy.linalg import expm
+
+        return expm(self.a_matrix * (self.terminal_time - current_time)) @ self.z_vector
+
+    def _calculate_ht(self, current_time: float) -> np.ndarray:
+        return np.log(self._calculate_omega(current_time)) / self.kappa
+
+    def h_table(self) -> np.ndarray:
+        """h(t_k, q) for k = 0..n_steps on the environment's time grid; columns ordered q = -Q..Q."""
+        if self._h is None:
+            from scipy.linalg import expm
+
+            n, dt = self.env.n_steps, self.env.step_size
+            step = expm(self.a_matrix * dt)
+            omega = np.empty((n + 1, self.a_matrix.shape[0]))
+            omega[n] = self.z_vector[:, 0]
+            for k in range(n - 1, -1, -1):
+                omega[k] = step @ omega[k + 1]
+            self._h = (np.log(omega) / self.kappa)[:, ::-1].copy()  # flip to ascending inventory
+        return self._h
+
+    def depth_table(self) -> np.ndarray:
+        """(n_steps + 1, 2Q + 1, 2) optimal (bid, ask) depths over (time step, inventory -Q..Q)."""
+        h = self.h_table()
+        up = np.concatenate((h[:, 1:], h[:, -1:]), axis=1)    # h(q + 1), clipped at +Q
+        down = np.concatenate((h[:, :1], h[:, :-1]), axis=1)  # h(q - 1), clipped at -Q
+        bid = 1 / self.kappa - up + h + self.large_depth * (up == h)
+        ask = 1 / self.kappa - down + h + self.large_depth * (down == h)
+        return np.stack((bid, ask), axis=2)
+
+    def get_action(self, state: np.ndarray) -> np.ndarray:
+        if self.inventory_neutral:
+            return self.risk_neutral_action
+        assert state[0, TIME_INDEX] == state[-1, TIME_INDEX], "CarteaJaimungalMmAgent needs a uniform time stamp."
+        k = int(np.clip(np.rint(state[0, TIME_INDEX] / self.env.step_size), 0, self.env.n_steps))
+        cols = np.clip(self.max_inventory + state[:, INVENTORY_INDEX], 0, 2 * self.max_inventory).astype(int)
+        return self.depth_table()[k, cols].astype(np.float32)
+
+    def calculate_true_value_function(self, state: np.ndarray) -> np.ndarray:
+        """h(t, q) + cash + q S: the closed-form value the Monte-Carlo mean of the total reward must match."""
+        h_t = self._calculate_ht(float(state[0, TIME_INDEX]))[::-1, 0]
+        cols = np.clip(self.max_inventory + state[:, INVENTORY_INDEX], 0, 2 * self.max_inventory).astype(int)
+        return h_t[cols] + state[:, CASH_INDEX] + state[:, INVENTORY_INDEX] * state[:, ASSET_PRICE_INDEX]
+
+    def device_policy(self) -> _native.MbtPolicy:
+        if self.inventory_neutral:
+            pol = _native.MbtPolicy(kind=_native.POLICY_FIXED)
+            pol.params[0] = pol.params[1] = 1 / self.kappa
+            return pol
+        return _native.table_policy(self.depth_table(), self.max_inventory)

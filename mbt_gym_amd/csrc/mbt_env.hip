@@ -145,6 +145,8 @@ struct mbt_env {
   double* wave_sums = nullptr;
   unsigned long long* clip_count = nullptr;
   double* reduce_out = nullptr;
+  float* policy_table = nullptr;  // device copy of a tabulated policy
+  size_t policy_table_floats = 0;
   // host clock (the reference keeps it in state[:, TIME])
   double time = 0.0, start_time = 0.0;
   uint32_t episode_step = 0, philox_step = 0;
@@ -265,6 +267,26 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
     R.policy = mbt::kPolicyAvellanedaStoikov;
     R.as_c1 = static_cast<float>(g * s2);
     R.as_c2 = static_cast<float>(g == 0.0 ? 2.0 / k : 2.0 / g * std::log(1.0 + g / k));  // BaselineAgents.py:74-79
+  } else if (policy->kind == MBT_POLICY_TIME_INVENTORY_TABLE) {
+    if (e->cfg.normalise_action) return fail(MBT_ERR_INVALID, "tabulated policies hold raw depths: needs normalise_action_space=False");
+    if (e->cfg.dynamics_kind != MBT_DYN_LIMIT) return fail(MBT_ERR_INVALID, "tabulated policies quote two depths (limit-order dynamics)");
+    if (policy->table == nullptr || policy->table_rows == 0 || policy->table_cols == 0) return fail(MBT_ERR_INVALID, "empty policy table");
+    const size_t floats = size_t(policy->table_rows) * policy->table_cols * 2;
+    if (floats > e->policy_table_floats) {
+      if (e->policy_table != nullptr) (void)hipFree(e->policy_table);
+      e->policy_table = nullptr;
+      e->policy_table_floats = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->policy_table), floats * sizeof(float)));
+      e->policy_table_floats = floats;
+    }
+    HIP_TRY(hipMemcpyAsync(e->policy_table, policy->table, floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the caller may free its table after the call
+    R.policy = mbt::kPolicyTable;
+    R.table = reinterpret_cast<const float2*>(e->policy_table);
+    R.table_rows = policy->table_rows;
+    R.table_cols = policy->table_cols;
+    R.table_q_offset = policy->table_q_offset;
+    R.table_row0 = static_cast<uint32_t>(std::llround(e->time / e->dt));
   } else {
     return fail(MBT_ERR_INVALID, "unknown policy kind %d", policy->kind);
   }
@@ -448,7 +470,8 @@ void mbt_env_destroy(mbt_env* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
   void* bufs[] = {e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
-                  e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out};
+                  e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
+                  e->policy_table};
   for (void* b : bufs)
     if (b != nullptr) (void)hipFree(b);
   if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);

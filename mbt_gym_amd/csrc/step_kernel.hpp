@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
 // rollout is bit-identical to the equivalent sequence of step() calls.  The caller's per-time-step Python loop
 // (generate_trajectory.py:21-34) disappears; HBM is touched only to record the trajectory (optional, time-major
 // so that every store is a coalesced float4) and once at the end for the final state.
-enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1 };
+enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1, kPolicyTable = 2 };
 
 struct RolloutParams {
   uint32_t n_steps;        // env-steps to run in this launch
@@ -440,6 +440,9 @@ struct RolloutParams {
   int32_t policy;
   float action[4];         // kPolicyFixed: the constant action (FixedActionAgent / FixedSpreadAgent, AG:25-42)
   float as_c1, as_c2;      // kPolicyAvellanedaStoikov: gamma sigma^2 and (2/gamma) ln(1 + gamma/kappa) (AG:70-83)
+  const float2* table;     // kPolicyTable: (rows, cols) of (bid, ask) depths, device memory
+  uint32_t table_row0, table_rows, table_cols;  // row of the first step of this launch
+  int32_t table_q_offset;
   float* obs_traj;         // (n_steps + 1, n_pad, D) or nullptr; row 0 is the observation before the first step
   float* act_traj;         // (n_steps, n_pad, A) or nullptr
   float* rew_traj;         // (n_steps, n_pad) or nullptr
@@ -477,6 +480,14 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       float4 act0, act1;
       if (R.policy == kPolicyFixed) {
         act0 = act1 = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
+      } else if (R.policy == kPolicyTable) {  // quotes tabulated over (time step, inventory), e.g. Cartea-Jaimungal
+        const uint32_t row = min(R.table_row0 + k, R.table_rows - 1u);
+        const int c0 = min(max(static_cast<int>(core0.y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
+        const int c1 = min(max(static_cast<int>(core1.y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
+        const float2 d0 = R.table[static_cast<size_t>(row) * R.table_cols + c0];
+        const float2 d1 = R.table[static_cast<size_t>(row) * R.table_cols + c1];
+        act0 = make_float4(d0.x, d0.y, 0.f, 0.f);
+        act1 = make_float4(d1.x, d1.y, 0.f, 0.f);
       } else {  // Avellaneda-Stoikov quotes from (inventory, time) of the current observation
         const float tau = static_cast<float>(R.terminal_time - t);
         const float half = 0.5f * (R.as_c1 * tau + R.as_c2);

@@ -16,19 +16,6 @@ from tests.env_factory import make_env
 from tests.golden_io import CASES, load_case
 
 
-@pytest.fixture()
-def no_device(monkeypatch):
-    resets = []
-    monkeypatch.setattr(TradingEnvironment, "_create_handle", lambda self, n, scale, offset=None: None)
-
-    def fake_reset(self, obs_out=None):
-        resets.append((self._get_start_time(), self._get_initial_inventories()))
-
-    monkeypatch.setattr(TradingEnvironment, "_reset_device", fake_reset)
-    monkeypatch.setattr(TradingEnvironment, "close", lambda self: None)
-    return resets
-
-
 @pytest.mark.parametrize("name", CASES)
 def test_spaces_bounds_and_columns_match_the_reference(name, no_device):
     cfg, g = load_case(name)
