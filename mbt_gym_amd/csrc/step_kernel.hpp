@@ -261,6 +261,19 @@ __device__ __forceinline__ void write_obs_row(float* obs, uint32_t lane, int dim
   }
 }
 
+// (x - lo) / grad - 1 per column (TE:112-118), float32 division like the reference's float arithmetic on Box bounds
+__device__ __forceinline__ void normalise_row(float4& core, float2& lam, int dim, const StepParams& P) {
+  if (!P.norm_obs) return;
+  core.x = (core.x - P.obs_lo[0]) / P.obs_grad[0] - 1.0f;
+  core.y = (core.y - P.obs_lo[1]) / P.obs_grad[1] - 1.0f;
+  core.z = (core.z - P.obs_lo[2]) / P.obs_grad[2] - 1.0f;
+  core.w = (core.w - P.obs_lo[3]) / P.obs_grad[3] - 1.0f;
+  if (dim == 6) {
+    lam.x = (lam.x - P.obs_lo[4]) / P.obs_grad[4] - 1.0f;
+    lam.y = (lam.y - P.obs_lo[5]) / P.obs_grad[5] - 1.0f;
+  }
+}
+
 // Everything one pair of trajectories reads from HBM.
 template <class V>
 struct PairLoads {
@@ -356,6 +369,15 @@ __device__ __forceinline__ void store_rows(float* base, uint32_t pair, const flo
   }
 }
 
+// normalised observation rows of a pair, as full-width vector stores
+template <class V>
+__device__ __forceinline__ void store_obs_rows(float* base, uint32_t pair, float4 core0, float2 lam0, float4 core1, float2 lam1,
+                                               const StepParams& P) {
+  normalise_row(core0, lam0, V::DIM, P);
+  normalise_row(core1, lam1, V::DIM, P);
+  store_rows<V>(base, pair, core0, lam0, core1, lam1);
+}
+
 // Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
 template <class V>
 __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
@@ -382,10 +404,7 @@ __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepPar
   const bool second = lane0 + 1 < P.n;  // the pad lane of an odd shard is computed but never reported
 
   // -- optional outputs (wave-uniform branches)
-  if (V::NORM && B.obs != nullptr) {
-    write_obs_row(B.obs, lane0, V::DIM, r0.core, r0.lam, P);
-    write_obs_row(B.obs, lane0 + 1, V::DIM, r1.core, r1.lam, P);
-  }
+  if (V::NORM && B.obs != nullptr) store_obs_rows<V>(B.obs, pair, r0.core, r0.lam, r1.core, r1.lam, P);
   if (B.events != nullptr) {
     reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
   }
@@ -468,8 +487,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     double t = R.t_start;
     if (R.obs_traj != nullptr) {
       if (V::NORM) {
-        write_obs_row(R.obs_traj, lane0, V::DIM, core0, lam0, P);
-        write_obs_row(R.obs_traj, lane0 + 1, V::DIM, core1, lam1, P);
+        store_obs_rows<V>(R.obs_traj, pair, core0, lam0, core1, lam1, P);
       } else {
         store_rows<V>(R.obs_traj, pair, core0, lam0, core1, lam1);
       }
@@ -506,8 +524,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       if (R.obs_traj != nullptr) {
         float* dst = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
         if (V::NORM) {
-          write_obs_row(dst, lane0, V::DIM, core0, lam0, P);
-          write_obs_row(dst, lane0 + 1, V::DIM, core1, lam1, P);
+          store_obs_rows<V>(dst, pair, core0, lam0, core1, lam1, P);
         } else {
           store_rows<V>(dst, pair, core0, lam0, core1, lam1);
         }
@@ -528,10 +545,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       }
     }
     store_rows<V>(B.state_out, pair, core0, lam0, core1, lam1);
-    if (V::NORM && B.obs != nullptr) {
-      write_obs_row(B.obs, lane0, V::DIM, core0, lam0, P);
-      write_obs_row(B.obs, lane0 + 1, V::DIM, core1, lam1, P);
-    }
+    if (V::NORM && B.obs != nullptr) store_obs_rows<V>(B.obs, pair, core0, lam0, core1, lam1, P);
     if (B.lane_returns != nullptr) {
       float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
       acc.x += ret0;

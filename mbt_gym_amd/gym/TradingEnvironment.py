@@ -446,9 +446,32 @@ class TradingEnvironment(_EnvBase):
     def step_size(self):
         return self._step_size
 
+    @step_size.setter
+    def step_size(self, step_size: float):
+        # TE:158-167 lets step_size drift away from terminal_time / n_steps; the device clock is defined by
+        # (terminal_time, n_steps), so only a consistent value is accepted
+        if abs(step_size - self.terminal_time / self.n_steps) > 1e-15:
+            raise ValueError("step_size is terminal_time / n_steps on the device; construct a new environment to change it")
+
     @property
     def num_trajectories(self):
         return self._num_trajectories
+
+    @num_trajectories.setter
+    def num_trajectories(self, num_trajectories: int):
+        """Resize the batch (TE:173-178): propagates to the processes and re-allocates the device state."""
+        if getattr(self, "_handle", None) is None:
+            self._num_trajectories = num_trajectories
+            return
+        self.close()
+        self._num_trajectories = num_trajectories
+        self.model_dynamics.num_trajectories = num_trajectories
+        for proc in self.stochastic_processes.values():
+            proc.num_trajectories = num_trajectories
+        self._empty_infos = None
+        self._handle = self._create_handle(num_trajectories, self.reward_scaling)
+        self._last_events, self._events_on = None, False
+        self._reset_device()
 
     @property
     def observation_dim(self) -> int:

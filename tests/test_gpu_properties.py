@@ -116,3 +116,29 @@ def test_avellaneda_stoikov_statistics_agree_with_the_published_table(gamma):
     assert q_t.mean() == pytest.approx(mean_q, abs=4 * std_q * se)
     assert q_t.std() == pytest.approx(std_q, rel=4 * se)
     env.close()
+
+
+def test_normalise_rewards_scale_and_batch_resize():
+    """normalise_rewards=True (TE:90-94, TE:329-343): rewards are divided by the mean episode return of the constant
+    quote 1/kappa, estimated on the device over 100k lanes - compared here with the exact expectation; and the
+    num_trajectories setter (TE:173-178) re-allocates the device state."""
+    from oracle.expected_return import expected_episode_return
+
+    cfg = _as_cfg(64, n_steps=200, max_inventory=200)
+    env = make_env(cfg, normalise_rewards=True)
+    exact, _ = expected_episode_return(cfg, lambda k, q: (np.full(q.size, 1 / 1.5), np.full(q.size, 1 / 1.5)))
+    assert 1 / env.reward_scaling == pytest.approx(exact, rel=0.01)
+    plain = make_env(cfg)
+    action = np.tile(np.array([[0.5, 0.5]], np.float32), (64, 1))
+    env.reset(), plain.reset()
+    _, r_scaled, _, _ = env.step(action)
+    _, r_plain, _, _ = plain.step(action)
+    np.testing.assert_allclose(r_scaled, r_plain * np.float32(env.reward_scaling), rtol=2e-7, atol=1e-9)
+    plain.num_trajectories = 1000
+    assert plain.reset().shape == (1000, 4) and plain.model_dynamics.midprice_model.num_trajectories == 1000
+    obs, rew, dones, infos = plain.step(np.tile(np.array([[0.5, 0.5]], np.float32), (1000, 1)))
+    assert obs.shape == (1000, 4) and rew.shape == (1000,) and len(infos) == 1000
+    with pytest.raises(ValueError):
+        plain.step_size = 0.1
+    env.close()
+    plain.close()

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Step-kernel timing of every BASELINE.json config at its own size (parity-test cases, not bench lines):
+algorithmic GB/s = 4*(D + A + D + 1) bytes x lanes / mean launch-to-launch time (HIP events)."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from mbt_gym_amd import _native  # noqa: E402
+from oracle.mbt_oracle import OracleConfig  # noqa: E402
+from tests.env_factory import make_env  # noqa: E402
+
+BASE = dict(n_steps=1000, terminal_time=1.0, volatility=2.0, initial_price=100.0, fill_exponent=1.5, initial_inventory=0,
+            max_inventory=1000, seed=50, normalise_action_space=False, normalise_observation_space=False)
+CASES = {
+    "cfg1 AS 2^20 (D=4,A=2,44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="pnl"), 20, [0.7, 0.7]),
+    "cfg2 CJP cjmm 2^20 (44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="cjmm", phi=0.01, alpha=0.001, max_inventory=100), 20, [0.7, 0.7]),
+    "cfg2 CJP running 2^20 (44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="running", phi=0.01, alpha=0.001, max_inventory=100), 20, [0.7, 0.7]),
+    "cfg3 Hawkes+OU 2^22 (D=6,60B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7]),
+    "cfg4 limit+market 2^21 (A=4,52B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), dynamics="limit_and_market", reward="pnl", initial_inventory=10), 21, [0.7, 0.7, 0.0, 1.0]),
+    "default normalised 2^20 (60B incl. obs)": (dict(midprice="bm", arrival="poisson", intensity=(100.0, 100.0), reward="pnl", normalise_action_space=True, normalise_observation_space=True, max_inventory=10000), 20, [-0.5, -0.5]),
+}
+
+
+def main():
+    lib = _native.load_library()
+    out = {}
+    for name, (kw, log2n, action) in CASES.items():
+        n = 1 << log2n
+        cfg = OracleConfig(**{**BASE, **kw, "num_trajectories": n})
+        env = make_env(cfg)
+        env.set_action_host(np.tile(np.array([action], np.float32), (n, 1)))
+        env.reset()
+        for _ in range(50):
+            env.step_device()
+        env.synchronize()
+        steps = 400
+        _native.check(lib.mbt_env_timer_begin(env._handle))
+        for _ in range(steps):
+            env.step_device()
+        ms = C.c_float(0)
+        _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
+        us = ms.value * 1e3 / steps
+        d, a = env.observation_dim, env.action_dim
+        bytes_step = 4 * (d + a + d + 1) + (4 * d if cfg.normalise_observation_space else 0)
+        out[name] = {"us_per_step": round(us, 2), "env_steps_per_s": n / us * 1e6, "algorithmic_GBps": bytes_step * n / us * 1e-3,
+                     "frac_of_8TBps": bytes_step * n / us * 1e-3 / 8000}
+        env.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
