@@ -18,7 +18,8 @@
  *     work on the environment's HIP stream and return immediately.
  *   - one host thread per environment handle at a time.
  *   - state rows are float32 [cash, inventory, time, midprice] (index_names.py:1-4); a Hawkes arrival
- *     model adds [bid intensity, ask intensity] (TE:311-318).  Side 0 = bid, 1 = ask (index_names.py:6-7).
+ *     model adds [bid intensity, ask intensity], a price-impact model with state adds [impact] (TE:311-318).
+ *     Side 0 = bid, 1 = ask (index_names.py:6-7).
  *   - there is NO CPU fallback: without a gfx950 device mbt_env_create fails with MBT_ERR_NO_DEVICE.
  */
 #ifndef MBT_ENV_H
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 1u
+#define MBT_ABI_VERSION 2u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -42,12 +43,29 @@ typedef enum mbt_status {
   MBT_ERR_ABI = -5          /* mbt_config.abi_version mismatch */
 } mbt_status;
 
-/* plugin kinds: the reference classes that have a device implementation */
-enum { MBT_MID_BROWNIAN = 0 /* MID:36-68 */, MBT_MID_OU = 1 /* MID:114-146 */ };
-enum { MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */ };
-enum { MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */ };
-enum { MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */ };
-enum { MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */ };
+/* plugin kinds: the reference classes that have a device implementation
+ * (IMP = stochastic_processes/price_impact_models.py) */
+enum {
+  MBT_MID_BROWNIAN = 0 /* MID:36-68 */, MBT_MID_OU = 1 /* MID:114-146 */, MBT_MID_GBM = 2 /* MID:71-111 */,
+  MBT_MID_BROWNIAN_JUMP = 3 /* MID:193-230 */, MBT_MID_OU_JUMP = 4 /* MID:233-273 */, MBT_MID_CONSTANT = 5 /* MID:12-33 */
+};
+enum {
+  MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
+  MBT_ARR_NONE = 3 /* speed dynamics: no order flow (MD:47-48) */
+};
+enum { MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */ };
+enum {
+  MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */, MBT_DYN_AT_THE_TOUCH = 2 /* MD:134-176 */,
+  MBT_DYN_SPEED = 3 /* MD:243-275 */
+};
+enum {
+  MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */,
+  MBT_REW_EXP_UTILITY = 3 /* RW:149-163 */, MBT_REW_CJ_OE = 4 /* RW:39-74, speed dynamics */
+};
+enum {
+  MBT_IMPACT_NONE = -1, MBT_IMPACT_TEMPORARY_POWER = 0 /* IMP:34-61 */, MBT_IMPACT_TEMPORARY_AND_PERMANENT = 1 /* IMP:64-96 */,
+  MBT_IMPACT_TEMPORARY_AND_TRANSIENT = 2 /* IMP:99-139 */, MBT_IMPACT_TRANSIENT = 3 /* IMP:142-179 */
+};
 enum {
   MBT_NOISE_PHILOX = 0,   /* counter-based Philox4x32-10 drawn inside the kernel (production) */
   MBT_NOISE_INJECTED = 1  /* noise supplied by mbt_env_set_noise_* (parity tests vs. the reference) */
@@ -59,7 +77,7 @@ typedef struct mbt_config {
   uint32_t abi_version;        /* MBT_ABI_VERSION */
   int32_t device;              /* HIP device ordinal */
   uint64_t num_trajectories;   /* lanes owned by this handle (TE:41) */
-  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; must be even */
+  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; even (multiple of 4 for speed dynamics) */
   uint32_t n_steps;            /* TE:30 */
   uint32_t reserved0;
   double terminal_time;        /* TE:29; step_size = terminal_time / n_steps (TE:49) */
@@ -88,7 +106,20 @@ typedef struct mbt_config {
   int32_t normalise_observation;             /* TE:44, TE:112-118 */
   int32_t normalise_action;                  /* TE:43, TE:120-126 */
   float obs_lo[8], obs_hi[8];                /* float32 Box bounds (TE:232-241) */
-  float act_lo[4], act_hi[4];                /* float32 Box bounds (MD:118-121, MD:224-231) */
+  float act_lo[4], act_hi[4];                /* float32 Box bounds (MD:118-121, MD:224-231, MD:269-271) */
+
+  /* every process keeps its OWN step_size constructor argument (SP:21) and the environment never synchronises
+   * them; 0 = terminal_time / n_steps */
+  double midprice_step_size;                 /* MID:63-64; also the volume of speed dynamics (MD:265) */
+  double arrival_step_size;                  /* ARR:56, ARR:83, ARR:115-123 */
+  double jump_size;                          /* MID:199, MID:240 */
+  double risk_aversion;                      /* RW:150 */
+  int32_t impact_kind;                       /* MBT_IMPACT_* (speed dynamics) */
+  int32_t reserved1;
+  double temporary_impact, impact_exponent;  /* IMP:37-38 */
+  double permanent_impact;                   /* IMP:68 */
+  double transient_impact, resilience, initial_transient_impact, kernel_coefficient; /* IMP:103-106 */
+  double impact_step_size;                   /* IMP:75: the impact model's own terminal_time / n_steps; 0 = env's */
 } mbt_config;
 
 typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
@@ -142,10 +173,12 @@ int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done)
 enum {
   MBT_POLICY_FIXED = 0,               /* params[0..A) = the action every lane takes every step (agents/BaselineAgents.py:25-42) */
   MBT_POLICY_AVELLANEDA_STOIKOV = 1,  /* params[0] = risk aversion gamma (agents/BaselineAgents.py:52-83); needs un-normalised actions */
-  MBT_POLICY_TIME_INVENTORY_TABLE = 2 /* (bid, ask) depths looked up by (time step, inventory): any policy that is a function
+  MBT_POLICY_TIME_INVENTORY_TABLE = 2, /* (bid, ask) depths looked up by (time step, inventory): any policy that is a function
                                          of (t, q) tabulated by the host, e.g. the Cartea-Jaimungal optimal quotes
                                          (agents/BaselineAgents.py:86-170).  table[(row * table_cols + col) * 2 + side], host
                                          memory, row = round(t / dt), col = clamp(q + table_q_offset, 0, table_cols - 1) */
+  MBT_POLICY_TIME_TABLE = 3           /* open-loop schedule: table[row * A + j], row = round(t / dt), table_cols = A; e.g. the
+                                         Cartea-Jaimungal optimal-execution speed (agents/BaselineAgents.py:173-210) */
 };
 typedef struct mbt_policy {
   int32_t kind;
@@ -165,7 +198,8 @@ int mbt_env_rollout_host(mbt_env* env, const mbt_policy* policy, uint32_t max_st
 uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to even: lanes per time slice of device trajectories */
 
 /* ---- injected noise (parity mode; replaces the three numpy Generators of SP:27) ---------------- */
-/* u_arr, u_fill: (N, 2) float32 in [0, 1); z: (N) float32.  Consumed by the next step. */
+/* u_arr, u_fill: (N, 2) float32 in [0, 1) (ignored, may be NULL, for speed dynamics); z: (N) float32.
+ * Consumed by the next step. */
 int mbt_env_set_noise_host(mbt_env* env, const float* u_arr, const float* u_fill, const float* z);
 
 /* ---- device buffers (zero-copy consumers) ------------------------------------------------------ */
@@ -202,18 +236,21 @@ int mbt_env_track_lane_returns(mbt_env* env, int enabled);
 int mbt_env_return_sums(mbt_env* env, double sums[3]);
 
 /* ---- RewardFunction.calculate on caller-supplied matrices (RW:23-33, RW:96-109, RW:128-138) ---------------------
- * cur, nxt: (n, dim) row-major float64 state matrices; q_init, episode_length: (n) float64, only for MBT_REW_CJ_MM
- * (what CjMmCriterion.reset captured, RW:111-113); out: (n) float64.  Evaluated on the device in double, in the
+ * cur, nxt: (n, dim) row-major float64 state matrices; q_init, episode_length: (n) float64, only for MBT_REW_CJ_MM /
+ * MBT_REW_CJ_OE (what their reset() captured, RW:72-74, RW:111-113); out: (n) float64.  Evaluated on the device in double, in the
  * reference's order of operations. */
 int mbt_reward_calculate_host(int device, int reward_kind, double phi, double alpha, double inventory_exponent,
                               const double* cur, const double* nxt, int dim, uint64_t n, int is_terminal,
-                              const double* q_init, const double* episode_length, double* out);
+                              const double* q_init, const double* episode_length, const double* action /* (n), CJ_OE */,
+                              double risk_aversion /* EXP_UTILITY */, double* out);
 
 /* ---- the generator itself (so tests can pin it) ------------------------------------------------ */
 /* Writes the noise lane ids [trajectory_offset, trajectory_offset + n) would draw at philox step `step`
  * under `seed` into host arrays (any may be NULL): u_arr (n,2), u_fill (n,2), z (n). */
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n,
                       float* u_arr, float* u_fill, float* z);
+/* Same for the speed-dynamics stream (one normal per lane, drawn per quad of lanes): z (n); offset multiple of 4. */
+int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z);
 /* Raw Philox4x32-10 block function on the device: out[4] = philox(ctr[4], key[2]) (known-answer tests). */
 int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -9,13 +9,14 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-MID_BROWNIAN, MID_OU = 0, 1
-ARR_POISSON, ARR_HAWKES = 0, 1
-FILL_EXPONENTIAL = 0
-DYN_LIMIT, DYN_LIMIT_AND_MARKET = 0, 1
-REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM = 0, 1, 2
+MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT = 0, 1, 2, 3, 4, 5
+ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE = 0, 1, 2, 3
+FILL_EXPONENTIAL, FILL_NONE = 0, 1
+DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
+REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE = 0, 1, 2, 3, 4
+IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT = -1, 0, 1, 2, 3
 NOISE_PHILOX, NOISE_INJECTED = 0, 1
 
 
@@ -41,10 +42,16 @@ class MbtConfig(C.Structure):
         ("normalise_observation", C.c_int32), ("normalise_action", C.c_int32),
         ("obs_lo", C.c_float * 8), ("obs_hi", C.c_float * 8),
         ("act_lo", C.c_float * 4), ("act_hi", C.c_float * 4),
+        ("midprice_step_size", C.c_double), ("arrival_step_size", C.c_double),
+        ("jump_size", C.c_double), ("risk_aversion", C.c_double),
+        ("impact_kind", C.c_int32), ("reserved1", C.c_int32),
+        ("temporary_impact", C.c_double), ("impact_exponent", C.c_double), ("permanent_impact", C.c_double),
+        ("transient_impact", C.c_double), ("resilience", C.c_double), ("initial_transient_impact", C.c_double),
+        ("kernel_coefficient", C.c_double), ("impact_step_size", C.c_double),
     ]
 
 
-POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE = 0, 1, 2
+POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE = 0, 1, 2, 3
 
 
 class MbtPolicy(C.Structure):
@@ -61,6 +68,15 @@ def table_policy(table: np.ndarray, q_offset: int) -> MbtPolicy:
     assert arr.ndim == 3 and arr.shape[2] == 2
     pol = MbtPolicy(kind=POLICY_TIME_INVENTORY_TABLE, table=arr.ctypes.data_as(C.POINTER(C.c_float)),
                     table_rows=arr.shape[0], table_cols=arr.shape[1], table_q_offset=int(q_offset))
+    pol._keepalive = arr
+    return pol
+
+
+def schedule_policy(schedule: np.ndarray) -> MbtPolicy:
+    """(rows = time steps, A) float32 open-loop actions -> policy descriptor (keeps the array alive)."""
+    arr = np.ascontiguousarray(schedule, dtype=np.float32)
+    assert arr.ndim == 2
+    pol = MbtPolicy(kind=POLICY_TIME_TABLE, table=arr.ctypes.data_as(C.POINTER(C.c_float)), table_rows=arr.shape[0], table_cols=arr.shape[1])
     pol._keepalive = arr
     return pol
 
@@ -114,8 +130,9 @@ SIGNATURES = {
     "mbt_env_return_sums": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
-                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),
     "mbt_rng_fill_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F, _F, _F]),
+    "mbt_rng_fill_quad_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F]),
     "mbt_philox4x32_10_host": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_timer_begin": (C.c_int, [_ENV]),
     "mbt_env_timer_end": (C.c_int, [_ENV, C.POINTER(C.c_float)]),
@@ -200,7 +217,8 @@ class DeviceView:
         return {"shape": self.shape, "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
 
 
-def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_terminal, q_init=None, episode_length=None, device=0):
+def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_terminal, q_init=None, episode_length=None,
+                     action=None, risk_aversion=0.0, device=0):
     """RewardFunction.calculate on float64 state matrices, evaluated on the device (mbt_reward_calculate_host)."""
     cur = np.ascontiguousarray(current_state, dtype=np.float64)
     nxt = np.ascontiguousarray(next_state, dtype=np.float64)
@@ -209,9 +227,11 @@ def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_t
     out = np.empty((n,), dtype=np.float64)
     dptr = lambda a: None if a is None else np.ascontiguousarray(np.broadcast_to(a, (n,)), dtype=np.float64)  # noqa: E731
     qi, ln = dptr(q_init), dptr(episode_length)
+    act = None if action is None else dptr(np.squeeze(np.asarray(action, dtype=np.float64)))
     as_p = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
     check(load_library().mbt_reward_calculate_host(device, kind, float(phi), float(alpha), float(exponent), as_p(cur), as_p(nxt),
-                                                   dim, n, int(bool(is_terminal)), as_p(qi), as_p(ln), as_p(out)))
+                                                   dim, n, int(bool(is_terminal)), as_p(qi), as_p(ln), as_p(act), float(risk_aversion),
+                                                   as_p(out)))
     return out
 
 
@@ -232,6 +252,13 @@ def philox4x32_10(ctr, key, device=0):
     out = (C.c_uint32 * 4)()
     check(lib.mbt_philox4x32_10_host(device, c, k, out))
     return [int(x) for x in out]
+
+
+def rng_fill_quad(seed, trajectory_offset, step, n, device=0):
+    """The normals lanes [offset, offset+n) of a speed-dynamics environment draw at one step."""
+    z = np.empty((n,), np.float32)
+    check(load_library().mbt_rng_fill_quad_host(device, int(seed), int(trajectory_offset), int(step), int(n), fptr(z)))
+    return z
 
 
 def rng_fill(seed, trajectory_offset, step, n, device=0):

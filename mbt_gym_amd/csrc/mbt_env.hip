@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/mbt_env.h"
+#include "speed_kernel.hpp"
 #include "step_kernel.hpp"
 
 namespace {
@@ -58,66 +59,66 @@ float round_up_f32(double x) {
 
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 
-// 2 x 2 x 2 x 3 x 2 x 2 = 96 instantiations: one lean kernel per plugin combination.
-template <int MID, int ARR, int DYN, int REW>
+// Limit-order-book family: arrivals {Poisson, Hawkes} x dynamics {limit, limit+market, touch} x {Brownian, other
+// midprice} x {PnL, other reward} x normalised x noise = 96 step kernels and 48 rollout kernels; WHICH other midprice
+// and reward are runtime parameters inside them.
+template <int ARR, int DYN, bool BM, bool PEN>
 StepKernel pick_flags(bool norm, bool inject) {
-  if (norm) return inject ? mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, true, true>>
-                          : mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, true, false>>;
-  return inject ? mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, false, true>>
-                : mbt::step_kernel<mbt::Variant<MID, ARR, DYN, REW, false, false>>;
+  if (norm) return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, true, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, true, false>>;
+  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, false, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, false, false>>;
 }
-template <int MID, int ARR, int DYN>
-StepKernel pick_rew(int rew, bool norm, bool inject) {
-  switch (rew) {
-    case MBT_REW_PNL: return pick_flags<MID, ARR, DYN, mbt::kRewPnl>(norm, inject);
-    case MBT_REW_RUNNING_PENALTY: return pick_flags<MID, ARR, DYN, mbt::kRewRunning>(norm, inject);
-    default: return pick_flags<MID, ARR, DYN, mbt::kRewCjMm>(norm, inject);
+template <int ARR, int DYN>
+StepKernel pick_pen(bool bm, bool pen, bool norm, bool inject) {
+  if (bm) return pen ? pick_flags<ARR, DYN, true, true>(norm, inject) : pick_flags<ARR, DYN, true, false>(norm, inject);
+  return pen ? pick_flags<ARR, DYN, false, true>(norm, inject) : pick_flags<ARR, DYN, false, false>(norm, inject);
+}
+template <int ARR>
+StepKernel pick_dyn(int dyn, bool bm, bool pen, bool norm, bool inject) {
+  switch (dyn) {
+    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, pen, norm, inject);
+    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, pen, norm, inject);
+    default: return pick_pen<ARR, mbt::kDynTouch>(bm, pen, norm, inject);
   }
 }
-template <int MID, int ARR>
-StepKernel pick_dyn(int dyn, int rew, bool norm, bool inject) {
-  return dyn == MBT_DYN_LIMIT ? pick_rew<MID, ARR, mbt::kDynLimit>(rew, norm, inject)
-                              : pick_rew<MID, ARR, mbt::kDynLimitAndMarket>(rew, norm, inject);
+template <bool STATE>
+StepKernel pick_speed(bool norm, bool inject) {
+  if (norm) return inject ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>>;
+  return inject ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>>;
 }
-template <int MID>
-StepKernel pick_arr(int arr, int dyn, int rew, bool norm, bool inject) {
-  return arr == MBT_ARR_POISSON ? pick_dyn<MID, mbt::kArrPoisson>(dyn, rew, norm, inject)
-                                : pick_dyn<MID, mbt::kArrHawkes>(dyn, rew, norm, inject);
-}
+bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
+
 StepKernel pick_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
-  return c.midprice_kind == MBT_MID_BROWNIAN ? pick_arr<mbt::kMidBrownian>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm, inject)
-                                             : pick_arr<mbt::kMidOu>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm, inject);
+  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject) : pick_speed<false>(norm, inject);
+  const bool pen = c.reward_kind != MBT_REW_PNL, bm = c.midprice_kind == MBT_MID_BROWNIAN;
+  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, pen, norm, inject)
+                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, pen, norm, inject);
 }
 
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
 
-template <int MID, int ARR, int DYN, int REW>
-RolloutKernel rpick_flags(bool norm) {
-  return norm ? mbt::rollout_kernel<mbt::Variant<MID, ARR, DYN, REW, true, false>>
-              : mbt::rollout_kernel<mbt::Variant<MID, ARR, DYN, REW, false, false>>;
+template <int ARR, int DYN, bool BM>
+RolloutKernel rpick_pen(bool pen, bool norm) {
+  if (pen) return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, true, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, true, false, false>>;
+  return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, false, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, false, false, false>>;
 }
-template <int MID, int ARR, int DYN>
-RolloutKernel rpick_rew(int rew, bool norm) {
-  switch (rew) {
-    case MBT_REW_PNL: return rpick_flags<MID, ARR, DYN, mbt::kRewPnl>(norm);
-    case MBT_REW_RUNNING_PENALTY: return rpick_flags<MID, ARR, DYN, mbt::kRewRunning>(norm);
-    default: return rpick_flags<MID, ARR, DYN, mbt::kRewCjMm>(norm);
+template <int ARR>
+RolloutKernel rpick_dyn(int dyn, bool bm, bool pen, bool norm) {
+  switch (dyn) {
+    case MBT_DYN_LIMIT: return bm ? rpick_pen<ARR, mbt::kDynLimit, true>(pen, norm) : rpick_pen<ARR, mbt::kDynLimit, false>(pen, norm);
+    case MBT_DYN_LIMIT_AND_MARKET: return bm ? rpick_pen<ARR, mbt::kDynLimitAndMarket, true>(pen, norm) : rpick_pen<ARR, mbt::kDynLimitAndMarket, false>(pen, norm);
+    default: return bm ? rpick_pen<ARR, mbt::kDynTouch, true>(pen, norm) : rpick_pen<ARR, mbt::kDynTouch, false>(pen, norm);
   }
-}
-template <int MID, int ARR>
-RolloutKernel rpick_dyn(int dyn, int rew, bool norm) {
-  return dyn == MBT_DYN_LIMIT ? rpick_rew<MID, ARR, mbt::kDynLimit>(rew, norm) : rpick_rew<MID, ARR, mbt::kDynLimitAndMarket>(rew, norm);
-}
-template <int MID>
-RolloutKernel rpick_arr(int arr, int dyn, int rew, bool norm) {
-  return arr == MBT_ARR_POISSON ? rpick_dyn<MID, mbt::kArrPoisson>(dyn, rew, norm) : rpick_dyn<MID, mbt::kArrHawkes>(dyn, rew, norm);
 }
 RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
-  return c.midprice_kind == MBT_MID_BROWNIAN ? rpick_arr<mbt::kMidBrownian>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm)
-                                             : rpick_arr<mbt::kMidOu>(c.arrival_kind, c.dynamics_kind, c.reward_kind, norm);
+  if (c.dynamics_kind == MBT_DYN_SPEED) {
+    if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
+    return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
+  }
+  const bool pen = c.reward_kind != MBT_REW_PNL, bm = c.midprice_kind == MBT_MID_BROWNIAN;
+  return c.arrival_kind == MBT_ARR_HAWKES ? rpick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, pen, norm) : rpick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, pen, norm);
 }
 
 }  // namespace
@@ -126,7 +127,8 @@ struct mbt_env {
   mbt_config cfg;
   int dim = 4, act_dim = 2;
   uint32_t n = 0, n_pad = 0, n_pairs = 0, n_blocks = 0, n_waves = 0;
-  double dt = 0.0;
+  bool speed = false;        // trading-with-speed family: one thread per QUAD of lanes, else one per PAIR
+  double dt = 0.0, mid_dt = 0.0, arr_dt = 0.0, imp_dt = 0.0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -168,27 +170,51 @@ void fill_static_params(mbt_env* e) {
   P.n_pairs = e->n_pairs;
   P.pair_offset = c.trajectory_offset >> 1;
   P.dt = static_cast<float>(e->dt);
-  P.drift_dt = static_cast<float>(c.drift * e->dt);
-  P.vol_sqrt_dt = static_cast<float>(c.volatility * std::sqrt(e->dt));
-  P.ou_speed = static_cast<float>(c.ou_speed);
-  P.ou_level = static_cast<float>(c.ou_level);
-  P.arr_thr_bid = round_up_f32(c.intensity[0] * e->dt);
-  P.arr_thr_ask = round_up_f32(c.intensity[1] * e->dt);
-  P.dt_f64 = e->dt;
+  // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
+  const int mk = c.midprice_kind;
+  const bool ou = mk == MBT_MID_OU || mk == MBT_MID_OU_JUMP, jump = mk == MBT_MID_BROWNIAN_JUMP || mk == MBT_MID_OU_JUMP;
+  P.mid_add = (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0f : 1.0f;
+  P.mid_mul = mk == MBT_MID_GBM ? 1.0f : 0.0f;
+  P.drift_dt = (ou || mk == MBT_MID_CONSTANT) ? 0.0f : static_cast<float>(c.drift * e->mid_dt);
+  P.vol_sqrt_dt = mk == MBT_MID_CONSTANT ? 0.0f : static_cast<float>(c.volatility * std::sqrt(e->mid_dt));
+  P.ou_speed = ou ? static_cast<float>(c.ou_speed) : 0.0f;
+  P.ou_level = ou ? static_cast<float>(c.ou_level) : 0.0f;
+  P.jump_size = jump ? static_cast<float>(c.jump_size) : 0.0f;
+  if (c.arrival_kind == MBT_ARR_POISSON_NONLINEAR) {  // ARR:83
+    P.arr_thr_bid = round_up_f32(1.0 - std::exp(-c.intensity[0] * e->arr_dt));
+    P.arr_thr_ask = round_up_f32(1.0 - std::exp(-c.intensity[1] * e->arr_dt));
+  } else {  // ARR:56
+    P.arr_thr_bid = round_up_f32(c.intensity[0] * e->arr_dt);
+    P.arr_thr_ask = round_up_f32(c.intensity[1] * e->arr_dt);
+  }
+  P.arr_dt_f64 = e->arr_dt;
+  P.arr_dt = static_cast<float>(e->arr_dt);
   P.hawkes_base_bid = static_cast<float>(c.intensity[0]);
   P.hawkes_base_ask = static_cast<float>(c.intensity[1]);
   P.hawkes_speed = static_cast<float>(c.hawkes_speed);
   P.hawkes_jump = static_cast<float>(c.hawkes_jump);
-  P.kappa = static_cast<float>(c.fill_exponent);
+  P.kappa_log2e_neg = static_cast<float>(-c.fill_exponent * 1.4426950408889634);
   P.kappa_f64 = c.fill_exponent;
   P.half_spread = static_cast<float>(c.market_half_spread);
   P.q_max = static_cast<float>(c.max_inventory);
   P.c_max = static_cast<float>(c.max_cash);
+  P.reward_kind = c.reward_kind;
   P.exponent_is_two = c.inventory_exponent == 2.0 ? 1 : 0;
   P.phi = static_cast<float>(c.phi);
   P.alpha = static_cast<float>(c.alpha);
   P.exponent = static_cast<float>(c.inventory_exponent);
+  P.risk_aversion = static_cast<float>(c.risk_aversion);
   P.reward_scale = static_cast<float>(c.reward_scale);
+  P.impact_kind = c.impact_kind;
+  P.impact_exponent_is_one = c.impact_exponent == 1.0 ? 1 : 0;
+  P.speed_dt = static_cast<float>(e->mid_dt);
+  P.impact_dt = static_cast<float>(e->imp_dt);
+  P.temp_coef = static_cast<float>(c.temporary_impact);
+  P.impact_exponent = static_cast<float>(c.impact_exponent);
+  P.perm_coef = static_cast<float>(c.permanent_impact);
+  P.trans_coef = static_cast<float>(c.transient_impact);
+  P.resilience = static_cast<float>(c.resilience);
+  P.kernel_coef = static_cast<float>(c.kernel_coefficient);
   P.norm_act = c.normalise_action;
   P.norm_obs = c.normalise_observation;
   for (int j = 0; j < 4; ++j) {
@@ -260,6 +286,26 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   if (policy->kind == MBT_POLICY_FIXED) {
     R.policy = mbt::kPolicyFixed;
     for (int j = 0; j < e->act_dim; ++j) R.action[j] = static_cast<float>(policy->params[j]);
+  } else if (policy->kind == MBT_POLICY_TIME_TABLE) {
+    if (policy->table == nullptr || policy->table_rows == 0 || policy->table_cols != static_cast<uint32_t>(e->act_dim))
+      return fail(MBT_ERR_INVALID, "a time-table policy holds table_rows x action_dim (%d) floats", e->act_dim);
+    const size_t floats = size_t(policy->table_rows) * policy->table_cols;
+    if (floats > e->policy_table_floats) {
+      if (e->policy_table != nullptr) (void)hipFree(e->policy_table);
+      e->policy_table = nullptr;
+      e->policy_table_floats = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->policy_table), floats * sizeof(float)));
+      e->policy_table_floats = floats;
+    }
+    HIP_TRY(hipMemcpyAsync(e->policy_table, policy->table, floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    R.policy = mbt::kPolicyTimeTable;
+    R.table = reinterpret_cast<const float2*>(e->policy_table);
+    R.table_rows = policy->table_rows;
+    R.table_cols = policy->table_cols;
+    R.table_row0 = static_cast<uint32_t>(std::llround(e->time / e->dt));
+  } else if (e->speed) {
+    return fail(MBT_ERR_INVALID, "speed dynamics support the fixed and time-table policies");
   } else if (policy->kind == MBT_POLICY_AVELLANEDA_STOIKOV) {
     if (e->cfg.normalise_action) return fail(MBT_ERR_INVALID, "the Avellaneda-Stoikov policy needs normalise_action_space=False");
     if (e->cfg.dynamics_kind != MBT_DYN_LIMIT) return fail(MBT_ERR_INVALID, "the Avellaneda-Stoikov policy quotes two depths (limit-order dynamics)");
@@ -340,7 +386,7 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   e->q_init_per_lane = false;
   if (q0_host != nullptr) {
     HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM;
+    e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM || c.reward_kind == MBT_REW_CJ_OE;
   }
   e->time = e->start_time = start_time;
   e->episode_step = 0;
@@ -348,12 +394,16 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   mbt::StepParams& P = e->params;
   P.q_init_scalar = static_cast<float>(c.initial_inventory);
   P.dt_over_episode = static_cast<float>(e->dt / (c.terminal_time - start_time));  // RW:106, RW:113
+  P.episode_length = static_cast<float>(c.terminal_time - start_time);              // RW:67, RW:74
   const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
                      q0_host != nullptr ? e->q_init : nullptr, static_cast<float>(c.initial_inventory),
                      static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
-                     static_cast<float>(c.intensity[0]), static_cast<float>(c.intensity[1]), e->n_pad, e->n_waves, e->dim, P);
+                     // columns 4, 5: Hawkes baselines (ARR:103) or the impact model's initial state (IMP:81, IMP:121)
+                     static_cast<float>(e->speed ? (c.impact_kind == MBT_IMPACT_TEMPORARY_AND_PERMANENT ? 0.0 : c.initial_transient_impact)
+                                                 : c.intensity[0]),
+                     static_cast<float>(c.intensity[1]), e->n_pad, e->n_waves, e->dim, P);
   HIP_TRY(hipGetLastError());
   if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
   e->was_reset = true;
@@ -395,15 +445,32 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
   if (cfg->trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even (noise is drawn per pair)");
   if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
-  if (cfg->midprice_kind != MBT_MID_BROWNIAN && cfg->midprice_kind != MBT_MID_OU)
+  const bool speed = cfg->dynamics_kind == MBT_DYN_SPEED;
+  if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_CONSTANT)
     return fail(MBT_ERR_INVALID, "midprice kind %d has no device implementation", cfg->midprice_kind);
-  if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES)
-    return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation", cfg->arrival_kind);
-  if (cfg->fill_kind != MBT_FILL_EXPONENTIAL) return fail(MBT_ERR_INVALID, "fill kind %d has no device implementation", cfg->fill_kind);
-  if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET)
+  if (cfg->dynamics_kind < MBT_DYN_LIMIT || cfg->dynamics_kind > MBT_DYN_SPEED)
     return fail(MBT_ERR_INVALID, "dynamics kind %d has no device implementation", cfg->dynamics_kind);
-  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_CJ_MM)
+  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_CJ_OE)
     return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", cfg->reward_kind);
+  if (speed) {
+    if (cfg->arrival_kind != MBT_ARR_NONE || cfg->fill_kind != MBT_FILL_NONE)
+      return fail(MBT_ERR_INVALID, "speed dynamics take no arrival or fill model (MD:273-275)");
+    if (cfg->impact_kind < MBT_IMPACT_TEMPORARY_POWER || cfg->impact_kind > MBT_IMPACT_TRANSIENT)
+      return fail(MBT_ERR_INVALID, "speed dynamics need a price impact model (impact kind %d)", cfg->impact_kind);
+    if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP)
+      return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
+    if (cfg->trajectory_offset & 3ull) return fail(MBT_ERR_INVALID, "speed dynamics draw noise per quad: trajectory_offset must be a multiple of 4");
+  } else {
+    if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR)
+      return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
+    if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
+      if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
+    } else if (cfg->fill_kind != MBT_FILL_EXPONENTIAL) {
+      return fail(MBT_ERR_INVALID, "fill kind %d has no device implementation", cfg->fill_kind);
+    }
+    if (cfg->reward_kind == MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the one-dimensional action of speed dynamics (RW:65)");
+    if (cfg->impact_kind != MBT_IMPACT_NONE) return fail(MBT_ERR_INVALID, "price impact models belong to speed dynamics");
+  }
   if (cfg->noise_mode != MBT_NOISE_PHILOX && cfg->noise_mode != MBT_NOISE_INJECTED)
     return fail(MBT_ERR_INVALID, "unknown noise mode %d", cfg->noise_mode);
   int rc = check_device(cfg->device);
@@ -413,14 +480,19 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   mbt_env* e = new (std::nothrow) mbt_env();
   if (e == nullptr) return fail(MBT_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
-  e->dim = cfg->arrival_kind == MBT_ARR_HAWKES ? 6 : 4;
-  e->act_dim = cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2;
+  e->speed = speed;
+  e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : (cfg->arrival_kind == MBT_ARR_HAWKES ? 6 : 4);
+  e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
   e->n = static_cast<uint32_t>(cfg->num_trajectories);
-  e->n_pad = (e->n + 1u) & ~1u;
+  e->n_pad = speed ? ((e->n + 3u) & ~3u) : ((e->n + 1u) & ~1u);  // a thread owns a quad (speed) or a pair of lanes
   e->n_pairs = e->n_pad / 2;
-  e->n_blocks = (e->n_pairs + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
+  const uint32_t n_threads = speed ? e->n_pad / 4 : e->n_pairs;
+  e->n_blocks = (n_threads + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
   e->n_waves = e->n_blocks * (mbt::kBlockThreads / 64);
   e->dt = cfg->terminal_time / cfg->n_steps;  // TE:49
+  e->mid_dt = cfg->midprice_step_size > 0.0 ? cfg->midprice_step_size : e->dt;
+  e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
+  e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
   e->kernel = pick_kernel(*cfg);
   e->rollout = pick_rollout_kernel(*cfg);
@@ -452,8 +524,10 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   ENV_TRY(dev_alloc(&e->action, np * e->act_dim));
   ENV_TRY(dev_alloc(&e->reward, np));
   if (cfg->noise_mode == MBT_NOISE_INJECTED) {
-    ENV_TRY(dev_alloc(&e->u_arr, np * 2));
-    ENV_TRY(dev_alloc(&e->u_fill, np * 2));
+    if (!speed) {
+      ENV_TRY(dev_alloc(&e->u_arr, np * 2));
+      ENV_TRY(dev_alloc(&e->u_fill, np * 2));
+    }
     ENV_TRY(dev_alloc(&e->z, np));
   }
   ENV_TRY(dev_alloc(&e->q_init, np));
@@ -534,7 +608,7 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
 
 int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
-  if (action_device != nullptr && (e->n & 1u)) {
+  if (action_device != nullptr && e->n != e->n_pad) {
     // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     action_device = nullptr;
@@ -589,11 +663,13 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
 }
 
 int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, const float* z) {
-  if (e == nullptr || u_arr == nullptr || u_fill == nullptr || z == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (e == nullptr || z == nullptr || (!e->speed && (u_arr == nullptr || u_fill == nullptr))) return fail(MBT_ERR_INVALID, "null argument");
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipMemcpyAsync(e->u_arr, u_arr, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->u_fill, u_fill, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (!e->speed) {
+    HIP_TRY(hipMemcpyAsync(e->u_arr, u_arr, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->u_fill, u_fill, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
   HIP_TRY(hipMemcpyAsync(e->z, z, size_t(e->n) * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->noise_ready = true;
@@ -714,25 +790,27 @@ int mbt_env_return_sums(mbt_env* e, double sums[3]) {
 
 int mbt_reward_calculate_host(int device, int reward_kind, double phi, double alpha, double inventory_exponent, const double* cur,
                               const double* nxt, int dim, uint64_t n, int is_terminal, const double* q_init,
-                              const double* episode_length, double* out) {
+                              const double* episode_length, const double* action, double risk_aversion, double* out) {
   if (cur == nullptr || nxt == nullptr || out == nullptr || n == 0 || dim < 4) return fail(MBT_ERR_INVALID, "bad argument");
-  if (reward_kind < MBT_REW_PNL || reward_kind > MBT_REW_CJ_MM) return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", reward_kind);
-  if (reward_kind == MBT_REW_CJ_MM && (q_init == nullptr || episode_length == nullptr))
-    return fail(MBT_ERR_STATE, "CjMmCriterion.calculate before reset(): initial inventory / episode length unknown");
+  if (reward_kind < MBT_REW_PNL || reward_kind > MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", reward_kind);
+  if ((reward_kind == MBT_REW_CJ_MM || reward_kind == MBT_REW_CJ_OE) && (q_init == nullptr || episode_length == nullptr))
+    return fail(MBT_ERR_STATE, "calculate() before reset(): initial inventory / episode length unknown");
+  if (reward_kind == MBT_REW_CJ_OE && action == nullptr) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the action (trading speed)");
   int rc = check_device(device);
   if (rc != MBT_OK) return rc;
   HIP_TRY(hipSetDevice(device));
   const size_t mat = n * dim * sizeof(double), vec = n * sizeof(double);
   double* d = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 2 * mat + 3 * vec));
-  double *d_cur = d, *d_nxt = d + n * dim, *d_qi = d_nxt + n * dim, *d_len = d_qi + n, *d_out = d_len + n;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 2 * mat + 4 * vec));
+  double *d_cur = d, *d_nxt = d + n * dim, *d_qi = d_nxt + n * dim, *d_len = d_qi + n, *d_out = d_len + n, *d_act = d_out + n;
   hipError_t he = hipMemcpy(d_cur, cur, mat, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(d_nxt, nxt, mat, hipMemcpyHostToDevice);
   if (he == hipSuccess && q_init != nullptr) he = hipMemcpy(d_qi, q_init, vec, hipMemcpyHostToDevice);
   if (he == hipSuccess && episode_length != nullptr) he = hipMemcpy(d_len, episode_length, vec, hipMemcpyHostToDevice);
+  if (he == hipSuccess && action != nullptr) he = hipMemcpy(d_act, action, vec, hipMemcpyHostToDevice);
   if (he == hipSuccess) {
     hipLaunchKernelGGL(mbt::reward_calculate_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, reward_kind, d_cur, d_nxt, dim,
-                       static_cast<uint32_t>(n), is_terminal, phi, alpha, inventory_exponent, d_qi, d_len, d_out);
+                       static_cast<uint32_t>(n), is_terminal, phi, alpha, inventory_exponent, d_qi, d_len, d_act, risk_aversion, d_out);
     he = hipGetLastError();
   }
   if (he == hipSuccess) he = hipMemcpy(out, d_out, vec, hipMemcpyDeviceToHost);
@@ -763,6 +841,24 @@ int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uin
   (void)hipFree(d_ua);
   (void)hipFree(d_uf);
   (void)hipFree(d_z);
+  return MBT_OK;
+}
+
+int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z) {
+  if (trajectory_offset & 3ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 4");
+  if (n == 0 || n > 0x7FFFFFF0ull || z == nullptr) return fail(MBT_ERR_INVALID, "bad argument");
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t n_pad = (static_cast<uint32_t>(n) + 3u) & ~3u, n_quads = n_pad / 4;
+  float* d_z = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_z), size_t(n_pad) * sizeof(float)));
+  hipLaunchKernelGGL(mbt::rng_fill_quad_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, nullptr, trajectory_offset >> 2, step,
+                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), n_quads, d_z);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipMemcpy(z, d_z, size_t(n) * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_z);
+  if (he != hipSuccess) return fail(MBT_ERR_HIP, "rng_fill_quad failed: %s", hipGetErrorString(he));
   return MBT_OK;
 }
 

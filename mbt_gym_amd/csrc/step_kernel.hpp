@@ -38,15 +38,19 @@ namespace mbt {
 #endif
 constexpr int kBlockThreads = MBT_BLOCK_THREADS;  // wave64 x 4 per workgroup by default
 
-enum : int { kMidBrownian = 0, kMidOu = 1 };
+enum : int { kMidBrownian = 0, kMidOu = 1, kMidGbm = 2, kMidBrownianJump = 3, kMidOuJump = 4, kMidConstant = 5 };
 enum : int { kArrPoisson = 0, kArrHawkes = 1 };
-enum : int { kDynLimit = 0, kDynLimitAndMarket = 1 };
-enum : int { kRewPnl = 0, kRewRunning = 1, kRewCjMm = 2 };
+enum : int { kDynLimit = 0, kDynLimitAndMarket = 1, kDynTouch = 2, kDynSpeed = 3 };
+enum : int { kRewPnl = 0, kRewRunning = 1, kRewCjMm = 2, kRewExpUtility = 3, kRewCjOe = 4 };
+enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2, kImpactTransient = 3 };
 
-// Compile-time shape of one kernel instantiation.
-template <int MID_, int ARR_, int DYN_, int REW_, bool NORM_, bool INJECT_>
+// Compile-time shape of one kernel instantiation: what changes the memory layout or the amount of noise is a
+// template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
+template <int ARR_, int DYN_, bool BROWNIAN_, bool PENALISED_, bool NORM_, bool INJECT_>
 struct Variant {
-  static constexpr int MID = MID_, ARR = ARR_, DYN = DYN_, REW = REW_;
+  static constexpr int ARR = ARR_, DYN = DYN_;
+  static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
+  static constexpr bool PENALISED = PENALISED_;  // any reward other than plain PnL (keeps the PnL kernels free of that code)
   static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
   static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
   static constexpr int DIM = (ARR_ == kArrHawkes) ? 6 : 4;
@@ -62,24 +66,36 @@ struct StepParams {
   uint32_t philox_step;  // Philox counter word 2
   int32_t is_terminal;   // this step ends the episode (TE:218-220), decided on the host
   float t_next;          // time written into the next state (TE:216)
-  float dt;
-  // midprice
-  float drift_dt;        // mu * dt                      (MID:63)
-  float vol_sqrt_dt;     // sigma * sqrt(dt)             (MID:64, MID:143)
+  float dt;              // terminal_time / n_steps (TE:49): the clock and the reward penalties
+  // midprice (each process scales with ITS OWN step size, SP:21; the environment never synchronises them)
+  float mid_add, mid_mul;  // midprice model as coefficients, see midprice_increment()
+  float drift_dt;        // mu * dt_mid                  (MID:63, MID:98)
+  float vol_sqrt_dt;     // sigma * sqrt(dt_mid)         (MID:64, MID:100-102, MID:143)
   float ou_speed, ou_level;
+  float jump_size;       // MID:226, MID:269
   // arrivals
-  float arr_thr_bid, arr_thr_ask;  // Poisson: smallest float32 >= lambda*dt computed in double (ARR:56)
-  double dt_f64;                   // Hawkes: threshold lambda_lane * dt in double (ARR:123)
+  float arr_thr_bid, arr_thr_ask;  // Poisson: smallest float32 >= lambda*dt_arr (ARR:56) or 1-exp(-lambda*dt_arr) (ARR:83)
+  double arr_dt_f64;               // Hawkes: threshold lambda_lane * dt_arr in double (ARR:123)
+  float arr_dt;
   float hawkes_base_bid, hawkes_base_ask, hawkes_speed, hawkes_jump;
   // fills
-  float kappa;
+  float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)
   double kappa_f64;
   // dynamics
   float half_spread;
   float q_max, c_max;
   // reward
+  int32_t reward_kind;
   int32_t exponent_is_two;
   float phi, alpha, exponent;
+  float risk_aversion;    // ExponentialUtility (RW:150)
+  float episode_length;   // CjOe: T - t_start (RW:73-74)
+  // trading-with-speed dynamics and price impact (MD:262-267, IMP:34-179)
+  int32_t impact_kind;
+  int32_t impact_exponent_is_one;
+  float speed_dt;         // the MIDPRICE model's step size (MD:265)
+  float impact_dt;        // the impact model's own step size (IMP:75)
+  float temp_coef, impact_exponent, perm_coef, trans_coef, resilience, kernel_coef;
   float dt_over_episode;  // CjMm: dt / (T - t_start)    (RW:106)
   float q_init_scalar;    // CjMm: initial inventory when it is the same for every lane
   float reward_scale;     // TE:128-129
@@ -105,19 +121,50 @@ struct StepBuffers {
   unsigned long long* clip_count;
 };
 
+// ---- structure of the arithmetic --------------------------------------------------------------------------------
+// (1) Everything that depends on noise and parameters only is precomputed into a LaneDraw while the loads are in
+//     flight; (2) the post-load arithmetic uses explicit FMAs / v_med3 and carries nothing optional (event bytes are
+//     assembled only when recording); (3) rare exact re-decisions live in cold blocks.  Explicit FMAs (the library is
+//     built with -ffp-contract=off) also make the step and rollout kernels, which inline the same code, agree bit
+//     for bit.  Measured (rocprofv3 PMC, 2^20 lanes): 334 VALU instructions per wave, 14 % of wave cycles issuing,
+//     38 % parked on memory - the kernel is bound by the memory system, not by this arithmetic.
+
+// Per-lane quantities that depend on noise and parameters only.
+struct LaneDraw {
+  float arr_bid, arr_ask;  // Poisson: arrival indicators 1.0f / 0.0f (ARR:56); Hawkes: the raw uniforms (decided with lambda)
+  float uf_bid, uf_ask;    // fill uniforms (FILL:33)
+  float dz;                // drift_dt + vol_sqrt_dt * Z: the whole midprice increment of Brownian motion (MID:60-65)
+};
+
+template <class V>
+__device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepParams& P) {
+  LaneDraw d;
+  if (V::ARR == kArrPoisson) {  // strict '<' against thresholds rounded UP to float32: exact vs the float64 compare
+    d.arr_bid = nz.ua_bid < P.arr_thr_bid ? 1.0f : 0.0f;
+    d.arr_ask = nz.ua_ask < P.arr_thr_ask ? 1.0f : 0.0f;
+  } else {
+    d.arr_bid = nz.ua_bid;
+    d.arr_ask = nz.ua_ask;
+  }
+  d.uf_bid = nz.uf_bid;
+  d.uf_ask = nz.uf_ask;
+  d.dz = __builtin_fmaf(P.vol_sqrt_dt, nz.z, P.drift_dt);
+  return d;
+}
+
 // ---- fill decisions --------------------------------------------------------------------------------------
 // float32 exponential fill test (FILL:34, FILL:57-58) that is exact against float64: v_exp_f32 decides unless the
-// draw lies inside its error band (plus the rounding of a normalised depth); `near` flags that case and ONE cold
-// block per pair re-decides the flagged entries in double.
+// draw lies inside its error band (plus the rounding of a normalised depth); `near` flags that case and a cold block
+// re-decides in double.  p = 2^(k2 * depth) with k2 = -kappa * log2(e) folded on the host.
 struct FillTest {
   bool fill;  // u < exp(-kappa * depth), fast evaluation
   bool near;  // the fast evaluation cannot be trusted
 };
 
 __device__ __forceinline__ FillTest fill_test(float u, float depth, const StepParams& P) {
-  const float x = P.kappa * depth;
-  const float p = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
-  const float band = p * (4e-6f + 4e-7f * __builtin_fabsf(x)) + 1e-30f;
+  const float y = P.kappa_log2e_neg * depth;
+  const float p = __builtin_amdgcn_exp2f(y);
+  const float band = __builtin_fmaf(p, __builtin_fmaf(__builtin_fabsf(y), 3e-7f, 4e-6f), 1e-30f);
   const float d = u - p;
   return FillTest{d < 0.0f, __builtin_fabsf(d) <= band};
 }
@@ -126,117 +173,165 @@ __device__ __forceinline__ float depth_of(float a, int side, bool norm, const St
   return norm ? static_cast<float>((static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side]) : a;  // TE:124
 }
 
-// cold: exact re-decision of the flagged entries of a pair (about 4e-6 of draws get here)
-__device__ __attribute__((cold)) void refine_fills_f64(const float (&u)[4], const float (&a)[4], bool norm, const StepParams& P,
-                                                       bool (&fill)[4], const bool (&near)[4]) {
+// cold: exact re-decision of one quote (about 4e-6 of draws get here)
+__device__ __attribute__((cold)) bool refine_fill_f64(float u, float a, int side, bool norm, const StepParams& P) {
+  double depth = a;
+  if (norm) depth = (static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side];
+  return static_cast<double>(u) < exp(-P.kappa_f64 * depth);
+}
+
+// numpy `q ** p` (RW:101-104, RW:133-137) of up to three inventories at once; p == 2 in every reference
+// configuration.  The general case runs ONE inlined powf in a rolled loop over register selects (no arrays, so no
+// scratch memory), which keeps it out of the instruction stream of the common path.
+__device__ __forceinline__ void inventory_powers(float a, float b, float c, float p, bool is_two, float& pa, float& pb, float& pc) {
+  if (__builtin_expect(is_two, 1)) {
+    pa = a * a; pb = b * b; pc = c * c;
+    return;
+  }
+  pa = pb = pc = 0.0f;
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) {
-    if (!near[k]) continue;
-    double depth = a[k];
-    if (norm) depth = (static_cast<double>(a[k]) + 1.0) * P.act_grad[k & 1] + P.act_lo[k & 1];
-    fill[k] = static_cast<double>(u[k]) < exp(-P.kappa_f64 * depth);
+  for (int i = 0; i < 3; ++i) {
+    const float y = powf(i == 0 ? a : (i == 1 ? b : c), p);
+    if (i == 0) pa = y; else if (i == 1) pb = y; else pc = y;
   }
 }
 
-// numpy `q ** p` (RW:101-104, RW:133-137); p == 2 in every reference configuration
-__device__ __forceinline__ float pow_inventory(float q, const StepParams& P) {
-  return __builtin_expect(P.exponent_is_two, 1) ? q * q : powf(q, P.exponent);
+// S' - S for the midprice models other than plain Brownian motion, branch-free: the host turns the model kind into
+// coefficients of
+//   dS = (mid_add + mid_mul * S) * dz - ou_speed * (S - ou_level) + jump_size * (n_ask - n_bid),   dz = mu dt + sigma sqrt(dt) Z
+//   GBM (MID:95-103)  mid_mul 1        OU (MID:140-143)  mid_add 1, mu 0, ou_speed theta (the pull is NOT scaled by dt)
+//   +jumps on the agent's own trades (MID:222-227, :264-270)        constant (MID:32-33)  all 0
+__device__ __forceinline__ float midprice_increment(float mid, float dz, float n_bid, float n_ask, const StepParams& P) {
+  const float scale = __builtin_fmaf(P.mid_mul, mid, P.mid_add);
+  const float pull = P.ou_speed * (mid - P.ou_level);
+  return __builtin_fmaf(P.jump_size, n_ask - n_bid, __builtin_fmaf(scale, dz, -pull));
+}
+
+// Everything a reward adds to the mark-to-market change `pnl` (RW:96-109, RW:128-138, RW:57-70, RW:156-163).
+__device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_new, float cash_new, float mid_new, float q_init,
+                                               float speed, bool is_terminal, const StepParams& P) {
+  float reward = pnl;
+  if (P.reward_kind == kRewExpUtility) {  // exponential utility of terminal wealth; zero before the terminal step
+    reward = is_terminal ? -__expf(-P.risk_aversion * (cash_new + q_new * mid_new)) : 0.0f;
+  } else if (P.reward_kind != kRewPnl) {
+    float qp, qp_old, qp_init;
+    const bool oe = P.reward_kind == kRewCjOe;  // needs q^(p-1) instead of q^p for the old inventory (RW:65)
+    inventory_powers(q_new, q_old, q_init, P.exponent, P.exponent_is_two != 0, qp, qp_old, qp_init);
+    reward -= P.dt * P.phi * qp;
+    if (P.reward_kind == kRewRunning) {
+      reward -= is_terminal ? P.alpha * qp : 0.0f;
+    } else if (!oe) {
+      reward -= P.alpha * ((qp - qp_old) + P.dt_over_episode * qp_init);
+    } else {  // the terminal term MULTIPLIES by the episode length in the reference (RW:67)
+      const float qpm1 = P.exponent_is_two ? q_old : powf(q_old, P.exponent - 1.0f);
+      reward -= P.dt * P.alpha * (P.exponent * speed * qpm1 + qp_init * P.episode_length);
+    }
+  }
+  return reward * P.reward_scale;
 }
 
 struct LaneResult {
   float4 core;
   float2 lam;
   float reward;
-  uint32_t events;
+  // what happened, kept as predicates (scalar masks); turned into the event byte only when someone asks for it
+  bool arr_bid, arr_ask, fill_bid, fill_ask, mo_buy, mo_sell, clipped_q, clipped_c;
 };
 
+__device__ __forceinline__ uint32_t event_byte(const LaneResult& r) {
+  return (r.arr_bid ? 1u : 0u) | (r.arr_ask ? 2u : 0u) | (r.fill_bid ? 4u : 0u) | (r.fill_ask ? 8u : 0u) | (r.mo_buy ? 16u : 0u) |
+         (r.mo_sell ? 32u : 0u) | (r.clipped_q ? 64u : 0u) | (r.clipped_c ? 128u : 0u);
+}
+
+// One env-step of one lane: everything that needs the loaded state and action.
 template <class V>
-__device__ __forceinline__ LaneResult step_lane(const float4 core, const float2 lam, const float4 act, const float d_bid,
-                                                const float d_ask, const bool raw_fill_bid, const bool raw_fill_ask,
-                                                const LaneNoise nz, const float q_init, const float t_next,
-                                                const bool is_terminal, const StepParams& P) {
+__device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
+                                                const float q_init, const float t_next, const bool is_terminal,
+                                                const StepParams& P) {
   const float cash = core.x, q = core.y, mid = core.w;
+  LaneResult r;
+  const bool norm_act = V::NORM && P.norm_act;
 
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
-  bool arr_bid, arr_ask;
-  if (V::ARR == kArrPoisson) {
-    arr_bid = nz.ua_bid < P.arr_thr_bid;
-    arr_ask = nz.ua_ask < P.arr_thr_ask;
-  } else {
-    arr_bid = static_cast<double>(nz.ua_bid) < static_cast<double>(lam.x) * P.dt_f64;
-    arr_ask = static_cast<double>(nz.ua_ask) < static_cast<double>(lam.y) * P.dt_f64;
+  float arr_bid = dr.arr_bid, arr_ask = dr.arr_ask;
+  if (V::ARR == kArrHawkes) {
+    arr_bid = static_cast<double>(dr.arr_bid) < static_cast<double>(lam.x) * P.arr_dt_f64 ? 1.0f : 0.0f;
+    arr_ask = static_cast<double>(dr.arr_ask) < static_cast<double>(lam.y) * P.arr_dt_f64 ? 1.0f : 0.0f;
   }
+  r.arr_bid = arr_bid != 0.0f;
+  r.arr_ask = arr_ask != 0.0f;
 
-  // -- fills (FILL:28-34, FILL:57-58) masked by the PRE-update inventory (TE:323-327)
-  const bool fill_bid = raw_fill_bid && !(q >= P.q_max);
-  const bool fill_ask = raw_fill_ask && !(q <= -P.q_max);
-  const float n_bid = (arr_bid && fill_bid) ? 1.0f : 0.0f;
-  const float n_ask = (arr_ask && fill_ask) ? 1.0f : 0.0f;
+  // -- fills masked by the PRE-update inventory (TE:323-327).  Limit orders: the exponential fill test
+  //    (FILL:28-34, FILL:57-58, after the de-normalisation of TE:104); at the touch: the action itself (MD:156-157)
+  const bool open_bid = !(q >= P.q_max), open_ask = !(q <= -P.q_max);
+  float n_bid, n_ask, off_bid, off_ask;
+  if (V::DYN == kDynTouch) {
+    const float f_bid = open_bid ? act.x : 0.0f, f_ask = open_ask ? act.y : 0.0f;  // `fills` is the posted size (0/1)
+    r.fill_bid = f_bid != 0.0f;
+    r.fill_ask = f_ask != 0.0f;
+    n_bid = arr_bid * f_bid;
+    n_ask = arr_ask * f_ask;
+    off_bid = off_ask = P.half_spread;
+  } else {
+    off_bid = depth_of(act.x, 0, norm_act, P);
+    off_ask = depth_of(act.y, 1, norm_act, P);
+    const FillTest tb = fill_test(dr.uf_bid, off_bid, P), ta = fill_test(dr.uf_ask, off_ask, P);
+    bool fb = tb.fill, fa = ta.fill;
+    if (__builtin_expect(tb.near | ta.near, 0)) {
+      if (tb.near) fb = refine_fill_f64(dr.uf_bid, act.x, 0, norm_act, P);
+      if (ta.near) fa = refine_fill_f64(dr.uf_ask, act.y, 1, norm_act, P);
+    }
+    r.fill_bid = fb && open_bid;
+    r.fill_ask = fa && open_ask;
+    n_bid = r.fill_bid ? arr_bid : 0.0f;
+    n_ask = r.fill_ask ? arr_ask : 0.0f;
+  }
 
   // -- cash / inventory with the OLD midprice (MD:82-84); market orders first (MD:208-214), then limit
-  //    fills (MD:108-116 / MD:215-222)
-  float q_new = q, cash_new = cash, gain = 0.0f;
-  uint32_t ev = (arr_bid ? 1u : 0u) | (arr_ask ? 2u : 0u) | (fill_bid ? 4u : 0u) | (fill_ask ? 8u : 0u);
+  //    fills (MD:108-116 / MD:215-222) or fills at the touch (MD:146-154)
+  float q_new = q, cash_new = cash, gain = n_bid * off_bid;
+  r.mo_buy = r.mo_sell = false;
   if (V::DYN == kDynLimitAndMarket) {
-    bool mo_buy, mo_sell;
-    if (V::NORM && P.norm_act) {
-      mo_buy = (static_cast<double>(act.z) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
-      mo_sell = (static_cast<double>(act.w) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
+    if (norm_act) {
+      r.mo_buy = (static_cast<double>(act.z) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
+      r.mo_sell = (static_cast<double>(act.w) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
     } else {
-      mo_buy = act.z > 0.5f;
-      mo_sell = act.w > 0.5f;
+      r.mo_buy = act.z > 0.5f;
+      r.mo_sell = act.w > 0.5f;
     }
-    const float mb = mo_buy ? 1.0f : 0.0f, ms = mo_sell ? 1.0f : 0.0f;
-    cash_new += ms * (mid - P.half_spread) - mb * (mid + P.half_spread);
+    const float mb = r.mo_buy ? 1.0f : 0.0f, ms = r.mo_sell ? 1.0f : 0.0f;
+    cash_new = __builtin_fmaf(ms, mid - P.half_spread, cash_new);
+    cash_new = __builtin_fmaf(-mb, mid + P.half_spread, cash_new);
     q_new += mb - ms;
-    gain -= P.half_spread * (mb + ms);
-    ev |= (mo_buy ? 16u : 0u) | (mo_sell ? 32u : 0u);
+    gain = __builtin_fmaf(-P.half_spread, mb + ms, gain);
   }
   q_new += n_bid - n_ask;
-  cash_new += n_ask * (mid + d_ask) - n_bid * (mid - d_bid);
-  gain += n_bid * d_bid + n_ask * d_ask;
+  cash_new = __builtin_fmaf(n_ask, mid + off_ask, cash_new);
+  cash_new = __builtin_fmaf(-n_bid, mid - off_bid, cash_new);
+  gain = __builtin_fmaf(n_ask, off_ask, gain);
 
-  // -- clip (TE:283-289)
-  const float q_clip = __builtin_fminf(__builtin_fmaxf(q_new, -P.q_max), P.q_max);
-  const float c_clip = __builtin_fminf(__builtin_fmaxf(cash_new, -P.c_max), P.c_max);
+  // -- clip (TE:283-289): v_med3_f32
+  const float q_clip = __builtin_amdgcn_fmed3f(q_new, -P.q_max, P.q_max);
+  const float c_clip = __builtin_amdgcn_fmed3f(cash_new, -P.c_max, P.c_max);
   const float dq_clip = q_clip - q_new;  // 0 unless the inventory clip fired
   const float dc_clip = c_clip - cash_new;
-  ev |= (dq_clip != 0.0f ? 64u : 0u) | (dc_clip != 0.0f ? 128u : 0u);
+  r.clipped_q = dq_clip != 0.0f;
+  r.clipped_c = dc_clip != 0.0f;
 
-  // -- midprice (MID:60-65 / MID:140-143: the OU pull is not scaled by dt in the reference)
-  float d_mid;
-  if (V::MID == kMidBrownian) {
-    d_mid = P.drift_dt + P.vol_sqrt_dt * nz.z;
-  } else {
-    d_mid = -P.ou_speed * (mid - P.ou_level) + P.vol_sqrt_dt * nz.z;
-  }
+  // -- midprice, then the Hawkes intensities, which jump on arrivals, not on fills (ARR:110-119)
+  const float d_mid = V::BROWNIAN ? dr.dz : midprice_increment(mid, dr.dz, n_bid, n_ask, P);
   const float mid_new = mid + d_mid;
-
-  // -- Hawkes intensities jump on arrivals, not on fills (ARR:110-119)
-  float2 lam_new = lam;
+  r.lam = lam;
   if (V::ARR == kArrHawkes) {
-    lam_new.x = (lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.dt) + (arr_bid ? P.hawkes_jump : 0.0f);
-    lam_new.y = (lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.dt) + (arr_ask ? P.hawkes_jump : 0.0f);
+    r.lam.x = __builtin_fmaf(P.hawkes_jump, arr_bid, lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.arr_dt);
+    r.lam.y = __builtin_fmaf(P.hawkes_jump, arr_ask, lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.arr_dt);
   }
 
-  // -- reward (RW:23-33, RW:96-109, RW:128-138): incremental mark-to-market, see the header comment
-  float reward = gain + q_clip * d_mid + dq_clip * mid + dc_clip;
-  if (V::REW != kRewPnl) {
-    const float qp = pow_inventory(q_clip, P);
-    reward -= P.dt * P.phi * qp;
-    if (V::REW == kRewRunning) {
-      reward -= is_terminal ? P.alpha * qp : 0.0f;
-    } else {
-      reward -= P.alpha * ((qp - pow_inventory(q, P)) + P.dt_over_episode * pow_inventory(q_init, P));
-    }
-  }
-  reward *= P.reward_scale;
-
-  LaneResult r;
+  // -- reward: the mark-to-market change (c'+q'S') - (c+qS) of RW:27-33 from the step's increments, then the reward
+  //    function's own terms
+  const float pnl = __builtin_fmaf(dq_clip, mid, __builtin_fmaf(q_clip, d_mid, gain)) + dc_clip;
+  r.reward = V::PENALISED ? finish_reward(pnl, q, q_clip, c_clip, mid_new, q_init, 0.0f, is_terminal, P) : pnl * P.reward_scale;
   r.core = make_float4(c_clip, q_clip, t_next, mid_new);
-  r.lam = lam_new;
-  r.reward = reward;
-  r.events = ev;
   return r;
 }
 
@@ -291,7 +386,7 @@ __device__ __forceinline__ PairLoads<V> load_pair(const StepBuffers& B, const St
   L.s0 = src[0];
   L.s1 = src[1];
   if (V::ARR == kArrHawkes) L.s2 = src[2];
-  if (V::DYN == kDynLimit) {
+  if (V::DYN != kDynLimitAndMarket) {
     L.a0 = reinterpret_cast<const float4*>(B.action)[pair];
   } else {
     L.a0 = reinterpret_cast<const float4*>(B.action)[2 * pair];
@@ -303,42 +398,18 @@ __device__ __forceinline__ PairLoads<V> load_pair(const StepBuffers& B, const St
     L.zz = reinterpret_cast<const float2*>(B.z)[pair];
   }
   L.qi = make_float2(P.q_init_scalar, P.q_init_scalar);
-  if (V::REW == kRewCjMm && B.q_init != nullptr) L.qi = reinterpret_cast<const float2*>(B.q_init)[pair];
+  if (V::PENALISED && B.q_init != nullptr) L.qi = reinterpret_cast<const float2*>(B.q_init)[pair];
   return L;
 }
 
 // Orders the schedule: every operand is an in/out of one empty asm, so the noise is complete before, and every
 // consumer of the loaded state/action after, this point.  Costs no instruction.
 template <class V>
-__device__ __forceinline__ void tie_loads_to_noise(PairLoads<V>& L, LaneNoise& a, LaneNoise& b) {
+__device__ __forceinline__ void tie_loads_to_draws(PairLoads<V>& L, LaneDraw& a, LaneDraw& b) {
   asm volatile("; loads are first consumed below this line"
                : "+v"(L.s0.x), "+v"(L.s0.y), "+v"(L.s0.z), "+v"(L.s0.w), "+v"(L.s1.x), "+v"(L.s1.y), "+v"(L.s1.z), "+v"(L.s1.w),
-                 "+v"(L.a0.x), "+v"(L.a0.y), "+v"(L.a0.z), "+v"(L.a0.w), "+v"(a.ua_bid), "+v"(a.ua_ask), "+v"(a.uf_bid), "+v"(a.uf_ask), "+v"(a.z),
-                 "+v"(b.ua_bid), "+v"(b.ua_ask), "+v"(b.uf_bid), "+v"(b.uf_ask), "+v"(b.z));
-}
-
-// One env-step of a pair of lanes held in registers: fill tests of the four quotes (TE:104 de-normalisation
-// first), then the per-lane dynamics.
-template <class V>
-__device__ __forceinline__ void advance_pair(const float4 core0, const float2 lam0, const float4 core1, const float2 lam1,
-                                             const float4 act0, const float4 act1, const LaneNoise& nz0, const LaneNoise& nz1,
-                                             const float2 q_init, const float t_next, const bool is_terminal,
-                                             const StepParams& P, LaneResult& r0, LaneResult& r1) {
-  const bool norm_act = V::NORM && P.norm_act;
-  const float a[4] = {act0.x, act0.y, act1.x, act1.y};
-  const float u[4] = {nz0.uf_bid, nz0.uf_ask, nz1.uf_bid, nz1.uf_ask};
-  float depth[4];
-  bool fill[4], near[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    depth[k] = depth_of(a[k], k & 1, norm_act, P);
-    const FillTest t = fill_test(u[k], depth[k], P);
-    fill[k] = t.fill;
-    near[k] = t.near;
-  }
-  if (__builtin_expect(near[0] | near[1] | near[2] | near[3], 0)) refine_fills_f64(u, a, norm_act, P, fill, near);
-  r0 = step_lane<V>(core0, lam0, act0, depth[0], depth[1], fill[0], fill[1], nz0, q_init.x, t_next, is_terminal, P);
-  r1 = step_lane<V>(core1, lam1, act1, depth[2], depth[3], fill[2], fill[3], nz1, q_init.y, t_next, is_terminal, P);
+                 "+v"(L.a0.x), "+v"(L.a0.y), "+v"(L.a0.z), "+v"(L.a0.w), "+v"(a.arr_bid), "+v"(a.arr_ask), "+v"(a.uf_bid), "+v"(a.uf_ask),
+                 "+v"(a.dz), "+v"(b.arr_bid), "+v"(b.arr_ask), "+v"(b.uf_bid), "+v"(b.uf_ask), "+v"(b.dz));
 }
 
 // rows of 6 are packed [c q t S | lb la c q | t S lb la] in three float4
@@ -381,13 +452,13 @@ __device__ __forceinline__ void store_obs_rows(float* base, uint32_t pair, float
 // Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
 template <class V>
 __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
-                                             const LaneNoise& nz0, const LaneNoise& nz1) {
+                                             const LaneDraw& d0, const LaneDraw& d1) {
   const uint32_t lane0 = 2u * pair;
   float4 core0, core1;
   float2 lam0, lam1;
   unpack_rows<V>(L.s0, L.s1, L.s2, core0, lam0, core1, lam1);
   float4 act0, act1;
-  if (V::DYN == kDynLimit) {
+  if (V::DYN != kDynLimitAndMarket) {
     act0 = make_float4(L.a0.x, L.a0.y, 0.f, 0.f);
     act1 = make_float4(L.a0.z, L.a0.w, 0.f, 0.f);
   } else {
@@ -395,8 +466,8 @@ __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepPar
     act1 = L.a1;
   }
 
-  LaneResult r0, r1;
-  advance_pair<V>(core0, lam0, core1, lam1, act0, act1, nz0, nz1, L.qi, P.t_next, P.is_terminal != 0, P, r0, r1);
+  const LaneResult r0 = lane_step<V>(core0, lam0, act0, d0, L.qi.x, P.t_next, P.is_terminal != 0, P);
+  const LaneResult r1 = lane_step<V>(core1, lam1, act1, d1, L.qi.y, P.t_next, P.is_terminal != 0, P);
 
   store_rows<V>(B.state_out, pair, r0.core, r0.lam, r1.core, r1.lam);
   reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
@@ -406,7 +477,7 @@ __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepPar
   // -- optional outputs (wave-uniform branches)
   if (V::NORM && B.obs != nullptr) store_obs_rows<V>(B.obs, pair, r0.core, r0.lam, r1.core, r1.lam, P);
   if (B.events != nullptr) {
-    reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
+    reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(event_byte(r0) | (event_byte(r1) << 8));
   }
   if (B.lane_returns != nullptr) {
     float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
@@ -414,8 +485,8 @@ __device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepPar
     acc.y += r1.reward;
     reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
   }
-  const uint32_t clipped = ((r0.events >> 6) != 0u ? 1u : 0u) + ((second && (r1.events >> 6) != 0u) ? 1u : 0u);
-  if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+  const bool clip0 = r0.clipped_q | r0.clipped_c, clip1 = (r1.clipped_q | r1.clipped_c) && second;
+  if (__builtin_expect(clip0 | clip1, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>((clip0 ? 1 : 0) + (clip1 ? 1 : 0)));
   return r0.reward + (second ? r1.reward : 0.0f);
 }
 
@@ -426,14 +497,19 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
   if (pair < P.n_pairs) {
     PairLoads<V> L = load_pair<V>(B, P, pair);  // issue every load ...
     LaneNoise nz0, nz1;
+    LaneDraw d0, d1;
     if (V::INJECT) {
       nz0 = LaneNoise{L.ua.x, L.ua.y, L.uf.x, L.uf.y, L.zz.x};
       nz1 = LaneNoise{L.ua.z, L.ua.w, L.uf.z, L.uf.w, L.zz.y};
+      d0 = make_draw<V>(nz0, P);
+      d1 = make_draw<V>(nz1, P);
     } else {
       philox_pair_noise(P.pair_offset + pair, P.philox_step, P.key0, P.key1, nz0, nz1);  // ... draw while they fly
-      tie_loads_to_noise<V>(L, nz0, nz1);
+      d0 = make_draw<V>(nz0, P);
+      d1 = make_draw<V>(nz1, P);
+      tie_loads_to_draws<V>(L, d0, d1);
     }
-    r_sum = finish_pair<V>(B, P, pair, L, nz0, nz1);
+    r_sum = finish_pair<V>(B, P, pair, L, d0, d1);
   }
   // -- per-wave running sum of rewards (numerator of the mean episode return): one slot per wave, one
   //    fire-and-forget hardware fp64 atomic per wave, no contention
@@ -450,7 +526,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
 // rollout is bit-identical to the equivalent sequence of step() calls.  The caller's per-time-step Python loop
 // (generate_trajectory.py:21-34) disappears; HBM is touched only to record the trajectory (optional, time-major
 // so that every store is a coalesced float4) and once at the end for the final state.
-enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1, kPolicyTable = 2 };
+enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1, kPolicyTable = 2, kPolicyTimeTable = 3 };
 
 struct RolloutParams {
   uint32_t n_steps;        // env-steps to run in this launch
@@ -481,7 +557,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     float2 lam0, lam1;
     unpack_rows<V>(src[0], src[1], V::ARR == kArrHawkes ? src[2] : make_float4(0.f, 0.f, 0.f, 0.f), core0, lam0, core1, lam1);
     float2 qi = make_float2(P.q_init_scalar, P.q_init_scalar);
-    if (V::REW == kRewCjMm && B.q_init != nullptr) qi = reinterpret_cast<const float2*>(B.q_init)[pair];
+    if (V::PENALISED && B.q_init != nullptr) qi = reinterpret_cast<const float2*>(B.q_init)[pair];
     float ret0 = 0.0f, ret1 = 0.0f;
     uint32_t clipped = 0;
     double t = R.t_start;
@@ -498,6 +574,9 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       float4 act0, act1;
       if (R.policy == kPolicyFixed) {
         act0 = act1 = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
+      } else if (R.policy == kPolicyTimeTable) {  // open-loop schedule over time steps
+        const float* row = reinterpret_cast<const float*>(R.table) + static_cast<size_t>(min(R.table_row0 + k, R.table_rows - 1u)) * A;
+        act0 = act1 = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);
       } else if (R.policy == kPolicyTable) {  // quotes tabulated over (time step, inventory), e.g. Cartea-Jaimungal
         const uint32_t row = min(R.table_row0 + k, R.table_rows - 1u);
         const int c0 = min(max(static_cast<int>(core0.y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
@@ -515,12 +594,12 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       }
       t += R.dt_f64;
       const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
-      LaneResult r0, r1;
-      advance_pair<V>(core0, lam0, core1, lam1, act0, act1, nz0, nz1, qi, static_cast<float>(t), terminal, P, r0, r1);
+      const LaneResult r0 = lane_step<V>(core0, lam0, act0, make_draw<V>(nz0, P), qi.x, static_cast<float>(t), terminal, P);
+      const LaneResult r1 = lane_step<V>(core1, lam1, act1, make_draw<V>(nz1, P), qi.y, static_cast<float>(t), terminal, P);
       core0 = r0.core; lam0 = r0.lam; core1 = r1.core; lam1 = r1.lam;
       ret0 += r0.reward;
       ret1 += r1.reward;
-      clipped += ((r0.events >> 6) != 0u ? 1u : 0u) + ((r1.events >> 6) != 0u && lane0 + 1 < P.n ? 1u : 0u);
+      clipped += ((r0.clipped_q | r0.clipped_c) ? 1u : 0u) + (((r1.clipped_q | r1.clipped_c) && lane0 + 1 < P.n) ? 1u : 0u);
       if (R.obs_traj != nullptr) {
         float* dst = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
         if (V::NORM) {
@@ -541,7 +620,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
       if (R.rew_traj != nullptr) reinterpret_cast<float2*>(R.rew_traj + static_cast<size_t>(k) * n_pad)[pair] = make_float2(r0.reward, r1.reward);
       if (k + 1 == R.n_steps) {  // what step() leaves behind: last rewards (and events) of the final step
         reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
-        if (B.events != nullptr) reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(r0.events | (r1.events << 8));
+        if (B.events != nullptr) reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(event_byte(r0) | (event_byte(r1) << 8));
       }
     }
     store_rows<V>(B.state_out, pair, core0, lam0, core1, lam1);
@@ -566,8 +645,9 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
 
 // reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price (, Hawkes baselines)], zeroed accumulators.
 __global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0,
-                             float q0_scalar, float cash0, float t0, float s0, float lam_bid, float lam_ask,
+                             float q0_scalar, float cash0, float t0, float s0, float extra0, float extra1,
                              uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P) {
+  const float lam_bid = extra0, lam_ask = extra1;  // columns 4, 5: Hawkes baselines, or the initial impact state in column 4
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
@@ -575,7 +655,8 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
   const float2 l = make_float2(lam_bid, lam_ask);
   float* row = state + static_cast<size_t>(i) * dim;
   row[0] = c.x; row[1] = c.y; row[2] = c.z; row[3] = c.w;
-  if (dim == 6) { row[4] = l.x; row[5] = l.y; }
+  if (dim > 4) row[4] = l.x;
+  if (dim > 5) row[5] = l.y;
   if (obs != nullptr) write_obs_row(obs, i, dim, c, l, P);
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
@@ -586,7 +667,7 @@ __global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n
   if (i >= n_pad) return;
   const float* r = state + static_cast<size_t>(i) * dim;
   const float4 c = make_float4(r[0], r[1], r[2], r[3]);
-  const float2 l = dim == 6 ? make_float2(r[4], r[5]) : make_float2(0.f, 0.f);
+  const float2 l = make_float2(dim > 4 ? r[4] : 0.f, dim > 5 ? r[5] : 0.f);
   write_obs_row(obs, i, dim, c, l, P);
 }
 
@@ -619,14 +700,22 @@ __global__ void reduce_returns_kernel(const double* wave_sums, uint32_t n_waves,
 // reference's own unit tests) gets the reference's float64 values without a CPU implementation.
 __global__ void reward_calculate_kernel(int kind, const double* cur, const double* nxt, int dim, uint32_t n, int is_terminal,
                                         double phi, double alpha, double p, const double* q_init, const double* episode_length,
-                                        double* out) {
+                                        const double* action, double risk_aversion, double* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* c = cur + static_cast<size_t>(i) * dim;
   const double* x = nxt + static_cast<size_t>(i) * dim;
   const double pnl = (x[0] + x[1] * x[3]) - (c[0] + c[1] * c[3]);
   double r = pnl;
-  if (kind != kRewPnl) {
+  if (kind == kRewExpUtility) {  // RW:156-163
+    r = is_terminal ? -exp(-risk_aversion * (x[0] + x[1] * x[3])) : 0.0;
+  } else if (kind == kRewCjOe) {  // RW:57-70
+    const double dt = x[2] - c[2];
+    const double qp = (p == 2.0) ? x[1] * x[1] : pow(x[1], p);
+    const double qpm1 = (p == 2.0) ? c[1] : pow(c[1], p - 1.0);
+    const double qip = (p == 2.0) ? q_init[i] * q_init[i] : pow(q_init[i], p);
+    r = pnl - dt * phi * qp - dt * alpha * (p * action[i] * qpm1 + qip * episode_length[i]);
+  } else if (kind != kRewPnl) {
     const double dt = x[2] - c[2];
     const double qp = (p == 2.0) ? x[1] * x[1] : pow(x[1], p);
     r = pnl - dt * phi * qp;

@@ -131,6 +131,8 @@ class TradingEnvironment(_EnvBase):
         if normalise_observation_space:
             self.observation_space = _unit_box(self.original_observation_space)
         if normalise_action_space:
+            if not hasattr(self.original_action_space, "low"):
+                raise UnsupportedOnDevice("a MultiBinary action space cannot be normalised: pass normalise_action_space=False")
             self.action_space = _unit_box(self.original_action_space)
         self.reward_scaling = 1.0
         if normalise_rewards:
@@ -150,19 +152,23 @@ class TradingEnvironment(_EnvBase):
     # ---------------------------------------------------------------------------------------------------
     def _device_config(self, num_trajectories: int, reward_scale: float, trajectory_offset=None) -> _native.MbtConfig:
         md = self.model_dynamics
-        parts = [md, md.midprice_model, md.arrival_model, md.fill_probability_model, self.reward_function]
+        if md.midprice_model is None:
+            raise UnsupportedOnDevice("a midprice model is required")
+        # processes a dynamics class does not use are simply absent (None), as in the reference
+        parts = [p for p in (md, md.midprice_model, md.arrival_model, md.fill_probability_model, md.price_impact_model,
+                             self.reward_function) if p is not None]
         for part in parts:
-            if part is None or getattr(part, "device_kind", None) is None:
+            if getattr(part, "device_kind", None) is None:
                 raise UnsupportedOnDevice(
-                    f"{type(part).__name__} has no HIP implementation; supported: BrownianMotion/Ou midprice, "
-                    "Poisson/Hawkes arrivals, exponential fills, limit / limit+market dynamics, PnL / "
-                    "RunningInventoryPenalty / CjMmCriterion rewards.  There is no CPU fallback."
+                    f"{type(part).__name__} has no HIP implementation (see DESIGN.md for the supported plugin classes).  "
+                    "There is no CPU fallback."
                 )
-        if md.price_impact_model is not None:
-            raise UnsupportedOnDevice("price impact models have no HIP implementation yet")
-        fields = {}
+        fields = dict(arrival_kind=_native.ARR_NONE, fill_kind=_native.FILL_NONE, impact_kind=_native.IMPACT_NONE)
         for part in parts:
             fields.update(part.device_params())
+        for key in ("midprice_step_size", "arrival_step_size", "impact_step_size"):
+            if fields.get(key) is None:
+                fields[key] = 0.0  # 0 = the environment's terminal_time / n_steps
         cfg = _native.MbtConfig()
         cfg.abi_version = _native.ABI_VERSION
         cfg.device = self.device
@@ -179,6 +185,7 @@ class TradingEnvironment(_EnvBase):
                 setattr(cfg, key, value)
         cfg.initial_cash = self.initial_cash
         cfg.initial_inventory = float(self.initial_inventory) if isinstance(self.initial_inventory, (int, float)) else 0.0
+        cfg.inventory_exponent = fields.get("inventory_exponent", 2.0)
         cfg.max_inventory = self.max_inventory
         cfg.max_cash = self.max_cash
         cfg.reward_scale = reward_scale
@@ -188,9 +195,10 @@ class TradingEnvironment(_EnvBase):
         lo, hi = self.original_observation_space.low, self.original_observation_space.high
         for j in range(len(lo)):
             cfg.obs_lo[j], cfg.obs_hi[j] = float(lo[j]), float(hi[j])
-        alo, ahi = self.original_action_space.low, self.original_action_space.high
-        for j in range(len(alo)):
-            cfg.act_lo[j], cfg.act_hi[j] = float(alo[j]), float(ahi[j])
+        if hasattr(self.original_action_space, "low"):  # MultiBinary (at the touch) has no bounds
+            alo, ahi = self.original_action_space.low, self.original_action_space.high
+            for j in range(len(alo)):
+                cfg.act_lo[j], cfg.act_hi[j] = float(alo[j]), float(ahi[j])
         return cfg
 
     def _create_handle(self, num_trajectories: int, reward_scale: float, trajectory_offset=None):

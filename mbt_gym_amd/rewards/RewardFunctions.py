@@ -3,6 +3,9 @@
 PnL                     (RW:20-36)    r = (c' + q' S') - (c + q S)
 RunningInventoryPenalty (RW:116-143)  r = PnL - dt phi q'^p - alpha [terminal] q'^p         (alias CjCriterion, RW:146)
 CjMmCriterion           (RW:77-113)   r = PnL - dt phi q'^p - alpha (q'^p - q^p + dt/L q0^p),  L = T - t0, q0 = q(reset)
+CjOeCriterion           (RW:39-74)    r = PnL - dt phi q'^p - dt alpha (p v q^(p-1) + q0^p L)   (v = trading speed; the
+                                      reference multiplies by L here, reproduced)
+ExponentialUtility      (RW:149-163)  r = -exp(-gamma (c' + q' S')) on the terminal step, 0 before
 
 Inside `TradingEnvironment.step()` the reward is part of the fused step kernel (csrc/step_kernel.hpp), computed in
 float32 from the step's increments.  `calculate()` - the reference's public method, which its unit tests and
@@ -24,11 +27,15 @@ class RewardFunction(metaclass=abc.ABCMeta):
     terminal_inventory_aversion = 0.0
     inventory_exponent = 2.0
 
+    risk_aversion = 0.0
+
     def calculate(self, current_state, action, next_state, is_terminal_step: bool = False) -> Union[float, np.ndarray]:
         assert len(np.shape(current_state)) > 1, "Reward functions must be calculated on state matrices."
+        q_init, episode_length = self._episode_constants()
         return _native.reward_calculate(
             self.device_kind, self.per_step_inventory_aversion, self.terminal_inventory_aversion, self.inventory_exponent,
-            current_state, next_state, np.all(is_terminal_step), *self._episode_constants(),
+            current_state, next_state, np.all(is_terminal_step), q_init, episode_length,
+            action=action if self.device_kind == _native.REW_CJ_OE else None, risk_aversion=self.risk_aversion,
         )
 
     def _episode_constants(self):
@@ -108,3 +115,24 @@ class CjMmCriterion(_InventoryAverse):
         state = np.asarray(initial_state, dtype=np.float64)
         self.initial_inventory = state[:, INVENTORY_INDEX].copy()
         self.episode_length = self.terminal_time - state[:, TIME_INDEX]
+
+
+class CjOeCriterion(CjMmCriterion):
+    """Cartea-Jaimungal optimal-execution criterion for trading-with-speed dynamics."""
+
+    device_kind = _native.REW_CJ_OE
+
+
+class ExponentialUtility(RewardFunction):
+    """Exponential utility of terminal wealth; every earlier step is rewarded with zero."""
+
+    device_kind = _native.REW_EXP_UTILITY
+
+    def __init__(self, risk_aversion: float = 0.1):
+        self.risk_aversion = risk_aversion
+
+    def reset(self, initial_state):
+        pass
+
+    def device_params(self):
+        return dict(reward_kind=self.device_kind, risk_aversion=self.risk_aversion)

@@ -6,7 +6,7 @@ stands in.  Bounds are float32, like the reference's (gym/TradingEnvironment.py:
 import numpy as np
 
 try:  # pragma: no cover - not installed in the build image
-    from gym.spaces import Box, Space  # type: ignore
+    from gym.spaces import Box, MultiBinary, Space  # type: ignore
     HAVE_GYM = True
 except Exception:  # noqa: BLE001
     HAVE_GYM = False
@@ -41,3 +41,17 @@ except Exception:  # noqa: BLE001
 
         def __repr__(self):
             return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+    class MultiBinary(Space):
+        """{0, 1}^n (the action space of at-the-touch dynamics, ModelDynamics.py:165-167)."""
+
+        def __init__(self, n):
+            super().__init__((n,), np.int8)
+            self.n = n
+
+        def sample(self):
+            return self._np_random.integers(0, 2, size=self.shape).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all((x == 0) | (x == 1)))

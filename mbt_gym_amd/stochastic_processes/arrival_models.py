@@ -4,6 +4,7 @@ Entry 0 of an arrival is an exogenous SELL order hitting the bid side, entry 1 a
 the ask side (ARR:9-13).
 
 PoissonArrivalModel (ARR:32-56):   arrival_s = U_s < intensity_s * dt
+PoissonArrivalNonLinearModel (ARR:59-83):  arrival_s = U_s < 1 - exp(-intensity_s * dt)
 HawkesArrivalModel  (ARR:86-126):  arrival_s = U_s < lambda_s * dt, then
                                    lambda_s <- lambda_s + beta (baseline_s - lambda_s) dt + eta * arrival_s
     (the jump is on ARRIVALS, not on fills, and the 10x-baseline `max_value` is only an observation bound).
@@ -42,7 +43,13 @@ class PoissonArrivalModel(ArrivalModel):
 
     def device_params(self):
         lam = np.asarray(self.intensity, dtype=np.float64).reshape(-1)
-        return dict(arrival_kind=self.device_kind, intensity=(float(lam[0]), float(lam[1])))
+        return dict(arrival_kind=self.device_kind, intensity=(float(lam[0]), float(lam[1])), arrival_step_size=self.step_size)
+
+
+class PoissonArrivalNonLinearModel(PoissonArrivalModel):
+    """Exact probability of at least one Poisson arrival in a step instead of its first-order approximation."""
+
+    device_kind = _native.ARR_POISSON_NONLINEAR
 
 
 class HawkesArrivalModel(ArrivalModel):
@@ -78,5 +85,5 @@ class HawkesArrivalModel(ArrivalModel):
         base = self.baseline_arrival_rate.reshape(-1)
         return dict(
             arrival_kind=self.device_kind, intensity=(float(base[0]), float(base[1])),
-            hawkes_jump=self.jump_size, hawkes_speed=self.mean_reversion_speed,
+            hawkes_jump=self.jump_size, hawkes_speed=self.mean_reversion_speed, arrival_step_size=self.step_size,
         )

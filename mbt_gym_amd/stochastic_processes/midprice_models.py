@@ -4,9 +4,16 @@ BrownianMotionMidpriceModel (MID:36-68):  S <- S + mu dt + sigma sqrt(dt) Z
 OuMidpriceModel            (MID:114-146): S <- S - theta (S - level) + sigma sqrt(dt) Z
     The mean-reversion term is NOT multiplied by dt in the reference (MID:140-143); this is reproduced.
 
-The other reference classes (GBM, jump models, short-term-alpha, Heston, CEV) have no kernel yet: constructing
-a TradingEnvironment with an unknown process raises - see SURVEY.md section 2.1 for which of them are broken
-upstream.
+GeometricBrownianMotionMidpriceModel (MID:71-111):  S <- S + mu S dt + sigma S sqrt(dt) Z
+BrownianMotionJumpMidpriceModel (MID:193-230):      Brownian + jump_size * (own ask fills - own bid fills)
+OuJumpMidpriceModel (MID:233-273):                  OU       + jump_size * (own ask fills - own bid fills)
+ConstantMidpriceModel (MID:12-33):                  S <- S
+
+`dt` is the step_size passed to THIS constructor: the reference never synchronises a process's step size with the
+environment's (only its step_size setter does), and neither do we.
+
+The remaining reference classes (ShortTerm*Alpha, Heston, CEV) are broken upstream for num_trajectories > 1
+ and have no kernel: constructing a TradingEnvironment with one raises.
 """
 from typing import Optional
 
@@ -58,7 +65,8 @@ class BrownianMotionMidpriceModel(_SymmetricBandMidprice):
         super().__init__(initial_price, 4 * volatility * np.sqrt(terminal_time), terminal_time, step_size, num_trajectories, seed)
 
     def device_params(self):
-        return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, initial_price=self.initial_price)
+        return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, initial_price=self.initial_price,
+                    midprice_step_size=self.step_size)
 
 
 class OuMidpriceModel(_SymmetricBandMidprice):
@@ -84,5 +92,97 @@ class OuMidpriceModel(_SymmetricBandMidprice):
     def device_params(self):
         return dict(
             midprice_kind=self.device_kind, volatility=self.volatility, initial_price=self.initial_price,
-            ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed,
+            ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed, midprice_step_size=self.step_size,
         )
+
+
+class GeometricBrownianMotionMidpriceModel(_SymmetricBandMidprice):
+    device_kind = _native.MID_GBM
+
+    def __init__(
+        self,
+        drift: float = 0.0,
+        volatility: float = 0.1,
+        initial_price: float = 100,
+        terminal_time: float = 1.0,
+        step_size: float = 0.01,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+    ):
+        self.drift = drift
+        self.volatility = volatility
+        # mean + four standard deviations of the log-normal S_T (MID:105-111)
+        stdev = np.sqrt(initial_price**2 * np.exp(2 * drift * terminal_time) * (np.exp(volatility**2 * terminal_time) - 1))
+        top = initial_price * np.exp(drift * terminal_time) + 4 * stdev
+        super().__init__(initial_price, top - initial_price, terminal_time, step_size, num_trajectories, seed)
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, initial_price=self.initial_price,
+                    midprice_step_size=self.step_size)
+
+
+class BrownianMotionJumpMidpriceModel(_SymmetricBandMidprice):
+    device_kind = _native.MID_BROWNIAN_JUMP
+
+    def __init__(
+        self,
+        drift: float = 0.0,
+        volatility: float = 2.0,
+        jump_size: float = 1.0,
+        initial_price: float = 100,
+        terminal_time: float = 1.0,
+        step_size: float = 0.01,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+    ):
+        self.drift = drift
+        self.volatility = volatility
+        self.jump_size = jump_size
+        super().__init__(initial_price, 4 * volatility * terminal_time, terminal_time, step_size, num_trajectories, seed)
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, jump_size=self.jump_size,
+                    initial_price=self.initial_price, midprice_step_size=self.step_size)
+
+
+class OuJumpMidpriceModel(_SymmetricBandMidprice):
+    device_kind = _native.MID_OU_JUMP
+
+    def __init__(
+        self,
+        mean_reversion_level: float = 0.0,
+        mean_reversion_speed: float = 1.0,
+        volatility: float = 2.0,
+        jump_size: float = 1.0,
+        initial_price: float = 100.0,
+        terminal_time: float = 1.0,
+        step_size: float = 0.01,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+    ):
+        self.mean_reversion_level = mean_reversion_level
+        self.mean_reversion_speed = mean_reversion_speed
+        self.volatility = volatility
+        self.jump_size = jump_size
+        super().__init__(initial_price, 4 * volatility * terminal_time, terminal_time, step_size, num_trajectories, seed)
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, volatility=self.volatility, jump_size=self.jump_size, initial_price=self.initial_price,
+                    ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed, midprice_step_size=self.step_size)
+
+
+class ConstantMidpriceModel(_SymmetricBandMidprice):
+    device_kind = _native.MID_CONSTANT
+
+    def __init__(
+        self,
+        initial_price: float = 100,
+        terminal_time: float = 1.0,
+        step_size: float = 0.01,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+    ):
+        super().__init__(initial_price, 0.0, terminal_time, step_size, num_trajectories, seed)
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, initial_price=self.initial_price, midprice_step_size=self.step_size)

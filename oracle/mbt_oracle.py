@@ -47,26 +47,45 @@ class OracleConfig:
     num_trajectories: int = 1
     n_steps: int = 200  # TE:30
     terminal_time: float = 1.0  # TE:29
-    # midprice: "bm" (MID:36-68) or "ou" (MID:114-146)
+    # midprice: "bm" (MID:36-68), "ou" (MID:114-146), "gbm" (MID:71-111), "bm_jump" (MID:193-230),
+    # "ou_jump" (MID:233-273), "constant" (MID:12-33)
     midprice: str = "bm"
     drift: float = 0.0
     volatility: float = 2.0
     initial_price: float = 100.0
     ou_level: float = 0.0  # mean_reversion_level MID:117
     ou_speed: float = 1.0  # mean_reversion_speed MID:118
-    # arrivals: "poisson" (ARR:32-56) or "hawkes" (ARR:86-126)
+    jump_size: float = 1.0  # MID:199 / MID:240: the midprice moves by +-jump_size on the agent's own fills
+    # arrivals: "poisson" (ARR:32-56), "poisson_nonlinear" (ARR:59-83), "hawkes" (ARR:86-126), "none" (speed dynamics)
     arrival: str = "poisson"
     intensity: Sequence[float] = (140.0, 140.0)  # Poisson rate / Hawkes baseline (bid, ask)
     hawkes_jump: float = 40.0
     hawkes_speed: float = 60.0
     # fills: exponential (FILL:42-65)
     fill_exponent: float = 1.5
-    # dynamics: "limit" (MD:87-131) or "limit_and_market" (MD:179-240)
+    # dynamics: "limit" (MD:87-131), "limit_and_market" (MD:179-240), "touch" (MD:134-176), "speed" (MD:243-275)
     dynamics: str = "limit"
     market_half_spread: float = 0.5  # MD:189
     max_depth: Optional[float] = None  # MD:103 / FILL:60-62
-    # reward: "pnl" (RW:20-36), "running" (RW:116-143), "cjmm" (RW:77-113)
+    # price impact (speed dynamics): "temp_power" (IMP:34-61), "temp_perm" (IMP:64-96), "temp_transient" (IMP:99-139),
+    # "transient" (IMP:142-179)
+    impact: str = "none"
+    temporary_impact: float = 0.01
+    impact_exponent: float = 1.0  # IMP:38
+    permanent_impact: float = 0.01  # IMP:68
+    transient_impact: float = 0.01  # kappa IMP:103
+    resilience: float = 0.01  # rho IMP:104
+    initial_transient_impact: float = 0.01  # y IMP:105
+    kernel_coefficient: float = 0.01  # gamma IMP:106
+    impact_step_size: Optional[float] = None  # the impact model's own terminal_time / n_steps (IMP:75, IMP:115)
+    # every process keeps its OWN step_size constructor argument (SP:21); the environment never synchronises them
+    # (only the step_size setter does, TE:158-167), so drift/volatility scaling (MID:63-64), arrival thresholds
+    # (ARR:56) and the traded volume of speed dynamics (MD:265) use these, not terminal_time / n_steps
+    midprice_step_size: Optional[float] = None
+    arrival_step_size: Optional[float] = None
+    # reward: "pnl" (RW:20-36), "running" (RW:116-143), "cjmm" (RW:77-113), "cjoe" (RW:39-74), "exp_utility" (RW:149-163)
     reward: str = "pnl"
+    risk_aversion: float = 0.1  # RW:150
     phi: float = 0.01  # per_step_inventory_aversion
     alpha: float = 0.0  # terminal_inventory_aversion
     inventory_exponent: float = 2.0
@@ -87,12 +106,20 @@ class OracleConfig:
         return self.terminal_time / self.n_steps  # TE:49
 
     @property
+    def impact_has_state(self) -> bool:
+        return self.impact in ("temp_perm", "temp_transient", "transient")
+
+    @property
     def state_dim(self) -> int:
-        return 4 + (2 if self.arrival == "hawkes" else 0)  # TE:311-318
+        return 4 + (2 if self.arrival == "hawkes" else 0) + (1 if self.impact_has_state else 0)  # TE:311-318
 
     @property
     def action_dim(self) -> int:
-        return 4 if self.dynamics == "limit_and_market" else 2  # MD:121, MD:227-230
+        return {"limit": 2, "limit_and_market": 4, "touch": 2, "speed": 1}[self.dynamics]  # MD:121, :167, :227-230, :271
+
+    @property
+    def max_speed(self) -> float:
+        return 100.0 if self.impact == "temp_power" else 10.0  # IMP:59-61, IMP:94-96
 
 
 # ----------------------------------------------------------------------------------------------
@@ -105,8 +132,15 @@ def midprice_bounds(cfg: OracleConfig) -> Tuple[float, float]:
     4 sigma T (MID:130-131, MID:145-146)."""
     if cfg.midprice == "bm":
         hi = cfg.initial_price + 4 * cfg.volatility * np.sqrt(cfg.terminal_time)
-    elif cfg.midprice == "ou":
+    elif cfg.midprice in ("ou", "bm_jump", "ou_jump"):  # MID:145-146, MID:229-230, MID:272-273
         hi = cfg.initial_price + 4 * cfg.volatility * cfg.terminal_time
+    elif cfg.midprice == "gbm":  # MID:105-111
+        stdev = math.sqrt(
+            cfg.initial_price**2 * np.exp(2 * cfg.drift * cfg.terminal_time) * (np.exp(cfg.volatility**2 * cfg.terminal_time) - 1)
+        )
+        hi = cfg.initial_price * np.exp(cfg.drift * cfg.terminal_time) + 4 * stdev
+    elif cfg.midprice == "constant":  # MID:21-23
+        return float(cfg.initial_price), float(cfg.initial_price)
     else:
         raise ValueError(cfg.midprice)
     lo = cfg.initial_price - (hi - cfg.initial_price)
@@ -138,11 +172,19 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
         base = np.asarray(cfg.intensity, dtype=np.float64).reshape(-1)
         lo += [0.0, 0.0]  # ARR:100
         hi += list(base * 10)  # ARR:101, ARR:125-126
+    if cfg.impact_has_state:  # IMP:77-78, IMP:117-118, IMP:158-159
+        coef = cfg.permanent_impact if cfg.impact == "temp_perm" else cfg.transient_impact
+        lo.append(-cfg.max_speed * cfg.terminal_time * coef)
+        hi.append(cfg.max_speed * cfg.terminal_time * coef)
     return np.float32(np.array(lo)), np.float32(np.array(hi))
 
 
 def action_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
     """float32 Box bounds of the un-normalised action (MD:118-121, MD:224-231)."""
+    if cfg.dynamics == "speed":  # MD:269-271
+        return np.float32([-cfg.max_speed]), np.float32([cfg.max_speed])
+    if cfg.dynamics == "touch":  # MD:165-167: MultiBinary(2) has no bounds; {0,1}^2
+        return np.zeros(2, np.float32), np.ones(2, np.float32)
     d = resolved_max_depth(cfg)
     if cfg.dynamics == "limit":
         return np.zeros(2, np.float32), np.full(2, np.float32(d), np.float32)
@@ -234,6 +276,9 @@ class OracleEnv:
         cols = [np.repeat(np.array([[cfg.initial_price]], dtype=np.float64), n, axis=0)]
         if cfg.arrival == "hawkes":
             cols.append(np.repeat(np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2), n, axis=0))
+        if cfg.impact_has_state:  # IMP:81 (0) / IMP:121, IMP:162 (initial transient impact)
+            y0 = 0 if cfg.impact == "temp_perm" else cfg.initial_transient_impact
+            cols.append(np.repeat(np.array([[y0]]), n, axis=0))
         for c in cols:
             s = np.append(s, c, axis=1)
         return s
@@ -267,55 +312,101 @@ class OracleEnv:
         prev = self.state.copy()  # TE:105
         st = self.state
         u_arr, u_fill, z = self.noise.draw(n)
-
-        # arrivals (ARR:54-56 / ARR:121-123) and raw fills (FILL:28-34, FILL:57-58)
-        if cfg.arrival == "poisson":
-            arrivals = u_arr < np.array(cfg.intensity) * dt
-        else:
-            arrivals = u_arr < st[:, 4:6] * dt
-        depths = action[:, 0:2]  # MD:50-51
-        fills = u_fill < np.exp(-cfg.fill_exponent * depths)
-        # no bid fill at +max inventory, no ask fill at -max inventory, pre-update q (TE:323-327)
-        at_max = st[:, INVENTORY] >= cfg.max_inventory
-        at_min = st[:, INVENTORY] <= -cfg.max_inventory
-        mask = np.concatenate(((1 - at_max).reshape(-1, 1), (1 - at_min).reshape(-1, 1)), axis=1)
-        fills = mask * fills
-
-        # cash / inventory (MD:108-116, MD:208-222); midprice is the OLD one (MD:82-84)
         mid = st[:, PRICE].reshape(-1, 1)
         sgn = self.bid_ask_sign
-        if cfg.dynamics == "limit_and_market":
-            mo_buy = np.single(action[:, 2] > 0.5)
-            mo_sell = np.single(action[:, 3] > 0.5)
-            best_bid = (mid - cfg.market_half_spread).reshape(-1)
-            best_ask = (mid + cfg.market_half_spread).reshape(-1)
-            st[:, CASH] += mo_sell * best_bid - mo_buy * best_ask
-            st[:, INVENTORY] += mo_buy - mo_sell
-        st[:, INVENTORY] += np.sum(arrivals * fills * -sgn, axis=1)
-        st[:, CASH] += np.sum(sgn * arrivals * fills * (mid + depths * sgn), axis=1)
+        arrivals = fills = None
+        if cfg.dynamics == "speed":
+            # MD:262-267: execution price = midprice + impact; volume = speed * (midprice model's step size)
+            y = prev[:, -1].reshape(-1, 1) if cfg.impact_has_state else None
+            if cfg.impact == "temp_power":
+                price_impact = cfg.temporary_impact * action**cfg.impact_exponent  # IMP:55-56
+            elif cfg.impact == "temp_perm":
+                price_impact = cfg.temporary_impact * action + y  # IMP:90-91
+            elif cfg.impact == "temp_transient":
+                price_impact = cfg.temporary_impact * action + cfg.transient_impact * y  # IMP:134-135
+            else:
+                price_impact = cfg.transient_impact * y  # IMP:174-175
+            execution_price = mid + price_impact
+            volume = action * (cfg.midprice_step_size or dt)
+            st[:, CASH] -= np.squeeze(volume * execution_price)
+            st[:, INVENTORY] += np.squeeze(volume)
+        else:
+            # arrivals (ARR:54-56 / ARR:81-83 / ARR:121-123) and raw fills (FILL:28-34, FILL:57-58 / MD:174-176)
+            adt = cfg.arrival_step_size or dt
+            if cfg.arrival == "poisson":
+                arrivals = u_arr < np.array(cfg.intensity) * adt
+            elif cfg.arrival == "poisson_nonlinear":
+                arrivals = u_arr < 1.0 - np.exp(-np.array(cfg.intensity) * adt)
+            else:
+                arrivals = u_arr < st[:, 4:6] * adt
+            depths = action[:, 0:2]  # MD:50-51
+            if cfg.dynamics == "touch":
+                fills = action[:, 0:2]  # the agent posts (or not) at the touch: MD:156-157
+            else:
+                fills = u_fill < np.exp(-cfg.fill_exponent * depths)
+            # no bid fill at +max inventory, no ask fill at -max inventory, pre-update q (TE:323-327)
+            at_max = st[:, INVENTORY] >= cfg.max_inventory
+            at_min = st[:, INVENTORY] <= -cfg.max_inventory
+            mask = np.concatenate(((1 - at_max).reshape(-1, 1), (1 - at_min).reshape(-1, 1)), axis=1)
+            fills = mask * fills
+            # cash / inventory (MD:108-116, MD:146-154, MD:208-222); midprice is the OLD one (MD:82-84)
+            if cfg.dynamics == "limit_and_market":
+                mo_buy = np.single(action[:, 2] > 0.5)
+                mo_sell = np.single(action[:, 3] > 0.5)
+                best_bid = (mid - cfg.market_half_spread).reshape(-1)
+                best_ask = (mid + cfg.market_half_spread).reshape(-1)
+                st[:, CASH] += mo_sell * best_bid - mo_buy * best_ask
+                st[:, INVENTORY] += mo_buy - mo_sell
+            if cfg.dynamics == "touch":
+                st[:, CASH] += np.sum(sgn * arrivals * fills * (mid + cfg.market_half_spread * sgn), axis=1)
+                st[:, INVENTORY] += np.sum(arrivals * fills * -sgn, axis=1)
+            else:
+                st[:, INVENTORY] += np.sum(arrivals * fills * -sgn, axis=1)
+                st[:, CASH] += np.sum(sgn * arrivals * fills * (mid + depths * sgn), axis=1)
         # clip (TE:283-289) and advance time (TE:216)
         st[:, INVENTORY] = np.clip(st[:, INVENTORY], -cfg.max_inventory, cfg.max_inventory)
         st[:, CASH] = np.clip(st[:, CASH], -self.max_cash, self.max_cash)
         st[:, TIME] += dt
 
-        # processes in registry order midprice, arrival (TE:206-211, TE:303-309)
+        # processes in registry order midprice, arrival, fill, impact (TE:206-211, TE:303-309)
         s_old = prev[:, PRICE].reshape(-1, 1)
+        mdt = cfg.midprice_step_size or dt
+        noise_term = cfg.volatility * math.sqrt(mdt) * z
+        if cfg.midprice in ("bm_jump", "ou_jump"):  # MID:220-221, MID:262-263
+            fills_bid = fills[:, 0] * arrivals[:, 0]
+            fills_ask = fills[:, 1] * arrivals[:, 1]
+            jump = (cfg.jump_size * fills_ask - cfg.jump_size * fills_bid).reshape(-1, 1)
         if cfg.midprice == "bm":  # MID:60-65
-            s_new = s_old + cfg.drift * dt * np.ones((n, 1)) + cfg.volatility * math.sqrt(dt) * z
-        else:  # MID:140-143 (mean reversion is NOT scaled by dt in the reference)
-            s_new = s_old + (
-                -cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + cfg.volatility * math.sqrt(dt) * z
-            )
+            s_new = s_old + cfg.drift * mdt * np.ones((n, 1)) + noise_term
+        elif cfg.midprice == "ou":  # MID:140-143 (mean reversion is NOT scaled by dt in the reference)
+            s_new = s_old + (-cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + noise_term)
+        elif cfg.midprice == "gbm":  # MID:95-103
+            s_new = s_old + cfg.drift * s_old * mdt + cfg.volatility * s_old * math.sqrt(mdt) * z
+        elif cfg.midprice == "bm_jump":  # MID:222-227
+            s_new = s_old + cfg.drift * mdt * np.ones((n, 1)) + noise_term + jump
+        elif cfg.midprice == "ou_jump":  # MID:264-270
+            s_new = s_old - cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + noise_term + jump
+        else:  # constant, MID:32-33
+            s_new = s_old
         st[:, PRICE] = s_new[:, 0]
         if cfg.arrival == "hawkes":  # ARR:110-119 (jumps on arrivals, not on fills)
             lam = prev[:, 4:6]
             base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
+            adt = cfg.arrival_step_size or dt
             st[:, 4:6] = (
-                lam + cfg.hawkes_speed * (np.ones((n, 2)) * base - lam) * dt * np.ones((n, 2)) + cfg.hawkes_jump * arrivals
+                lam + cfg.hawkes_speed * (np.ones((n, 2)) * base - lam) * adt * np.ones((n, 2)) + cfg.hawkes_jump * arrivals
             )
+        if cfg.impact_has_state:
+            y = prev[:, -1].reshape(-1, 1)
+            h = cfg.impact_step_size or dt
+            if cfg.impact == "temp_perm":  # IMP:87-88
+                y_new = y + cfg.permanent_impact * action * h
+            else:  # IMP:130-132, IMP:170-172
+                y_new = y - cfg.resilience * y * h + cfg.kernel_coefficient * action * h
+            st[:, -1] = y_new[:, 0]
 
         done = bool(st[0, TIME] >= cfg.terminal_time - dt / 2)  # TE:218-220
-        rewards = self._reward(prev, st, done)
+        rewards = self._reward(prev, st, done, action)
         if cfg.reward_scaling is not None:
             rewards = cfg.reward_scaling * rewards  # TE:128-129
         self.last_arrivals = arrivals
@@ -324,9 +415,13 @@ class OracleEnv:
         return self.normalise_observation(st.copy()), rewards, dones
 
     # -- rewards -------------------------------------------------------------------------------
-    def _reward(self, cur: np.ndarray, nxt: np.ndarray, done: bool) -> np.ndarray:
+    def _reward(self, cur: np.ndarray, nxt: np.ndarray, done: bool, action=None) -> np.ndarray:
         cfg = self.cfg
         pnl = pnl_reward(cur, nxt)
+        if cfg.reward == "exp_utility":  # RW:156-163 (the reference returns the scalar 0 off the terminal step)
+            return exponential_utility(nxt, cfg.risk_aversion) if done else np.zeros(cfg.num_trajectories)
+        if cfg.reward == "cjoe":
+            return cj_oe_criterion(cur, action, nxt, cfg.phi, cfg.alpha, cfg.inventory_exponent, self.q_init, self.episode_length)
         if cfg.reward == "pnl":
             return pnl
         if cfg.reward == "running":
@@ -357,6 +452,21 @@ def cj_mm_criterion(cur, nxt, phi: float, alpha: float, p: float, q_init, episod
         - dt * phi * nxt[:, INVENTORY] ** p
         - alpha * (nxt[:, INVENTORY] ** p - cur[:, INVENTORY] ** p + dt / episode_length * q_init**p)
     )
+
+
+def cj_oe_criterion(cur, action, nxt, phi: float, alpha: float, p: float, q_init, episode_length) -> np.ndarray:
+    """RW:57-70 (note: the terminal term multiplies, not divides, by the episode length)."""
+    dt = nxt[:, TIME] - cur[:, TIME]
+    return (
+        pnl_reward(cur, nxt)
+        - dt * phi * nxt[:, INVENTORY] ** p
+        - dt * alpha * (p * np.squeeze(action) * (cur[:, INVENTORY]) ** (p - 1) + q_init**p * episode_length)
+    )
+
+
+def exponential_utility(nxt, risk_aversion: float) -> np.ndarray:
+    """RW:157-160."""
+    return -np.exp(-risk_aversion * (nxt[:, CASH] + nxt[:, INVENTORY] * nxt[:, PRICE]))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -4,37 +4,61 @@ import numpy as np
 
 
 def make_env(cfg, noise="philox", **overrides):
-    from mbt_gym_amd.gym.ModelDynamics import LimitAndMarketOrderModelDynamics, LimitOrderModelDynamics
+    from mbt_gym_amd.gym import ModelDynamics as dyn
     from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
-    from mbt_gym_amd.rewards.RewardFunctions import CjMmCriterion, PnL, RunningInventoryPenalty
-    from mbt_gym_amd.stochastic_processes.arrival_models import HawkesArrivalModel, PoissonArrivalModel
+    from mbt_gym_amd.rewards import RewardFunctions as rw
+    from mbt_gym_amd.stochastic_processes import arrival_models as arr_m
+    from mbt_gym_amd.stochastic_processes import midprice_models as mid_m
+    from mbt_gym_amd.stochastic_processes import price_impact_models as imp_m
     from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
-    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel, OuMidpriceModel
 
     n, dt, T = cfg.num_trajectories, cfg.step_size, cfg.terminal_time
-    if cfg.midprice == "bm":
-        mid = BrownianMotionMidpriceModel(drift=cfg.drift, volatility=cfg.volatility, initial_price=cfg.initial_price,
-                                          terminal_time=T, step_size=dt, num_trajectories=n)
-    else:
-        mid = OuMidpriceModel(mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, volatility=cfg.volatility,
-                              initial_price=cfg.initial_price, terminal_time=T, step_size=dt, num_trajectories=n)
-    if cfg.arrival == "poisson":
-        arr = PoissonArrivalModel(intensity=np.array(cfg.intensity), step_size=dt, num_trajectories=n)
-    else:
-        arr = HawkesArrivalModel(baseline_arrival_rate=np.array([list(cfg.intensity)]), step_size=dt, jump_size=cfg.hawkes_jump,
-                                 mean_reversion_speed=cfg.hawkes_speed, terminal_time=T, num_trajectories=n)
+    mid_dt = cfg.midprice_step_size or dt
+    arr_dt = cfg.arrival_step_size or dt
+    common = dict(terminal_time=T, step_size=mid_dt, num_trajectories=n)
+    mid = {
+        "bm": lambda: mid_m.BrownianMotionMidpriceModel(drift=cfg.drift, volatility=cfg.volatility, initial_price=cfg.initial_price, **common),
+        "ou": lambda: mid_m.OuMidpriceModel(mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, volatility=cfg.volatility,
+                                            initial_price=cfg.initial_price, **common),
+        "gbm": lambda: mid_m.GeometricBrownianMotionMidpriceModel(drift=cfg.drift, volatility=cfg.volatility, initial_price=cfg.initial_price, **common),
+        "bm_jump": lambda: mid_m.BrownianMotionJumpMidpriceModel(drift=cfg.drift, volatility=cfg.volatility, jump_size=cfg.jump_size,
+                                                                 initial_price=cfg.initial_price, **common),
+        "ou_jump": lambda: mid_m.OuJumpMidpriceModel(mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, volatility=cfg.volatility,
+                                                     jump_size=cfg.jump_size, initial_price=cfg.initial_price, **common),
+        "constant": lambda: mid_m.ConstantMidpriceModel(initial_price=cfg.initial_price, **common),
+    }[cfg.midprice]()
+    arr = {
+        "poisson": lambda: arr_m.PoissonArrivalModel(intensity=np.array(cfg.intensity), step_size=arr_dt, num_trajectories=n),
+        "poisson_nonlinear": lambda: arr_m.PoissonArrivalNonLinearModel(intensity=np.array(cfg.intensity), step_size=arr_dt, num_trajectories=n),
+        "hawkes": lambda: arr_m.HawkesArrivalModel(baseline_arrival_rate=np.array([list(cfg.intensity)]), step_size=arr_dt, jump_size=cfg.hawkes_jump,
+                                                   mean_reversion_speed=cfg.hawkes_speed, terminal_time=T, num_trajectories=n),
+        "none": lambda: None,
+    }[cfg.arrival]()
     fill = ExponentialFillFunction(fill_exponent=cfg.fill_exponent, step_size=dt, num_trajectories=n)
     if cfg.dynamics == "limit":
-        md = LimitOrderModelDynamics(midprice_model=mid, arrival_model=arr, fill_probability_model=fill, num_trajectories=n,
-                                     max_depth=cfg.max_depth)
+        md = dyn.LimitOrderModelDynamics(midprice_model=mid, arrival_model=arr, fill_probability_model=fill, num_trajectories=n, max_depth=cfg.max_depth)
+    elif cfg.dynamics == "limit_and_market":
+        md = dyn.LimitAndMarketOrderModelDynamics(midprice_model=mid, arrival_model=arr, fill_probability_model=fill, num_trajectories=n,
+                                                  max_depth=cfg.max_depth, fixed_market_half_spread=cfg.market_half_spread)
+    elif cfg.dynamics == "touch":
+        md = dyn.AtTheTouchModelDynamics(midprice_model=mid, arrival_model=arr, num_trajectories=n, fixed_market_half_spread=cfg.market_half_spread)
     else:
-        md = LimitAndMarketOrderModelDynamics(midprice_model=mid, arrival_model=arr, fill_probability_model=fill,
-                                              num_trajectories=n, max_depth=cfg.max_depth,
-                                              fixed_market_half_spread=cfg.market_half_spread)
+        imp_steps = int(round(T / (cfg.impact_step_size or dt)))
+        impact = {
+            "temp_power": lambda: imp_m.TemporaryPowerPriceImpact(cfg.temporary_impact, cfg.impact_exponent, num_trajectories=n),
+            "temp_perm": lambda: imp_m.TemporaryAndPermanentPriceImpact(cfg.temporary_impact, cfg.permanent_impact, n_steps=imp_steps, terminal_time=T, num_trajectories=n),
+            "temp_transient": lambda: imp_m.TemporaryAndTransientPriceImpact(cfg.temporary_impact, cfg.transient_impact, cfg.resilience, cfg.initial_transient_impact,
+                                                                             cfg.kernel_coefficient, n_steps=imp_steps, terminal_time=T, num_trajectories=n),
+            "transient": lambda: imp_m.TransientPriceImpact(cfg.transient_impact, cfg.resilience, cfg.initial_transient_impact, cfg.kernel_coefficient,
+                                                            n_steps=imp_steps, terminal_time=T, num_trajectories=n),
+        }[cfg.impact]()
+        md = dyn.TradinghWithSpeedModelDynamics(midprice_model=mid, price_impact_model=impact, num_trajectories=n)
     rew = {
-        "pnl": lambda: PnL(),
-        "running": lambda: RunningInventoryPenalty(cfg.phi, cfg.alpha, cfg.inventory_exponent),
-        "cjmm": lambda: CjMmCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
+        "pnl": lambda: rw.PnL(),
+        "running": lambda: rw.RunningInventoryPenalty(cfg.phi, cfg.alpha, cfg.inventory_exponent),
+        "cjmm": lambda: rw.CjMmCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
+        "cjoe": lambda: rw.CjOeCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
+        "exp_utility": lambda: rw.ExponentialUtility(cfg.risk_aversion),
     }[cfg.reward]()
     kwargs = dict(
         terminal_time=T, n_steps=cfg.n_steps, reward_function=rew, model_dynamics=md, initial_cash=cfg.initial_cash,

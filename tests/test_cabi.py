@@ -42,7 +42,8 @@ def test_config_struct_layout_matches_a_c_compiler(lib, tmp_path):
     src = tmp_path / "layout.c"
     fields = ["abi_version", "num_trajectories", "n_steps", "terminal_time", "midprice_kind", "noise_mode", "drift",
               "intensity", "fill_exponent", "inventory_exponent", "initial_inventory", "reward_scale", "seed",
-              "normalise_observation", "obs_lo", "act_hi"]
+              "normalise_observation", "obs_lo", "act_hi", "midprice_step_size", "impact_kind", "temporary_impact",
+              "impact_step_size"]
     body = "\n".join(f'  printf("{f} %zu\\n", offsetof(mbt_config, {f}));' for f in fields)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(void) {{\n'
                    f'  printf("sizeof %zu\\n", sizeof(mbt_config));\n{body}\n  return 0; }}\n')
@@ -65,7 +66,7 @@ def test_no_cpu_fallback_without_a_device(lib):
         pytest.skip("a GPU is visible")
     cfg = _native.MbtConfig()
     cfg.abi_version = _native.ABI_VERSION
-    cfg.num_trajectories, cfg.n_steps, cfg.terminal_time = 4, 10, 1.0
+    cfg.num_trajectories, cfg.n_steps, cfg.terminal_time, cfg.impact_kind = 4, 10, 1.0, _native.IMPACT_NONE
     handle = C.c_void_p()
     rc = lib.mbt_env_create(C.byref(cfg), C.byref(handle))
     assert rc == -2 and not handle.value  # MBT_ERR_NO_DEVICE

@@ -22,8 +22,11 @@ def test_spaces_bounds_and_columns_match_the_reference(name, no_device):
     env = make_env(cfg)
     np.testing.assert_array_equal(env.original_observation_space.low, g["obs_lo"])
     np.testing.assert_array_equal(env.original_observation_space.high, g["obs_hi"])
-    np.testing.assert_array_equal(env.original_action_space.low, g["act_lo"])
-    np.testing.assert_array_equal(env.original_action_space.high, g["act_hi"])
+    if cfg.dynamics == "touch":  # MultiBinary(2) (MD:165-167)
+        assert env.original_action_space.n == 2 and not hasattr(env.original_action_space, "low")
+    else:
+        np.testing.assert_array_equal(env.original_action_space.low, g["act_lo"])
+        np.testing.assert_array_equal(env.original_action_space.high, g["act_hi"])
     assert env.max_cash == float(g["max_cash"])
     assert env.original_observation_space.low.dtype == np.float32
     np.testing.assert_array_equal(np.array(list(env.stochastic_process_indices.values())), g["process_indices"])

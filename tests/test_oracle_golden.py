@@ -21,6 +21,8 @@ from tests.golden_io import CASES, load_case
 def test_fixture_set_is_complete():
     assert set(CASES) >= {
         "as_limit_pnl", "cjp_running", "cjp_cjmm", "hawkes_ou", "limit_and_market", "default_normalised", "clip_cash",
+        "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice",
+        "speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transient_pnl", "speed_transient_pnl",
     }
 
 
@@ -40,8 +42,9 @@ def test_oracle_reproduces_reference_bit_for_bit(name):
     np.testing.assert_array_equal(obs0, g["obs0"])
     for k in range(g["actions"].shape[0]):
         obs, rew, done = env.step(g["actions"][k].astype(np.float64))
-        np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"arrivals step {k}")
-        np.testing.assert_array_equal(np.asarray(env.last_fills, dtype=np.uint8), g["fills"][k], err_msg=f"fills step {k}")
+        if env.last_arrivals is not None:  # speed dynamics have neither arrivals nor fills (MD:47-48)
+            np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"arrivals step {k}")
+            np.testing.assert_array_equal(np.asarray(env.last_fills, dtype=np.uint8), g["fills"][k], err_msg=f"fills step {k}")
         np.testing.assert_array_equal(obs, g["obs"][k], err_msg=f"obs step {k}")
         np.testing.assert_array_equal(rew, g["rewards"][k], err_msg=f"rewards step {k}")
         assert bool(done[0]) == bool(g["done"][k])

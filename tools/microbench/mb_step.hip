@@ -60,8 +60,8 @@ int main(int argc, char** argv) {
 
   mbt::StepParams P{};
   P.n = n; P.n_pairs = n_pairs; P.key0 = 50; P.dt = 1e-3f; P.vol_sqrt_dt = 2.f * sqrtf(1e-3f);
-  P.arr_thr_bid = P.arr_thr_ask = 0.14f; P.dt_f64 = 1e-3; P.kappa = 1.5f; P.kappa_f64 = 1.5; P.q_max = 1000.f; P.c_max = 1e8f;
-  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f;
+  P.arr_thr_bid = P.arr_thr_ask = 0.14f; P.kappa_log2e_neg = -1.5f * 1.4426950408889634f; P.kappa_f64 = 1.5; P.q_max = 1000.f; P.c_max = 1e8f;
+  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f; P.mid_add = 1.f; P.reward_kind = 2; P.arr_dt = 1e-3f; P.arr_dt_f64 = 1e-3;
   mbt::StepBuffers B{};
   B.action = act; B.reward = rew; B.u_arr = ua; B.u_fill = uf; B.z = z; B.wave_sums = ws; B.clip_count = clip;
   float* st[2] = {s0, s1};
@@ -76,9 +76,9 @@ int main(int argc, char** argv) {
   t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
                            hipLaunchKernelGGL((mbt::step_kernel<VARIANT>), dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
   printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, BYTES * n / t * 1e-3);
-  using AS = mbt::Variant<0, 0, 0, 0, false, false>;
-  using ASI = mbt::Variant<0, 0, 0, 0, false, true>;
-  using CJ = mbt::Variant<0, 0, 0, 2, false, false>;
+  using AS = mbt::Variant<0, 0, true, false, false, false>;
+  using ASI = mbt::Variant<0, 0, true, false, false, true>;
+  using CJ = mbt::Variant<0, 0, true, true, false, false>;
   RUN(AS, "step AS philox (44 B)", 44.0)
   RUN(CJ, "step CjMm philox (44 B)", 44.0)
   RUN(ASI, "step AS inject (64 B)", 64.0)

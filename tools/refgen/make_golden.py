@@ -28,12 +28,40 @@ sys.path.insert(0, "/root/reference")
 
 import numpy as np  # noqa: E402
 
-from mbt_gym.gym.ModelDynamics import LimitAndMarketOrderModelDynamics, LimitOrderModelDynamics  # noqa: E402
+from mbt_gym.gym.ModelDynamics import (  # noqa: E402
+    AtTheTouchModelDynamics,
+    LimitAndMarketOrderModelDynamics,
+    LimitOrderModelDynamics,
+    TradinghWithSpeedModelDynamics,
+)
 from mbt_gym.gym.TradingEnvironment import TradingEnvironment  # noqa: E402
-from mbt_gym.rewards.RewardFunctions import CjMmCriterion, PnL, RunningInventoryPenalty  # noqa: E402
-from mbt_gym.stochastic_processes.arrival_models import HawkesArrivalModel, PoissonArrivalModel  # noqa: E402
+from mbt_gym.rewards.RewardFunctions import (  # noqa: E402
+    CjMmCriterion,
+    CjOeCriterion,
+    ExponentialUtility,
+    PnL,
+    RunningInventoryPenalty,
+)
+from mbt_gym.stochastic_processes.arrival_models import (  # noqa: E402
+    HawkesArrivalModel,
+    PoissonArrivalModel,
+    PoissonArrivalNonLinearModel,
+)
 from mbt_gym.stochastic_processes.fill_probability_models import ExponentialFillFunction  # noqa: E402
-from mbt_gym.stochastic_processes.midprice_models import BrownianMotionMidpriceModel, OuMidpriceModel  # noqa: E402
+from mbt_gym.stochastic_processes.midprice_models import (  # noqa: E402
+    BrownianMotionJumpMidpriceModel,
+    BrownianMotionMidpriceModel,
+    ConstantMidpriceModel,
+    GeometricBrownianMotionMidpriceModel,
+    OuJumpMidpriceModel,
+    OuMidpriceModel,
+)
+from mbt_gym.stochastic_processes.price_impact_models import (  # noqa: E402
+    TemporaryAndPermanentPriceImpact,
+    TemporaryAndTransientPriceImpact,
+    TemporaryPowerPriceImpact,
+    TransientPriceImpact,
+)
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -69,7 +97,13 @@ def draw_noise(rng, k, n):
     return u_arr, u_fill, z
 
 
-def draw_actions(rng, k, n, a_dim, max_depth, normalised):
+def draw_actions(rng, k, n, a_dim, max_depth, normalised, kind="depths", max_speed=10.0):
+    if kind == "touch":  # MultiBinary(2): post at the touch or not
+        return rng.integers(0, 2, size=(k, n, 2)).astype(np.float32)
+    if kind == "speed":
+        return rng.uniform(-0.4 * max_speed, 0.4 * max_speed, size=(k, n, 1)).astype(np.float32)
+    if kind == "speed_positive":
+        return rng.uniform(0.0, 0.05 * max_speed, size=(k, n, 1)).astype(np.float32)
     if normalised:
         act = rng.uniform(-1, 1, size=(k, n, a_dim))
     else:
@@ -82,27 +116,29 @@ def draw_actions(rng, k, n, a_dim, max_depth, normalised):
     return act.astype(np.float32)
 
 
-def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None):
+def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None, action_kind="depths"):
     rng = np.random.default_rng(1000 + seed)
     with contextlib.redirect_stdout(io.StringIO()):
         env = build_env()
     md = env.model_dynamics
-    max_depth = md.max_depth
+    max_depth = getattr(md, "max_depth", None)
     u_arr, u_fill, z = draw_noise(rng, k_steps, n)
-    actions = draw_actions(rng, k_steps, n, a_dim, max_depth, normalised)
+    actions = draw_actions(rng, k_steps, n, a_dim, max_depth, normalised, action_kind, getattr(md, "max_speed", 10.0))
     # threshold-adjacent draws (strict '<' in float64): arrivals on lanes 0..2, fills on lanes 3..5
     if poisson_thr is not None:
         lo, c, hi = f32_neighbours(np.float64(poisson_thr))
         for j, v in enumerate((lo, c, hi)):
             u_arr[::3, j % n, :] = v
-    if not normalised:
+    if not normalised and action_kind == "depths":
         p = np.exp(-kappa * actions[:, :, 0:2].astype(np.float64))
         lo, c, hi = f32_neighbours(p)
         for j, v in enumerate((lo, c, hi)):
             u_fill[1::4, (3 + j) % n, :] = v[1::4, (3 + j) % n, :]
     md.midprice_model.rng = Replay(normals=z)
-    md.arrival_model.rng = Replay(uniforms=u_arr)
-    md.fill_probability_model.rng = Replay(uniforms=u_fill)
+    if md.arrival_model is not None:
+        md.arrival_model.rng = Replay(uniforms=u_arr)
+    if md.fill_probability_model is not None:
+        md.fill_probability_model.rng = Replay(uniforms=u_fill)
 
     rec = {"arr": [], "fill": []}
     orig_af = md.get_arrivals_and_fills
@@ -110,7 +146,9 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
 
     def spy_af(action):
         a, f = orig_af(action)
-        rec["arr"].append(np.array(a, dtype=np.uint8))
+        rec["arr"].append(np.zeros((n, 2), np.uint8) if a is None else np.array(a, dtype=np.uint8))
+        if f is None:
+            rec["fill"].append(np.zeros((n, 2), np.uint8))
         return a, f
 
     def spy_mask(fills):
@@ -129,13 +167,14 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         for k in range(k_steps):
             o, r, d, _ = env.step(actions[k].astype(np.float64))
             obs.append(np.array(o, dtype=np.float64))
-            rew.append(np.array(r, dtype=np.float64))
+            rew.append(np.array(np.broadcast_to(np.asarray(r, dtype=np.float64), (n,))))  # ExponentialUtility returns the scalar 0
             done.append(bool(d[0]))
     assert done[-1] and not any(done[:-1]), (name, done)
     lo = env.original_observation_space.low if normalised else env.observation_space.low
     hi = env.original_observation_space.high if normalised else env.observation_space.high
-    alo = env.original_action_space.low if env.normalise_action_space_ else env.action_space.low
-    ahi = env.original_action_space.high if env.normalise_action_space_ else env.action_space.high
+    aspace = env.original_action_space if env.normalise_action_space_ else env.action_space
+    alo = aspace.low if hasattr(aspace, "low") else np.zeros(2)  # MultiBinary(2) has no bounds
+    ahi = aspace.high if hasattr(aspace, "high") else np.ones(2)
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
@@ -148,7 +187,8 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
     )
     fills_total = int(np.sum(np.stack(rec["arr"]) * np.stack(rec["fill"])))
     print(f"{name}: N={n} steps={k_steps} D={obs[0].shape[1]} trades={fills_total} "
-          f"clip_q={int(np.sum(np.abs(np.stack(obs)[:, :, 1]) >= env.max_inventory)) if not normalised else '-'}")
+          f"clip_q={int(np.sum(np.abs(np.stack(obs)[:, :, 1]) >= env.max_inventory)) if not normalised else '-'} "
+          f"reward range [{np.min(rew):.4g}, {np.max(rew):.4g}]")
 
 
 def lo_dynamics(n, dt, T, mid, arr, kappa=1.5, cls=LimitOrderModelDynamics, **kw):
@@ -261,6 +301,113 @@ def main():
              intensity=[40.0, 40.0], fill_exponent=1.5, dynamics='limit', reward='pnl', initial_inventory=0,
              max_inventory=2, max_cash=150.0, seed=5, normalise_action_space=False, normalise_observation_space=False),
         poisson_thr=40 * (1 / ns))
+
+    extra_cases()
+
+
+def extra_cases():
+    """Plugin classes beyond the five BASELINE configurations."""
+    common = dict(normalise_action_space=False, normalise_observation_space=False)
+
+    # G. geometric Brownian motion + non-linear Poisson arrivals + posting at the touch
+    n, ns = 32, 80
+    run_case(
+        "gbm_nonlinear_touch",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=21, initial_inventory=0, max_inventory=4, num_trajectories=n,
+            model_dynamics=AtTheTouchModelDynamics(
+                midprice_model=GeometricBrownianMotionMidpriceModel(drift=0.05, volatility=0.2, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=PoissonArrivalNonLinearModel(intensity=np.array([60.0, 45.0]), step_size=1 / ns, num_trajectories=n),
+                num_trajectories=n, fixed_market_half_spread=0.25),
+            **common),
+        ns, n, 2, 21,
+        dict(n_steps=ns, terminal_time=1.0, midprice="gbm", drift=0.05, volatility=0.2, initial_price=100.0, arrival="poisson_nonlinear",
+             intensity=[60.0, 45.0], dynamics="touch", market_half_spread=0.25, reward="pnl", initial_inventory=0, max_inventory=4, seed=21,
+             **common),
+        poisson_thr=1.0 - np.exp(-45.0 / ns), action_kind="touch")
+
+    # H. Brownian motion with jumps on the agent's fills + terminal exponential utility
+    n, ns = 32, 60
+    run_case(
+        "bmjump_exputility",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=22, initial_inventory=1, max_inventory=30, num_trajectories=n,
+            reward_function=ExponentialUtility(risk_aversion=0.01),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionJumpMidpriceModel(drift=0.1, volatility=2.0, jump_size=0.3, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([50.0, 50.0]), step_size=1 / ns, num_trajectories=n)),
+            **common),
+        ns, n, 2, 22,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm_jump", drift=0.1, volatility=2.0, jump_size=0.3, initial_price=100.0, arrival="poisson",
+             intensity=[50.0, 50.0], fill_exponent=1.5, dynamics="limit", reward="exp_utility", risk_aversion=0.01, initial_inventory=1,
+             max_inventory=30, seed=22, **common),
+        poisson_thr=50.0 / ns)
+
+    # I. OU with jumps + Hawkes arrivals + running inventory penalty (D = 6)
+    n, ns = 32, 90
+    run_case(
+        "oujump_hawkes_running",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=23, initial_inventory=0, max_inventory=25, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.02, 0.1),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                OuJumpMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.05, volatility=1.5, jump_size=0.2, initial_price=100.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                HawkesArrivalModel(baseline_arrival_rate=np.array([[12.0, 8.0]]), step_size=1 / ns, jump_size=30.0, mean_reversion_speed=50.0, terminal_time=1.0, num_trajectories=n)),
+            **common),
+        ns, n, 2, 23,
+        dict(n_steps=ns, terminal_time=1.0, midprice="ou_jump", ou_level=100.0, ou_speed=0.05, volatility=1.5, jump_size=0.2, initial_price=100.0,
+             arrival="hawkes", intensity=[12.0, 8.0], hawkes_jump=30.0, hawkes_speed=50.0, fill_exponent=1.5, dynamics="limit",
+             reward="running", phi=0.02, alpha=0.1, initial_inventory=0, max_inventory=25, seed=23, **common))
+
+    # J. constant midprice
+    n, ns = 16, 40
+    run_case(
+        "constant_midprice",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=24, initial_inventory=0, max_inventory=10, num_trajectories=n,
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                ConstantMidpriceModel(initial_price=50, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([30.0, 30.0]), step_size=1 / ns, num_trajectories=n)),
+            **common),
+        ns, n, 2, 24,
+        dict(n_steps=ns, terminal_time=1.0, midprice="constant", initial_price=50.0, arrival="poisson", intensity=[30.0, 30.0],
+             fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=10, seed=24, **common),
+        poisson_thr=30.0 / ns)
+
+    # K-N. trading-with-speed dynamics with the four price-impact models (optimal execution)
+    n, ns = 32, 100
+    speed_cases = [
+        ("speed_temp_perm_cjoe", lambda: TemporaryAndPermanentPriceImpact(temporary_impact_coefficient=0.02, permanent_impact_coefficient=0.015, n_steps=ns, terminal_time=1.0, num_trajectories=n),
+         CjOeCriterion(per_step_inventory_aversion=0.01, terminal_inventory_aversion=0.05, terminal_time=1.0),
+         dict(impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, impact_step_size=1.0 / ns, reward="cjoe", phi=0.01, alpha=0.05), "speed"),
+        ("speed_power_running", lambda: TemporaryPowerPriceImpact(temporary_impact_coefficient=0.03, temporary_impact_exponent=1.5, num_trajectories=n),
+         RunningInventoryPenalty(0.01, 0.2),
+         dict(impact="temp_power", temporary_impact=0.03, impact_exponent=1.5, reward="running", phi=0.01, alpha=0.2), "speed_positive"),
+        ("speed_temp_transient_pnl", lambda: TemporaryAndTransientPriceImpact(temporary_impact_coefficient=0.02, transient_impact_coefficient=0.5, resilience_coefficient=2.0, initial_transient_impact=0.1, linear_kernel_coefficient=0.3, n_steps=ns, terminal_time=1.0, num_trajectories=n),
+         PnL(),
+         dict(impact="temp_transient", temporary_impact=0.02, transient_impact=0.5, resilience=2.0, initial_transient_impact=0.1, kernel_coefficient=0.3, impact_step_size=1.0 / ns, reward="pnl"), "speed"),
+        ("speed_transient_pnl", lambda: TransientPriceImpact(transient_impact_coefficient=0.4, resilience_coefficient=1.0, initial_transient_impact=0.05, linear_kernel_coefficient=0.2, n_steps=ns, terminal_time=1.0, num_trajectories=n),
+         PnL(),
+         dict(impact="transient", transient_impact=0.4, resilience=1.0, initial_transient_impact=0.05, kernel_coefficient=0.2, impact_step_size=1.0 / ns, reward="pnl"), "speed"),
+    ]
+    for tag, make_impact, reward, cfg_extra, action_kind in speed_cases:
+        mid_dt = 0.02 if tag == "speed_power_running" else 1 / ns  # MD:265 uses the MIDPRICE model's step size
+        run_case(
+            tag,
+            lambda: TradingEnvironment(
+                terminal_time=1.0, n_steps=ns, seed=31, initial_inventory=10, max_inventory=1000, num_trajectories=n,
+                reward_function=reward,
+                model_dynamics=TradinghWithSpeedModelDynamics(
+                    midprice_model=BrownianMotionMidpriceModel(drift=0.02, volatility=1.0, initial_price=100, terminal_time=1.0, step_size=mid_dt, num_trajectories=n),
+                    price_impact_model=make_impact(), num_trajectories=n),
+                **common),
+            ns, n, 1, 31 + len(tag),
+            dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.02, volatility=1.0, initial_price=100.0, arrival="none", dynamics="speed",
+                 midprice_step_size=mid_dt, initial_inventory=10, max_inventory=1000, seed=31, **cfg_extra, **common),
+            action_kind=action_kind)
 
 
 if __name__ == "__main__":
