@@ -344,7 +344,8 @@ class TradingEnvironment(_EnvBase):
         """Injected-noise mode: the uniforms/normal the next step consumes in place of the three numpy
         generators of the reference (arrival_models.py:55, fill_probability_models.py:33, midprice_models.py:64)."""
         n = self.num_trajectories
-        ua, uf = _native.as_f32(u_arr, (n, 2)), _native.as_f32(u_fill, (n, 2))
+        ua = None if u_arr is None else _native.as_f32(u_arr, (n, 2))  # speed dynamics have no order flow: pass None
+        uf = None if u_fill is None else _native.as_f32(u_fill, (n, 2))
         zz = _native.as_f32(np.asarray(z).reshape(-1), (n,))
         _native.check(_native.load_library().mbt_env_set_noise_host(self._handle, _native.fptr(ua), _native.fptr(uf), _native.fptr(zz)))
 

@@ -40,7 +40,8 @@ def _roll(env, actions, noise=None):
     return out
 
 
-@pytest.mark.parametrize("name", ["as_limit_pnl", "hawkes_ou", "limit_and_market", "cjp_cjmm", "default_normalised"])
+@pytest.mark.parametrize("name", ["as_limit_pnl", "hawkes_ou", "limit_and_market", "cjp_cjmm", "default_normalised",
+                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice"])
 def test_philox_mode_equals_injected_mode_on_the_same_draws(name):
     """The kernel body is shared: feeding the injected-noise instantiation with the draws the Philox instantiation
     makes must give bit-identical states and rewards - this carries the parity result over to production mode."""
@@ -66,7 +67,8 @@ def test_philox_mode_equals_injected_mode_on_the_same_draws(name):
         if not cfg.normalise_observation_space:
             np.testing.assert_array_equal(got_p[k][0][:, 1].astype(np.float64), o_obs[:, 1])
         err = np.abs(got_p[k][1] - o_rew)
-        assert np.all(err <= (1e-3 if name == "limit_and_market" else 1e-5)), err.max()
+        tol = {"limit_and_market": 1e-3, "gbm_nonlinear_touch": 5e-5}.get(name, 1e-5)  # see test_gpu_parity.py
+        assert np.all(err <= tol), err.max()
     env_p.close()
     env_i.close()
 

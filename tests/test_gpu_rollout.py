@@ -26,7 +26,8 @@ def _step_loop(env, actions_or_agent, steps):
     return np.stack(obs), np.stack(acts), np.stack(rews), bool(d[0])
 
 
-@pytest.mark.parametrize("name", ["as_limit_pnl", "cjp_running", "cjp_cjmm", "hawkes_ou", "limit_and_market", "default_normalised"])
+@pytest.mark.parametrize("name", ["as_limit_pnl", "cjp_running", "cjp_cjmm", "hawkes_ou", "limit_and_market", "default_normalised",
+                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice"])
 def test_fixed_policy_rollout_equals_the_step_loop_bit_for_bit(name):
     cfg, g = load_case(name)
     cfg.seed = 4321
@@ -36,6 +37,8 @@ def test_fixed_policy_rollout_equals_the_step_loop_bit_for_bit(name):
     fixed = np.array([0.6, 0.9, 1.0, 0.0][: g["actions"].shape[2]], np.float32)
     if cfg.normalise_action_space:
         fixed = np.array([-0.55, -0.35], np.float32)
+    if cfg.dynamics == "touch":
+        fixed = np.array([1.0, 1.0], np.float32)
     env_a, env_b = make_env(cfg), make_env(cfg)
     agent = FixedActionAgent(fixed, env_a)
     obs_s, act_s, rew_s, done_s = _step_loop(env_b, [agent.get_action(None)] * steps, steps)
