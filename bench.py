@@ -89,7 +89,7 @@ def pmc_traffic(n):
     if n != LANES_PER_GPU or not os.path.exists(path):
         return None
     for name, row in json.load(open(path)).items():
-        if "Variant<0, 0, 0, 0, false, false>" in name:
+        if "step_kernel" in name:
             return row["hbm_bytes_per_launch"]
     return None
 

@@ -27,7 +27,10 @@ for name in CASES:
             q = np.rint((obs[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
             bad_q += int(np.sum(q != np.rint((g["obs"][k][:, 1] + 1) * cfg.max_inventory - cfg.max_inventory)))
         else:
-            bad_q += int(np.sum(obs[:, 1] != g["obs"][k][:, 1]))
+            if cfg.dynamics == "speed":  # real-valued inventory: count lanes off by more than float32 rounding
+                bad_q += int(np.sum(np.abs(obs[:, 1] - g["obs"][k][:, 1]) > 1e-6 * (1 + np.abs(g["obs"][k][:, 1]))))
+            else:
+                bad_q += int(np.sum(obs[:, 1] != g["obs"][k][:, 1]))
             e_c = max(e_c, float(np.max(np.abs(obs[:, 0] - g["obs"][k][:, 0]))))
             e_s = max(e_s, float(np.max(np.abs(obs[:, 3] - g["obs"][k][:, 3]))))
     shape = f"{cfg.num_trajectories} x {g['actions'].shape[0]}"
