@@ -576,13 +576,11 @@ class TradingEnvironment(_EnvBase):
         _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
         try:
             _native.check(lib.mbt_env_reset(handle, 0.0, None))
-            quote = 1.0 / self.model_dynamics.fill_probability_model.fill_exponent
-            act = np.full((n, self.original_action_space.shape[0]), 0.0, dtype=np.float32)
-            act[:, 0:2] = quote
-            done = C.c_int32(0)
-            _native.check(lib.mbt_env_step_host(handle, _native.fptr(act), None, None, C.byref(done)))
-            while not done.value:
-                _native.check(lib.mbt_env_step_device(handle, None, C.byref(done)))
+            policy = _native.MbtPolicy(kind=_native.POLICY_FIXED)  # the constant quote 1/kappa on both sides (TE:330)
+            policy.params[0] = policy.params[1] = 1.0 / self.model_dynamics.fill_probability_model.fill_exponent
+            steps, done = C.c_uint32(0), C.c_int32(0)
+            _native.check(lib.mbt_env_rollout_device(handle, C.byref(policy), self.n_steps, None, None, None, C.byref(steps), C.byref(done)))
+            assert done.value and steps.value == self.n_steps
             sums = (C.c_double * 3)()
             _native.check(lib.mbt_env_return_sums(handle, sums))
         finally:
