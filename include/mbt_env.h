@@ -77,7 +77,7 @@ typedef struct mbt_config {
   uint32_t abi_version;        /* MBT_ABI_VERSION */
   int32_t device;              /* HIP device ordinal */
   uint64_t num_trajectories;   /* lanes owned by this handle (TE:41) */
-  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; even (multiple of 4 for speed dynamics) */
+  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; a multiple of 512 (4 for speed dynamics) */
   uint32_t n_steps;            /* TE:30 */
   uint32_t reserved0;
   double terminal_time;        /* TE:29; step_size = terminal_time / n_steps (TE:49) */
@@ -195,7 +195,8 @@ int mbt_env_rollout_device(mbt_env* env, const mbt_policy* policy, uint32_t max_
 /* Host variant: trajectory pointers are host memory with exactly N lanes per time slice; synchronous. */
 int mbt_env_rollout_host(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
                          float* rew_traj, uint32_t* steps_done, int32_t* done);
-uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to even: lanes per time slice of device trajectories */
+uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to whole 512-lane tiles (quads for speed dynamics):
+                                                lanes per time slice of device trajectories */
 
 /* ---- injected noise (parity mode; replaces the three numpy Generators of SP:27) ---------------- */
 /* u_arr, u_fill: (N, 2) float32 in [0, 1) (ignored, may be NULL, for speed dynamics); z: (N) float32.

@@ -441,9 +441,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   *out = nullptr;
   if (cfg->abi_version != MBT_ABI_VERSION)
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
-  if (cfg->num_trajectories == 0 || cfg->num_trajectories > 0x7FFFFFF0ull)
+  if (cfg->num_trajectories == 0 || cfg->num_trajectories > 0x7FFFF000ull)
     return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
-  if (cfg->trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even (noise is drawn per pair)");
   if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
   const bool speed = cfg->dynamics_kind == MBT_DYN_SPEED;
   if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_CONSTANT)
@@ -470,6 +469,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     }
     if (cfg->reward_kind == MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the one-dimensional action of speed dynamics (RW:65)");
     if (cfg->impact_kind != MBT_IMPACT_NONE) return fail(MBT_ERR_INVALID, "price impact models belong to speed dynamics");
+    if (cfg->trajectory_offset % mbt::kTileLanes != 0)
+      return fail(MBT_ERR_INVALID, "order-book dynamics draw noise per 512-lane tile: trajectory_offset must be a multiple of 512");
   }
   if (cfg->noise_mode != MBT_NOISE_PHILOX && cfg->noise_mode != MBT_NOISE_INJECTED)
     return fail(MBT_ERR_INVALID, "unknown noise mode %d", cfg->noise_mode);
@@ -484,7 +485,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : (cfg->arrival_kind == MBT_ARR_HAWKES ? 6 : 4);
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
   e->n = static_cast<uint32_t>(cfg->num_trajectories);
-  e->n_pad = speed ? ((e->n + 3u) & ~3u) : ((e->n + 1u) & ~1u);  // a thread owns a quad (speed) or a pair of lanes
+  // a thread owns a quad of adjacent lanes (speed) or two lanes of a 512-lane tile (order book): pad to whole units
+  e->n_pad = speed ? ((e->n + 3u) & ~3u) : ((e->n + mbt::kTileLanes - 1u) / mbt::kTileLanes) * mbt::kTileLanes;
   e->n_pairs = e->n_pad / 2;
   const uint32_t n_threads = speed ? e->n_pad / 4 : e->n_pairs;
   e->n_blocks = (n_threads + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
@@ -821,18 +823,18 @@ int mbt_reward_calculate_host(int device, int reward_kind, double phi, double al
 
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* u_arr,
                       float* u_fill, float* z) {
-  if (trajectory_offset & 1ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be even");
-  if (n == 0 || n > 0x7FFFFFF0ull) return fail(MBT_ERR_INVALID, "n out of range");
+  if (trajectory_offset % mbt::kTileLanes != 0) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 512");
+  if (n == 0 || n > 0x7FFFF000ull) return fail(MBT_ERR_INVALID, "n out of range");
   int rc = check_device(device);
   if (rc != MBT_OK) return rc;
   HIP_TRY(hipSetDevice(device));
-  const uint32_t n_pad = (static_cast<uint32_t>(n) + 1u) & ~1u, n_pairs = n_pad / 2;
+  const uint32_t tiles = (static_cast<uint32_t>(n) + mbt::kTileLanes - 1u) / mbt::kTileLanes, n_pad = tiles * mbt::kTileLanes;
   float *d_ua = nullptr, *d_uf = nullptr, *d_z = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ua), size_t(n_pad) * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_uf), size_t(n_pad) * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_z), size_t(n_pad) * sizeof(float)));
-  hipLaunchKernelGGL(mbt::rng_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, nullptr, trajectory_offset >> 1, step,
-                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), n_pairs, d_ua, d_uf, d_z);
+  hipLaunchKernelGGL(mbt::rng_fill_kernel, dim3(tiles), dim3(mbt::kBlockThreads), 0, nullptr, trajectory_offset >> 1, step,
+                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), d_ua, d_uf, d_z);
   HIP_TRY(hipGetLastError());
   if (u_arr != nullptr) HIP_TRY(hipMemcpy(u_arr, d_ua, size_t(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));
   if (u_fill != nullptr) HIP_TRY(hipMemcpy(u_fill, d_uf, size_t(n) * 2 * sizeof(float), hipMemcpyDeviceToHost));

@@ -5,13 +5,15 @@
 // (seed, global trajectory id, philox step).  It costs zero bytes of HBM traffic, is restart-safe and is
 // independent of how the trajectory axis is sharded over GPUs.
 //
-// Stream layout.  Trajectories are grouped in PAIRS p = gid >> 1 (one GPU thread owns one pair, so all
-// twelve words of its three blocks are used):
-//   block 0: ctr = (p.lo, p.hi, step, 0)  -> lane 2p   : u_arr_bid, u_arr_ask, u_fill_bid, u_fill_ask
-//   block 1: ctr = (p.lo, p.hi, step, 1)  -> lane 2p+1 : same four
+// Stream layout (order-book dynamics).  Global lane ids are grouped in tiles of 512; lanes g and g + 256 of a tile
+// form PAIR p = (g / 512) * 256 + g % 256 - the two lanes one GPU thread owns (step_kernel.hpp), so all of its
+// three blocks are used:
+//   block 0: ctr = (p.lo, p.hi, step, 0)  -> lane g       : u_arr_bid, u_arr_ask, u_fill_bid, u_fill_ask
+//   block 1: ctr = (p.lo, p.hi, step, 1)  -> lane g + 256 : same four
 //   block 2: ctr = (p.lo, p.hi, step, 2)  -> words 0,1 feed one Box-Muller transform:
-//                                            z(2p) = r cos(theta), z(2p+1) = r sin(theta); words 2,3 unused
+//                                            z(g) = r cos(theta), z(g + 256) = r sin(theta); words 2,3 unused
 //   key = (seed.lo, seed.hi)
+// (Speed dynamics need one normal per lane: one block per quad of adjacent lanes, counter word 3 = 3, speed_kernel.hpp.)
 // Uniforms are u = (w >> 8) * 2^-24 in [0,1): exactly representable in float32, which is what lets the
 // Bernoulli decisions of the step be bit-exact against a float64 evaluation of the same draws.
 #pragma once
@@ -65,7 +67,7 @@ struct LaneNoise {
   float ua_bid, ua_ask, uf_bid, uf_ask, z;
 };
 
-// Noise of the pair `pair` (global pair index) at `step`: lane 0 = trajectory 2*pair, lane 1 = 2*pair+1.
+// Noise of the pair `pair` (global pair index) at `step`: a = its lower lane, b = the lane 256 above.
 __device__ __forceinline__ void philox_pair_noise(uint64_t pair, uint32_t step, uint32_t k0, uint32_t k1,
                                                   LaneNoise& a, LaneNoise& b) {
   const uint32_t plo = static_cast<uint32_t>(pair), phi = static_cast<uint32_t>(pair >> 32);

@@ -1,11 +1,12 @@
 // The fused TradingEnvironment.step() kernel for gfx950 (CDNA4, wave64).
 //
 // One launch = one env.step(action) over all lanes (reference: gym/TradingEnvironment.py:103-110 and the
-// ~35 NumPy kernels it fans out to).  One GPU thread owns a PAIR of adjacent trajectories:
-//   reads   2 state rows = D/2 x float4: [cash, inventory, time, midprice (, bid intensity, ask intensity)]
-//           1 x float4 (A=2) or 2 x float4 (A=4) action rows
+// ~35 NumPy kernels it fans out to).  One GPU thread owns a PAIR of trajectories, 256 lanes apart inside a 512-lane tile
+// (see "lane <-> thread mapping" below), so that every memory instruction of a wave covers one contiguous span:
+//   reads   2 state rows [cash, inventory, time, midprice (, bid intensity, ask intensity)]: one float4 each (D = 4)
+//           2 action rows: float2 (A=2) or float4 (A=4)
 //   draws   3 Philox4x32-10 blocks = all the noise of the pair (philox.hpp), or loads injected noise
-//   writes  2 next-state rows (D/2 x float4), 1 x float2 rewards
+//   writes  2 next-state rows, 2 rewards
 // The state is row-major (N, D) float32 - exactly the un-normalised observation the API returns - and is
 // ping-ponged between two buffers, so the observation of step k stays valid while step k+1 is computed.
 // Nothing else touches HBM: `dones` is a host scalar (TE:218-220), time is a kernel argument, the generator is
@@ -54,13 +55,12 @@ struct Variant {
   static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
   static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
   static constexpr int DIM = (ARR_ == kArrHawkes) ? 6 : 4;
-  static constexpr int VEC_PER_PAIR = DIM / 2;  // float4 per pair of state rows
 };
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
 struct StepParams {
   uint32_t n;            // lanes of this shard
-  uint32_t n_pairs;      // ceil(n / 2)
+  uint32_t n_pairs;      // padded lanes / 2 (a whole number of 512-lane tiles for order-book dynamics)
   uint64_t pair_offset;  // global pair index of local pair 0
   uint32_t key0, key1;   // Philox key (seed)
   uint32_t philox_step;  // Philox counter word 2
@@ -369,148 +369,114 @@ __device__ __forceinline__ void normalise_row(float4& core, float2& lam, int dim
   }
 }
 
-// Everything one pair of trajectories reads from HBM.
-template <class V>
-struct PairLoads {
-  float4 s0, s1, s2;  // D/2 float4 of state (s2: Hawkes only)
-  float4 a0, a1;      // actions (a1: limit+market only)
-  float4 ua, uf;      // injected noise
-  float2 zz;
-  float2 qi;          // CjMm per-lane initial inventories
+// ---- lane <-> thread mapping --------------------------------------------------------------------------------------
+// A workgroup of 256 threads owns a TILE of 512 consecutive lanes; thread j owns lanes tile*512 + j and tile*512 + 256 + j.
+// Consecutive threads touch consecutive rows, so every wave-level load/store covers one contiguous span (a state row is
+// one 16-byte vector per lane for D = 4).  Measured with a copy kernel moving the same 44 B/lane at 2^20 lanes
+// (tools/microbench/mb_copy.hip): 7.2 us for this mapping against 8.3 us when a thread owns two ADJACENT rows - there
+// each 16-byte-per-lane instruction strides 32 bytes and requests every cache line twice.  The two lanes of a thread
+// form the PAIR that shares three Philox blocks (philox.hpp); buffers are padded to whole tiles, so no load is ever
+// out of bounds and only the reductions need to know which lanes are real.
+constexpr uint32_t kTileLanes = 2 * kBlockThreads;
+
+struct LaneLoads {
+  float4 core;  // [cash, inventory, time, midprice]
+  float2 lam;   // Hawkes intensities
+  float4 act;   // (bid depth, ask depth[, market buy, market sell])
+  float2 ua, uf;  // injected noise
+  float z;
+  float qi;     // per-lane initial inventory (CjMm)
 };
 
 template <class V>
-__device__ __forceinline__ PairLoads<V> load_pair(const StepBuffers& B, const StepParams& P, uint32_t pair) {
-  PairLoads<V> L;
-  const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
-  L.s0 = src[0];
-  L.s1 = src[1];
-  if (V::ARR == kArrHawkes) L.s2 = src[2];
-  if (V::DYN != kDynLimitAndMarket) {
-    L.a0 = reinterpret_cast<const float4*>(B.action)[pair];
+__device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepParams& P, uint32_t lane) {
+  LaneLoads L;
+  if (V::ARR == kArrHawkes) {  // rows of 6 floats: 8-byte aligned
+    const float2* row = reinterpret_cast<const float2*>(B.state_in) + static_cast<size_t>(lane) * 3;
+    const float2 a = row[0], b = row[1];
+    L.core = make_float4(a.x, a.y, b.x, b.y);
+    L.lam = row[2];
   } else {
-    L.a0 = reinterpret_cast<const float4*>(B.action)[2 * pair];
-    L.a1 = reinterpret_cast<const float4*>(B.action)[2 * pair + 1];
+    L.core = reinterpret_cast<const float4*>(B.state_in)[lane];
+    L.lam = make_float2(0.f, 0.f);
+  }
+  if (V::DYN == kDynLimitAndMarket) {
+    L.act = reinterpret_cast<const float4*>(B.action)[lane];
+  } else {
+    const float2 a = reinterpret_cast<const float2*>(B.action)[lane];
+    L.act = make_float4(a.x, a.y, 0.f, 0.f);
   }
   if (V::INJECT) {
-    L.ua = reinterpret_cast<const float4*>(B.u_arr)[pair];
-    L.uf = reinterpret_cast<const float4*>(B.u_fill)[pair];
-    L.zz = reinterpret_cast<const float2*>(B.z)[pair];
+    L.ua = reinterpret_cast<const float2*>(B.u_arr)[lane];
+    L.uf = reinterpret_cast<const float2*>(B.u_fill)[lane];
+    L.z = B.z[lane];
   }
-  L.qi = make_float2(P.q_init_scalar, P.q_init_scalar);
-  if (V::PENALISED && B.q_init != nullptr) L.qi = reinterpret_cast<const float2*>(B.q_init)[pair];
+  L.qi = P.q_init_scalar;
+  if (V::PENALISED && B.q_init != nullptr) L.qi = B.q_init[lane];
   return L;
 }
 
-// Orders the schedule: every operand is an in/out of one empty asm, so the noise is complete before, and every
+// Orders the schedule: every operand is an in/out of one empty asm, so the draws are complete before, and every
 // consumer of the loaded state/action after, this point.  Costs no instruction.
-template <class V>
-__device__ __forceinline__ void tie_loads_to_draws(PairLoads<V>& L, LaneDraw& a, LaneDraw& b) {
+__device__ __forceinline__ void tie_loads_to_draws(LaneLoads& a, LaneLoads& b, LaneDraw& da, LaneDraw& db) {
   asm volatile("; loads are first consumed below this line"
-               : "+v"(L.s0.x), "+v"(L.s0.y), "+v"(L.s0.z), "+v"(L.s0.w), "+v"(L.s1.x), "+v"(L.s1.y), "+v"(L.s1.z), "+v"(L.s1.w),
-                 "+v"(L.a0.x), "+v"(L.a0.y), "+v"(L.a0.z), "+v"(L.a0.w), "+v"(a.arr_bid), "+v"(a.arr_ask), "+v"(a.uf_bid), "+v"(a.uf_ask),
-                 "+v"(a.dz), "+v"(b.arr_bid), "+v"(b.arr_ask), "+v"(b.uf_bid), "+v"(b.uf_ask), "+v"(b.dz));
+               : "+v"(a.core.x), "+v"(a.core.y), "+v"(a.core.z), "+v"(a.core.w), "+v"(b.core.x), "+v"(b.core.y), "+v"(b.core.z), "+v"(b.core.w),
+                 "+v"(a.act.x), "+v"(a.act.y), "+v"(b.act.x), "+v"(b.act.y), "+v"(da.arr_bid), "+v"(da.arr_ask), "+v"(da.uf_bid), "+v"(da.uf_ask),
+                 "+v"(da.dz), "+v"(db.arr_bid), "+v"(db.arr_ask), "+v"(db.uf_bid), "+v"(db.uf_ask), "+v"(db.dz));
 }
 
-// rows of 6 are packed [c q t S | lb la c q | t S lb la] in three float4
+// one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
 template <class V>
-__device__ __forceinline__ void unpack_rows(const float4 s0, const float4 s1, const float4 s2, float4& core0, float2& lam0,
-                                            float4& core1, float2& lam1) {
-  core0 = s0;
-  core1 = s1;
-  lam0 = lam1 = make_float2(0.f, 0.f);
+__device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
+  if (normalise) normalise_row(core, lam, V::DIM, P);
   if (V::ARR == kArrHawkes) {
-    lam0 = make_float2(s1.x, s1.y);
-    core1 = make_float4(s1.z, s1.w, s2.x, s2.y);
-    lam1 = make_float2(s2.z, s2.w);
-  }
-}
-
-template <class V>
-__device__ __forceinline__ void store_rows(float* base, uint32_t pair, const float4 core0, const float2 lam0, const float4 core1,
-                                           const float2 lam1) {
-  float4* dst = reinterpret_cast<float4*>(base) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
-  if (V::ARR == kArrHawkes) {
-    dst[0] = core0;
-    dst[1] = make_float4(lam0.x, lam0.y, core1.x, core1.y);
-    dst[2] = make_float4(core1.z, core1.w, lam1.x, lam1.y);
+    float2* row = reinterpret_cast<float2*>(base) + static_cast<size_t>(lane) * 3;
+    row[0] = make_float2(core.x, core.y);
+    row[1] = make_float2(core.z, core.w);
+    row[2] = lam;
   } else {
-    dst[0] = core0;
-    dst[1] = core1;
+    reinterpret_cast<float4*>(base)[lane] = core;
   }
 }
 
-// normalised observation rows of a pair, as full-width vector stores
+// Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
-__device__ __forceinline__ void store_obs_rows(float* base, uint32_t pair, float4 core0, float2 lam0, float4 core1, float2 lam1,
-                                               const StepParams& P) {
-  normalise_row(core0, lam0, V::DIM, P);
-  normalise_row(core1, lam1, V::DIM, P);
-  store_rows<V>(base, pair, core0, lam0, core1, lam1);
-}
-
-// Arithmetic and stores of one pair; returns the pair's reward sum (pad lane excluded).
-template <class V>
-__device__ __forceinline__ float finish_pair(const StepBuffers& B, const StepParams& P, uint32_t pair, const PairLoads<V>& L,
-                                             const LaneDraw& d0, const LaneDraw& d1) {
-  const uint32_t lane0 = 2u * pair;
-  float4 core0, core1;
-  float2 lam0, lam1;
-  unpack_rows<V>(L.s0, L.s1, L.s2, core0, lam0, core1, lam1);
-  float4 act0, act1;
-  if (V::DYN != kDynLimitAndMarket) {
-    act0 = make_float4(L.a0.x, L.a0.y, 0.f, 0.f);
-    act1 = make_float4(L.a0.z, L.a0.w, 0.f, 0.f);
-  } else {
-    act0 = L.a0;
-    act1 = L.a1;
-  }
-
-  const LaneResult r0 = lane_step<V>(core0, lam0, act0, d0, L.qi.x, P.t_next, P.is_terminal != 0, P);
-  const LaneResult r1 = lane_step<V>(core1, lam1, act1, d1, L.qi.y, P.t_next, P.is_terminal != 0, P);
-
-  store_rows<V>(B.state_out, pair, r0.core, r0.lam, r1.core, r1.lam);
-  reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
-
-  const bool second = lane0 + 1 < P.n;  // the pad lane of an odd shard is computed but never reported
-
+__device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
+                                             const LaneDraw& d, uint32_t& clips) {
+  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P);
+  store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
+  B.reward[lane] = r.reward;
   // -- optional outputs (wave-uniform branches)
-  if (V::NORM && B.obs != nullptr) store_obs_rows<V>(B.obs, pair, r0.core, r0.lam, r1.core, r1.lam, P);
-  if (B.events != nullptr) {
-    reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(event_byte(r0) | (event_byte(r1) << 8));
-  }
-  if (B.lane_returns != nullptr) {
-    float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
-    acc.x += r0.reward;
-    acc.y += r1.reward;
-    reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
-  }
-  const bool clip0 = r0.clipped_q | r0.clipped_c, clip1 = (r1.clipped_q | r1.clipped_c) && second;
-  if (__builtin_expect(clip0 | clip1, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>((clip0 ? 1 : 0) + (clip1 ? 1 : 0)));
-  return r0.reward + (second ? r1.reward : 0.0f);
+  if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lane, r.core, r.lam, true, P);
+  if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));
+  if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
+  const bool real = lane < P.n;  // pad lanes of the last tile are computed but never reported
+  clips += (real && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
+  return real ? r.reward : 0.0f;
 }
 
 template <class V>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
-  const uint32_t pair = blockIdx.x * kBlockThreads + threadIdx.x;
-  float r_sum = 0.0f;
-  if (pair < P.n_pairs) {
-    PairLoads<V> L = load_pair<V>(B, P, pair);  // issue every load ...
-    LaneNoise nz0, nz1;
-    LaneDraw d0, d1;
-    if (V::INJECT) {
-      nz0 = LaneNoise{L.ua.x, L.ua.y, L.uf.x, L.uf.y, L.zz.x};
-      nz1 = LaneNoise{L.ua.z, L.ua.w, L.uf.z, L.uf.w, L.zz.y};
-      d0 = make_draw<V>(nz0, P);
-      d1 = make_draw<V>(nz1, P);
-    } else {
-      philox_pair_noise(P.pair_offset + pair, P.philox_step, P.key0, P.key1, nz0, nz1);  // ... draw while they fly
-      d0 = make_draw<V>(nz0, P);
-      d1 = make_draw<V>(nz1, P);
-      tie_loads_to_draws<V>(L, d0, d1);
-    }
-    r_sum = finish_pair<V>(B, P, pair, L, d0, d1);
+  const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
+  const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
+  LaneLoads L0 = load_lane<V>(B, P, lane0), L1 = load_lane<V>(B, P, lane1);  // issue every load ...
+  LaneNoise nz0, nz1;
+  LaneDraw d0, d1;
+  if (V::INJECT) {
+    nz0 = LaneNoise{L0.ua.x, L0.ua.y, L0.uf.x, L0.uf.y, L0.z};
+    nz1 = LaneNoise{L1.ua.x, L1.ua.y, L1.uf.x, L1.uf.y, L1.z};
+    d0 = make_draw<V>(nz0, P);
+    d1 = make_draw<V>(nz1, P);
+  } else {
+    philox_pair_noise(pair, P.philox_step, P.key0, P.key1, nz0, nz1);  // ... draw while they fly
+    d0 = make_draw<V>(nz0, P);
+    d1 = make_draw<V>(nz1, P);
+    tie_loads_to_draws(L0, L1, d0, d1);
   }
+  uint32_t clips = 0;
+  float r_sum = finish_lane<V>(B, P, lane0, L0, d0, clips);
+  r_sum += finish_lane<V>(B, P, lane1, L1, d1, clips);
+  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
   // -- per-wave running sum of rewards (numerator of the mean episode return): one slot per wave, one
   //    fire-and-forget hardware fp64 atomic per wave, no contention
   const float total = wave_sum(r_sum);
@@ -547,93 +513,81 @@ template <class V>
 __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
   static_assert(!V::INJECT, "rollouts draw their own noise");
   constexpr int A = (V::DYN == kDynLimitAndMarket) ? 4 : 2;
-  const uint32_t pair = blockIdx.x * kBlockThreads + threadIdx.x;
-  float ret_sum = 0.0f;
-  if (pair < P.n_pairs) {
-    const uint32_t lane0 = 2u * pair;
-    const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
-    const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(pair) * V::VEC_PER_PAIR;
-    float4 core0, core1;
-    float2 lam0, lam1;
-    unpack_rows<V>(src[0], src[1], V::ARR == kArrHawkes ? src[2] : make_float4(0.f, 0.f, 0.f, 0.f), core0, lam0, core1, lam1);
-    float2 qi = make_float2(P.q_init_scalar, P.q_init_scalar);
-    if (V::PENALISED && B.q_init != nullptr) qi = reinterpret_cast<const float2*>(B.q_init)[pair];
-    float ret0 = 0.0f, ret1 = 0.0f;
-    uint32_t clipped = 0;
-    double t = R.t_start;
-    if (R.obs_traj != nullptr) {
-      if (V::NORM) {
-        store_obs_rows<V>(R.obs_traj, pair, core0, lam0, core1, lam1, P);
-      } else {
-        store_rows<V>(R.obs_traj, pair, core0, lam0, core1, lam1);
+  const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
+  const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
+  const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
+  float4 core[2];
+  float2 lam[2];
+  float qi[2], ret[2] = {0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const LaneLoads L = load_lane<V>(B, P, lanes[l]);  // (the action slot of L is ignored: the policy acts here)
+    core[l] = L.core;
+    lam[l] = L.lam;
+    qi[l] = L.qi;
+    if (R.obs_traj != nullptr) store_row<V>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
+  }
+  uint32_t clips = 0;
+  double t = R.t_start;
+  LaneResult last[2];
+  for (uint32_t k = 0; k < R.n_steps; ++k) {
+    LaneNoise nz[2];
+    philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);
+    float4 act[2];
+    if (R.policy == kPolicyFixed) {
+      act[0] = act[1] = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
+    } else if (R.policy == kPolicyTimeTable) {  // open-loop schedule over time steps
+      const float* row = reinterpret_cast<const float*>(R.table) + static_cast<size_t>(min(R.table_row0 + k, R.table_rows - 1u)) * A;
+      act[0] = act[1] = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);
+    } else if (R.policy == kPolicyTable) {  // quotes tabulated over (time step, inventory), e.g. Cartea-Jaimungal
+      const uint32_t row = min(R.table_row0 + k, R.table_rows - 1u);
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int col = min(max(static_cast<int>(core[l].y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
+        const float2 d = R.table[static_cast<size_t>(row) * R.table_cols + col];
+        act[l] = make_float4(d.x, d.y, 0.f, 0.f);
+      }
+    } else {  // Avellaneda-Stoikov quotes from (inventory, time) of the current observation
+      const float tau = static_cast<float>(R.terminal_time - t);
+      const float half = 0.5f * (R.as_c1 * tau + R.as_c2);
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const float shift = core[l].y * R.as_c1 * tau;
+        act[l] = make_float4(shift + half, -shift + half, 0.f, 0.f);
       }
     }
-    for (uint32_t k = 0; k < R.n_steps; ++k) {
-      LaneNoise nz0, nz1;
-      philox_pair_noise(P.pair_offset + pair, P.philox_step + k, P.key0, P.key1, nz0, nz1);
-      float4 act0, act1;
-      if (R.policy == kPolicyFixed) {
-        act0 = act1 = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
-      } else if (R.policy == kPolicyTimeTable) {  // open-loop schedule over time steps
-        const float* row = reinterpret_cast<const float*>(R.table) + static_cast<size_t>(min(R.table_row0 + k, R.table_rows - 1u)) * A;
-        act0 = act1 = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);
-      } else if (R.policy == kPolicyTable) {  // quotes tabulated over (time step, inventory), e.g. Cartea-Jaimungal
-        const uint32_t row = min(R.table_row0 + k, R.table_rows - 1u);
-        const int c0 = min(max(static_cast<int>(core0.y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
-        const int c1 = min(max(static_cast<int>(core1.y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
-        const float2 d0 = R.table[static_cast<size_t>(row) * R.table_cols + c0];
-        const float2 d1 = R.table[static_cast<size_t>(row) * R.table_cols + c1];
-        act0 = make_float4(d0.x, d0.y, 0.f, 0.f);
-        act1 = make_float4(d1.x, d1.y, 0.f, 0.f);
-      } else {  // Avellaneda-Stoikov quotes from (inventory, time) of the current observation
-        const float tau = static_cast<float>(R.terminal_time - t);
-        const float half = 0.5f * (R.as_c1 * tau + R.as_c2);
-        const float s0 = core0.y * R.as_c1 * tau, s1 = core1.y * R.as_c1 * tau;
-        act0 = make_float4(s0 + half, -s0 + half, 0.f, 0.f);
-        act1 = make_float4(s1 + half, -s1 + half, 0.f, 0.f);
-      }
-      t += R.dt_f64;
-      const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
-      const LaneResult r0 = lane_step<V>(core0, lam0, act0, make_draw<V>(nz0, P), qi.x, static_cast<float>(t), terminal, P);
-      const LaneResult r1 = lane_step<V>(core1, lam1, act1, make_draw<V>(nz1, P), qi.y, static_cast<float>(t), terminal, P);
-      core0 = r0.core; lam0 = r0.lam; core1 = r1.core; lam1 = r1.lam;
-      ret0 += r0.reward;
-      ret1 += r1.reward;
-      clipped += ((r0.clipped_q | r0.clipped_c) ? 1u : 0u) + (((r1.clipped_q | r1.clipped_c) && lane0 + 1 < P.n) ? 1u : 0u);
-      if (R.obs_traj != nullptr) {
-        float* dst = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
-        if (V::NORM) {
-          store_obs_rows<V>(dst, pair, core0, lam0, core1, lam1, P);
-        } else {
-          store_rows<V>(dst, pair, core0, lam0, core1, lam1);
-        }
-      }
+    t += R.dt_f64;
+    const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P);
+      core[l] = r.core;
+      lam[l] = r.lam;
+      ret[l] += r.reward;
+      clips += (lanes[l] < P.n && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
+      last[l] = r;
+      if (R.obs_traj != nullptr) store_row<V>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lanes[l], core[l], lam[l], V::NORM, P);
       if (R.act_traj != nullptr) {
         float* dst = R.act_traj + static_cast<size_t>(k) * n_pad * A;
-        if (A == 2) {
-          reinterpret_cast<float4*>(dst)[pair] = make_float4(act0.x, act0.y, act1.x, act1.y);
-        } else {
-          reinterpret_cast<float4*>(dst)[2 * pair] = act0;
-          reinterpret_cast<float4*>(dst)[2 * pair + 1] = act1;
-        }
+        if (A == 2) reinterpret_cast<float2*>(dst)[lanes[l]] = make_float2(act[l].x, act[l].y);
+        else reinterpret_cast<float4*>(dst)[lanes[l]] = act[l];
       }
-      if (R.rew_traj != nullptr) reinterpret_cast<float2*>(R.rew_traj + static_cast<size_t>(k) * n_pad)[pair] = make_float2(r0.reward, r1.reward);
-      if (k + 1 == R.n_steps) {  // what step() leaves behind: last rewards (and events) of the final step
-        reinterpret_cast<float2*>(B.reward)[pair] = make_float2(r0.reward, r1.reward);
-        if (B.events != nullptr) reinterpret_cast<uint16_t*>(B.events)[pair] = static_cast<uint16_t>(event_byte(r0) | (event_byte(r1) << 8));
-      }
+      if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lanes[l]] = r.reward;
     }
-    store_rows<V>(B.state_out, pair, core0, lam0, core1, lam1);
-    if (V::NORM && B.obs != nullptr) store_obs_rows<V>(B.obs, pair, core0, lam0, core1, lam1, P);
-    if (B.lane_returns != nullptr) {
-      float2 acc = reinterpret_cast<float2*>(B.lane_returns)[pair];
-      acc.x += ret0;
-      acc.y += ret1;
-      reinterpret_cast<float2*>(B.lane_returns)[pair] = acc;
-    }
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
-    ret_sum = ret0 + (lane0 + 1 < P.n ? ret1 : 0.0f);
   }
+  float ret_sum = 0.0f;
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {  // what step() leaves behind: final state, last rewards (and events) of the final step
+    store_row<V>(B.state_out, lanes[l], core[l], lam[l], false, P);
+    if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
+    if (R.n_steps > 0) {
+      B.reward[lanes[l]] = last[l].reward;
+      if (B.events != nullptr) B.events[lanes[l]] = static_cast<uint8_t>(event_byte(last[l]));
+    }
+    if (B.lane_returns != nullptr) B.lane_returns[lanes[l]] += ret[l];
+    ret_sum += lanes[l] < P.n ? ret[l] : 0.0f;
+  }
+  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
   const float total = wave_sum(ret_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
@@ -730,16 +684,24 @@ __global__ void reward_calculate_kernel(int kind, const double* cur, const doubl
   out[i] = r;
 }
 
-// The production noise, written out (tests pin the generator and tie Philox mode to injected mode with it).
-__global__ void rng_fill_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0, uint32_t k1, uint32_t n_pairs,
-                                float* u_arr, float* u_fill, float* z) {
-  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pair >= n_pairs) return;
+// The production noise, written out in the step kernel's own lane <-> pair mapping (tests pin the generator and tie
+// Philox mode to injected mode with it).  One 256-thread block per tile.
+__global__ void rng_fill_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0, uint32_t k1, float* u_arr, float* u_fill, float* z) {
+  const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   LaneNoise a, b;
-  philox_pair_noise(pair_offset + pair, step, k0, k1, a, b);
-  if (u_arr != nullptr) reinterpret_cast<float4*>(u_arr)[pair] = make_float4(a.ua_bid, a.ua_ask, b.ua_bid, b.ua_ask);
-  if (u_fill != nullptr) reinterpret_cast<float4*>(u_fill)[pair] = make_float4(a.uf_bid, a.uf_ask, b.uf_bid, b.uf_ask);
-  if (z != nullptr) reinterpret_cast<float2*>(z)[pair] = make_float2(a.z, b.z);
+  philox_pair_noise(pair_offset + blockIdx.x * kBlockThreads + threadIdx.x, step, k0, k1, a, b);
+  if (u_arr != nullptr) {
+    reinterpret_cast<float2*>(u_arr)[lane0] = make_float2(a.ua_bid, a.ua_ask);
+    reinterpret_cast<float2*>(u_arr)[lane1] = make_float2(b.ua_bid, b.ua_ask);
+  }
+  if (u_fill != nullptr) {
+    reinterpret_cast<float2*>(u_fill)[lane0] = make_float2(a.uf_bid, a.uf_ask);
+    reinterpret_cast<float2*>(u_fill)[lane1] = make_float2(b.uf_bid, b.uf_ask);
+  }
+  if (z != nullptr) {
+    z[lane0] = a.z;
+    z[lane1] = b.z;
+  }
 }
 
 __global__ void philox_kat_kernel(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {

@@ -12,12 +12,15 @@ from typing import Tuple
 import numpy as np
 
 
+SHARD_ALIGN = 512  # noise is drawn per 512-lane tile (csrc/philox.hpp): shards start on tile boundaries
+
+
 def shard_bounds(total_lanes: int, rank: int, world_size: int) -> Tuple[int, int]:
-    """(offset, count) of rank's contiguous lane range.  Offsets are even because noise is drawn per pair of lanes."""
+    """(offset, count) of rank's contiguous lane range; offsets are multiples of 512."""
     assert 0 <= rank < world_size
     per = -(-total_lanes // world_size)
-    per += per & 1
-    offset = min(rank * per, total_lanes)
+    per = -(-per // SHARD_ALIGN) * SHARD_ALIGN
+    offset = rank * per  # an empty shard (count 0) still sits on a tile boundary
     return offset, max(0, min(per, total_lanes - offset))
 
 

@@ -37,28 +37,36 @@ def uniform24(w):
     return ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24)).astype(np.float32)
 
 
+TILE = 512  # lanes per tile; lanes g and g + 256 of a tile share one Philox pair (csrc/philox.hpp)
+
+
 def pair_stream_noise(seed, trajectory_offset, step, n):
     """(u_arr (n,2), u_fill (n,2), z (n)) for lanes [offset, offset+n) at philox step `step` - the layout
-    documented at the top of mbt_gym_amd/csrc/philox.hpp.  `trajectory_offset` must be even."""
-    assert trajectory_offset % 2 == 0
-    n_pad = (n + 1) & ~1
-    pairs = np.arange(n_pad // 2, dtype=np.uint64) + np.uint64(trajectory_offset // 2)
+    documented at the top of mbt_gym_amd/csrc/philox.hpp.  `trajectory_offset` must be a multiple of 512."""
+    assert trajectory_offset % TILE == 0
+    tiles = (n + TILE - 1) // TILE
+    n_pad = tiles * TILE
+    half = TILE // 2
+    pairs = np.arange(tiles * half, dtype=np.uint64) + np.uint64(trajectory_offset // 2)
     plo = (pairs & MASK).astype(np.uint32)
     phi = (pairs >> np.uint64(32)).astype(np.uint32)
     key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     st = np.full_like(plo, np.uint32(step))
     blocks = [philox4x32_10((plo, phi, st, np.full_like(plo, np.uint32(b))), key) for b in range(3)]
+    local = np.arange(tiles * half)
+    lower = (local // half) * TILE + local % half  # local lane of each pair's first member; the second is + 256
     u_arr = np.empty((n_pad, 2), np.float32)
     u_fill = np.empty((n_pad, 2), np.float32)
-    for lane, blk in enumerate(blocks[:2]):
-        u_arr[lane::2, 0], u_arr[lane::2, 1] = uniform24(blk[0]), uniform24(blk[1])
-        u_fill[lane::2, 0], u_fill[lane::2, 1] = uniform24(blk[2]), uniform24(blk[3])
+    for member, blk in enumerate(blocks[:2]):
+        lanes = lower + member * half
+        u_arr[lanes, 0], u_arr[lanes, 1] = uniform24(blk[0]), uniform24(blk[1])
+        u_fill[lanes, 0], u_fill[lanes, 1] = uniform24(blk[2]), uniform24(blk[3])
     wr, wt = blocks[2][0], blocks[2][1]
     u1 = ((wr >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0**-24
     r = np.sqrt(-2.0 * np.log(u1))
     theta = 2.0 * np.pi * (wt >> np.uint32(8)).astype(np.float64) * 2.0**-24
     z = np.empty((n_pad,), np.float64)
-    z[0::2], z[1::2] = r * np.cos(theta), r * np.sin(theta)
+    z[lower], z[lower + half] = r * np.cos(theta), r * np.sin(theta)
     return u_arr[:n], u_fill[:n], z[:n]
 
 

@@ -11,7 +11,7 @@ from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics, sh
 from oracle.mbt_oracle import OracleConfig, OracleEnv
 from oracle.philox_ref import PhiloxNoise
 
-N, STEPS, SEED = 1000, 12, 31
+N, STEPS, SEED = 1500, 12, 31
 
 
 def _cfg(n):
@@ -30,10 +30,10 @@ def _returns(offset, count):
     return total
 
 
-def test_shard_bounds_cover_the_axis_with_even_offsets():
-    for total, world in [(1000, 2), (1 << 24, 8), (7, 4), (1 << 20, 1), (1001, 3)]:
+def test_shard_bounds_cover_the_axis_on_tile_boundaries():
+    for total, world in [(1000, 2), (1 << 24, 8), (7, 4), (1 << 20, 1), (100001, 3)]:
         spans = [shard_bounds(total, r, world) for r in range(world)]
-        assert all(off % 2 == 0 for off, _ in spans)
+        assert all(off % 512 == 0 for off, _ in spans)
         assert sum(c for _, c in spans) == total
         assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1) if spans[i + 1][1] > 0)
 

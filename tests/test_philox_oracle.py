@@ -22,11 +22,14 @@ def test_random123_known_answers():
 
 
 def test_pair_stream_is_a_pure_function_of_global_lane_and_step():
-    full = pair_stream_noise(50, 0, 7, 64)
-    tail = pair_stream_noise(50, 32, 7, 32)
+    full = pair_stream_noise(50, 0, 7, 1536)
+    tail = pair_stream_noise(50, 1024, 7, 512)
     for a, b in zip(full, tail):
-        np.testing.assert_array_equal(a[32:], b)
-    other_step = pair_stream_noise(50, 0, 8, 64)
+        np.testing.assert_array_equal(a[1024:], b)
+    head = pair_stream_noise(50, 0, 7, 700)  # a ragged request is a prefix of the padded one
+    for a, b in zip(full, head):
+        np.testing.assert_array_equal(a[:700], b)
+    other_step = pair_stream_noise(50, 0, 8, 1536)
     assert not np.array_equal(full[0], other_step[0])
 
 

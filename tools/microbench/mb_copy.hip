@@ -24,13 +24,22 @@ __global__ __launch_bounds__(BLOCK) void copy_pair(const float4* s_in, float4* s
   else { out[2 * p] = a; out[2 * p + 1] = b; reinterpret_cast<v2*>(rew)[p] = r; }
 }
 
+// NOTE: every kernel here uses clang ext_vector types.  With HIP's float4 (a struct of a union) a read-modify-write of
+// one member made clang's "promote alloca to LDS" pass route the vector through LDS (ds_write/ds_read in the ISA),
+// which halves the speed of such a micro-kernel and says nothing about the access pattern.  Check the .s for `ds_`.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // one row per thread: perfectly coalesced 16 B / lane
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void copy_row(const float4* s_in, float4* s_out, const float2* act, float* rew, uint32_t n) {
+__global__ __launch_bounds__(BLOCK) void copy_row(const float4* s_in_, float4* s_out_, const float2* act_, float* rew, uint32_t n) {
+  const v4f* s_in = reinterpret_cast<const v4f*>(s_in_);
+  v4f* s_out = reinterpret_cast<v4f*>(s_out_);
+  const v2f* act = reinterpret_cast<const v2f*>(act_);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  float4 a = s_in[i];
-  const float2 c = act[i];
+  v4f a = s_in[i];
+  const v2f c = act[i];
   a.x += c.x;
   s_out[i] = a;
   rew[i] = c.y;
@@ -38,11 +47,14 @@ __global__ __launch_bounds__(BLOCK) void copy_row(const float4* s_in, float4* s_
 
 // pair per thread, rows t and t + BLOCK of the block's 2*BLOCK-row tile: every instruction is fully coalesced
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void copy_split(const float4* s_in, float4* s_out, const float2* act, float* rew, uint32_t n) {
+__global__ __launch_bounds__(BLOCK) void copy_split(const float4* s_in_, float4* s_out_, const float2* act_, float* rew, uint32_t n) {
+  const v4f* s_in = reinterpret_cast<const v4f*>(s_in_);
+  v4f* s_out = reinterpret_cast<v4f*>(s_out_);
+  const v2f* act = reinterpret_cast<const v2f*>(act_);
   const uint32_t i = blockIdx.x * (2 * BLOCK) + threadIdx.x;
   if (i + BLOCK >= n) return;
-  float4 a = s_in[i], b = s_in[i + BLOCK];
-  const float2 c = act[i], d = act[i + BLOCK];
+  v4f a = s_in[i], b = s_in[i + BLOCK];
+  const v2f c = act[i], d = act[i + BLOCK];
   a.x += c.x; b.x += d.x;
   s_out[i] = a; s_out[i + BLOCK] = b;
   rew[i] = c.y; rew[i + BLOCK] = d.y;
