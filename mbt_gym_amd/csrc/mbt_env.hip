@@ -60,24 +60,36 @@ float round_up_f32(double x) {
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 
 // Limit-order-book family: arrivals {Poisson, Hawkes} x dynamics {limit, limit+market, touch} x {Brownian, other
-// midprice} x {PnL, other reward} x normalised x noise = 96 step kernels and 48 rollout kernels; WHICH other midprice
-// and reward are runtime parameters inside them.
-template <int ARR, int DYN, bool BM, bool PEN>
+// midprice} x reward weight {PnL, quadratic inventory penalties, general} x normalised x noise = 144 step kernels and
+// 72 rollout kernels; WHICH other midprice and reward are runtime parameters inside them.
+int reward_weight(const mbt_config& c) {
+  if (c.reward_kind == MBT_REW_PNL) return mbt::kRewardPnl;
+  const bool quadratic = (c.reward_kind == MBT_REW_RUNNING_PENALTY || c.reward_kind == MBT_REW_CJ_MM) && c.inventory_exponent == 2.0;
+  return quadratic ? mbt::kRewardQuadratic : mbt::kRewardGeneral;
+}
+template <int ARR, int DYN, bool BM, int REW>
 StepKernel pick_flags(bool norm, bool inject) {
-  if (norm) return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, true, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, true, false>>;
-  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, false, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, PEN, false, false>>;
+  if (norm) return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, true, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, true, false>>;
+  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, false, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, false, false>>;
+}
+template <int ARR, int DYN, bool BM>
+StepKernel pick_rew(int rew, bool norm, bool inject) {
+  switch (rew) {
+    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject);
+    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject);
+    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject);
+  }
 }
 template <int ARR, int DYN>
-StepKernel pick_pen(bool bm, bool pen, bool norm, bool inject) {
-  if (bm) return pen ? pick_flags<ARR, DYN, true, true>(norm, inject) : pick_flags<ARR, DYN, true, false>(norm, inject);
-  return pen ? pick_flags<ARR, DYN, false, true>(norm, inject) : pick_flags<ARR, DYN, false, false>(norm, inject);
+StepKernel pick_pen(bool bm, int rew, bool norm, bool inject) {
+  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject) : pick_rew<ARR, DYN, false>(rew, norm, inject);
 }
 template <int ARR>
-StepKernel pick_dyn(int dyn, bool bm, bool pen, bool norm, bool inject) {
+StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, pen, norm, inject);
-    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, pen, norm, inject);
-    default: return pick_pen<ARR, mbt::kDynTouch>(bm, pen, norm, inject);
+    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject);
+    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject);
+    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject);
   }
 }
 template <bool STATE>
@@ -91,24 +103,28 @@ StepKernel pick_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject) : pick_speed<false>(norm, inject);
-  const bool pen = c.reward_kind != MBT_REW_PNL, bm = c.midprice_kind == MBT_MID_BROWNIAN;
-  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, pen, norm, inject)
-                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, pen, norm, inject);
+  const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
+  const int rew = reward_weight(c);
+  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject)
+                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject);
 }
 
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
 
 template <int ARR, int DYN, bool BM>
-RolloutKernel rpick_pen(bool pen, bool norm) {
-  if (pen) return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, true, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, true, false, false>>;
-  return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, false, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, false, false, false>>;
+RolloutKernel rpick_rew(int rew, bool norm) {
+  switch (rew) {
+    case mbt::kRewardPnl: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardPnl, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardPnl, false, false>>;
+    case mbt::kRewardQuadratic: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardQuadratic, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardQuadratic, false, false>>;
+    default: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardGeneral, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardGeneral, false, false>>;
+  }
 }
 template <int ARR>
-RolloutKernel rpick_dyn(int dyn, bool bm, bool pen, bool norm) {
+RolloutKernel rpick_dyn(int dyn, bool bm, int rew, bool norm) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return bm ? rpick_pen<ARR, mbt::kDynLimit, true>(pen, norm) : rpick_pen<ARR, mbt::kDynLimit, false>(pen, norm);
-    case MBT_DYN_LIMIT_AND_MARKET: return bm ? rpick_pen<ARR, mbt::kDynLimitAndMarket, true>(pen, norm) : rpick_pen<ARR, mbt::kDynLimitAndMarket, false>(pen, norm);
-    default: return bm ? rpick_pen<ARR, mbt::kDynTouch, true>(pen, norm) : rpick_pen<ARR, mbt::kDynTouch, false>(pen, norm);
+    case MBT_DYN_LIMIT: return bm ? rpick_rew<ARR, mbt::kDynLimit, true>(rew, norm) : rpick_rew<ARR, mbt::kDynLimit, false>(rew, norm);
+    case MBT_DYN_LIMIT_AND_MARKET: return bm ? rpick_rew<ARR, mbt::kDynLimitAndMarket, true>(rew, norm) : rpick_rew<ARR, mbt::kDynLimitAndMarket, false>(rew, norm);
+    default: return bm ? rpick_rew<ARR, mbt::kDynTouch, true>(rew, norm) : rpick_rew<ARR, mbt::kDynTouch, false>(rew, norm);
   }
 }
 RolloutKernel pick_rollout_kernel(const mbt_config& c) {
@@ -117,8 +133,9 @@ RolloutKernel pick_rollout_kernel(const mbt_config& c) {
     if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
     return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
   }
-  const bool pen = c.reward_kind != MBT_REW_PNL, bm = c.midprice_kind == MBT_MID_BROWNIAN;
-  return c.arrival_kind == MBT_ARR_HAWKES ? rpick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, pen, norm) : rpick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, pen, norm);
+  const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
+  const int rew = reward_weight(c);
+  return c.arrival_kind == MBT_ARR_HAWKES ? rpick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm) : rpick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm);
 }
 
 }  // namespace
@@ -199,6 +216,8 @@ void fill_static_params(mbt_env* e) {
   P.q_max = static_cast<float>(c.max_inventory);
   P.c_max = static_cast<float>(c.max_cash);
   P.reward_kind = c.reward_kind;
+  P.alpha_running = c.reward_kind == MBT_REW_RUNNING_PENALTY ? static_cast<float>(c.alpha) : 0.0f;
+  P.alpha_cjmm = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha) : 0.0f;
   P.exponent_is_two = c.inventory_exponent == 2.0 ? 1 : 0;
   P.phi = static_cast<float>(c.phi);
   P.alpha = static_cast<float>(c.alpha);

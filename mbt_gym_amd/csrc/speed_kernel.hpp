@@ -22,7 +22,8 @@ namespace mbt {
 template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_>
 struct SpeedVariant {
   static constexpr bool HAS_IMPACT_STATE = HAS_IMPACT_STATE_, NORM = NORM_, INJECT = INJECT_;
-  static constexpr bool PENALISED = true;  // optimal-execution rewards are almost never plain PnL: one variant
+  static constexpr bool PENALISED = true;  // optimal-execution rewards are almost never plain PnL: one (general) variant
+  static constexpr int REWARD = kRewardGeneral;
   static constexpr int DIM = HAS_IMPACT_STATE_ ? 5 : 4;
 };
 

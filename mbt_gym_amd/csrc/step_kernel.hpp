@@ -47,11 +47,16 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 
 // Compile-time shape of one kernel instantiation: what changes the memory layout or the amount of noise is a
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
-template <int ARR_, int DYN_, bool BROWNIAN_, bool PENALISED_, bool NORM_, bool INJECT_>
+enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
+
+template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
-  static constexpr bool PENALISED = PENALISED_;  // any reward other than plain PnL (keeps the PnL kernels free of that code)
+  // how heavy the reward is: plain PnL | RunningInventoryPenalty / CjMmCriterion with exponent 2 (branch-free) |
+  // everything else (other exponents via powf, exponential utility) - keeps the common kernels free of that code
+  static constexpr int REWARD = REWARD_;
+  static constexpr bool PENALISED = REWARD_ != kRewardPnl;
   static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
   static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
   static constexpr int DIM = (ARR_ == kArrHawkes) ? 6 : 4;
@@ -85,6 +90,7 @@ struct StepParams {
   float half_spread;
   float q_max, c_max;
   // reward
+  float alpha_running, alpha_cjmm;  // kRewardQuadratic: alpha routed to the terminal (RW:135-137) or the spread (RW:102-108) term
   int32_t reward_kind;
   int32_t exponent_is_two;
   float phi, alpha, exponent;
@@ -330,7 +336,20 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   // -- reward: the mark-to-market change (c'+q'S') - (c+qS) of RW:27-33 from the step's increments, then the reward
   //    function's own terms
   const float pnl = __builtin_fmaf(dq_clip, mid, __builtin_fmaf(q_clip, d_mid, gain)) + dc_clip;
-  r.reward = V::PENALISED ? finish_reward(pnl, q, q_clip, c_clip, mid_new, q_init, 0.0f, is_terminal, P) : pnl * P.reward_scale;
+  if (V::REWARD == kRewardPnl) {
+    r.reward = pnl * P.reward_scale;
+  } else if (V::REWARD == kRewardQuadratic) {
+    // RunningInventoryPenalty (RW:128-138) and CjMmCriterion (RW:96-109) with exponent 2, branch-free: the host
+    // routes alpha into exactly one of the two terms
+    const float qp = q_clip * q_clip;
+    const float spread = __builtin_fmaf(P.dt_over_episode, q_init * q_init, qp - q * q);
+    float pen = P.dt * P.phi * qp;
+    pen = __builtin_fmaf(is_terminal ? P.alpha_running : 0.0f, qp, pen);
+    pen = __builtin_fmaf(P.alpha_cjmm, spread, pen);
+    r.reward = (pnl - pen) * P.reward_scale;
+  } else {
+    r.reward = finish_reward(pnl, q, q_clip, c_clip, mid_new, q_init, 0.0f, is_terminal, P);
+  }
   r.core = make_float4(c_clip, q_clip, t_next, mid_new);
   return r;
 }
@@ -412,8 +431,17 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
     L.z = B.z[lane];
   }
   L.qi = P.q_init_scalar;
-  if (V::PENALISED && B.q_init != nullptr) L.qi = B.q_init[lane];
   return L;
+}
+
+// Per-lane initial inventories (CjMm with random initial inventories only).  Issued AFTER the state/action loads of
+// both lanes: the pointer test is a scalar branch behind an s_waitcnt, and must not sit between those loads.
+template <class V>
+__device__ __forceinline__ void load_initial_inventories(const StepBuffers& B, uint32_t lane0, uint32_t lane1, float& qi0, float& qi1) {
+  if (V::PENALISED && B.q_init != nullptr) {
+    qi0 = B.q_init[lane0];
+    qi1 = B.q_init[lane1];
+  }
 }
 
 // Orders the schedule: every operand is an in/out of one empty asm, so the draws are complete before, and every
@@ -460,6 +488,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
   const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
   LaneLoads L0 = load_lane<V>(B, P, lane0), L1 = load_lane<V>(B, P, lane1);  // issue every load ...
+  load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
   LaneNoise nz0, nz1;
   LaneDraw d0, d1;
   if (V::INJECT) {
@@ -527,6 +556,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     qi[l] = L.qi;
     if (R.obs_traj != nullptr) store_row<V>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
   }
+  load_initial_inventories<V>(B, lanes[0], lanes[1], qi[0], qi[1]);
   uint32_t clips = 0;
   double t = R.t_start;
   LaneResult last[2];

@@ -12,13 +12,20 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-__global__ __launch_bounds__(mbt::kBlockThreads) void copy44(const float4* s_in, float4* s_out, const float4* act, float2* rew, uint32_t n_pairs) {
-  const uint32_t p = blockIdx.x * mbt::kBlockThreads + threadIdx.x;
-  if (p >= n_pairs) return;
-  const float4 a = s_in[2 * p], b = s_in[2 * p + 1], c = act[p];
-  s_out[2 * p] = make_float4(a.x + c.x, a.y, a.z, a.w);
-  s_out[2 * p + 1] = make_float4(b.x + c.z, b.y, b.z, b.w);
-  rew[p] = make_float2(c.y, c.w);
+// the step kernel's own lane mapping (thread j of a 256-thread block: lanes tile*512 + j and + 256), nothing but the traffic
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(mbt::kBlockThreads) void copy44(const float4* s_in_, float4* s_out_, const float4* act_, float2* rew_, uint32_t n_pairs) {
+  const v4f* s_in = reinterpret_cast<const v4f*>(s_in_);
+  v4f* s_out = reinterpret_cast<v4f*>(s_out_);
+  const v2f* act = reinterpret_cast<const v2f*>(act_);
+  float* rew = reinterpret_cast<float*>(rew_);
+  const uint32_t l0 = blockIdx.x * mbt::kTileLanes + threadIdx.x, l1 = l0 + mbt::kBlockThreads;
+  v4f a = s_in[l0], b = s_in[l1];
+  const v2f c = act[l0], d = act[l1];
+  a.x += c.x; b.x += d.x;
+  s_out[l0] = a; s_out[l1] = b;
+  rew[l0] = c.y; rew[l1] = d.y;
 }
 
 __global__ __launch_bounds__(mbt::kBlockThreads) void philox3(float* sink, uint32_t n_pairs, uint32_t step, uint32_t k0, uint32_t k1) {
@@ -61,7 +68,7 @@ int main(int argc, char** argv) {
   mbt::StepParams P{};
   P.n = n; P.n_pairs = n_pairs; P.key0 = 50; P.dt = 1e-3f; P.vol_sqrt_dt = 2.f * sqrtf(1e-3f);
   P.arr_thr_bid = P.arr_thr_ask = 0.14f; P.kappa_log2e_neg = -1.5f * 1.4426950408889634f; P.kappa_f64 = 1.5; P.q_max = 1000.f; P.c_max = 1e8f;
-  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f; P.mid_add = 1.f; P.reward_kind = 2; P.arr_dt = 1e-3f; P.arr_dt_f64 = 1e-3;
+  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f; P.mid_add = 1.f; P.reward_kind = 2; P.alpha_cjmm = 0.001f; P.phi = 0.01f; P.arr_dt = 1e-3f; P.arr_dt_f64 = 1e-3;
   mbt::StepBuffers B{};
   B.action = act; B.reward = rew; B.u_arr = ua; B.u_fill = uf; B.z = z; B.wave_sums = ws; B.clip_count = clip;
   float* st[2] = {s0, s1};
@@ -76,9 +83,9 @@ int main(int argc, char** argv) {
   t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
                            hipLaunchKernelGGL((mbt::step_kernel<VARIANT>), dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
   printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, BYTES * n / t * 1e-3);
-  using AS = mbt::Variant<0, 0, true, false, false, false>;
-  using ASI = mbt::Variant<0, 0, true, false, false, true>;
-  using CJ = mbt::Variant<0, 0, true, true, false, false>;
+  using AS = mbt::Variant<0, 0, true, 0, false, false>;
+  using ASI = mbt::Variant<0, 0, true, 0, false, true>;
+  using CJ = mbt::Variant<0, 0, true, 1, false, false>;
   RUN(AS, "step AS philox (44 B)", 44.0)
   RUN(CJ, "step CjMm philox (44 B)", 44.0)
   RUN(ASI, "step AS inject (64 B)", 64.0)
