@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 2u
+#define MBT_ABI_VERSION 3u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -53,7 +53,10 @@ enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
   MBT_ARR_NONE = 3 /* speed dynamics: no order flow (MD:47-48) */
 };
-enum { MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */ };
+enum {
+  MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */,
+  MBT_FILL_EXOGENOUS_MM = 2 /* FILL:126-170: certain inside an exogenous best depth, exponential beyond; adds two state columns */
+};
 enum {
   MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */, MBT_DYN_AT_THE_TOUCH = 2 /* MD:134-176 */,
   MBT_DYN_SPEED = 3 /* MD:243-275 */
@@ -120,6 +123,12 @@ typedef struct mbt_config {
   double permanent_impact;                   /* IMP:68 */
   double transient_impact, resilience, initial_transient_impact, kernel_coefficient; /* IMP:103-106 */
   double impact_step_size;                   /* IMP:75: the impact model's own terminal_time / n_steps; 0 = env's */
+
+  /* MBT_FILL_EXOGENOUS_MM: the (bid, ask) best depths = initial states of the two depth processes (FILL:148-154).
+   * The reference never copies the processes' updates into the fill model's state (FILL:168-170), so the two state
+   * columns and the depths of FILL:159-163 hold these values for the whole episode. */
+  double exogenous_depth[2];
+  double base_fill_probability;              /* FILL:132 */
 } mbt_config;
 
 typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */

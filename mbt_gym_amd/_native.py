@@ -9,11 +9,11 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT = 0, 1, 2, 3, 4, 5
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE = 0, 1, 2, 3
-FILL_EXPONENTIAL, FILL_NONE = 0, 1
+FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM = 0, 1, 2
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
 REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE = 0, 1, 2, 3, 4
 IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT = -1, 0, 1, 2, 3
@@ -48,6 +48,7 @@ class MbtConfig(C.Structure):
         ("temporary_impact", C.c_double), ("impact_exponent", C.c_double), ("permanent_impact", C.c_double),
         ("transient_impact", C.c_double), ("resilience", C.c_double), ("initial_transient_impact", C.c_double),
         ("kernel_coefficient", C.c_double), ("impact_step_size", C.c_double),
+        ("exogenous_depth", C.c_double * 2), ("base_fill_probability", C.c_double),
     ]
 
 

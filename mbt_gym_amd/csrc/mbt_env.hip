@@ -99,10 +99,26 @@ StepKernel pick_speed(bool norm, bool inject) {
 }
 bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
 
+// ExogenousMmFillProbabilityModel: the general tier only (runtime midprice coefficients, every reward, runtime
+// normalisation flags), 8 step + 4 rollout kernels.
+bool exogenous_fill(const mbt_config& c) {
+  return c.fill_kind == MBT_FILL_EXOGENOUS_MM && (c.dynamics_kind == MBT_DYN_LIMIT || c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET);
+}
+template <int ARR, int DYN>
+StepKernel pick_exogenous(bool inject) {
+  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, true>>
+                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>>;
+}
+
 StepKernel pick_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject) : pick_speed<false>(norm, inject);
+  if (exogenous_fill(c)) {
+    const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
+    if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject);
+    return market ? pick_exogenous<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrPoisson, mbt::kDynLimit>(inject);
+  }
   const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
   const int rew = reward_weight(c);
   return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject)
@@ -132,6 +148,14 @@ RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   if (c.dynamics_kind == MBT_DYN_SPEED) {
     if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
     return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
+  }
+  if (exogenous_fill(c)) {
+    const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
+    if (c.arrival_kind == MBT_ARR_HAWKES)
+      return market ? mbt::rollout_kernel<mbt::Variant<mbt::kArrHawkes, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true>>
+                    : mbt::rollout_kernel<mbt::Variant<mbt::kArrHawkes, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true>>;
+    return market ? mbt::rollout_kernel<mbt::Variant<mbt::kArrPoisson, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true>>
+                  : mbt::rollout_kernel<mbt::Variant<mbt::kArrPoisson, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true>>;
   }
   const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
   const int rew = reward_weight(c);
@@ -212,6 +236,12 @@ void fill_static_params(mbt_env* e) {
   P.hawkes_jump = static_cast<float>(c.hawkes_jump);
   P.kappa_log2e_neg = static_cast<float>(-c.fill_exponent * 1.4426950408889634);
   P.kappa_f64 = c.fill_exponent;
+  for (int side = 0; side < 2; ++side) {  // the state columns are float32; the exact re-decision keeps the float64 depths
+    P.exo_depth[side] = static_cast<float>(c.exogenous_depth[side]);
+    P.exo_depth_f64[side] = c.exogenous_depth[side];
+  }
+  P.exo_base = static_cast<float>(c.base_fill_probability);
+  P.exo_base_f64 = c.base_fill_probability;
   P.half_spread = static_cast<float>(c.market_half_spread);
   P.q_max = static_cast<float>(c.max_inventory);
   P.c_max = static_cast<float>(c.max_cash);
@@ -240,7 +270,7 @@ void fill_static_params(mbt_env* e) {
     P.act_lo[j] = c.act_lo[j];
     P.act_grad[j] = (c.act_hi[j] - c.act_lo[j]) / 2.0f;  // float32 arithmetic, as TE:193 does on the Box bounds
   }
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < 8; ++j) {
     P.obs_lo[j] = c.obs_lo[j];
     P.obs_grad[j] = (c.obs_hi[j] - c.obs_lo[j]) / 2.0f;  // TE:185
   }
@@ -415,14 +445,24 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   P.dt_over_episode = static_cast<float>(e->dt / (c.terminal_time - start_time));  // RW:106, RW:113
   P.episode_length = static_cast<float>(c.terminal_time - start_time);              // RW:67, RW:74
   const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
+  mbt::ResetRow row0{static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
+                     static_cast<float>(c.initial_inventory), {0.f, 0.f, 0.f, 0.f}};
+  int col = 0;  // process columns in registry order: arrival model, fill model, price impact model (TE:303-318)
+  if (e->speed) {
+    row0.extra[col++] = static_cast<float>(c.impact_kind == MBT_IMPACT_TEMPORARY_AND_PERMANENT ? 0.0 : c.initial_transient_impact);  // IMP:81, IMP:121
+  } else {
+    if (c.arrival_kind == MBT_ARR_HAWKES) {  // ARR:103
+      row0.extra[col++] = static_cast<float>(c.intensity[0]);
+      row0.extra[col++] = static_cast<float>(c.intensity[1]);
+    }
+    if (exogenous_fill(c)) {  // FILL:148-154
+      row0.extra[col++] = static_cast<float>(c.exogenous_depth[0]);
+      row0.extra[col++] = static_cast<float>(c.exogenous_depth[1]);
+    }
+  }
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
-                     q0_host != nullptr ? e->q_init : nullptr, static_cast<float>(c.initial_inventory),
-                     static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
-                     // columns 4, 5: Hawkes baselines (ARR:103) or the impact model's initial state (IMP:81, IMP:121)
-                     static_cast<float>(e->speed ? (c.impact_kind == MBT_IMPACT_TEMPORARY_AND_PERMANENT ? 0.0 : c.initial_transient_impact)
-                                                 : c.intensity[0]),
-                     static_cast<float>(c.intensity[1]), e->n_pad, e->n_waves, e->dim, P);
+                     q0_host != nullptr ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P);
   HIP_TRY(hipGetLastError());
   if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
   e->was_reset = true;
@@ -483,6 +523,9 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
     if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
       if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
+    } else if (cfg->fill_kind == MBT_FILL_EXOGENOUS_MM) {
+      if (!(cfg->base_fill_probability >= 0.0 && cfg->base_fill_probability <= 1.0))
+        return fail(MBT_ERR_INVALID, "base_fill_probability %g is not a probability", cfg->base_fill_probability);
     } else if (cfg->fill_kind != MBT_FILL_EXPONENTIAL) {
       return fail(MBT_ERR_INVALID, "fill kind %d has no device implementation", cfg->fill_kind);
     }
@@ -501,7 +544,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
   e->speed = speed;
-  e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : (cfg->arrival_kind == MBT_ARR_HAWKES ? 6 : 4);
+  e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0);
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
   e->n = static_cast<uint32_t>(cfg->num_trajectories);
   // a thread owns a quad of adjacent lanes (speed) or two lanes of a 512-lane tile (order book): pad to whole units

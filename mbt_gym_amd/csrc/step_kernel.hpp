@@ -49,7 +49,7 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
-template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_>
+template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -59,7 +59,12 @@ struct Variant {
   static constexpr bool PENALISED = REWARD_ != kRewardPnl;
   static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
   static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
-  static constexpr int DIM = (ARR_ == kArrHawkes) ? 6 : 4;
+  // ExogenousMmFillProbabilityModel (FILL:126-170): two more columns holding the exogenous best depths, which the
+  // reference never advances (FILL:168-170) - the kernel does not load them, it writes the constants.  Instantiated
+  // only on the general tier (BROWNIAN false, kRewardGeneral, NORM true: each a superset of the specialised code).
+  static constexpr bool EXO = EXO_;
+  static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
+  static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
 };
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
@@ -86,6 +91,8 @@ struct StepParams {
   // fills
   float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)
   double kappa_f64;
+  float exo_depth[2], exo_base;          // exogenous best depths (bid, ask) and base fill probability (FILL:159-163)
+  double exo_depth_f64[2], exo_base_f64;
   // dynamics
   float half_spread;
   float q_max, c_max;
@@ -108,7 +115,7 @@ struct StepParams {
   // normalisation (TE:112-126); gradients are float32 like the reference's Box bounds
   int32_t norm_act, norm_obs;
   float act_lo[4], act_grad[4];
-  float obs_lo[6], obs_grad[6];
+  float obs_lo[8], obs_grad[8];
 };
 
 struct StepBuffers {
@@ -175,6 +182,20 @@ __device__ __forceinline__ FillTest fill_test(float u, float depth, const StepPa
   return FillTest{d < 0.0f, __builtin_fabsf(d) <= band};
 }
 
+// ExogenousMmFillProbabilityModel (FILL:159-163): p = 1 for a quote at or inside the exogenous best depth,
+// base * exp(-kappa (depth - best)) beyond it.  `near` additionally covers a quote within rounding of the best depth.
+__device__ __forceinline__ FillTest fill_test_exogenous(float u, float depth, int side, const StepParams& P) {
+  const float best = P.exo_depth[side];
+  const float x = depth - best;
+  const float y = P.kappa_log2e_neg * x;
+  const float p = P.exo_base * __builtin_amdgcn_exp2f(y);
+  const float slack = (__builtin_fabsf(depth) + __builtin_fabsf(best)) * 2.4e-7f;  // roundings of depth, best and x
+  const float band = __builtin_fmaf(p, __builtin_fmaf(__builtin_fabsf(y), 3e-7f, __builtin_fmaf(__builtin_fabsf(P.kappa_log2e_neg), slack, 4e-6f)), 1e-30f);
+  const bool inside = x <= 0.0f;  // p = 1 exactly: the strict `u < 1` of FILL:34 holds for every uniform in [0, 1)
+  const float d = u - (inside ? 1.0f : p);
+  return FillTest{d < 0.0f, (!inside && __builtin_fabsf(d) <= band) || __builtin_fabsf(x) <= slack};
+}
+
 __device__ __forceinline__ float depth_of(float a, int side, bool norm, const StepParams& P) {
   return norm ? static_cast<float>((static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side]) : a;  // TE:124
 }
@@ -184,6 +205,13 @@ __device__ __attribute__((cold)) bool refine_fill_f64(float u, float a, int side
   double depth = a;
   if (norm) depth = (static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side];
   return static_cast<double>(u) < exp(-P.kappa_f64 * depth);
+}
+
+__device__ __attribute__((cold)) bool refine_fill_exogenous_f64(float u, float a, int side, bool norm, const StepParams& P) {
+  double depth = a;
+  if (norm) depth = (static_cast<double>(a) + 1.0) * P.act_grad[side] + P.act_lo[side];
+  const double best = P.exo_depth_f64[side];
+  return static_cast<double>(u) < (depth > best ? P.exo_base_f64 * exp(-P.kappa_f64 * (depth - best)) : 1.0);
 }
 
 // numpy `q ** p` (RW:101-104, RW:133-137) of up to three inventories at once; p == 2 in every reference
@@ -281,11 +309,17 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   } else {
     off_bid = depth_of(act.x, 0, norm_act, P);
     off_ask = depth_of(act.y, 1, norm_act, P);
-    const FillTest tb = fill_test(dr.uf_bid, off_bid, P), ta = fill_test(dr.uf_ask, off_ask, P);
+    const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(dr.uf_bid, off_bid, P);
+    const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(dr.uf_ask, off_ask, P);
     bool fb = tb.fill, fa = ta.fill;
     if (__builtin_expect(tb.near | ta.near, 0)) {
-      if (tb.near) fb = refine_fill_f64(dr.uf_bid, act.x, 0, norm_act, P);
-      if (ta.near) fa = refine_fill_f64(dr.uf_ask, act.y, 1, norm_act, P);
+      if (V::EXO) {
+        if (tb.near) fb = refine_fill_exogenous_f64(dr.uf_bid, act.x, 0, norm_act, P);
+        if (ta.near) fa = refine_fill_exogenous_f64(dr.uf_ask, act.y, 1, norm_act, P);
+      } else {
+        if (tb.near) fb = refine_fill_f64(dr.uf_bid, act.x, 0, norm_act, P);
+        if (ta.near) fa = refine_fill_f64(dr.uf_ask, act.y, 1, norm_act, P);
+      }
     }
     r.fill_bid = fb && open_bid;
     r.fill_ask = fa && open_ask;
@@ -365,27 +399,17 @@ __device__ __forceinline__ float wave_sum(float v) {
          __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
 }
 
-__device__ __forceinline__ void write_obs_row(float* obs, uint32_t lane, int dim, const float4 core, const float2 lam,
-                                              const StepParams& P) {
-  float* row = obs + static_cast<size_t>(lane) * dim;
-  const float v[6] = {core.x, core.y, core.z, core.w, lam.x, lam.y};
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    if (j < dim) row[j] = P.norm_obs ? (v[j] - P.obs_lo[j]) / P.obs_grad[j] - 1.0f : v[j];
-  }
-}
+// (x - lo) / grad - 1 (TE:112-118), float32 division like the reference's float arithmetic on Box bounds
+__device__ __forceinline__ float normalise_column(float x, int col, const StepParams& P) { return (x - P.obs_lo[col]) / P.obs_grad[col] - 1.0f; }
 
-// (x - lo) / grad - 1 per column (TE:112-118), float32 division like the reference's float arithmetic on Box bounds
-__device__ __forceinline__ void normalise_row(float4& core, float2& lam, int dim, const StepParams& P) {
+__device__ __forceinline__ void normalise_row(float4& core, float2& lam, const StepParams& P) {
   if (!P.norm_obs) return;
-  core.x = (core.x - P.obs_lo[0]) / P.obs_grad[0] - 1.0f;
-  core.y = (core.y - P.obs_lo[1]) / P.obs_grad[1] - 1.0f;
-  core.z = (core.z - P.obs_lo[2]) / P.obs_grad[2] - 1.0f;
-  core.w = (core.w - P.obs_lo[3]) / P.obs_grad[3] - 1.0f;
-  if (dim == 6) {
-    lam.x = (lam.x - P.obs_lo[4]) / P.obs_grad[4] - 1.0f;
-    lam.y = (lam.y - P.obs_lo[5]) / P.obs_grad[5] - 1.0f;
-  }
+  core.x = normalise_column(core.x, 0, P);
+  core.y = normalise_column(core.y, 1, P);
+  core.z = normalise_column(core.z, 2, P);
+  core.w = normalise_column(core.w, 3, P);
+  lam.x = normalise_column(lam.x, 4, P);  // (dead code unless the row has Hawkes columns)
+  lam.y = normalise_column(lam.y, 5, P);
 }
 
 // ---- lane <-> thread mapping --------------------------------------------------------------------------------------
@@ -410,11 +434,14 @@ struct LaneLoads {
 template <class V>
 __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepParams& P, uint32_t lane) {
   LaneLoads L;
-  if (V::ARR == kArrHawkes) {  // rows of 6 floats: 8-byte aligned
+  if (V::DIM == 8) {  // Hawkes + exogenous depths: 32-byte rows, the (constant) depth columns are not read
+    L.core = reinterpret_cast<const float4*>(B.state_in)[static_cast<size_t>(lane) * 2];
+    L.lam = reinterpret_cast<const float2*>(B.state_in)[static_cast<size_t>(lane) * 4 + 2];
+  } else if (V::DIM == 6) {  // rows of 6 floats: 8-byte aligned
     const float2* row = reinterpret_cast<const float2*>(B.state_in) + static_cast<size_t>(lane) * 3;
     const float2 a = row[0], b = row[1];
     L.core = make_float4(a.x, a.y, b.x, b.y);
-    L.lam = row[2];
+    L.lam = V::ARR == kArrHawkes ? row[2] : make_float2(0.f, 0.f);
   } else {
     L.core = reinterpret_cast<const float4*>(B.state_in)[lane];
     L.lam = make_float2(0.f, 0.f);
@@ -456,12 +483,18 @@ __device__ __forceinline__ void tie_loads_to_draws(LaneLoads& a, LaneLoads& b, L
 // one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
 template <class V>
 __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
-  if (normalise) normalise_row(core, lam, V::DIM, P);
-  if (V::ARR == kArrHawkes) {
+  if (normalise) normalise_row(core, lam, P);
+  float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);  // the exogenous best depths never move (FILL:168-170)
+  if (V::EXO && normalise && P.norm_obs) best = make_float2(normalise_column(best.x, V::EXO_COL, P), normalise_column(best.y, V::EXO_COL + 1, P));
+  if (V::DIM == 8) {
+    float4* row = reinterpret_cast<float4*>(base) + static_cast<size_t>(lane) * 2;
+    row[0] = core;
+    row[1] = make_float4(lam.x, lam.y, best.x, best.y);
+  } else if (V::DIM == 6) {
     float2* row = reinterpret_cast<float2*>(base) + static_cast<size_t>(lane) * 3;
     row[0] = make_float2(core.x, core.y);
     row[1] = make_float2(core.z, core.w);
-    row[2] = lam;
+    row[2] = V::ARR == kArrHawkes ? lam : best;
   } else {
     reinterpret_cast<float4*>(base)[lane] = core;
   }
@@ -627,21 +660,24 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
 
 // ---- small helper kernels ----------------------------------------------------------------------------------
 
-// reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price (, Hawkes baselines)], zeroed accumulators.
-__global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0,
-                             float q0_scalar, float cash0, float t0, float s0, float extra0, float extra1,
+// reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...], zeroed accumulators.
+struct ResetRow {
+  float cash0, t0, s0, q0_scalar;
+  float extra[4];  // columns 4..: Hawkes baselines (ARR:103), exogenous best depths (FILL:148-154), or the impact model's initial state (IMP:81, IMP:121)
+};
+
+__global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0, const ResetRow row0,
                              uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P) {
-  const float lam_bid = extra0, lam_ask = extra1;  // columns 4, 5: Hawkes baselines, or the initial impact state in column 4
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
-  const float4 c = make_float4(cash0, q0 != nullptr ? q0[i] : q0_scalar, t0, s0);
-  const float2 l = make_float2(lam_bid, lam_ask);
   float* row = state + static_cast<size_t>(i) * dim;
-  row[0] = c.x; row[1] = c.y; row[2] = c.z; row[3] = c.w;
-  if (dim > 4) row[4] = l.x;
-  if (dim > 5) row[5] = l.y;
-  if (obs != nullptr) write_obs_row(obs, i, dim, c, l, P);
+  float* orow = obs != nullptr ? obs + static_cast<size_t>(i) * dim : nullptr;
+  for (int j = 0; j < dim; ++j) {
+    const float v = j == 0 ? row0.cash0 : j == 1 ? (q0 != nullptr ? q0[i] : row0.q0_scalar) : j == 2 ? row0.t0 : j == 3 ? row0.s0 : row0.extra[j - 4];
+    row[j] = v;
+    if (orow != nullptr) orow[j] = P.norm_obs ? normalise_column(v, j, P) : v;
+  }
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
 
@@ -650,9 +686,8 @@ __global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   const float* r = state + static_cast<size_t>(i) * dim;
-  const float4 c = make_float4(r[0], r[1], r[2], r[3]);
-  const float2 l = make_float2(dim > 4 ? r[4] : 0.f, dim > 5 ? r[5] : 0.f);
-  write_obs_row(obs, i, dim, c, l, P);
+  float* o = obs + static_cast<size_t>(i) * dim;
+  for (int j = 0; j < dim; ++j) o[j] = P.norm_obs ? normalise_column(r[j], j, P) : r[j];
 }
 
 // [sum of wave_sums, sum of lane_returns^2] -> out[0], out[1]; one block.

@@ -179,8 +179,8 @@ class TradingEnvironment(_EnvBase):
         cfg.noise_mode = {"philox": _native.NOISE_PHILOX, "injected": _native.NOISE_INJECTED}[self.noise]
         cfg.inventory_exponent = 2.0
         for key, value in fields.items():
-            if key == "intensity":
-                cfg.intensity[0], cfg.intensity[1] = value
+            if key in ("intensity", "exogenous_depth"):
+                getattr(cfg, key)[0], getattr(cfg, key)[1] = value
             else:
                 setattr(cfg, key, value)
         cfg.initial_cash = self.initial_cash

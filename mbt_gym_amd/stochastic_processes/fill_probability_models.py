@@ -2,8 +2,13 @@
 (reference: mbt_gym/stochastic_processes/fill_probability_models.py).
 
 ExponentialFillFunction (FILL:42-65):  fill_s = U_s < exp(-kappa * depth_s);  max_depth = -ln(0.01) / kappa.
+ExogenousMmFillProbabilityModel (FILL:126-170):  fill_s = U_s < 1 for a quote at or inside the exogenous best depth
+    b_s, else U_s < base * exp(-kappa * (depth_s - b_s)); contributes the two columns (b_bid, b_ask) to the state.
+
+TriangularFillFunction / PowerFillFunction (FILL:68-123) reduce over the TRAJECTORY axis (`np.max(depths, 0)`), i.e.
+they are not per-trajectory models for num_trajectories > 1; they have no device implementation.
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -44,3 +49,59 @@ class ExponentialFillFunction(FillProbabilityModel):
 
     def device_params(self):
         return dict(fill_kind=self.device_kind, fill_exponent=self.fill_exponent)
+
+
+class ExogenousMmFillProbabilityModel(FillProbabilityModel):
+    """Fill probability relative to an exogenous best bid / ask depth (FILL:126-170).
+
+    Reference behaviour kept on purpose: `update` advances the two depth processes but never copies their state into
+    this model's `current_state` (FILL:168-170), and `reset` re-tiles `initial_state` (SP:30-31), so the best depths
+    the environment observes and prices fills against are the two processes' INITIAL states for the whole episode.
+    The device therefore needs only those two numbers; the processes' own dynamics are never evaluated."""
+
+    device_kind = _native.FILL_EXOGENOUS_MM
+
+    def __init__(
+        self,
+        exogenous_best_depth_processes: Tuple[StochasticProcessModel],
+        fill_exponent: float = 1.5,
+        base_fill_probability: float = 1.0,
+        step_size: float = 0.1,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+    ):
+        assert len(exogenous_best_depth_processes) == 2, "exogenous_best_depth_processes must be length 2 (bid and ask)"
+        assert all(
+            len(process.initial_state) > 0 for process in exogenous_best_depth_processes
+        ), "Exogenous best depth processes must have a state of at least size 1."
+        self.exogenous_best_depth_processes = exogenous_best_depth_processes
+        self.fill_exponent = fill_exponent
+        self.base_fill_probability = base_fill_probability
+        bid, ask = exogenous_best_depth_processes
+        super().__init__(
+            np.concatenate([bid.min_value, ask.min_value], axis=1),
+            np.concatenate([bid.max_value, ask.max_value], axis=1),
+            step_size,
+            0.0,
+            np.concatenate((bid.initial_state, ask.initial_state), axis=1),
+            num_trajectories,
+            seed,
+        )
+
+    def _get_fill_probabilities(self, depths: np.ndarray) -> np.ndarray:
+        """Closed-form probability against the constant best depths (host utility; the kernel has its own evaluation)."""
+        depths = np.asarray(depths, dtype=np.float64)
+        best = self.initial_state
+        return (depths > best) * self.base_fill_probability * np.exp(-self.fill_exponent * (depths - best)) + (depths <= best)
+
+    @property
+    def max_depth(self) -> float:
+        return -np.log(0.01) / self.fill_exponent + np.max(self.exogenous_best_depth_processes[0].max_value)
+
+    def device_params(self):
+        if self.initial_state.shape[1] != 2:  # FILL:159-163 compares (N, 2) depths with this state
+            raise DeviceResidentError("each exogenous best-depth process must have a one-dimensional state")
+        return dict(
+            fill_kind=self.device_kind, fill_exponent=self.fill_exponent, base_fill_probability=self.base_fill_probability,
+            exogenous_depth=(float(self.initial_state[0, 0]), float(self.initial_state[0, 1])),
+        )

@@ -61,8 +61,16 @@ class OracleConfig:
     intensity: Sequence[float] = (140.0, 140.0)  # Poisson rate / Hawkes baseline (bid, ask)
     hawkes_jump: float = 40.0
     hawkes_speed: float = 60.0
-    # fills: exponential (FILL:42-65)
+    # fills: "exponential" (FILL:42-65) or "exogenous" (FILL:126-170): exponential beyond an exogenous best depth.
+    # The reference's ExogenousMmFillProbabilityModel.update advances its two depth processes but never copies their
+    # state into its own current_state (FILL:168-170), so the best depths the environment sees - the two state
+    # columns and the depths in FILL:159-163 - stay at the processes' initial values for the whole episode.
+    fill: str = "exponential"
     fill_exponent: float = 1.5
+    base_fill_probability: float = 1.0  # FILL:132
+    exo_depth: Sequence[float] = (0.0, 0.0)  # initial states of the (bid, ask) best-depth processes (FILL:148-154)
+    exo_depth_lo: Sequence[float] = (0.0, 0.0)  # their min_value / max_value (FILL:146-147): observation bounds
+    exo_depth_hi: Sequence[float] = (0.0, 0.0)
     # dynamics: "limit" (MD:87-131), "limit_and_market" (MD:179-240), "touch" (MD:134-176), "speed" (MD:243-275)
     dynamics: str = "limit"
     market_half_spread: float = 0.5  # MD:189
@@ -111,7 +119,16 @@ class OracleConfig:
 
     @property
     def state_dim(self) -> int:
-        return 4 + (2 if self.arrival == "hawkes" else 0) + (1 if self.impact_has_state else 0)  # TE:311-318
+        return 4 + (2 if self.arrival == "hawkes" else 0) + (2 if self.has_exogenous_fill else 0) + (1 if self.impact_has_state else 0)  # TE:311-318
+
+    @property
+    def has_exogenous_fill(self) -> bool:
+        return self.fill == "exogenous" and self.dynamics in ("limit", "limit_and_market")
+
+    @property
+    def exo_column(self) -> int:
+        """First of the two best-depth columns: after the midprice and the arrival model's columns (TE:303-318)."""
+        return 4 + (2 if self.arrival == "hawkes" else 0)
 
     @property
     def action_dim(self) -> int:
@@ -148,8 +165,12 @@ def midprice_bounds(cfg: OracleConfig) -> Tuple[float, float]:
 
 
 def resolved_max_depth(cfg: OracleConfig) -> float:
-    """-ln(0.01)/kappa unless given (FILL:60-62, MD:103)."""
-    return cfg.max_depth or float(-np.log(0.01) / cfg.fill_exponent)
+    """-ln(0.01)/kappa unless given (FILL:60-62, MD:103); the exogenous model adds the bid process' upper bound (FILL:164-166)."""
+    if cfg.max_depth:
+        return cfg.max_depth
+    if cfg.has_exogenous_fill:
+        return float(-np.log(0.01) / cfg.fill_exponent + np.max(np.asarray(cfg.exo_depth_hi, dtype=np.float64)[0]))
+    return float(-np.log(0.01) / cfg.fill_exponent)
 
 
 def resolved_max_stock_price(cfg: OracleConfig) -> float:
@@ -172,6 +193,9 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
         base = np.asarray(cfg.intensity, dtype=np.float64).reshape(-1)
         lo += [0.0, 0.0]  # ARR:100
         hi += list(base * 10)  # ARR:101, ARR:125-126
+    if cfg.has_exogenous_fill:  # FILL:146-147
+        lo += [float(v) for v in cfg.exo_depth_lo]
+        hi += [float(v) for v in cfg.exo_depth_hi]
     if cfg.impact_has_state:  # IMP:77-78, IMP:117-118, IMP:158-159
         coef = cfg.permanent_impact if cfg.impact == "temp_perm" else cfg.transient_impact
         lo.append(-cfg.max_speed * cfg.terminal_time * coef)
@@ -252,6 +276,7 @@ class OracleEnv:
         self.episode_length = None
         self.last_arrivals = None
         self.last_fills = None
+        self.last_clipped = None
 
     # -- reset ---------------------------------------------------------------------------------
     def _start_time(self) -> float:
@@ -276,6 +301,8 @@ class OracleEnv:
         cols = [np.repeat(np.array([[cfg.initial_price]], dtype=np.float64), n, axis=0)]
         if cfg.arrival == "hawkes":
             cols.append(np.repeat(np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2), n, axis=0))
+        if cfg.has_exogenous_fill:  # FILL:148-154
+            cols.append(np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0))
         if cfg.impact_has_state:  # IMP:81 (0) / IMP:121, IMP:162 (initial transient impact)
             y0 = 0 if cfg.impact == "temp_perm" else cfg.initial_transient_impact
             cols.append(np.repeat(np.array([[y0]]), n, axis=0))
@@ -342,6 +369,10 @@ class OracleEnv:
             depths = action[:, 0:2]  # MD:50-51
             if cfg.dynamics == "touch":
                 fills = action[:, 0:2]  # the agent posts (or not) at the touch: MD:156-157
+            elif cfg.has_exogenous_fill:  # FILL:159-163: certain inside the exogenous best depth, exponential beyond it
+                best = np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0)
+                prob = (depths > best) * cfg.base_fill_probability * np.exp(-cfg.fill_exponent * (depths - best)) + (depths <= best)
+                fills = u_fill < prob
             else:
                 fills = u_fill < np.exp(-cfg.fill_exponent * depths)
             # no bid fill at +max inventory, no ask fill at -max inventory, pre-update q (TE:323-327)
@@ -364,8 +395,10 @@ class OracleEnv:
                 st[:, INVENTORY] += np.sum(arrivals * fills * -sgn, axis=1)
                 st[:, CASH] += np.sum(sgn * arrivals * fills * (mid + depths * sgn), axis=1)
         # clip (TE:283-289) and advance time (TE:216)
+        unclipped = st[:, (CASH, INVENTORY)].copy()
         st[:, INVENTORY] = np.clip(st[:, INVENTORY], -cfg.max_inventory, cfg.max_inventory)
         st[:, CASH] = np.clip(st[:, CASH], -self.max_cash, self.max_cash)
+        self.last_clipped = np.any(unclipped != st[:, (CASH, INVENTORY)], axis=1)  # the lanes TE:291-297 would print for
         st[:, TIME] += dt
 
         # processes in registry order midprice, arrival, fill, impact (TE:206-211, TE:303-309)

@@ -41,7 +41,8 @@ def _roll(env, actions, noise=None):
 
 
 @pytest.mark.parametrize("name", ["as_limit_pnl", "hawkes_ou", "limit_and_market", "cjp_cjmm", "default_normalised",
-                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice"])
+                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice", "exo_fill_bm_poisson",
+                                  "exo_fill_hawkes_market", "exo_fill_normalised"])
 def test_philox_mode_equals_injected_mode_on_the_same_draws(name):
     """The kernel body is shared: feeding the injected-noise instantiation with the draws the Philox instantiation
     makes must give bit-identical states and rewards - this carries the parity result over to production mode."""
@@ -67,7 +68,7 @@ def test_philox_mode_equals_injected_mode_on_the_same_draws(name):
         if not cfg.normalise_observation_space:
             np.testing.assert_array_equal(got_p[k][0][:, 1].astype(np.float64), o_obs[:, 1])
         err = np.abs(got_p[k][1] - o_rew)
-        tol = {"limit_and_market": 1e-3, "gbm_nonlinear_touch": 5e-5}.get(name, 1e-5)  # see test_gpu_parity.py
+        tol = {"limit_and_market": 1e-3, "exo_fill_hawkes_market": 1e-3, "gbm_nonlinear_touch": 5e-5}.get(name, 1e-5)  # see test_gpu_parity.py
         assert np.all(err <= tol), err.max()
     env_p.close()
     env_i.close()

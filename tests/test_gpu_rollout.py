@@ -27,7 +27,8 @@ def _step_loop(env, actions_or_agent, steps):
 
 
 @pytest.mark.parametrize("name", ["as_limit_pnl", "cjp_running", "cjp_cjmm", "hawkes_ou", "limit_and_market", "default_normalised",
-                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice"])
+                                  "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice", "exo_fill_bm_poisson",
+                                  "exo_fill_hawkes_market", "exo_fill_normalised"])
 def test_fixed_policy_rollout_equals_the_step_loop_bit_for_bit(name):
     cfg, g = load_case(name)
     cfg.seed = 4321

@@ -47,7 +47,10 @@ from mbt_gym.stochastic_processes.arrival_models import (  # noqa: E402
     PoissonArrivalModel,
     PoissonArrivalNonLinearModel,
 )
-from mbt_gym.stochastic_processes.fill_probability_models import ExponentialFillFunction  # noqa: E402
+from mbt_gym.stochastic_processes.fill_probability_models import (  # noqa: E402
+    ExogenousMmFillProbabilityModel,
+    ExponentialFillFunction,
+)
 from mbt_gym.stochastic_processes.midprice_models import (  # noqa: E402
     BrownianMotionJumpMidpriceModel,
     BrownianMotionMidpriceModel,
@@ -116,7 +119,8 @@ def draw_actions(rng, k, n, a_dim, max_depth, normalised, kind="depths", max_spe
     return act.astype(np.float32)
 
 
-def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None, action_kind="depths"):
+def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None, action_kind="depths",
+             fill_prob=None, action_hook=None):
     rng = np.random.default_rng(1000 + seed)
     with contextlib.redirect_stdout(io.StringIO()):
         env = build_env()
@@ -129,8 +133,11 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         lo, c, hi = f32_neighbours(np.float64(poisson_thr))
         for j, v in enumerate((lo, c, hi)):
             u_arr[::3, j % n, :] = v
+    if action_hook is not None:
+        action_hook(actions)
     if not normalised and action_kind == "depths":
-        p = np.exp(-kappa * actions[:, :, 0:2].astype(np.float64))
+        depths64 = actions[:, :, 0:2].astype(np.float64)
+        p = np.exp(-kappa * depths64) if fill_prob is None else fill_prob(depths64)
         lo, c, hi = f32_neighbours(p)
         for j, v in enumerate((lo, c, hi)):
             u_fill[1::4, (3 + j) % n, :] = v[1::4, (3 + j) % n, :]
@@ -409,6 +416,92 @@ def extra_cases():
                  midprice_step_size=mid_dt, initial_inventory=10, max_inventory=1000, seed=31, **cfg_extra, **common),
             action_kind=action_kind)
 
+    exogenous_fill_cases()
+
+
+def exogenous_fill_cases():
+    """ExogenousMmFillProbabilityModel (FILL:126-170): two more state columns that hold the exogenous best depths."""
+    best = np.array([0.25, 0.375])  # float32-representable, so quotes can sit exactly ON the best depth
+    kappa, base = 1.5, 0.8
+
+    def make_fill(n, dt):
+        bid = OuMidpriceModel(mean_reversion_level=best[0], mean_reversion_speed=0.1, volatility=0.05, initial_price=best[0],
+                              terminal_time=1.0, step_size=dt, num_trajectories=n)
+        ask = BrownianMotionMidpriceModel(drift=0.0, volatility=0.04, initial_price=best[1], terminal_time=1.0, step_size=dt, num_trajectories=n)
+        bounds = (np.concatenate([bid.min_value, ask.min_value], axis=1)[0], np.concatenate([bid.max_value, ask.max_value], axis=1)[0])
+        return ExogenousMmFillProbabilityModel((bid, ask), fill_exponent=kappa, base_fill_probability=base, step_size=dt, num_trajectories=n), bounds
+
+    def prob(depths):
+        return (depths > best) * base * np.exp(-kappa * (depths - best)) + (depths <= best)
+
+    def quotes_on_the_best_depth(actions):
+        for side in range(2):
+            lo, c, hi = f32_neighbours(best[side])
+            for j, v in enumerate((lo, c, hi)):
+                actions[2::5, (6 + j) % actions.shape[1], side] = v
+
+    common = dict(normalise_action_space=False, normalise_observation_space=False)
+    exo_cfg = lambda bounds: dict(fill="exogenous", fill_exponent=kappa, base_fill_probability=base, exo_depth=list(best),  # noqa: E731
+                                  exo_depth_lo=[float(v) for v in bounds[0]], exo_depth_hi=[float(v) for v in bounds[1]])
+
+    # O. Brownian midprice + Poisson arrivals + exogenous best depths (D = 6)
+    n, ns = 32, 80
+    _, bounds = make_fill(n, 1 / ns)
+    run_case(
+        "exo_fill_bm_poisson",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=41, initial_inventory=0, max_inventory=3, num_trajectories=n,
+            model_dynamics=LimitOrderModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=PoissonArrivalModel(intensity=np.array([50.0, 50.0]), step_size=1 / ns, num_trajectories=n),
+                fill_probability_model=make_fill(n, 1 / ns)[0], num_trajectories=n),
+            **common),
+        ns, n, 2, 41,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson", intensity=[50.0, 50.0],
+             dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=3, seed=41, **exo_cfg(bounds), **common),
+        poisson_thr=50.0 / ns, fill_prob=prob, action_hook=quotes_on_the_best_depth)
+
+    # P. OU midprice + Hawkes arrivals + exogenous best depths + market orders + running penalty (D = 8, A = 4)
+    n, ns = 32, 90
+    run_case(
+        "exo_fill_hawkes_market",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=42, initial_inventory=(-3, 4), max_inventory=6, num_trajectories=n,
+            reward_function=CjMmCriterion(0.02, 0.05, terminal_time=1.0),
+            model_dynamics=LimitAndMarketOrderModelDynamics(
+                midprice_model=OuMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.02, volatility=1.5, initial_price=100.0,
+                                               terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=HawkesArrivalModel(baseline_arrival_rate=np.array([[15.0, 10.0]]), step_size=1 / ns, jump_size=30.0,
+                                                 mean_reversion_speed=50.0, terminal_time=1.0, num_trajectories=n),
+                fill_probability_model=make_fill(n, 1 / ns)[0], num_trajectories=n, fixed_market_half_spread=0.4),
+            **common),
+        ns, n, 4, 42,
+        dict(n_steps=ns, terminal_time=1.0, midprice="ou", ou_level=100.0, ou_speed=0.02, volatility=1.5, initial_price=100.0, arrival="hawkes",
+             intensity=[15.0, 10.0], hawkes_jump=30.0, hawkes_speed=50.0, dynamics="limit_and_market", market_half_spread=0.4, reward="cjmm",
+             phi=0.02, alpha=0.05, initial_inventory=[-3, 4], max_inventory=6, seed=42, **exo_cfg(bounds), **common),
+        fill_prob=prob, action_hook=quotes_on_the_best_depth)
+
+    # Q. the same model behind normalised actions and observations (TE:112-126 with the extra columns' bounds)
+    n, ns = 16, 50
+    both = dict(normalise_action_space=True, normalise_observation_space=True)
+    run_case(
+        "exo_fill_normalised",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=43, initial_inventory=0, max_inventory=5, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.1),
+            model_dynamics=LimitOrderModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=PoissonArrivalModel(intensity=np.array([40.0, 60.0]), step_size=1 / ns, num_trajectories=n),
+                fill_probability_model=make_fill(n, 1 / ns)[0], num_trajectories=n),
+            **both),
+        ns, n, 2, 43,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson", intensity=[40.0, 60.0],
+             dynamics="limit", reward="running", phi=0.01, alpha=0.1, initial_inventory=0, max_inventory=5, seed=43, **exo_cfg(bounds), **both),
+        normalised=True)
+
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
+        exogenous_fill_cases()
+    else:
+        main()
