@@ -313,9 +313,9 @@ class TradingEnvironment(_EnvBase):
         n = self.num_trajectories
         obs = act = rew = None
         if record:
-            obs = np.zeros((k + 1, n, self.observation_dim), dtype=np.float32)
-            act = np.zeros((k, n, self.action_dim), dtype=np.float32)
-            rew = np.zeros((k, n), dtype=np.float32)
+            obs = np.empty((k + 1, n, self.observation_dim), dtype=np.float32)
+            act = np.empty((k, n, self.action_dim), dtype=np.float32)
+            rew = np.empty((k, n), dtype=np.float32)
         steps, done = C.c_uint32(0), C.c_int32(0)
         _native.check(_native.load_library().mbt_env_rollout_host(
             self._handle, C.byref(pol), k, _native.fptr(obs), _native.fptr(act), _native.fptr(rew), C.byref(steps), C.byref(done)))

@@ -4,8 +4,11 @@ observations (N, D, n_steps + 1), actions (N, A, n_steps), rewards (N, 1, n_step
 Two execution paths with identical results:
   * the reference's loop - agent.get_action(obs) on the host, one env.step() launch per time step;
   * `fused=True` (default whenever the agent can describe itself to the device, `agent.device_policy()`): the whole
-    episode in ONE kernel launch (csrc/step_kernel.hpp: rollout_kernel).  The device records time-major; the arrays
-    returned are transposed views with the reference's shapes.
+    episode in ONE kernel launch (csrc/step_kernel.hpp: rollout_kernel).  The device records time-major (every store
+    a coalesced row); the arrays returned are transposed VIEWS of that recording with the reference's shapes - no
+    host-side transpose pass over what is 5.9 GB at 2^20 trajectories x 200 steps.  Reductions over the time axis
+    (episode returns, plotting.py:96-108) run at full speed on them; `np.ascontiguousarray` gives the reference's
+    memory order when a consumer needs it.
 """
 import numpy as np
 
@@ -21,13 +24,11 @@ def generate_trajectory(env, agent, seed: int = None, include_log_probs: bool = 
     if fused:
         env.reset()
         obs_t, act_t, rew_t, steps, _ = env.rollout(agent, max_steps=horizon, record=True)
-        observations = np.zeros((n, obs_t.shape[2], horizon + 1), dtype=np.float32)
-        actions = np.zeros((n, act_t.shape[2], horizon), dtype=np.float32)
-        rewards = np.zeros((n, 1, horizon), dtype=np.float32)
-        observations[:, :, : steps + 1] = np.transpose(obs_t, (1, 2, 0))
-        actions[:, :, :steps] = np.transpose(act_t, (1, 2, 0))
-        rewards[:, 0, :steps] = rew_t.T
-        return observations, actions, rewards
+        if steps < horizon:  # an episode that starts late (start_time > 0) leaves the tail zero, as GT:11-13 allocates it
+            obs_t = np.concatenate([obs_t, np.zeros((horizon - steps,) + obs_t.shape[1:], np.float32)])
+            act_t = np.concatenate([act_t, np.zeros((horizon - steps,) + act_t.shape[1:], np.float32)])
+            rew_t = np.concatenate([rew_t, np.zeros((horizon - steps, n), np.float32)])
+        return np.transpose(obs_t, (1, 2, 0)), np.transpose(act_t, (1, 2, 0)), rew_t.T[:, None, :]
     observations = np.zeros((n, env.observation_space.shape[0], horizon + 1), dtype=np.float32)
     actions = np.zeros((n, env.action_space.shape[0], horizon), dtype=np.float32)
     rewards = np.zeros((n, 1, horizon), dtype=np.float32)
