@@ -138,7 +138,8 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    gpu = 0 if args.single_device else local_rank
+    # one process per GPU; a launcher that narrows each rank's visible devices leaves fewer ordinals than ranks
+    gpu = 0 if args.single_device else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(gpu)
     if world > 1:
         if args.backend == "nccl":
