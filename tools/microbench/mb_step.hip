@@ -36,6 +36,37 @@ __global__ __launch_bounds__(mbt::kBlockThreads) void philox3(float* sink, uint3
   if (s == 12345.678f) sink[p] = s;  // never true: keeps the work alive without a store
 }
 
+// Experiment: a workgroup owns T consecutive tiles, issues all their loads first and then finishes them one after the
+// other, so that the stores of tile t overlap the generator of tile t + 1 (the grid is then a fraction of one residency).
+template <class V, int T>
+__global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_tiles(const mbt::StepBuffers B, const mbt::StepParams P) {
+  using namespace mbt;
+  LaneLoads L0[T], L1[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint32_t lane0 = (blockIdx.x * T + t) * kTileLanes + threadIdx.x;
+    L0[t] = load_lane<V>(B, P, lane0);
+    L1[t] = load_lane<V>(B, P, lane0 + kBlockThreads);
+  }
+  uint32_t clips = 0;
+  float r_sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint32_t tile = blockIdx.x * T + t;
+    const uint32_t lane0 = tile * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
+    const uint64_t pair = P.pair_offset + tile * kBlockThreads + threadIdx.x;
+    LaneNoise nz0, nz1;
+    philox_pair_noise(pair, P.philox_step, P.key0, P.key1, nz0, nz1);
+    LaneDraw d0 = make_draw<V>(nz0, P), d1 = make_draw<V>(nz1, P);
+    tie_loads_to_draws(L0[t], L1[t], d0, d1);
+    r_sum += finish_lane<V>(B, P, lane0, L0[t], d0, clips);
+    r_sum += finish_lane<V>(B, P, lane1, L1[t], d1, clips);
+  }
+  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
+  const float total = wave_sum(r_sum);
+  if ((threadIdx.x & 63u) == 0u) unsafeAtomicAdd(&B.wave_sums[blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)], static_cast<double>(total));
+}
+
 template <typename F>
 float time_it(F launch, int iters) {
   hipEvent_t e0, e1;
@@ -87,6 +118,14 @@ int main(int argc, char** argv) {
   using ASI = mbt::Variant<0, 0, true, 0, false, true>;
   using CJ = mbt::Variant<0, 0, true, 1, false, false>;
   RUN(AS, "step AS philox (44 B)", 44.0)
+#define RUNT(VARIANT, T, LABEL)                                                                                          \
+  t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
+                           hipLaunchKernelGGL((step_kernel_tiles<VARIANT, T>), dim3(blocks / T), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
+  printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, 44.0 * n / t * 1e-3);
+  RUNT(AS, 1, "  tiles/block 1")
+  RUNT(AS, 2, "  tiles/block 2")
+  RUNT(AS, 4, "  tiles/block 4")
+  RUNT(CJ, 2, "  CjMm tiles/block 2")
   RUN(CJ, "step CjMm philox (44 B)", 44.0)
   RUN(ASI, "step AS inject (64 B)", 64.0)
   return 0;
