@@ -236,6 +236,8 @@ void fill_static_params(mbt_env* e) {
   P.hawkes_jump = static_cast<float>(c.hawkes_jump);
   P.kappa_log2e_neg = static_cast<float>(-c.fill_exponent * 1.4426950408889634);
   P.kappa_f64 = c.fill_exponent;
+  P.fill_depth_per_log2 = static_cast<float>(-0.6931471805599453 / c.fill_exponent);
+  P.fill_band_abs = static_cast<float>(2e-7 / c.fill_exponent);
   for (int side = 0; side < 2; ++side) {  // the state columns are float32; the exact re-decision keeps the float64 depths
     P.exo_depth[side] = static_cast<float>(c.exogenous_depth[side]);
     P.exo_depth_f64[side] = c.exogenous_depth[side];
@@ -523,6 +525,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
     if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
       if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
+    } else if (!(cfg->fill_exponent > 0.0)) {
+      return fail(MBT_ERR_INVALID, "fill_exponent must be positive (got %g)", cfg->fill_exponent);
     } else if (cfg->fill_kind == MBT_FILL_EXOGENOUS_MM) {
       if (!(cfg->base_fill_probability >= 0.0 && cfg->base_fill_probability <= 1.0))
         return fail(MBT_ERR_INVALID, "base_fill_probability %g is not a probability", cfg->base_fill_probability);

@@ -89,7 +89,9 @@ struct StepParams {
   float arr_dt;
   float hawkes_base_bid, hawkes_base_ask, hawkes_speed, hawkes_jump;
   // fills
-  float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)
+  float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)  (exogenous-depth model)
+  float fill_depth_per_log2;  // -ln(2) / kappa: the depth threshold is log2(u) times this
+  float fill_band_abs;        // 2e-7 / kappa
   double kappa_f64;
   float exo_depth[2], exo_base;          // exogenous best depths (bid, ask) and base fill probability (FILL:159-163)
   double exo_depth_f64[2], exo_base_f64;
@@ -145,9 +147,12 @@ struct StepBuffers {
 // Per-lane quantities that depend on noise and parameters only.
 struct LaneDraw {
   float arr_bid, arr_ask;  // Poisson: arrival indicators 1.0f / 0.0f (ARR:56); Hawkes: the raw uniforms (decided with lambda)
-  float uf_bid, uf_ask;    // fill uniforms (FILL:33)
+  float uf_bid, uf_ask;    // fill uniforms (FILL:33); only the exact re-decision and the exogenous model read them after the loads
+  float lo_bid, hi_bid, lo_ask, hi_ask;  // depth thresholds of the exponential fill test, see fill_thresholds()
   float dz;                // drift_dt + vol_sqrt_dt * Z: the whole midprice increment of Brownian motion (MID:60-65)
 };
+
+__device__ __forceinline__ void fill_thresholds(float u, const StepParams& P, float& lo, float& hi);
 
 template <class V>
 __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepParams& P) {
@@ -161,25 +166,40 @@ __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepPar
   }
   d.uf_bid = nz.uf_bid;
   d.uf_ask = nz.uf_ask;
+  d.lo_bid = d.hi_bid = d.lo_ask = d.hi_ask = 0.0f;
+  if (!V::EXO && V::DYN != kDynTouch) {
+    fill_thresholds(nz.uf_bid, P, d.lo_bid, d.hi_bid);
+    fill_thresholds(nz.uf_ask, P, d.lo_ask, d.hi_ask);
+  }
   d.dz = __builtin_fmaf(P.vol_sqrt_dt, nz.z, P.drift_dt);
   return d;
 }
 
 // ---- fill decisions --------------------------------------------------------------------------------------
-// float32 exponential fill test (FILL:34, FILL:57-58) that is exact against float64: v_exp_f32 decides unless the
-// draw lies inside its error band (plus the rounding of a normalised depth); `near` flags that case and a cold block
-// re-decides in double.  p = 2^(k2 * depth) with k2 = -kappa * log2(e) folded on the host.
+// Exponential fill test (FILL:34, FILL:57-58), exact against float64:  u < exp(-kappa * depth)  <=>  depth < t(u),
+// t(u) = -ln(u) / kappa.  The threshold depends on the draw only, so it is computed BEFORE the state/action loads are
+// consumed (v_log_f32, one multiply) and the decision after the loads is two compares: every wave of a SIMD leaves
+// the load wait at about the same time, so arithmetic after it is serialised across the resident waves - moving the
+// exponential in front of the wait took the AS step from 8.37 to 8.16 us (2^20 lanes).  [lo, hi] brackets the exact
+// threshold: relative 1e-6 (v_log_f32 is good to 1e-7 relative away from u ~ 1 - checked exhaustively over all 2^24
+// uniforms, tests/test_gpu_rng.py - plus the rounding of a de-normalised depth) and absolute 2e-7 / kappa (u ~ 1).
+// A depth inside the bracket (probability ~2e-6) is re-decided in double by the cold block.  u = 0 gives t = +inf and
+// lo = NaN: every depth counts as inside the bracket and the double evaluation decides (exp underflow, FILL:58).
 struct FillTest {
-  bool fill;  // u < exp(-kappa * depth), fast evaluation
-  bool near;  // the fast evaluation cannot be trusted
+  bool fill;  // depth < t(u), certain unless `near`
+  bool near;  // the depth lies inside the bracket: the fast decision cannot be trusted
 };
 
-__device__ __forceinline__ FillTest fill_test(float u, float depth, const StepParams& P) {
-  const float y = P.kappa_log2e_neg * depth;
-  const float p = __builtin_amdgcn_exp2f(y);
-  const float band = __builtin_fmaf(p, __builtin_fmaf(__builtin_fabsf(y), 3e-7f, 4e-6f), 1e-30f);
-  const float d = u - p;
-  return FillTest{d < 0.0f, __builtin_fabsf(d) <= band};
+__device__ __forceinline__ void fill_thresholds(float u, const StepParams& P, float& lo, float& hi) {
+  const float t = __builtin_amdgcn_logf(u) * P.fill_depth_per_log2;  // -ln(u) / kappa  (v_log_f32 is log2)
+  const float band = __builtin_fmaf(__builtin_fabsf(t), 1e-6f, P.fill_band_abs);
+  lo = t - band;
+  hi = t + band;
+}
+
+__device__ __forceinline__ FillTest fill_test(float depth, float lo, float hi) {
+  const bool sure = depth < lo;
+  return FillTest{sure, !sure && !(depth > hi)};
 }
 
 // ExogenousMmFillProbabilityModel (FILL:159-163): p = 1 for a quote at or inside the exogenous best depth,
@@ -309,8 +329,8 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   } else {
     off_bid = depth_of(act.x, 0, norm_act, P);
     off_ask = depth_of(act.y, 1, norm_act, P);
-    const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(dr.uf_bid, off_bid, P);
-    const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(dr.uf_ask, off_ask, P);
+    const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(off_bid, dr.lo_bid, dr.hi_bid);
+    const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(off_ask, dr.lo_ask, dr.hi_ask);
     bool fb = tb.fill, fa = ta.fill;
     if (__builtin_expect(tb.near | ta.near, 0)) {
       if (V::EXO) {
@@ -477,7 +497,8 @@ __device__ __forceinline__ void tie_loads_to_draws(LaneLoads& a, LaneLoads& b, L
   asm volatile("; loads are first consumed below this line"
                : "+v"(a.core.x), "+v"(a.core.y), "+v"(a.core.z), "+v"(a.core.w), "+v"(b.core.x), "+v"(b.core.y), "+v"(b.core.z), "+v"(b.core.w),
                  "+v"(a.act.x), "+v"(a.act.y), "+v"(b.act.x), "+v"(b.act.y), "+v"(da.arr_bid), "+v"(da.arr_ask), "+v"(da.uf_bid), "+v"(da.uf_ask),
-                 "+v"(da.dz), "+v"(db.arr_bid), "+v"(db.arr_ask), "+v"(db.uf_bid), "+v"(db.uf_ask), "+v"(db.dz));
+                 "+v"(da.dz), "+v"(db.arr_bid), "+v"(db.arr_ask), "+v"(db.uf_bid), "+v"(db.uf_ask), "+v"(db.dz), "+v"(da.lo_bid),
+                 "+v"(da.hi_bid), "+v"(da.lo_ask), "+v"(da.hi_ask), "+v"(db.lo_bid), "+v"(db.hi_bid), "+v"(db.lo_ask), "+v"(db.hi_ask));
 }
 
 // one state row (un-normalised, or normalised per TE:112-118 when `normalise`)

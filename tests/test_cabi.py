@@ -66,7 +66,7 @@ def test_no_cpu_fallback_without_a_device(lib):
         pytest.skip("a GPU is visible")
     cfg = _native.MbtConfig()
     cfg.abi_version = _native.ABI_VERSION
-    cfg.num_trajectories, cfg.n_steps, cfg.terminal_time, cfg.impact_kind = 4, 10, 1.0, _native.IMPACT_NONE
+    cfg.num_trajectories, cfg.n_steps, cfg.terminal_time, cfg.impact_kind, cfg.fill_exponent = 4, 10, 1.0, _native.IMPACT_NONE, 1.5
     handle = C.c_void_p()
     rc = lib.mbt_env_create(C.byref(cfg), C.byref(handle))
     assert rc == -2 and not handle.value  # MBT_ERR_NO_DEVICE

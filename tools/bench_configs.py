@@ -37,7 +37,7 @@ def main():
         for _ in range(50):
             env.step_device()
         env.synchronize()
-        steps = 400
+        steps = int(os.environ.get("MBT_BENCH_STEPS", "400"))
         _native.check(lib.mbt_env_timer_begin(env._handle))
         for _ in range(steps):
             env.step_device()
