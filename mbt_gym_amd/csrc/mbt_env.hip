@@ -6,6 +6,8 @@
 // point that needs one fails with MBT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -600,7 +602,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   }
   ENV_TRY(dev_alloc(&e->q_init, np));
   ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves));
-  ENV_TRY(dev_alloc(&e->clip_count, 1));
+  ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots));
   ENV_TRY(dev_alloc(&e->reduce_out, 2));
 #undef ENV_TRY
   *out = e;
@@ -823,10 +825,13 @@ int mbt_env_get_events_host(mbt_env* e, uint8_t* events_host) {
 int mbt_env_clip_count(mbt_env* e, uint64_t* count) {
   if (e == nullptr || count == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  unsigned long long v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, e->clip_count, sizeof v, hipMemcpyDeviceToHost, e->stream));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+  std::vector<unsigned long long> slots(mbt::kClipSlots);
+  HIP_TRY(hipMemcpyAsync(slots.data(), e->clip_count, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  *count = v;
+  uint64_t total = 0;
+  for (unsigned long long v : slots) total += v;
+  *count = total;
   return MBT_OK;
 }
 

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
       acc.x += rew[0]; acc.y += rew[1]; acc.z += rew[2]; acc.w += rew[3];
       reinterpret_cast<float4*>(B.lane_returns)[quad] = acc;
     }
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
   }
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
       acc.x += ret[0]; acc.y += ret[1]; acc.z += ret[2]; acc.w += ret[3];
       reinterpret_cast<float4*>(B.lane_returns)[quad] = acc;
     }
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clipped));
+    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
 #pragma unroll
     for (int l = 0; l < 4; ++l) ret_sum += (4u * quad + l < P.n) ? ret[l] : 0.0f;
   }

@@ -37,7 +37,8 @@ namespace mbt {
 #ifndef MBT_BLOCK_THREADS
 #define MBT_BLOCK_THREADS 256
 #endif
-constexpr int kBlockThreads = MBT_BLOCK_THREADS;  // wave64 x 4 per workgroup by default
+constexpr int kBlockThreads = MBT_BLOCK_THREADS;
+constexpr uint32_t kClipSlots = 1024;  // power of two  // wave64 x 4 per workgroup by default
 
 enum : int { kMidBrownian = 0, kMidOu = 1, kMidGbm = 2, kMidBrownianJump = 3, kMidOuJump = 4, kMidConstant = 5 };
 enum : int { kArrPoisson = 0, kArrHawkes = 1 };
@@ -133,7 +134,8 @@ struct StepBuffers {
   uint8_t* events;         // nullptr unless recording
   float* lane_returns;     // nullptr unless tracking
   double* wave_sums;       // one slot per wave: running sum of rewards since reset
-  unsigned long long* clip_count;
+  unsigned long long* clip_count;  // kClipSlots counters, indexed by workgroup: a step in which every lane clips must not
+                                   // serialise 8192 atomics on one address (17 -> 144 us at 2^21 lanes before the split)
 };
 
 // ---- structure of the arithmetic --------------------------------------------------------------------------------
@@ -347,9 +349,11 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
     n_ask = r.fill_ask ? arr_ask : 0.0f;
   }
 
-  // -- cash / inventory with the OLD midprice (MD:82-84); market orders first (MD:208-214), then limit
-  //    fills (MD:108-116 / MD:215-222) or fills at the touch (MD:146-154)
-  float q_new = q, cash_new = cash, gain = n_bid * off_bid;
+  // -- cash / inventory with the OLD midprice (MD:82-84); market orders (MD:208-214) and limit fills (MD:108-116 /
+  //    MD:215-222) or fills at the touch (MD:146-154) together: buying dq units in total costs dq * mid, and every
+  //    trade earns its distance from the midprice (`gain`: + depth for a limit fill, - half spread for a market order)
+  float dq = n_bid - n_ask;
+  float gain = __builtin_fmaf(n_ask, off_ask, n_bid * off_bid);
   r.mo_buy = r.mo_sell = false;
   if (V::DYN == kDynLimitAndMarket) {
     if (norm_act) {
@@ -360,15 +364,11 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
       r.mo_sell = act.w > 0.5f;
     }
     const float mb = r.mo_buy ? 1.0f : 0.0f, ms = r.mo_sell ? 1.0f : 0.0f;
-    cash_new = __builtin_fmaf(ms, mid - P.half_spread, cash_new);
-    cash_new = __builtin_fmaf(-mb, mid + P.half_spread, cash_new);
-    q_new += mb - ms;
+    dq += mb - ms;
     gain = __builtin_fmaf(-P.half_spread, mb + ms, gain);
   }
-  q_new += n_bid - n_ask;
-  cash_new = __builtin_fmaf(n_ask, mid + off_ask, cash_new);
-  cash_new = __builtin_fmaf(-n_bid, mid - off_bid, cash_new);
-  gain = __builtin_fmaf(n_ask, off_ask, gain);
+  const float q_new = q + dq;
+  const float cash_new = __builtin_fmaf(-dq, mid, cash + gain);
 
   // -- clip (TE:283-289): v_med3_f32
   const float q_clip = __builtin_amdgcn_fmed3f(q_new, -P.q_max, P.q_max);
@@ -524,7 +524,7 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
-                                             const LaneDraw& d, uint32_t& clips) {
+                                             const LaneDraw& d, bool& clipped) {
   const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P);
   store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
   B.reward[lane] = r.reward;
@@ -532,9 +532,8 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lane, r.core, r.lam, true, P);
   if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));
   if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
-  const bool real = lane < P.n;  // pad lanes of the last tile are computed but never reported
-  clips += (real && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
-  return real ? r.reward : 0.0f;
+  clipped = r.clipped_q | r.clipped_c;
+  return r.reward;
 }
 
 template <class V>
@@ -556,16 +555,25 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
     d1 = make_draw<V>(nz1, P);
     tie_loads_to_draws(L0, L1, d0, d1);
   }
-  uint32_t clips = 0;
-  float r_sum = finish_lane<V>(B, P, lane0, L0, d0, clips);
-  r_sum += finish_lane<V>(B, P, lane1, L1, d1, clips);
-  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
+  bool clipped0, clipped1;
+  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0), r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1);
+  if ((blockIdx.x + 1u) * kTileLanes > P.n) {  // only the last tile can hold pad lanes: computed, never reported
+    const bool real0 = lane0 < P.n, real1 = lane1 < P.n;
+    r0 = real0 ? r0 : 0.0f;
+    r1 = real1 ? r1 : 0.0f;
+    clipped0 &= real0;
+    clipped1 &= real1;
+  }
+  const float r_sum = r0 + r1;
+  // clipped lanes of this wave, counted on the scalar unit (two ballots + popcounts)
+  const uint32_t clips = __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped1));
   // -- per-wave running sum of rewards (numerator of the mean episode return): one slot per wave, one
   //    fire-and-forget hardware fp64 atomic per wave, no contention
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
+    if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
   }
 }
 
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     if (B.lane_returns != nullptr) B.lane_returns[lanes[l]] += ret[l];
     ret_sum += lanes[l] < P.n ? ret[l] : 0.0f;
   }
-  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
+  if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
   const float total = wave_sum(ret_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);

@@ -142,3 +142,19 @@ def test_normalise_rewards_scale_and_batch_resize():
         plain.step_size = 0.1
     env.close()
     plain.close()
+
+
+def test_clip_counter_counts_every_clipped_lane_step():
+    """Market sells against an inventory floor: from the step the floor is reached EVERY lane clips every step
+    (MD:208-222 ignores the limit, TE:283-289 clips afterwards); the device counter is spread over many slots and
+    must still add up exactly."""
+    n, floor = 3000, 3
+    cfg = _as_cfg(n, n_steps=40, dynamics="limit_and_market", initial_inventory=0, max_inventory=floor, intensity=(0.0, 0.0))
+    env = make_env(cfg)
+    env.reset()
+    action = np.tile(np.array([[0.7, 0.7, 0.0, 1.0]], np.float32), (n, 1))  # sell one unit at market, no limit fills (no arrivals)
+    for _ in range(10):
+        obs, _, _, _ = env.step(action)
+    assert np.all(obs[:, 1] == -floor)
+    assert env.clip_count == n * (10 - floor)
+    env.close()

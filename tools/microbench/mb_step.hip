@@ -48,7 +48,7 @@ __global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_tiles(const mb
     L0[t] = load_lane<V>(B, P, lane0);
     L1[t] = load_lane<V>(B, P, lane0 + kBlockThreads);
   }
-  uint32_t clips = 0;
+  bool clipped = false, c = false;
   float r_sum = 0.f;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -59,10 +59,12 @@ __global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_tiles(const mb
     philox_pair_noise(pair, P.philox_step, P.key0, P.key1, nz0, nz1);
     LaneDraw d0 = make_draw<V>(nz0, P), d1 = make_draw<V>(nz1, P);
     tie_loads_to_draws(L0[t], L1[t], d0, d1);
-    r_sum += finish_lane<V>(B, P, lane0, L0[t], d0, clips);
-    r_sum += finish_lane<V>(B, P, lane1, L1[t], d1, clips);
+    r_sum += finish_lane<V>(B, P, lane0, L0[t], d0, c);
+    clipped |= c;
+    r_sum += finish_lane<V>(B, P, lane1, L1[t], d1, c);
+    clipped |= c;
   }
-  if (__builtin_expect(clips != 0u, 0)) atomicAdd(B.clip_count, static_cast<unsigned long long>(clips));
+  if (__builtin_expect(clipped, 0)) atomicAdd(B.clip_count, 1ull);
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) unsafeAtomicAdd(&B.wave_sums[blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)], static_cast<double>(total));
 }
@@ -87,8 +89,8 @@ int main(int argc, char** argv) {
   float *s0, *s1, *act, *rew, *ua, *uf, *z; double* ws; unsigned long long* clip;
   CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
   CK(hipMalloc(&ua, n * 8)); CK(hipMalloc(&uf, n * 8)); CK(hipMalloc(&z, n * 4));
-  CK(hipMalloc(&ws, blocks * 4 * 8)); CK(hipMalloc(&clip, 8));
-  CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(act, 0, n * 8)); CK(hipMemset(ws, 0, blocks * 32)); CK(hipMemset(clip, 0, 8));
+  CK(hipMalloc(&ws, blocks * 4 * 8)); CK(hipMalloc(&clip, 8 * mbt::kClipSlots));
+  CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(act, 0, n * 8)); CK(hipMemset(ws, 0, blocks * 32)); CK(hipMemset(clip, 0, 8 * mbt::kClipSlots));
   CK(hipMemset(ua, 0, n * 8)); CK(hipMemset(uf, 0, n * 8)); CK(hipMemset(z, 0, n * 4));
   std::vector<float> h(n * 4);
   for (uint32_t i = 0; i < n; ++i) { h[4 * i] = 0; h[4 * i + 1] = 0; h[4 * i + 2] = 0; h[4 * i + 3] = 100.f; }
