@@ -6,13 +6,16 @@
 // independent of how the trajectory axis is sharded over GPUs.
 //
 // Stream layout (order-book dynamics).  Global lane ids are grouped in tiles of 512; lanes g and g + 256 of a tile
-// form PAIR p = (g / 512) * 256 + g % 256 - the two lanes one GPU thread owns (step_kernel.hpp), so all of its
-// three blocks are used:
+// form PAIR p = (g / 512) * 256 + g % 256 - the two lanes one GPU thread owns (step_kernel.hpp).  A pair consumes
+// exactly two blocks, every bit of which is used:
 //   block 0: ctr = (p.lo, p.hi, step, 0)  -> lane g       : u_arr_bid, u_arr_ask, u_fill_bid, u_fill_ask
 //   block 1: ctr = (p.lo, p.hi, step, 1)  -> lane g + 256 : same four
-//   block 2: ctr = (p.lo, p.hi, step, 2)  -> words 0,1 feed one Box-Muller transform:
-//                                            z(g) = r cos(theta), z(g + 256) = r sin(theta); words 2,3 unused
+//            each uniform takes the TOP 24 bits of its word (u = (w >> 8) * 2^-24)
+//   the four LOW bytes of block 0 form the 32-bit word of the Box-Muller radius, those of block 1 the angle:
+//            z(g) = r cos(theta), z(g + 256) = r sin(theta)
 //   key = (seed.lo, seed.hi)
+// (The first layout spent a third block on the two normals; the generator is the largest share of the arithmetic of
+// every kernel here, and of the fused rollout in particular.)
 // (Speed dynamics need one normal per lane: one block per quad of adjacent lanes, counter word 3 = 3, speed_kernel.hpp.)
 // Uniforms are u = (w >> 8) * 2^-24 in [0,1): exactly representable in float32, which is what lets the
 // Bernoulli decisions of the step be bit-exact against a float64 evaluation of the same draws.
@@ -63,6 +66,13 @@ __device__ __forceinline__ void box_muller(uint32_t wr, uint32_t wt, float& z_co
   z_sin = r * __builtin_amdgcn_sinf(rev);
 }
 
+// The byte of each word that uniform24() discards, packed w0 | w1 << 8 | w2 << 16 | w3 << 24 (three v_perm_b32).
+__device__ __forceinline__ uint32_t low_bytes(const PhiloxWords& w) {
+  const uint32_t lo = __builtin_amdgcn_perm(w.w1, w.w0, 0x0c0c0400u);  // byte 0 <- w0.b0, byte 1 <- w1.b0, rest zero
+  const uint32_t hi = __builtin_amdgcn_perm(w.w3, w.w2, 0x04000c0cu);  // byte 2 <- w2.b0, byte 3 <- w3.b0
+  return lo | hi;
+}
+
 struct LaneNoise {
   float ua_bid, ua_ask, uf_bid, uf_ask, z;
 };
@@ -73,10 +83,9 @@ __device__ __forceinline__ void philox_pair_noise(uint64_t pair, uint32_t step, 
   const uint32_t plo = static_cast<uint32_t>(pair), phi = static_cast<uint32_t>(pair >> 32);
   const PhiloxWords wa = philox4x32_10(plo, phi, step, 0u, k0, k1);
   const PhiloxWords wb = philox4x32_10(plo, phi, step, 1u, k0, k1);
-  const PhiloxWords wn = philox4x32_10(plo, phi, step, 2u, k0, k1);
   a.ua_bid = uniform24(wa.w0); a.ua_ask = uniform24(wa.w1); a.uf_bid = uniform24(wa.w2); a.uf_ask = uniform24(wa.w3);
   b.ua_bid = uniform24(wb.w0); b.ua_ask = uniform24(wb.w1); b.uf_bid = uniform24(wb.w2); b.uf_ask = uniform24(wb.w3);
-  box_muller(wn.w0, wn.w1, a.z, b.z);
+  box_muller(low_bytes(wa), low_bytes(wb), a.z, b.z);
 }
 
 }  // namespace mbt

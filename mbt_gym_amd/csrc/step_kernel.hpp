@@ -438,7 +438,7 @@ __device__ __forceinline__ void normalise_row(float4& core, float2& lam, const S
 // one 16-byte vector per lane for D = 4).  Measured with a copy kernel moving the same 44 B/lane at 2^20 lanes
 // (tools/microbench/mb_copy.hip): 7.2 us for this mapping against 8.3 us when a thread owns two ADJACENT rows - there
 // each 16-byte-per-lane instruction strides 32 bytes and requests every cache line twice.  The two lanes of a thread
-// form the PAIR that shares three Philox blocks (philox.hpp); buffers are padded to whole tiles, so no load is ever
+// form the PAIR that shares two Philox blocks (philox.hpp); buffers are padded to whole tiles, so no load is ever
 // out of bounds and only the reductions need to know which lanes are real.
 constexpr uint32_t kTileLanes = 2 * kBlockThreads;
 

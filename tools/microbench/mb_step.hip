@@ -1,7 +1,8 @@
 // Micro-benchmarks behind the kernel design decisions in DESIGN.md (GPU box only):
 //   copy44      - a kernel that moves exactly the step's algorithmic traffic (2 float4 + 1 float4 in, 2 float4 +
 //                 float2 out per pair) and does nothing else: the memory floor for this access pattern
-//   philox3     - the three Philox blocks + Box-Muller of a pair with no memory traffic: the RNG floor
+//   philox3     - the Philox blocks + Box-Muller of a pair with no memory traffic: the RNG floor (named after the
+//                 first, three-block layout)
 //   step(philox)- the production kernel;  step(inject) - the same arithmetic with noise loaded from HBM
 #include <hip/hip_runtime.h>
 
@@ -124,6 +125,17 @@ int main(int argc, char** argv) {
   t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
                            hipLaunchKernelGGL((step_kernel_tiles<VARIANT, T>), dim3(blocks / T), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
   printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, 44.0 * n / t * 1e-3);
+#define RUNL(VARIANT, LDS, LABEL)                                                                                        \
+  t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
+                           hipLaunchKernelGGL((mbt::step_kernel<VARIANT>), dim3(blocks), dim3(mbt::kBlockThreads), LDS, 0, B, P); }, iters); \
+  printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, 44.0 * n / t * 1e-3);
+  // occupancy limited through a dynamic LDS allocation (160 KB per CU): 7, 6, 5, 4, 3 workgroups per CU instead of 8
+  RUNL(AS, 22 * 1024, "  AS, 7 workgroups/CU")
+  RUNL(AS, 26 * 1024, "  AS, 6 workgroups/CU")
+  RUNL(AS, 32 * 1024, "  AS, 5 workgroups/CU")
+  RUNL(AS, 40 * 1024, "  AS, 4 workgroups/CU")
+  RUNL(AS, 53 * 1024, "  AS, 3 workgroups/CU")
+  RUNL(CJ, 32 * 1024, "  CjMm, 5 workgroups/CU")
   RUNT(AS, 1, "  tiles/block 1")
   RUNT(AS, 2, "  tiles/block 2")
   RUNT(AS, 4, "  tiles/block 4")
