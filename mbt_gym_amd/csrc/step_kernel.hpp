@@ -710,6 +710,18 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
 
+// Small batches over the host API: observation rows and rewards written straight into pinned, device-mapped host
+// memory (posted PCIe writes) by one launch, instead of two pageable-memory DMA copies (~25 us each at any size).
+// The same launch files the staged actions in the library's device action buffer, which is what a later
+// step_device() without an action pointer reads.
+__global__ void export_step_kernel(const float* obs, const float* reward, float* host_obs, float* host_reward, uint32_t n_obs, uint32_t n,
+                                   const float* staged_action, float* action, uint32_t n_act) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (host_obs != nullptr && i < n_obs) host_obs[i] = obs[i];
+  if (host_reward != nullptr && i < n) host_reward[i] = reward[i];
+  if (i < n_act) action[i] = staged_action[i];
+}
+
 // un-normalised state rows -> normalised observation rows (after set_state)
 __global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n_pad, int dim, const StepParams P) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
