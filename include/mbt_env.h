@@ -80,7 +80,7 @@ typedef struct mbt_config {
   uint32_t abi_version;        /* MBT_ABI_VERSION */
   int32_t device;              /* HIP device ordinal */
   uint64_t num_trajectories;   /* lanes owned by this handle (TE:41) */
-  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; a multiple of 512 (4 for speed dynamics) */
+  uint64_t trajectory_offset;  /* global id of lane 0 when the trajectory axis is sharded; a multiple of 512 (1024 for speed dynamics) */
   uint32_t n_steps;            /* TE:30 */
   uint32_t reserved0;
   double terminal_time;        /* TE:29; step_size = terminal_time / n_steps (TE:49) */
@@ -259,7 +259,7 @@ int mbt_reward_calculate_host(int device, int reward_kind, double phi, double al
  * under `seed` into host arrays (any may be NULL): u_arr (n,2), u_fill (n,2), z (n). */
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n,
                       float* u_arr, float* u_fill, float* z);
-/* Same for the speed-dynamics stream (one normal per lane, drawn per quad of lanes): z (n); offset multiple of 4. */
+/* Same for the speed-dynamics stream (one normal per lane, drawn per quad of lanes 256 apart in a 1024-lane tile): z (n); offset multiple of 1024. */
 int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z);
 /* Raw Philox4x32-10 block function on the device: out[4] = philox(ctr[4], key[2]) (known-answer tests). */
 int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -528,7 +528,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
       return fail(MBT_ERR_INVALID, "speed dynamics need a price impact model (impact kind %d)", cfg->impact_kind);
     if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP)
       return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
-    if (cfg->trajectory_offset & 3ull) return fail(MBT_ERR_INVALID, "speed dynamics draw noise per quad: trajectory_offset must be a multiple of 4");
+    if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
+      return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
   } else {
     if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR)
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
@@ -560,8 +561,9 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0);
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
   e->n = static_cast<uint32_t>(cfg->num_trajectories);
-  // a thread owns a quad of adjacent lanes (speed) or two lanes of a 512-lane tile (order book): pad to whole units
-  e->n_pad = speed ? ((e->n + 3u) & ~3u) : ((e->n + mbt::kTileLanes - 1u) / mbt::kTileLanes) * mbt::kTileLanes;
+  // a thread owns four lanes of a 1024-lane tile (speed) or two lanes of a 512-lane tile (order book): pad to whole tiles
+  const uint32_t tile = speed ? mbt::kSpeedTileLanes : mbt::kTileLanes;
+  e->n_pad = ((e->n + tile - 1u) / tile) * tile;
   e->n_pairs = e->n_pad / 2;
   const uint32_t n_threads = speed ? e->n_pad / 4 : e->n_pairs;
   e->n_blocks = (n_threads + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
@@ -962,12 +964,12 @@ int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uin
 }
 
 int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z) {
-  if (trajectory_offset & 3ull) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 4");
-  if (n == 0 || n > 0x7FFFFFF0ull || z == nullptr) return fail(MBT_ERR_INVALID, "bad argument");
+  if (trajectory_offset % mbt::kSpeedTileLanes != 0) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 1024");
+  if (n == 0 || n > 0x7FFFF000ull || z == nullptr) return fail(MBT_ERR_INVALID, "bad argument");
   int rc = check_device(device);
   if (rc != MBT_OK) return rc;
   HIP_TRY(hipSetDevice(device));
-  const uint32_t n_pad = (static_cast<uint32_t>(n) + 3u) & ~3u, n_quads = n_pad / 4;
+  const uint32_t n_pad = ((static_cast<uint32_t>(n) + mbt::kSpeedTileLanes - 1u) / mbt::kSpeedTileLanes) * mbt::kSpeedTileLanes, n_quads = n_pad / 4;
   float* d_z = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_z), size_t(n_pad) * sizeof(float)));
   hipLaunchKernelGGL(mbt::rng_fill_quad_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, nullptr, trajectory_offset >> 2, step,

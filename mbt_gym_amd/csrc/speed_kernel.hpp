@@ -9,10 +9,14 @@
 //     y         <- y + perm * v * dt_imp    |   y - rho * y * dt_imp + gamma * v * dt_imp  (IMP:87, IMP:130, IMP:170)
 // There are no arrivals or fills (MD:47-48): the only noise is the midprice's normal draw.
 //
-// Layout: rows of D = 4 (no impact state) or D = 5 ([cash, inventory, time, midprice, y]) float32; one GPU thread
-// owns a QUAD of adjacent lanes = D float4 of state, one float4 of actions, one float4 of rewards - every access is a
-// 16-byte coalesced vector, and ONE Philox4x32-10 block (counter word 3 = 3) feeds the two Box-Muller transforms the
-// quad needs.  Algorithmic traffic per env-step: 4*(D + 1 + D + 1) = 40 B (D = 4) or 48 B (D = 5).
+// Layout: rows of D = 4 (no impact state) or D = 5 ([cash, inventory, time, midprice, y]) float32.  A workgroup of 256
+// threads owns a TILE of 1024 consecutive lanes and thread j the QUAD of lanes tile*1024 + j + {0, 256, 512, 768}: as in
+// the order-book kernel every wave-level access covers one contiguous span of rows (a D = 4 row is one dwordx4 per lane; a
+// D = 5 row, 20 bytes and only 4-byte aligned, is five dwords per lane that walk the same cache lines), and ONE
+// Philox4x32-10 block (counter word 3 = 3) feeds the two Box-Muller transforms the quad needs.  The first version gave a
+// thread four ADJACENT rows (D float4 at a stride of 64-80 bytes between lanes): 11.1 / 13.5 us per step at 2^20 lanes
+// (0.47 of peak) against the figures in profiles/ for this mapping.
+// Algorithmic traffic per env-step: 4*(D + 1 + D + 1) = 40 B (D = 4) or 48 B (D = 5).
 // Inventory is real-valued here, so "bit-exact inventory" does not apply; all state is float32 (a few ulps).
 #pragma once
 #include "step_kernel.hpp"
@@ -31,7 +35,8 @@ struct QuadNoise {
   float z[4];
 };
 
-// quad stream: ctr = (quad.lo, quad.hi, step, 3); words (0,1) -> z of lanes 4q, 4q+1; words (2,3) -> lanes 4q+2, 4q+3
+// quad stream: ctr = (quad.lo, quad.hi, step, 3), quad = (g / 1024) * 256 + g % 256 for the global lanes g, g + 256, g + 512,
+// g + 768 of a 1024-lane tile; words (0,1) -> z of the first two of them, words (2,3) -> the other two
 __device__ __forceinline__ QuadNoise philox_quad_noise(uint64_t quad, uint32_t step, uint32_t k0, uint32_t k1) {
   const PhiloxWords w = philox4x32_10(static_cast<uint32_t>(quad), static_cast<uint32_t>(quad >> 32), step, 3u, k0, k1);
   QuadNoise nz;
@@ -87,87 +92,80 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
   return r;
 }
 
-// quad <-> D float4
+constexpr uint32_t kSpeedTileLanes = 4 * kBlockThreads;
+
+// one state row of a lane: [cash, inventory, time, midprice (, y)]
 template <class V>
-__device__ __forceinline__ void unpack_quad(const float4* src, SpeedLane (&s)[4]) {
-  float f[4 * V::DIM];
-#pragma unroll
-  for (int j = 0; j < V::DIM; ++j) {
-    const float4 v = src[j];
-    f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w;
+__device__ __forceinline__ SpeedLane load_speed_row(const float* state, uint32_t lane) {
+  if (V::DIM == 4) {
+    const float4 r = reinterpret_cast<const float4*>(state)[lane];
+    return SpeedLane{r.x, r.y, r.w, 0.0f};
   }
-#pragma unroll
-  for (int l = 0; l < 4; ++l) s[l] = SpeedLane{f[l * V::DIM], f[l * V::DIM + 1], f[l * V::DIM + 3], V::HAS_IMPACT_STATE ? f[l * V::DIM + 4] : 0.0f};
+  const float* r = state + static_cast<size_t>(lane) * 5;
+  return SpeedLane{r[0], r[1], r[3], r[4]};
 }
 
 template <class V>
-__device__ __forceinline__ void pack_quad(float4* dst, const SpeedLane (&s)[4], float t, bool normalise, const StepParams& P) {
-  float f[4 * V::DIM];
+__device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, const SpeedLane& s, float t, bool normalise, const StepParams& P) {
+  float row[5] = {s.cash, s.q, t, s.mid, s.y};
+  if (normalise) {
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    float row[5] = {s[l].cash, s[l].q, t, s[l].mid, s[l].y};
-    if (normalise) {
-#pragma unroll
-      for (int c = 0; c < V::DIM; ++c) row[c] = (row[c] - P.obs_lo[c]) / P.obs_grad[c] - 1.0f;  // TE:112-118
-    }
-#pragma unroll
-    for (int c = 0; c < V::DIM; ++c) f[l * V::DIM + c] = row[c];
+    for (int c = 0; c < V::DIM; ++c) row[c] = normalise_column(row[c], c, P);  // TE:112-118
   }
+  if (V::DIM == 4) {
+    reinterpret_cast<float4*>(base)[lane] = make_float4(row[0], row[1], row[2], row[3]);
+  } else {
+    float* r = base + static_cast<size_t>(lane) * 5;
 #pragma unroll
-  for (int j = 0; j < V::DIM; ++j) dst[j] = make_float4(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+    for (int c = 0; c < 5; ++c) r[c] = row[c];
+  }
 }
-
-__device__ __forceinline__ float lane_of(const float4 v, int l) { return l == 0 ? v.x : l == 1 ? v.y : l == 2 ? v.z : v.w; }
 
 template <class V>
 __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuffers B, const StepParams P) {
-  const uint32_t quad = blockIdx.x * kBlockThreads + threadIdx.x;
-  const uint32_t n_quads = (P.n_pairs + 1) / 2;
+  const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
+  const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
+  SpeedLane s[4];
+  float act[4], qi[4], z[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    s[l] = load_speed_row<V>(B.state_in, lane);
+    act[l] = B.action[lane];
+    if (V::INJECT) z[l] = B.z[lane];
+    qi[l] = P.q_init_scalar;
+  }
+  if (B.q_init != nullptr) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) qi[l] = B.q_init[lane0 + l * kBlockThreads];
+  }
+  if (!V::INJECT) {
+    const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
+  }
   float r_sum = 0.0f;
-  if (quad < n_quads) {
-    const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(quad) * V::DIM;
-    float4 loaded[V::DIM];
+  bool clipped = false;
+  uint32_t n_clipped = 0;
 #pragma unroll
-    for (int j = 0; j < V::DIM; ++j) loaded[j] = src[j];
-    const float4 act = reinterpret_cast<const float4*>(B.action)[quad];
-    float4 qi = make_float4(P.q_init_scalar, P.q_init_scalar, P.q_init_scalar, P.q_init_scalar);
-    if (B.q_init != nullptr) qi = reinterpret_cast<const float4*>(B.q_init)[quad];
-    QuadNoise nz;
-    if (V::INJECT) {
-      const float4 zz = reinterpret_cast<const float4*>(B.z)[quad];
-      nz = QuadNoise{{zz.x, zz.y, zz.z, zz.w}};
-    } else {
-      nz = philox_quad_noise((P.pair_offset >> 1) + quad, P.philox_step, P.key0, P.key1);
-    }
-    SpeedLane s[4];
-    unpack_quad<V>(loaded, s);
-    float rew[4];
-    uint32_t clipped = 0, ev = 0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const SpeedResult r = speed_lane<V>(s[l], lane_of(act, l), nz.z[l], lane_of(qi, l), P.is_terminal != 0, P);
-      s[l] = r.next;
-      rew[l] = r.reward;
-      const bool real = 4u * quad + l < P.n;
-      r_sum += real ? r.reward : 0.0f;
-      clipped += (real && r.events != 0u) ? 1u : 0u;
-      ev |= r.events << (8 * l);
-    }
-    pack_quad<V>(reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(quad) * V::DIM, s, P.t_next, false, P);
-    reinterpret_cast<float4*>(B.reward)[quad] = make_float4(rew[0], rew[1], rew[2], rew[3]);
-    if (V::NORM && B.obs != nullptr) pack_quad<V>(reinterpret_cast<float4*>(B.obs) + static_cast<size_t>(quad) * V::DIM, s, P.t_next, P.norm_obs != 0, P);
-    if (B.events != nullptr) reinterpret_cast<uint32_t*>(B.events)[quad] = ev;
-    if (B.lane_returns != nullptr) {
-      float4 acc = reinterpret_cast<float4*>(B.lane_returns)[quad];
-      acc.x += rew[0]; acc.y += rew[1]; acc.z += rew[2]; acc.w += rew[3];
-      reinterpret_cast<float4*>(B.lane_returns)[quad] = acc;
-    }
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    const SpeedResult r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
+    store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
+    B.reward[lane] = r.reward;
+    if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, r.next, P.t_next, P.norm_obs != 0, P);
+    if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
+    if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
+    const bool real = lane < P.n;
+    r_sum += real ? r.reward : 0.0f;
+    clipped = real && r.events != 0u;
+    n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped));
   }
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
+    if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
 }
 
@@ -176,55 +174,56 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
 template <class V>
 __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
   static_assert(!V::INJECT, "rollouts draw their own noise");
-  const uint32_t quad = blockIdx.x * kBlockThreads + threadIdx.x;
-  const uint32_t n_quads = (P.n_pairs + 1) / 2;
-  float ret_sum = 0.0f;
-  if (quad < n_quads) {
-    const size_t n_pad4 = static_cast<size_t>(n_quads) * 4;
-    const float4* src = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(quad) * V::DIM;
-    float4 loaded[V::DIM];
+  const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;
+  const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
+  const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
+  SpeedLane s[4];
+  float qi[4], ret[4] = {0.f, 0.f, 0.f, 0.f}, rew[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t ev[4] = {0u, 0u, 0u, 0u};
+  double t = R.t_start;
 #pragma unroll
-    for (int j = 0; j < V::DIM; ++j) loaded[j] = src[j];
-    SpeedLane s[4];
-    unpack_quad<V>(loaded, s);
-    float4 qi = make_float4(P.q_init_scalar, P.q_init_scalar, P.q_init_scalar, P.q_init_scalar);
-    if (B.q_init != nullptr) qi = reinterpret_cast<const float4*>(B.q_init)[quad];
-    float ret[4] = {0.f, 0.f, 0.f, 0.f}, rew[4] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t clipped = 0;
-    double t = R.t_start;
-    if (R.obs_traj != nullptr) pack_quad<V>(reinterpret_cast<float4*>(R.obs_traj) + static_cast<size_t>(quad) * V::DIM, s, static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
-    for (uint32_t k = 0; k < R.n_steps; ++k) {
-      const QuadNoise nz = philox_quad_noise((P.pair_offset >> 1) + quad, P.philox_step + k, P.key0, P.key1);
-      float speed = R.action[0];
-      if (R.policy == kPolicyTimeTable) speed = reinterpret_cast<const float*>(R.table)[min(R.table_row0 + k, R.table_rows - 1u)];
-      t += R.dt_f64;
-      const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const SpeedResult r = speed_lane<V>(s[l], speed, nz.z[l], lane_of(qi, l), terminal, P);
-        s[l] = r.next;
-        rew[l] = r.reward;
-        ret[l] += r.reward;
-        clipped += (4u * quad + l < P.n && r.events != 0u) ? 1u : 0u;
-      }
-      if (R.obs_traj != nullptr)
-        pack_quad<V>(reinterpret_cast<float4*>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad4 * V::DIM) + static_cast<size_t>(quad) * V::DIM, s,
-                     static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
-      if (R.act_traj != nullptr) reinterpret_cast<float4*>(R.act_traj + static_cast<size_t>(k) * n_pad4)[quad] = make_float4(speed, speed, speed, speed);
-      if (R.rew_traj != nullptr) reinterpret_cast<float4*>(R.rew_traj + static_cast<size_t>(k) * n_pad4)[quad] = make_float4(rew[0], rew[1], rew[2], rew[3]);
-    }
-    pack_quad<V>(reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(quad) * V::DIM, s, static_cast<float>(t), false, P);
-    reinterpret_cast<float4*>(B.reward)[quad] = make_float4(rew[0], rew[1], rew[2], rew[3]);
-    if (V::NORM && B.obs != nullptr) pack_quad<V>(reinterpret_cast<float4*>(B.obs) + static_cast<size_t>(quad) * V::DIM, s, static_cast<float>(t), P.norm_obs != 0, P);
-    if (B.lane_returns != nullptr) {
-      float4 acc = reinterpret_cast<float4*>(B.lane_returns)[quad];
-      acc.x += ret[0]; acc.y += ret[1]; acc.z += ret[2]; acc.w += ret[3];
-      reinterpret_cast<float4*>(B.lane_returns)[quad] = acc;
-    }
-    if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
-#pragma unroll
-    for (int l = 0; l < 4; ++l) ret_sum += (4u * quad + l < P.n) ? ret[l] : 0.0f;
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    s[l] = load_speed_row<V>(B.state_in, lane);
+    qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
+    if (R.obs_traj != nullptr) store_speed_row<V>(R.obs_traj, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
   }
+  uint32_t clipped = 0;
+  for (uint32_t k = 0; k < R.n_steps; ++k) {
+    const QuadNoise nz = philox_quad_noise(quad, P.philox_step + k, P.key0, P.key1);
+    float speed = R.action[0];
+    if (R.policy == kPolicyTimeTable) speed = reinterpret_cast<const float*>(R.table)[min(R.table_row0 + k, R.table_rows - 1u)];
+    t += R.dt_f64;
+    const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const uint32_t lane = lane0 + l * kBlockThreads;
+      const SpeedResult r = speed_lane<V>(s[l], speed, nz.z[l], qi[l], terminal, P);
+      s[l] = r.next;
+      rew[l] = r.reward;
+      ev[l] = r.events;
+      ret[l] += r.reward;
+      clipped += (lane < P.n && r.events != 0u) ? 1u : 0u;
+      if (R.obs_traj != nullptr)
+        store_speed_row<V>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
+      if (R.act_traj != nullptr) R.act_traj[static_cast<size_t>(k) * n_pad + lane] = speed;
+      if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lane] = r.reward;
+    }
+  }
+  float ret_sum = 0.0f;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {  // what step() leaves behind: final state, rewards (and events) of the final step
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    store_speed_row<V>(B.state_out, lane, s[l], static_cast<float>(t), false, P);
+    if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, s[l], static_cast<float>(t), P.norm_obs != 0, P);
+    if (R.n_steps > 0) {
+      B.reward[lane] = rew[l];
+      if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(ev[l]);
+    }
+    if (B.lane_returns != nullptr) B.lane_returns[lane] += ret[l];
+    ret_sum += lane < P.n ? ret[l] : 0.0f;
+  }
+  if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
   const float total = wave_sum(ret_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
@@ -232,12 +231,14 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
   }
 }
 
-// the quad stream's normals, written out for tests
+// the quad stream's normals, written out for tests: tile-split like the kernels (lane = tile * 1024 + slot + 256 * l)
 __global__ void rng_fill_quad_kernel(uint64_t quad_offset, uint32_t step, uint32_t k0, uint32_t k1, uint32_t n_quads, float* z) {
   const uint32_t quad = blockIdx.x * blockDim.x + threadIdx.x;
   if (quad >= n_quads) return;
   const QuadNoise nz = philox_quad_noise(quad_offset + quad, step, k0, k1);
-  reinterpret_cast<float4*>(z)[quad] = make_float4(nz.z[0], nz.z[1], nz.z[2], nz.z[3]);
+  const uint32_t lane0 = (quad / kBlockThreads) * kSpeedTileLanes + quad % kBlockThreads;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) z[lane0 + l * kBlockThreads] = nz.z[l];
 }
 
 }  // namespace mbt

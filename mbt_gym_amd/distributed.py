@@ -12,11 +12,12 @@ from typing import Tuple
 import numpy as np
 
 
-SHARD_ALIGN = 512  # noise is drawn per 512-lane tile (csrc/philox.hpp): shards start on tile boundaries
+SHARD_ALIGN = 1024  # noise is drawn per tile of 512 lanes (order book, csrc/philox.hpp) or 1024 lanes (speed dynamics,
+# csrc/speed_kernel.hpp): shards start on tile boundaries
 
 
 def shard_bounds(total_lanes: int, rank: int, world_size: int) -> Tuple[int, int]:
-    """(offset, count) of rank's contiguous lane range; offsets are multiples of 512."""
+    """(offset, count) of rank's contiguous lane range; offsets are multiples of 1024."""
     assert 0 <= rank < world_size
     per = -(-total_lanes // world_size)
     per = -(-per // SHARD_ALIGN) * SHARD_ALIGN

@@ -33,7 +33,7 @@ def _returns(offset, count):
 def test_shard_bounds_cover_the_axis_on_tile_boundaries():
     for total, world in [(1000, 2), (1 << 24, 8), (7, 4), (1 << 20, 1), (100001, 3)]:
         spans = [shard_bounds(total, r, world) for r in range(world)]
-        assert all(off % 512 == 0 for off, _ in spans)
+        assert all(off % 1024 == 0 for off, _ in spans)
         assert sum(c for _, c in spans) == total
         assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1) if spans[i + 1][1] > 0)
 

@@ -16,8 +16,9 @@ SPEED_CASES = ["speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transi
 
 
 def _quad_normals_reference(seed, offset, step, n):
-    """Quad stream of csrc/speed_kernel.hpp: ctr = (quad.lo, quad.hi, step, 3); words (0,1) / (2,3) -> two Box-Muller pairs."""
-    n_pad = (n + 3) & ~3
+    """Quad stream of csrc/speed_kernel.hpp: ctr = (quad.lo, quad.hi, step, 3); words (0,1) / (2,3) -> two Box-Muller pairs;
+    the quad of a 1024-lane tile's slot j holds lanes j, j + 256, j + 512, j + 768."""
+    n_pad = -(-n // 1024) * 1024
     quads = np.arange(n_pad // 4, dtype=np.uint64) + np.uint64(offset // 4)
     w = philox4x32_10(((quads & np.uint64(0xFFFFFFFF)).astype(np.uint32), (quads >> np.uint64(32)).astype(np.uint32),
                        np.full(quads.shape, step, np.uint32), np.full(quads.shape, 3, np.uint32)), (seed & 0xFFFFFFFF, seed >> 32))
@@ -25,12 +26,14 @@ def _quad_normals_reference(seed, offset, step, n):
     for pair, (wr, wt) in enumerate(((w[0], w[1]), (w[2], w[3]))):
         r = np.sqrt(-2.0 * np.log(((wr >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0**-24))
         th = 2.0 * np.pi * (wt >> np.uint32(8)).astype(np.float64) * 2.0**-24
-        z[2 * pair::4], z[2 * pair + 1::4] = r * np.cos(th), r * np.sin(th)
+        local = np.arange(n_pad // 4)
+        lane0 = (local // 256) * 1024 + local % 256
+        z[lane0 + 256 * (2 * pair)], z[lane0 + 256 * (2 * pair + 1)] = r * np.cos(th), r * np.sin(th)
     return z[:n]
 
 
 def test_quad_stream_matches_the_restatement():
-    for seed, offset, step, n in [(31, 0, 0, 1000), (2**40 + 5, 1 << 20, 77, 4099)]:
+    for seed, offset, step, n in [(31, 0, 0, 1000), (2**40 + 5, 1 << 20, 77, 4099), (9, 3072, 5, 2500)]:
         z = _native.rng_fill_quad(seed, offset, step, n)
         np.testing.assert_allclose(z, _quad_normals_reference(seed, offset, step, n), rtol=0, atol=3e-5)
     assert abs(float(_native.rng_fill_quad(1, 0, 0, 1 << 16).std()) - 1.0) < 0.02
@@ -58,7 +61,7 @@ def test_philox_mode_equals_injected_mode_and_the_oracle(name):
     env_i.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 258])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 258, 1030])
 def test_ragged_sizes_and_sharding(n):
     cfg, _ = load_case("speed_temp_perm_cjoe")
     cfg.num_trajectories, cfg.seed = n, 4
@@ -71,19 +74,19 @@ def test_ragged_sizes_and_sharding(n):
         assert obs.shape == (n, 5) and rew.shape == (n,)
         total += rew
     assert env.episode_return_sums()[0] == pytest.approx(total.sum(), abs=1e-3)
-    cfg.num_trajectories = 260
+    cfg.num_trajectories = 1032
     big = make_env(cfg)
     big.reset()
     for _ in range(10):
-        obs_big, _, _, _ = big.step(np.full((260, 1), 1.5, np.float32))
+        obs_big, _, _, _ = big.step(np.full((1032, 1), 1.5, np.float32))
     np.testing.assert_array_equal(obs, obs_big[:n])
-    if n == 258:  # a shard starting at global lane 256 reproduces lanes 256.. of the whole run
-        cfg.num_trajectories = 4
-        tail = make_env(cfg, trajectory_offset=256)
+    if n == 1030:  # a shard starting on the second tile (global lane 1024) reproduces lanes 1024.. of the whole run
+        cfg.num_trajectories = 6
+        tail = make_env(cfg, trajectory_offset=1024)
         tail.reset()
         for _ in range(10):
-            obs_tail, _, _, _ = tail.step(np.full((4, 1), 1.5, np.float32))
-        np.testing.assert_array_equal(obs_tail, obs_big[256:260])
+            obs_tail, _, _, _ = tail.step(np.full((6, 1), 1.5, np.float32))
+        np.testing.assert_array_equal(obs_tail, obs_big[1024:1030])
         tail.close()
     env.close()
     big.close()

@@ -21,6 +21,8 @@ CASES = {
     "cfg2 CJP running 2^20 (44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="running", phi=0.01, alpha=0.001, max_inventory=100), 20, [0.7, 0.7]),
     "cfg3 Hawkes+OU 2^22 (D=6,60B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7]),
     "cfg4 limit+market 2^21 (A=4,52B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), dynamics="limit_and_market", reward="pnl", initial_inventory=10), 21, [0.7, 0.7, 0.0, 1.0]),
+    "speed temp+perm impact, CjOe 2^20 (D=5,A=1,48B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5]),
+    "speed power impact, PnL 2^20 (D=4,A=1,40B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.0, reward="pnl", initial_inventory=10), 20, [0.5]),
     "default normalised 2^20 (60B incl. obs)": (dict(midprice="bm", arrival="poisson", intensity=(100.0, 100.0), reward="pnl", normalise_action_space=True, normalise_observation_space=True, max_inventory=10000), 20, [-0.5, -0.5]),
 }
 
