@@ -259,6 +259,8 @@ void fill_static_params(mbt_env* e) {
   P.reward_kind = c.reward_kind;
   P.alpha_running = c.reward_kind == MBT_REW_RUNNING_PENALTY ? static_cast<float>(c.alpha) : 0.0f;
   P.alpha_cjmm = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha) : 0.0f;
+  P.quad_new = static_cast<float>(e->dt * c.phi + (c.reward_kind == MBT_REW_CJ_MM ? c.alpha : 0.0));
+  P.quad_init = 0.0f;  // needs the episode length: reset()
   P.exponent_is_two = c.inventory_exponent == 2.0 ? 1 : 0;
   P.phi = static_cast<float>(c.phi);
   P.alpha = static_cast<float>(c.alpha);
@@ -454,6 +456,7 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   mbt::StepParams& P = e->params;
   P.q_init_scalar = static_cast<float>(c.initial_inventory);
   P.dt_over_episode = static_cast<float>(e->dt / (c.terminal_time - start_time));  // RW:106, RW:113
+  P.quad_init = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha * e->dt / (c.terminal_time - start_time)) : 0.0f;
   P.episode_length = static_cast<float>(c.terminal_time - start_time);              // RW:67, RW:74
   const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
   mbt::ResetRow row0{static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),

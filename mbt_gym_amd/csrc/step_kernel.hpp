@@ -101,6 +101,7 @@ struct StepParams {
   float q_max, c_max;
   // reward
   float alpha_running, alpha_cjmm;  // kRewardQuadratic: alpha routed to the terminal (RW:135-137) or the spread (RW:102-108) term
+  float quad_new, quad_init;        // kRewardQuadratic: dt phi + alpha_cjmm, and alpha_cjmm dt / (T - t_start) (set by reset)
   int32_t reward_kind;
   int32_t exponent_is_two;
   float phi, alpha, exponent;
@@ -395,11 +396,11 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   } else if (V::REWARD == kRewardQuadratic) {
     // RunningInventoryPenalty (RW:128-138) and CjMmCriterion (RW:96-109) with exponent 2, branch-free: the host
     // routes alpha into exactly one of the two terms
-    const float qp = q_clip * q_clip;
-    const float spread = __builtin_fmaf(P.dt_over_episode, q_init * q_init, qp - q * q);
-    float pen = P.dt * P.phi * qp;
-    pen = __builtin_fmaf(is_terminal ? P.alpha_running : 0.0f, qp, pen);
-    pen = __builtin_fmaf(P.alpha_cjmm, spread, pen);
+    //   penalty = (dt phi + alpha_cjmm [+ alpha_running at the terminal step]) q'^2 - alpha_cjmm q^2 + alpha_cjmm dt/L q0^2
+    // with the coefficients folded on the host (wave-uniform; the q0 term needs no loaded value when q0 is a scalar),
+    // which leaves four dependent VALU operations after the loads
+    const float c_new = P.quad_new + (is_terminal ? P.alpha_running : 0.0f);
+    const float pen = __builtin_fmaf(-P.alpha_cjmm, q * q, __builtin_fmaf(c_new, q_clip * q_clip, P.quad_init * (q_init * q_init)));
     r.reward = (pnl - pen) * P.reward_scale;
   } else {
     r.reward = finish_reward(pnl, q, q_clip, c_clip, mid_new, q_init, 0.0f, is_terminal, P);

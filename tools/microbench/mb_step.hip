@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
   mbt::StepParams P{};
   P.n = n; P.n_pairs = n_pairs; P.key0 = 50; P.dt = 1e-3f; P.vol_sqrt_dt = 2.f * sqrtf(1e-3f);
   P.arr_thr_bid = P.arr_thr_ask = 0.14f; P.kappa_log2e_neg = -1.5f * 1.4426950408889634f; P.kappa_f64 = 1.5; P.q_max = 1000.f; P.c_max = 1e8f;
-  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f; P.mid_add = 1.f; P.reward_kind = 2; P.alpha_cjmm = 0.001f; P.phi = 0.01f; P.arr_dt = 1e-3f; P.arr_dt_f64 = 1e-3;
+  P.reward_scale = 1.f; P.exponent_is_two = 1; P.exponent = 2.f; P.mid_add = 1.f; P.reward_kind = 2; P.alpha_cjmm = 0.001f; P.phi = 0.01f; P.quad_new = 1e-3f * 0.01f + 0.001f; P.quad_init = 0.001f * 1e-3f; P.arr_dt = 1e-3f; P.arr_dt_f64 = 1e-3;
   mbt::StepBuffers B{};
   B.action = act; B.reward = rew; B.u_arr = ua; B.u_fill = uf; B.z = z; B.wave_sums = ws; B.clip_count = clip;
   float* st[2] = {s0, s1};
