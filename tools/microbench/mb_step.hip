@@ -88,10 +88,10 @@ int main(int argc, char** argv) {
   const uint32_t n = argc > 1 ? (1u << atoi(argv[1])) : (1u << 20);
   const uint32_t n_pairs = n / 2, blocks = (n_pairs + mbt::kBlockThreads - 1) / mbt::kBlockThreads;
   float *s0, *s1, *act, *rew, *ua, *uf, *z; double* ws; unsigned long long* clip;
-  CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
+  CK(hipMalloc(&s0, n * 32)); CK(hipMalloc(&s1, n * 32)); /* room for D = 6 / 8 rows */ CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
   CK(hipMalloc(&ua, n * 8)); CK(hipMalloc(&uf, n * 8)); CK(hipMalloc(&z, n * 4));
   CK(hipMalloc(&ws, blocks * 4 * 8)); CK(hipMalloc(&clip, 8 * mbt::kClipSlots));
-  CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(act, 0, n * 8)); CK(hipMemset(ws, 0, blocks * 32)); CK(hipMemset(clip, 0, 8 * mbt::kClipSlots));
+  CK(hipMemset(s0, 0, n * 32)); CK(hipMemset(s1, 0, n * 32)); CK(hipMemset(act, 0, n * 8)); CK(hipMemset(ws, 0, blocks * 32)); CK(hipMemset(clip, 0, 8 * mbt::kClipSlots));
   CK(hipMemset(ua, 0, n * 8)); CK(hipMemset(uf, 0, n * 8)); CK(hipMemset(z, 0, n * 4));
   std::vector<float> h(n * 4);
   for (uint32_t i = 0; i < n; ++i) { h[4 * i] = 0; h[4 * i + 1] = 0; h[4 * i + 2] = 0; h[4 * i + 3] = 100.f; }
@@ -142,5 +142,13 @@ int main(int argc, char** argv) {
   RUNT(CJ, 2, "  CjMm tiles/block 2")
   RUN(CJ, "step CjMm philox (44 B)", 44.0)
   RUN(ASI, "step AS inject (64 B)", 64.0)
+  // where the Hawkes + OU kernel (BASELINE config 3) spends its time: each ingredient alone
+  P.hawkes_base_bid = P.hawkes_base_ask = 10.f; P.hawkes_speed = 60.f; P.hawkes_jump = 40.f; P.ou_speed = 0.01f; P.ou_level = 100.f;
+  using OU = mbt::Variant<0, 0, false, 0, false, false>;
+  using HK = mbt::Variant<1, 0, true, 0, false, false>;
+  using HKOU = mbt::Variant<1, 0, false, 0, false, false>;
+  RUN(OU, "step Poisson + OU (44 B)", 44.0)
+  RUN(HK, "step Hawkes + BM (60 B)", 60.0)
+  RUN(HKOU, "step Hawkes + OU (60 B)", 60.0)
   return 0;
 }
