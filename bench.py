@@ -78,7 +78,7 @@ def run_steps(env, k, device, returns):
     for _ in range(k):
         if env.step_device():
             returns.append(allreduce_return_sums(env.episode_return_sums(), device=device))
-            env._reset_device()
+            env.reset_device()
 
 
 def pmc_traffic(n):

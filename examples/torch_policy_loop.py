@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""An on-GPU policy consuming the environment without a host round trip.
+
+obs (library buffer, zero-copy torch view) -> a small MLP in PyTorch-ROCm -> actions written in place into the library's
+action buffer -> env.step_device(): everything on one HIP stream, nothing crosses PCIe.  PyTorch is the consumer here,
+not the product: the environment side is the fused HIP step kernel.
+
+    python examples/torch_policy_loop.py [log2_lanes] [steps]
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics  # noqa: E402
+from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment  # noqa: E402
+from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel  # noqa: E402
+from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction  # noqa: E402
+from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def main():
+    log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    n, n_steps = 1 << log2n, 1000
+    dt = 1.0 / n_steps
+    dynamics = LimitOrderModelDynamics(
+        midprice_model=BrownianMotionMidpriceModel(volatility=2.0, step_size=dt, num_trajectories=n),
+        arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
+        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n),
+        num_trajectories=n)
+    env = TradingEnvironment(terminal_time=1.0, n_steps=n_steps, model_dynamics=dynamics, num_trajectories=n, seed=1,
+                             max_inventory=1000)  # normalised observations and actions: what a learning agent consumes
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    env.reset_device()
+    policy = torch.nn.Sequential(torch.nn.Linear(env.observation_dim, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                                 torch.nn.Linear(64, env.action_dim), torch.nn.Tanh()).cuda().half()
+    action = torch.as_tensor(env.action_device, device="cuda")  # (N, 2) float32, the buffer the step kernel reads
+
+    def one_step():
+        obs = torch.as_tensor(env.obs_device, device="cuda")  # ping-pongs between two buffers: re-wrap every step
+        with torch.no_grad():
+            action.copy_(policy(obs.half()))
+        if env.step_device():  # True when the episode ended
+            env.reset_device()
+
+    for _ in range(20):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    rew = torch.as_tensor(env.reward_device, device="cuda")
+    print(json.dumps({"lanes": n, "steps": steps, "us_per_step_env_plus_policy": wall / steps * 1e6,
+                      "env_steps_per_s_with_mlp_policy": n * steps / wall, "mean_last_reward": float(rew.mean())}))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

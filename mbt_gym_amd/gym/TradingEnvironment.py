@@ -258,6 +258,10 @@ class TradingEnvironment(_EnvBase):
     # ---------------------------------------------------------------------------------------------------
     # zero-copy / asynchronous path
     # ---------------------------------------------------------------------------------------------------
+    def reset_device(self):
+        """reset() without the host copy of the observation: the rows are written in HBM (`obs_device`)."""
+        self._reset_device()
+
     def step_device(self, action_ptr: int = None) -> bool:
         """Enqueue one step on the environment's stream without any host transfer.  `action_ptr` is a device
         pointer to (N, A) float32 (default: `action_device`).  Results stay in HBM (`obs_device`,

@@ -22,7 +22,7 @@ def timed(env, agent, episodes, lib):
     env.synchronize()
     _native.check(lib.mbt_env_timer_begin(env._handle))
     for _ in range(episodes):
-        env._reset_device()
+        env.reset_device()
         steps, done = env.rollout_device(agent)
         assert done and steps == env.n_steps
     ms = C.c_float(0)
@@ -56,7 +56,7 @@ def main():
     env.synchronize()
     _native.check(lib.mbt_env_timer_begin(env._handle))
     for _ in range(3):
-        env._reset_device()
+        env.reset_device()
         env.rollout_device(agent, obs_ptr=obs.data_ptr(), act_ptr=act.data_ptr(), rew_ptr=rew.data_ptr())
     ms = C.c_float(0)
     _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
