@@ -37,17 +37,6 @@ SEED = 50
 QUOTE = (0.7, 0.7)
 
 
-def as_config(n, offset_seed=SEED):
-    from oracle.mbt_oracle import OracleConfig
-
-    return OracleConfig(
-        num_trajectories=n, n_steps=N_STEPS, terminal_time=1.0, midprice="bm", drift=0.0, volatility=2.0,
-        initial_price=100.0, arrival="poisson", intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit",
-        reward="pnl", initial_inventory=0, max_inventory=N_STEPS, seed=offset_seed,
-        normalise_action_space=False, normalise_observation_space=False,
-    )
-
-
 def build_env(n, rank, device):
     """The environment through the public plugin API, one shard of the trajectory axis per rank."""
     from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
@@ -97,10 +86,15 @@ def pmc_traffic(n):
 def cpu_baseline(budget_s=12.0):
     """The reference's algorithm (oracle = NumPy restatement, bit-matched to the reference) on this host, one
     process / one core like the reference, same model and N = 2^20 lanes, numpy PCG64 noise as the reference."""
-    from oracle.mbt_oracle import NumpyProtocolNoise, OracleEnv
+    from oracle.mbt_oracle import NumpyProtocolNoise, OracleConfig, OracleEnv  # the ONLY use of oracle/ in this file
 
     n = LANES_PER_GPU
-    cfg = as_config(n)
+    cfg = OracleConfig(
+        num_trajectories=n, n_steps=N_STEPS, terminal_time=1.0, midprice="bm", drift=0.0, volatility=2.0,
+        initial_price=100.0, arrival="poisson", intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit",
+        reward="pnl", initial_inventory=0, max_inventory=N_STEPS, seed=SEED,
+        normalise_action_space=False, normalise_observation_space=False,
+    )
     env = OracleEnv(cfg, NumpyProtocolNoise(SEED))
     env.reset()
     action = np.tile(np.array([QUOTE], dtype=np.float64), (n, 1))

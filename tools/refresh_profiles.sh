@@ -24,10 +24,10 @@ F=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc_summary.json" > /dev/null
 
-python tools/parity_report.py > "$OUT/${TAG}_parity_report.txt" 2> /dev/null
-MBT_BENCH_STEPS=1000 python tools/bench_configs.py > "$OUT/${TAG}_step_kernel_all_configs.json" 2> /dev/null
+python tests/perf/parity_report.py > "$OUT/${TAG}_parity_report.txt" 2> /dev/null
+MBT_BENCH_STEPS=1000 python tests/perf/bench_configs.py > "$OUT/${TAG}_step_kernel_all_configs.json" 2> /dev/null
 python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null
-python tools/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null
+python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null
 
 make -C tools/microbench > /dev/null 2>&1
 {
