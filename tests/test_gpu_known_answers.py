@@ -85,3 +85,29 @@ def test_closed_form_policies_hit_the_exact_expectation(reward, policy):
     for q in (-4, 0, 3):
         assert float((q_t == q).mean()) == pytest.approx(dist[q], abs=5 * np.sqrt(dist[q] / N) + 1e-4)
     env.close()
+
+
+def test_two_to_the_24_lanes_hit_the_exact_expectation():
+    """BASELINE config 4's total size on ONE device: 2^24 lanes x 200 steps of the Avellaneda-Stoikov policy in one
+    fused launch.  The standard error of the mean return is 1.6e-3 here, so this pins the generator and the decision
+    thresholds four times more sharply than the 2^20-lane runs - and exercises the largest lane count of the configs."""
+    n = 1 << 24
+    cfg = cj_config(n=n, n_steps=200, q_max=60)
+    cfg.reward, cfg.drift = "pnl", 0.0
+    env = make_env(cfg)
+    agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
+
+    def depth(k, grid):
+        st = np.zeros((grid.size, 4))
+        st[:, 1], st[:, 2] = grid, np.float32(k * cfg.step_size)
+        a = avellaneda_stoikov_action(cfg, 0.1, st)
+        return a[:, 0], a[:, 1]
+
+    exact, dist = expected_episode_return(cfg, depth)
+    mean, std, steps = _mc(env, agent)
+    assert steps == 200
+    assert mean == pytest.approx(exact, abs=5 * std / np.sqrt(n)), (mean, exact, std / np.sqrt(n))
+    q_t = env.state[:, 1]
+    for q in (-5, -1, 0, 2, 6):
+        assert float((q_t == q).mean()) == pytest.approx(dist[q], abs=5 * np.sqrt(dist[q] / n) + 2e-5)
+    env.close()
