@@ -5,7 +5,7 @@
 // (see "lane <-> thread mapping" below), so that every memory instruction of a wave covers one contiguous span:
 //   reads   2 state rows [cash, inventory, time, midprice (, bid intensity, ask intensity)]: one float4 each (D = 4)
 //           2 action rows: float2 (A=2) or float4 (A=4)
-//   draws   3 Philox4x32-10 blocks = all the noise of the pair (philox.hpp), or loads injected noise
+//   draws   2 Philox4x32-10 blocks = all the noise of the pair (philox.hpp), or loads injected noise
 //   writes  2 next-state rows, 2 rewards
 // The state is row-major (N, D) float32 - exactly the un-normalised observation the API returns - and is
 // ping-ponged between two buffers, so the observation of step k stays valid while step k+1 is computed.
@@ -20,8 +20,9 @@
 //   * arrivals, fills, market-order flags, inventory: BIT-EXACT against the float64 reference on the same
 //     float32-representable draws.  Decisions are taken on exact thresholds: Poisson thresholds arrive rounded
 //     UP to float32 (u < t_f64 <=> u < roundup32(t_f64) for float32 u); Hawkes thresholds and normalised
-//     market-order flags are evaluated in double; the fill test uses v_exp_f32 and re-evaluates in double only
-//     when the draw lies within the error band of the float32 exponential (about 4e-6 of draws).
+//     market-order flags are evaluated in double; the fill test compares the depth with a bracket of the threshold
+//     -ln(u)/kappa (v_log_f32, computed before the loads are consumed) and re-decides in double only a depth inside
+//     the bracket (about 2e-6 of draws).
 //   * rewards: float32 but computed from the step's INCREMENTS, never as a difference of two large
 //     mark-to-market values: PnL = n_b*d_b + n_a*d_a - h*(mb+ms) + q'*dS (+ clip corrections), which is the
 //     reference's (c'+q'S') - (c+qS) (RW:27-33) with the S terms cancelled analytically.
@@ -144,8 +145,9 @@ struct StepBuffers {
 //     flight; (2) the post-load arithmetic uses explicit FMAs / v_med3 and carries nothing optional (event bytes are
 //     assembled only when recording); (3) rare exact re-decisions live in cold blocks.  Explicit FMAs (the library is
 //     built with -ffp-contract=off) also make the step and rollout kernels, which inline the same code, agree bit
-//     for bit.  Measured (rocprofv3 PMC, 2^20 lanes): 334 VALU instructions per wave, 14 % of wave cycles issuing,
-//     38 % parked on memory - the kernel is bound by the memory system, not by this arithmetic.
+//     for bit.  Measured (rocprofv3 PMC, 2^20 lanes, profiles/r01_pmc_sq.txt): 296 VALU instructions per wave; a wave is
+//     resident for ~2500 quad-cycles of which 304 issue VALU - times the 8 resident waves of a SIMD that is most of the
+//     residency window, so at this size arithmetic and the memory system co-limit the kernel.
 
 // Per-lane quantities that depend on noise and parameters only.
 struct LaneDraw {
