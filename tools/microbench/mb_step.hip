@@ -142,6 +142,35 @@ int main(int argc, char** argv) {
   RUNT(CJ, 2, "  CjMm tiles/block 2")
   RUN(CJ, "step CjMm philox (44 B)", 44.0)
   RUN(ASI, "step AS inject (64 B)", 64.0)
+  {  // upper bound of any scheme that overlaps the launch/drain bubbles of consecutive steps: the two HALVES of the batch
+     // stepped as independent environments on two streams (no join between steps).  Not used by the library - a step
+     // that a consumer can observe needs both halves - but it bounds what a single in-order stream leaves on the table.
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    const uint32_t half_blocks = blocks / 2;
+    mbt::StepParams PA = P, PB = P;
+    PA.n = PB.n = n / 2; PA.n_pairs = PB.n_pairs = n_pairs / 2; PB.pair_offset = n_pairs / 2;
+    mbt::StepBuffers BA = B, BB = B;
+    BB.action = act + n; BB.reward = rew + n / 2; BB.wave_sums = ws + half_blocks * 4;  // second halves of the same buffers
+    hipEvent_t e0, e1, eb;
+    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&eb);
+    auto both = [&](int i) {
+      BA.state_in = st[i & 1]; BA.state_out = st[(i & 1) ^ 1];
+      BB.state_in = st[i & 1] + (size_t)n * 2; BB.state_out = st[(i & 1) ^ 1] + (size_t)n * 2;  // rows n/2.. (4 floats each)
+      PA.philox_step = PB.philox_step = i;
+      hipLaunchKernelGGL((mbt::step_kernel<AS>), dim3(half_blocks), dim3(mbt::kBlockThreads), 0, sa, BA, PA);
+      hipLaunchKernelGGL((mbt::step_kernel<AS>), dim3(half_blocks), dim3(mbt::kBlockThreads), 0, sb, BB, PB);
+    };
+    for (int i = 0; i < 20; ++i) both(i);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, sa);
+    for (int i = 0; i < iters; ++i) both(i);
+    hipEventRecord(e1, sa); hipEventRecord(eb, sb);
+    hipEventSynchronize(e1); hipEventSynchronize(eb);
+    float ma = 0, mb2 = 0; hipEventElapsedTime(&ma, e0, e1); hipEventElapsedTime(&mb2, e0, eb);
+    t = (ma > mb2 ? ma : mb2) * 1e3f / iters;
+    printf("%-28s %8.2f us  %7.0f GB/s\n", "  AS, halves on two streams", t, 44.0 * n / t * 1e-3);
+  }
   // where the Hawkes + OU kernel (BASELINE config 3) spends its time: each ingredient alone
   P.hawkes_base_bid = P.hawkes_base_ask = 10.f; P.hawkes_speed = 60.f; P.hawkes_jump = 40.f; P.ou_speed = 0.01f; P.ou_level = 100.f;
   using OU = mbt::Variant<0, 0, false, 0, false, false>;
