@@ -1,0 +1,110 @@
+"""Differential test over the plugin space: random combinations of midprice / arrival / dynamics / reward kinds and
+parameters (seeded), the HIP environment in production (Philox) mode against the float64 oracle fed with the very draws the
+kernel made.  The fixtures pin the oracle to the reference on 18 hand-picked configurations; this spreads the same
+comparison over combinations nobody picked by hand (at-the-touch + Hawkes + CjMm, normalised limit-and-market, late start
+times, tight inventory limits ...).  Tolerances are those of test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from mbt_gym_amd import _native
+from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv, action_bounds
+from tests.env_factory import make_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_config(rng, n):
+    dynamics = rng.choice(["limit", "limit", "limit_and_market", "touch"])
+    arrival = rng.choice(["poisson", "poisson_nonlinear", "hawkes"])
+    midprice = rng.choice(["bm", "ou", "gbm", "bm_jump", "ou_jump", "constant"])
+    reward = rng.choice(["pnl", "running", "cjmm", "exp_utility"])
+    n_steps = int(rng.integers(20, 60))
+    normalised = bool(rng.integers(0, 2)) and dynamics != "touch"
+    s0 = float(rng.choice([10.0, 50.0, 100.0]))
+    cfg = OracleConfig(
+        num_trajectories=n, n_steps=n_steps, terminal_time=float(rng.choice([0.5, 1.0, 2.0])), midprice=midprice,
+        drift=float(rng.uniform(-0.2, 0.2)), volatility=float(rng.uniform(0.05, 0.3) if midprice == "gbm" else rng.uniform(0.5, 3.0)),
+        initial_price=s0, ou_level=s0 + float(rng.uniform(-1, 1)), ou_speed=float(rng.uniform(0.0, 0.1)), jump_size=float(rng.uniform(0.0, 0.3)),
+        arrival=arrival, intensity=(float(rng.uniform(5, 60)), float(rng.uniform(5, 60))), hawkes_jump=float(rng.uniform(5, 40)),
+        hawkes_speed=float(rng.uniform(20, 80)), fill_exponent=float(rng.uniform(0.5, 3.0)), dynamics=dynamics,
+        market_half_spread=float(rng.uniform(0.1, 0.6)), reward=reward, risk_aversion=float(rng.uniform(0.001, 0.05)),
+        phi=float(rng.uniform(0.0, 0.05)), alpha=float(rng.uniform(0.0, 0.1)), inventory_exponent=2.0,
+        initial_inventory=int(rng.integers(-2, 3)), max_inventory=int(rng.choice([2, 5, 50])), seed=int(rng.integers(1, 2**31)),
+        normalise_action_space=normalised, normalise_observation_space=normalised,
+    )
+    # the explicit Euler recursion of the Hawkes intensity (ARR:110-119) amplifies rounding when speed * dt > 1: keep
+    # the random draw inside the stable range, where float32 and float64 stay together
+    cfg.hawkes_speed = min(cfg.hawkes_speed, 0.9 / cfg.step_size)
+    if rng.integers(0, 4) == 0:
+        cfg.start_time = cfg.terminal_time * 0.25
+    return cfg
+
+
+def _random_actions(rng, cfg, steps):
+    lo, hi = action_bounds(cfg)
+    n, a = cfg.num_trajectories, cfg.action_dim
+    if cfg.dynamics == "touch":
+        return rng.integers(0, 2, size=(steps, n, 2)).astype(np.float32)
+    if cfg.normalise_action_space:
+        act = rng.uniform(-1, 1, size=(steps, n, a))
+        if a == 4:  # market orders: mostly clearly off / clearly on
+            act[:, :, 2:] = rng.choice([-1.0, 1.0, 0.3], p=[0.85, 0.1, 0.05], size=(steps, n, 2))
+        return act.astype(np.float32)
+    act = rng.uniform(0, 0.8, size=(steps, n, a)) * hi
+    if a == 4:
+        act[:, :, 2:] = rng.choice([0.0, 1.0, 0.4], p=[0.85, 0.1, 0.05], size=(steps, n, 2))
+    return act.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", range(150))
+def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
+    rng = np.random.default_rng(7000 + case)
+    n = int(rng.choice([7, 192, 600]))
+    cfg = _random_config(rng, n)
+    env = make_env(cfg, noise="philox")
+    steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+    actions = _random_actions(rng, cfg, steps)
+    draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    obs = env.reset()
+    o_obs = oracle.reset()
+    tag = f"case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-5, err_msg=tag)
+    scale = np.maximum(1.0, np.abs(o_obs[:, 0])) if not cfg.normalise_observation_space else None
+    for k in range(steps):
+        obs, rew, dones, _ = env.step(actions[k])
+        o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
+        o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
+        clipped = oracle.last_clipped
+        if cfg.normalise_observation_space:
+            np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-4, err_msg=f"{tag} step {k}")
+            q = np.rint((obs[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
+            np.testing.assert_array_equal(q, np.rint((o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory), err_msg=f"{tag} step {k}: inventory")
+        else:
+            np.testing.assert_array_equal(obs[:, 1].astype(np.float64), o_obs[:, 1], err_msg=f"{tag} step {k}: inventory")
+            scale = np.maximum(scale, np.abs(o_obs[:, 0]))
+            assert np.all(np.abs(obs[:, 0] - o_obs[:, 0]) <= 1e-4 + 2e-6 * scale), f"{tag} step {k}: cash"
+            np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
+            if obs.shape[1] > 4:
+                np.testing.assert_allclose(obs[:, 4:], o_obs[:, 4:], rtol=5e-6, atol=5e-5, err_msg=f"{tag} step {k}: intensities")
+        if cfg.reward == "exp_utility":
+            # zero before the terminal step; there -exp(-gamma W) of the float32 terminal wealth W = cash + q S (RW:156-163):
+            # compared through W, whose float32 error is that of cash (checked above) plus |q| times that of the midprice
+            if not dones[0]:
+                assert np.all(rew == 0.0) and np.all(o_rew == 0.0)
+            else:
+                w_got, w_want = -np.log(-rew.astype(np.float64)) / cfg.risk_aversion, -np.log(-o_rew) / cfg.risk_aversion
+                wealth_tol = 1e-3 + 4e-6 * (np.abs(w_want) + (scale if scale is not None else 0.0)) + 1e-2 * clipped
+                assert np.all(np.abs(w_got - w_want) <= wealth_tol), f"{tag} step {k}: terminal wealth off by {np.max(np.abs(w_got - w_want))}"
+        else:
+            # rewards: 1e-5, except where the reward itself carries float32 state (a clip; state-proportional diffusion)
+            tol = 1e-5 + (2e-6 * np.abs(o_rew) if cfg.midprice == "gbm" else 0.0)
+            if cfg.midprice in ("ou", "ou_jump"):  # the pull -theta (S - level) carries the float32 error of S (<= 3e-4) times q
+                inventory = o_obs[:, 1] if not cfg.normalise_observation_space else (o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory
+                tol = tol + cfg.ou_speed * np.abs(inventory) * 1e-4
+            err = np.abs(rew - o_rew)
+            assert np.all(err[clipped] <= 2e-3), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
+            assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
+        assert bool(dones[0]) == bool(o_dones[0])
+    assert dones[0]
+    env.close()
