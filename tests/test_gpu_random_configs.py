@@ -108,3 +108,68 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]
     env.close()
+
+
+def _random_speed_config(rng, n):
+    impact = rng.choice(["temp_power", "temp_perm", "temp_transient", "transient"])
+    n_steps = int(rng.integers(20, 60))
+    T = float(rng.choice([0.5, 1.0, 2.0]))
+    normalised = bool(rng.integers(0, 2))
+    cfg = OracleConfig(
+        num_trajectories=n, n_steps=n_steps, terminal_time=T, midprice=rng.choice(["bm", "ou", "gbm", "constant"]),
+        drift=float(rng.uniform(-0.1, 0.1)), volatility=float(rng.uniform(0.05, 0.3)), initial_price=float(rng.choice([20.0, 100.0])),
+        ou_level=100.0, ou_speed=float(rng.uniform(0.0, 0.05)), arrival="none", dynamics="speed", impact=impact,
+        temporary_impact=float(rng.uniform(0.005, 0.05)), impact_exponent=float(rng.choice([1.0, 1.0, 1.5, 0.6])),
+        permanent_impact=float(rng.uniform(0.0, 0.03)), transient_impact=float(rng.uniform(0.1, 0.6)), resilience=float(rng.uniform(0.5, 3.0)),
+        initial_transient_impact=float(rng.uniform(0.0, 0.2)), kernel_coefficient=float(rng.uniform(0.0, 0.4)), impact_step_size=T / n_steps,
+        reward=rng.choice(["pnl", "running", "cjoe"]), phi=float(rng.uniform(0.0, 0.05)), alpha=float(rng.uniform(0.0, 0.2)),
+        initial_inventory=int(rng.integers(1, 20)), max_inventory=int(rng.choice([15, 1000])), seed=int(rng.integers(1, 2**31)),
+        normalise_action_space=normalised, normalise_observation_space=normalised,
+    )
+    if rng.integers(0, 3) == 0:  # MD:265 trades the MIDPRICE model's step size, which need not be the environment's
+        cfg.midprice_step_size = float(rng.choice([0.5, 2.0])) * cfg.step_size
+    return cfg
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_random_speed_configuration_matches_the_oracle(case):
+    rng = np.random.default_rng(9000 + case)
+    n = int(rng.choice([5, 300, 1100]))
+    cfg = _random_speed_config(rng, n)
+    steps = cfg.n_steps
+    lo, hi = action_bounds(cfg)
+    positive = cfg.impact == "temp_power" and cfg.impact_exponent != 1.0  # v ** e with a fractional exponent needs v >= 0
+    if cfg.normalise_action_space:
+        actions = rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)).astype(np.float32)
+    else:
+        actions = (rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)) * hi).astype(np.float32)
+    z = np.stack([_native.rng_fill_quad(cfg.seed, 0, k, n) for k in range(steps)])
+    env = make_env(cfg, noise="philox")
+    oracle = OracleEnv(cfg, InjectedNoise(np.zeros((steps, n, 2)), np.zeros((steps, n, 2)), z))
+    obs, o_obs = env.reset(), oracle.reset()
+    tag = f"speed case {case}: {cfg.midprice}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    for k in range(steps):
+        obs, rew, dones, _ = env.step(actions[k])
+        o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
+        clipped = oracle.last_clipped
+        if cfg.normalise_observation_space:  # compare in raw units: a narrow Box (small volatility) magnifies float32 rounding
+            grad = (oracle.obs_hi.astype(np.float64) - oracle.obs_lo) / 2
+            obs, o_obs = (obs.astype(np.float64) + 1) * grad + oracle.obs_lo, (o_obs + 1) * grad + oracle.obs_lo
+            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=0, atol=2e-6 * cfg.max_inventory + 1e-6, err_msg=f"{tag} step {k}: inventory")
+            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=0, atol=1e-3 + 2e-7 * oracle.max_cash, err_msg=f"{tag} step {k}: cash")
+            np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
+        else:
+            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=2e-6, atol=2e-6, err_msg=f"{tag} step {k}: inventory")
+            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=4e-6, atol=1e-3, err_msg=f"{tag} step {k}: cash")
+            np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
+            if obs.shape[1] > 4:
+                np.testing.assert_allclose(obs[:, 4], o_obs[:, 4], rtol=1e-5, atol=1e-6, err_msg=f"{tag} step {k}: impact state")
+        err = np.abs(rew - o_rew)
+        tol = 1e-5 + 4e-6 * np.abs(o_rew)
+        if cfg.midprice == "ou":
+            tol = tol + cfg.ou_speed * np.abs(o_obs[:, 1] if not cfg.normalise_observation_space else cfg.max_inventory) * 1e-4
+        assert np.all(err[clipped] <= 5e-3 + 1e-5 * np.abs(o_rew[clipped])), f"{tag} step {k}: reward on clipped lanes"
+        assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
+        assert bool(dones[0]) == bool(o_dones[0])
+    assert dones[0]
+    env.close()
