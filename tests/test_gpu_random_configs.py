@@ -173,3 +173,47 @@ def test_random_speed_configuration_matches_the_oracle(case):
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]
     env.close()
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_random_configuration_rollout_equals_the_step_loop(case):
+    """The fused rollout kernel inlines the step kernel's arithmetic and draws the same Philox counters: for any
+    configuration a fixed-action rollout must equal the loop of step() calls bit for bit (states, rewards, return sums)."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+
+    rng = np.random.default_rng(11000 + case)
+    n = int(rng.choice([3, 513, 1500]))
+    cfg = _random_speed_config(rng, n) if case % 3 == 2 else _random_config(rng, n)
+    lo, hi = action_bounds(cfg)
+    if cfg.dynamics == "touch":
+        fixed = rng.integers(0, 2, size=2).astype(np.float32)
+    elif cfg.normalise_action_space:
+        fixed = rng.uniform(0.0 if cfg.dynamics == "speed" else -1.0, 0.5, size=cfg.action_dim).astype(np.float32)
+    else:
+        fixed = (rng.uniform(0.05, 0.5, size=cfg.action_dim) * hi).astype(np.float32)
+    env_a, env_b = make_env(cfg), make_env(cfg)
+    agent = FixedActionAgent(fixed, env_a)
+    env_a.track_lane_returns(True)
+    env_b.track_lane_returns(True)
+    obs0 = env_a.reset()
+    obs_r, act_r, rew_r, steps, done = env_a.rollout(agent)
+    np.testing.assert_array_equal(obs_r[0], obs0)
+    obs = env_b.reset()
+    action = agent.get_action(obs)
+    k = 0
+    while True:
+        obs, rew, dones, _ = env_b.step(action)
+        np.testing.assert_array_equal(obs, obs_r[k + 1], err_msg=f"case {case} step {k}: obs")
+        np.testing.assert_array_equal(rew, rew_r[k], err_msg=f"case {case} step {k}: rewards")
+        np.testing.assert_array_equal(action, act_r[k])
+        k += 1
+        if dones[0]:
+            break
+    assert done and steps == k
+    np.testing.assert_array_equal(env_a.state, env_b.state)
+    sums_a, sums_b = env_a.episode_return_sums(), env_b.episode_return_sums()
+    assert sums_a[2] == sums_b[2] == n
+    np.testing.assert_allclose(sums_a[:2], sums_b[:2], rtol=1e-5, atol=1e-5, equal_nan=True)
+    assert env_a.clip_count == env_b.clip_count
+    env_a.close()
+    env_b.close()
