@@ -112,8 +112,8 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
 #pragma unroll
     for (int c = 0; c < V::DIM; ++c) row[c] = normalise_column(row[c], c, P);  // TE:112-118
   }
-  if (V::DIM == 4) {
-    reinterpret_cast<float4*>(base)[lane] = make_float4(row[0], row[1], row[2], row[3]);
+  if (V::DIM == 4) {  // one whole row per lane: written through the L2 (step_kernel.hpp: store_through)
+    store_through(reinterpret_cast<float4*>(base) + lane, make_float4(row[0], row[1], row[2], row[3]));
   } else {
     float* r = base + static_cast<size_t>(lane) * 5;
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     const uint32_t lane = lane0 + l * kBlockThreads;
     const SpeedResult r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
     store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
-    B.reward[lane] = r.reward;
+    store_through(B.reward + lane, r.reward);
     if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, r.next, P.t_next, P.norm_obs != 0, P);
     if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
     if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;

@@ -504,6 +504,31 @@ __device__ __forceinline__ void tie_loads_to_draws(LaneLoads& a, LaneLoads& b, L
                  "+v"(da.hi_bid), "+v"(da.lo_ask), "+v"(da.hi_ask), "+v"(db.lo_bid), "+v"(db.hi_bid), "+v"(db.lo_ask), "+v"(db.hi_ask));
 }
 
+// ---- stores that write THROUGH the XCD's L2 -------------------------------------------------------------------------
+// A step leaves ~21 MB of new state and rewards at 2^20 lanes.  With ordinary stores those lines sit dirty in the eight
+// XCD-private L2s until the end-of-kernel release writes them back - serial time between two dependent launches.  With the
+// system-scope bit (sc1) the data streams out to the Infinity Cache / HBM while the kernel is still running, and the next
+// step (which reads it through a freshly invalidated L2 anyway) starts sooner: 6.76 -> 5.82 us for the copy kernel of the
+// same traffic (tools/microbench/mb_copy.hip), the non-temporal bit (nt) instead costs 18 %.  The builtins offer no
+// per-store scope, hence the inline assembly; stores have no consumer in the kernel, so the compiler's wait counters are
+// unaffected.  One hazard the compiler handles for its own stores and cannot see through the asm: gfx9 reads the data
+// registers of a store wider than 8 bytes over more than one cycle, so a VALU write to them needs a wait state after the
+// store - without the s_nop the next address computation overwrote (cash, inventory) of rows in flight.  (The leading
+// s_nop 0 keeps a transcendental result that might feed the store one wait state away, as the compiler would.)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_through(float4* p, const float4 v) {
+  const v4f_t t = {v.x, v.y, v.z, v.w};
+  asm volatile("s_nop 0\n\tglobal_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void store_through(float2* p, const float2 v) {
+  const v2f_t t = {v.x, v.y};
+  asm volatile("s_nop 0\n\tglobal_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void store_through(float* p, const float v) {
+  asm volatile("s_nop 0\n\tglobal_store_dword %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+}
+
 // one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
 template <class V>
 __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
@@ -512,15 +537,16 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
   if (V::EXO && normalise && P.norm_obs) best = make_float2(normalise_column(best.x, V::EXO_COL, P), normalise_column(best.y, V::EXO_COL + 1, P));
   if (V::DIM == 8) {
     float4* row = reinterpret_cast<float4*>(base) + static_cast<size_t>(lane) * 2;
-    row[0] = core;
-    row[1] = make_float4(lam.x, lam.y, best.x, best.y);
+    row[0] = core;  // (rows wider than 16 bytes are written by several instructions that each cover PART of a cache line:
+    row[1] = make_float4(lam.x, lam.y, best.x, best.y);  // written through, partial lines double the step time - 38 -> 80 us
+                                                          // for Hawkes at 2^22 lanes - so these stay ordinary write-back stores)
   } else if (V::DIM == 6) {
     float2* row = reinterpret_cast<float2*>(base) + static_cast<size_t>(lane) * 3;
     row[0] = make_float2(core.x, core.y);
     row[1] = make_float2(core.z, core.w);
     row[2] = V::ARR == kArrHawkes ? lam : best;
   } else {
-    reinterpret_cast<float4*>(base)[lane] = core;
+    store_through(reinterpret_cast<float4*>(base) + lane, core);
   }
 }
 
@@ -530,7 +556,7 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
                                              const LaneDraw& d, bool& clipped) {
   const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P);
   store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
-  B.reward[lane] = r.reward;
+  store_through(B.reward + lane, r.reward);
   // -- optional outputs (wave-uniform branches)
   if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lane, r.core, r.lam, true, P);
   if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -60,6 +61,45 @@ __global__ __launch_bounds__(BLOCK) void copy_split(const float4* s_in_, float4*
   rew[i] = c.y; rew[i + BLOCK] = d.y;
 }
 
+// the tile-split copy with explicit cache-policy bits on the stores (gfx942/gfx950: sc0 / sc1 = coherence scope bits, nt =
+// non-temporal): does writing THROUGH the XCD's L2 (instead of leaving 21 MB of dirty lines to the end-of-kernel
+// write-back) shorten the launch-to-launch time?
+#define STORE_ASM(BITS)                                                                                         \
+  asm volatile("global_store_dwordx4 %0, %1, off " BITS : : "v"(&s_out[i]), "v"(a) : "memory");              \
+  asm volatile("global_store_dwordx4 %0, %1, off " BITS : : "v"(&s_out[i + BLOCK]), "v"(b) : "memory");      \
+  asm volatile("global_store_dword %0, %1, off " BITS : : "v"(&rew[i]), "v"(c.y) : "memory");                \
+  asm volatile("global_store_dword %0, %1, off " BITS : : "v"(&rew[i + BLOCK]), "v"(d.y) : "memory");
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void copy_split_policy(const float4* s_in_, float4* s_out_, const float2* act_, float* rew, uint32_t n) {
+  const v4f* s_in = reinterpret_cast<const v4f*>(s_in_);
+  v4f* s_out = reinterpret_cast<v4f*>(s_out_);
+  const v2f* act = reinterpret_cast<const v2f*>(act_);
+  const uint32_t i = blockIdx.x * (2 * BLOCK) + threadIdx.x;
+  if (i + BLOCK >= n) return;
+  v4f a = s_in[i], b = s_in[i + BLOCK];
+  const v2f c = act[i], d = act[i + BLOCK];
+  a.x += c.x; b.x += d.x;
+  if (MODE == 0) { STORE_ASM("") }
+  if (MODE == 1) { STORE_ASM("sc0") }
+  if (MODE == 2) { STORE_ASM("sc1") }
+  if (MODE == 3) { STORE_ASM("sc0 sc1") }
+  if (MODE == 4) { STORE_ASM("nt") }
+  if (MODE == 5) { STORE_ASM("sc1 nt") }
+  if (MODE == 6) {  // no assembly: relaxed SYSTEM-scope atomic stores (64-bit halves of a row, 32-bit rewards) also carry sc0 sc1
+    typedef unsigned long long u64;
+    const u64* pa = reinterpret_cast<const u64*>(&a);
+    const u64* pb = reinterpret_cast<const u64*>(&b);
+    u64* oa = reinterpret_cast<u64*>(&s_out[i]);
+    u64* ob = reinterpret_cast<u64*>(&s_out[i + BLOCK]);
+    __hip_atomic_store(oa, pa[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(oa + 1, pa[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ob, pb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ob + 1, pb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&rew[i], c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&rew[i + BLOCK], d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ void empty_kernel(uint32_t n) {}
 
 template <typename F>
@@ -80,7 +120,15 @@ int main(int argc, char** argv) {
   const uint32_t n = argc > 1 ? (1u << atoi(argv[1])) : (1u << 20);
   const uint32_t n_pairs = n / 2;
   float *s0, *s1, *act, *rew;
-  CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
+  // MB_FINEGRAINED=1: state and reward buffers in fine-grained device memory (system-coherent: is that the same as sc1 stores?)
+  const bool fine = getenv("MB_FINEGRAINED") != nullptr;
+  if (fine) {
+    CK(hipExtMallocWithFlags((void**)&s0, n * 16, hipDeviceMallocFinegrained)); CK(hipExtMallocWithFlags((void**)&s1, n * 16, hipDeviceMallocFinegrained));
+    CK(hipExtMallocWithFlags((void**)&rew, n * 4, hipDeviceMallocFinegrained)); CK(hipMalloc(&act, n * 8));
+    printf("(fine-grained state / reward buffers)\n");
+  } else {
+    CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
+  }
   CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(s1, 0, n * 16)); CK(hipMemset(act, 0, n * 8));
   float* st[2] = {s0, s1};
   const int iters = 500;
@@ -108,5 +156,14 @@ int main(int argc, char** argv) {
   t = time_it([&](int i) { hipLaunchKernelGGL((copy_split<BLOCK>), dim3((n + 2 * BLOCK - 1) / (2 * BLOCK)), dim3(BLOCK), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float2*)act, rew, n); }, iters); REPORT(LABEL);
   SPLIT(256, "2 rows/thread coalesced block 256")
   SPLIT(512, "2 rows/thread coalesced block 512")
+#define POLICY(MODE, LABEL) \
+  t = time_it([&](int i) { hipLaunchKernelGGL((copy_split_policy<256, MODE>), dim3((n + 511) / 512), dim3(256), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float2*)act, rew, n); }, iters); REPORT(LABEL);
+  POLICY(0, "  tile-split, stores (asm) default")
+  POLICY(1, "  tile-split, stores sc0")
+  POLICY(2, "  tile-split, stores sc1")
+  POLICY(3, "  tile-split, stores sc0 sc1")
+  POLICY(4, "  tile-split, stores nt")
+  POLICY(5, "  tile-split, stores sc1 nt")
+  POLICY(6, "  tile-split, system-scope atomic stores")
   return 0;
 }
