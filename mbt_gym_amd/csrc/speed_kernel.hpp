@@ -105,7 +105,7 @@ __device__ __forceinline__ SpeedLane load_speed_row(const float* state, uint32_t
   return SpeedLane{r[0], r[1], r[3], r[4]};
 }
 
-template <class V>
+template <class V, bool THROUGH = true>
 __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, const SpeedLane& s, float t, bool normalise, const StepParams& P) {
   float row[5] = {s.cash, s.q, t, s.mid, s.y};
   if (normalise) {
@@ -113,7 +113,8 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
     for (int c = 0; c < V::DIM; ++c) row[c] = normalise_column(row[c], c, P);  // TE:112-118
   }
   if (V::DIM == 4) {  // one whole row per lane: written through the L2 (step_kernel.hpp: store_through)
-    store_through(reinterpret_cast<float4*>(base) + lane, make_float4(row[0], row[1], row[2], row[3]));
+    if (THROUGH) store_through(reinterpret_cast<float4*>(base) + lane, make_float4(row[0], row[1], row[2], row[3]));
+    else reinterpret_cast<float4*>(base)[lane] = make_float4(row[0], row[1], row[2], row[3]);
   } else {
     float* r = base + static_cast<size_t>(lane) * 5;
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
     const uint32_t lane = lane0 + l * kBlockThreads;
     s[l] = load_speed_row<V>(B.state_in, lane);
     qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
-    if (R.obs_traj != nullptr) store_speed_row<V>(R.obs_traj, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
+    if (R.obs_traj != nullptr) store_speed_row<V, false>(R.obs_traj, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
   }
   uint32_t clipped = 0;
   for (uint32_t k = 0; k < R.n_steps; ++k) {
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
       ret[l] += r.reward;
       clipped += (lane < P.n && r.events != 0u) ? 1u : 0u;
       if (R.obs_traj != nullptr)
-        store_speed_row<V>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
+        store_speed_row<V, false>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
       if (R.act_traj != nullptr) R.act_traj[static_cast<size_t>(k) * n_pad + lane] = speed;
       if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lane] = r.reward;
     }

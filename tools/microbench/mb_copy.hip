@@ -100,6 +100,32 @@ __global__ __launch_bounds__(BLOCK) void copy_split_policy(const float4* s_in_, 
   }
 }
 
+// ... and on the LOADS (stores fixed at sc1): all four loads of the thread in one asm block, one wait at its end
+#define LOAD_ASM(BITS)                                                                                                     \
+  asm volatile("global_load_dwordx4 %0, %4, off " BITS "\n\tglobal_load_dwordx4 %1, %5, off " BITS                        \
+               "\n\tglobal_load_dwordx2 %2, %6, off " BITS "\n\tglobal_load_dwordx2 %3, %7, off " BITS "\n\ts_waitcnt vmcnt(0)" \
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                                     \
+               : "v"(&s_in[i]), "v"(&s_in[i + BLOCK]), "v"(&act[i]), "v"(&act[i + BLOCK])                                  \
+               : "memory");
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void copy_split_load_policy(const float4* s_in_, float4* s_out_, const float2* act_, float* rew, uint32_t n) {
+  const v4f* s_in = reinterpret_cast<const v4f*>(s_in_);
+  v4f* s_out = reinterpret_cast<v4f*>(s_out_);
+  const v2f* act = reinterpret_cast<const v2f*>(act_);
+  const uint32_t i = blockIdx.x * (2 * BLOCK) + threadIdx.x;
+  if (i + BLOCK >= n) return;
+  v4f a, b;
+  v2f c, d;
+  if (MODE == 0) { LOAD_ASM("") }
+  if (MODE == 1) { LOAD_ASM("sc0") }
+  if (MODE == 2) { LOAD_ASM("sc1") }
+  if (MODE == 3) { LOAD_ASM("sc0 sc1") }
+  if (MODE == 4) { LOAD_ASM("nt") }
+  if (MODE == 5) { LOAD_ASM("sc1 nt") }
+  a.x += c.x; b.x += d.x;
+  STORE_ASM("sc1")
+}
+
 __global__ void empty_kernel(uint32_t n) {}
 
 template <typename F>
@@ -165,5 +191,13 @@ int main(int argc, char** argv) {
   POLICY(4, "  tile-split, stores nt")
   POLICY(5, "  tile-split, stores sc1 nt")
   POLICY(6, "  tile-split, system-scope atomic stores")
+#define LPOLICY(MODE, LABEL) \
+  t = time_it([&](int i) { hipLaunchKernelGGL((copy_split_load_policy<256, MODE>), dim3((n + 511) / 512), dim3(256), 0, 0, (const float4*)st[i & 1], (float4*)st[(i & 1) ^ 1], (const float2*)act, rew, n); }, iters); REPORT(LABEL);
+  LPOLICY(0, "  stores sc1, loads (asm) default")
+  LPOLICY(1, "  stores sc1, loads sc0")
+  LPOLICY(2, "  stores sc1, loads sc1")
+  LPOLICY(3, "  stores sc1, loads sc0 sc1")
+  LPOLICY(4, "  stores sc1, loads nt")
+  LPOLICY(5, "  stores sc1, loads sc1 nt")
   return 0;
 }
