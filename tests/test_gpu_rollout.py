@@ -153,3 +153,28 @@ def test_generate_trajectory_on_device_equals_the_host_version():
     np.testing.assert_array_equal(rew_d.cpu().numpy(), rew_h)
     env_h.close()
     env_d.close()
+
+
+@pytest.mark.parametrize("log2n", [20, 22])
+def test_back_to_back_launches_equal_the_fused_rollout_at_full_size(log2n):
+    """1000 dependent step launches enqueued without any host synchronisation (the benchmark's pattern; each reads what the
+    previous one wrote through the L2) must leave exactly the state the single fused rollout launch computes in registers:
+    any stale or torn read between launches would show up as a differing row."""
+    cfg, _ = load_case("as_limit_pnl")
+    cfg.num_trajectories, cfg.n_steps, cfg.seed, cfg.max_inventory = 1 << log2n, 1000, 31, 1000
+    env_a, env_b = make_env(cfg), make_env(cfg)
+    agent = FixedActionAgent(np.array([0.7, 0.7], np.float32), env_a)
+    env_a.reset_device()
+    steps, done = env_a.rollout_device(agent)
+    assert steps == 1000 and done
+    env_b.reset_device()
+    env_b.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (cfg.num_trajectories, 1)))
+    finished = False
+    for _ in range(1000):
+        finished = env_b.step_device()
+    assert finished
+    state_a, state_b = env_a.state, env_b.state
+    assert np.array_equal(state_a, state_b), f"{np.count_nonzero(np.any(state_a != state_b, axis=1))} rows differ"
+    np.testing.assert_allclose(env_a.episode_return_sums()[0], env_b.episode_return_sums()[0], rtol=1e-6)
+    env_a.close()
+    env_b.close()
