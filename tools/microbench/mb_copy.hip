@@ -156,6 +156,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&s0, n * 16)); CK(hipMalloc(&s1, n * 16)); CK(hipMalloc(&act, n * 8)); CK(hipMalloc(&rew, n * 4));
   }
   CK(hipMemset(s0, 0, n * 16)); CK(hipMemset(s1, 0, n * 16)); CK(hipMemset(act, 0, n * 8));
+  if (getenv("MB_RANDOM_DATA") != nullptr) {  // does the floor depend on WHAT is copied?  (all-zero buffers vs noise)
+    uint32_t* h = (uint32_t*)malloc((size_t)n * 16);
+    uint32_t x = 12345u;
+    for (size_t k = 0; k < (size_t)n * 4; ++k) { x = x * 1664525u + 1013904223u; h[k] = (x >> 9) | 0x3f800000u; }  // floats in [1,2)
+    CK(hipMemcpy(s0, h, (size_t)n * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(s1, h, (size_t)n * 16, hipMemcpyHostToDevice));
+    CK(hipMemcpy(act, h, (size_t)n * 8, hipMemcpyHostToDevice));
+    free(h);
+    printf("(random data)\n");
+  }
   float* st[2] = {s0, s1};
   const int iters = 500;
   const double bytes = 44.0 * n;

@@ -31,7 +31,8 @@ python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null
 
 make -C tools/microbench > /dev/null 2>&1
 {
-  for n in 20 22 24; do echo "== mb_copy $n"; tools/microbench/mb_copy $n; done
+  for n in 20 22 24; do echo "== mb_copy $n (buffers of zeros)"; tools/microbench/mb_copy $n; done
+  for n in 20 22 24; do echo "== mb_copy $n, random data"; MB_RANDOM_DATA=1 tools/microbench/mb_copy $n; done
   for n in 18 20 22 24; do echo "== mb_step $n"; tools/microbench/mb_step $n; done
   for n in 20 22 24; do echo "== mb_rows6 $n"; tools/microbench/mb_rows6 $n; done
 } > "$OUT/${TAG}_microbench_raw.txt" 2>&1
