@@ -145,6 +145,11 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
 #pragma unroll
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
   }
+  // 20-byte rows (D = 5) would leave the thread as five 4-byte stores per lane, each covering part of a cache line: such
+  // stores cannot be written through the L2 (step_kernel.hpp: store_through).  The workgroup therefore assembles its
+  // 1024 x 5 floats in LDS (20 KB; consecutive threads write at a stride of 5 words: no bank conflicts) and writes them
+  // out as 1280 contiguous, whole-line float4 - through the L2.
+  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];
   float r_sum = 0.0f;
   bool clipped = false;
   uint32_t n_clipped = 0;
@@ -152,7 +157,12 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
   for (int l = 0; l < 4; ++l) {
     const uint32_t lane = lane0 + l * kBlockThreads;
     const SpeedResult r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
-    store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
+    if (V::DIM == 5) {
+      float* row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
+      row[0] = r.next.cash; row[1] = r.next.q; row[2] = P.t_next; row[3] = r.next.mid; row[4] = r.next.y;
+    } else {
+      store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
+    }
     store_through(B.reward + lane, r.reward);
     if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, r.next, P.t_next, P.norm_obs != 0, P);
     if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
@@ -161,6 +171,13 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     r_sum += real ? r.reward : 0.0f;
     clipped = real && r.events != 0u;
     n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped));
+  }
+  if (V::DIM == 5) {
+    __syncthreads();
+    const float4* staged = reinterpret_cast<const float4*>(staged_rows);
+    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
   }
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
