@@ -556,9 +556,21 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
-                                             const LaneDraw& d, bool& clipped) {
+                                             const LaneDraw& d, bool& clipped, float* staged_row) {
   const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P);
-  store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
+  if (V::DIM == 4) {
+    store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
+  } else {  // rows wider than 16 bytes go through LDS (see step_kernel): this lane's row, 8-byte pieces
+    float2* row = reinterpret_cast<float2*>(staged_row);
+    row[0] = make_float2(r.core.x, r.core.y);
+    row[1] = make_float2(r.core.z, r.core.w);
+    if (V::DIM == 6) {
+      row[2] = V::ARR == kArrHawkes ? r.lam : make_float2(P.exo_depth[0], P.exo_depth[1]);
+    } else {
+      row[2] = r.lam;
+      row[3] = make_float2(P.exo_depth[0], P.exo_depth[1]);
+    }
+  }
   store_through(B.reward + lane, r.reward);
   // -- optional outputs (wave-uniform branches)
   if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lane, r.core, r.lam, true, P);
@@ -587,8 +599,21 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
     d1 = make_draw<V>(nz1, P);
     tie_loads_to_draws(L0, L1, d0, d1);
   }
+  // Rows of 24 or 32 bytes (Hawkes intensities, exogenous depths) would leave a thread as several stores that each cover
+  // part of a cache line, which cannot be written through the L2 (store_through).  The workgroup assembles its 512 rows
+  // in LDS instead (12 / 16 KB) and writes them out as contiguous whole-line float4 - through the L2.
+  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM > 4 ? kTileLanes * V::DIM : 4];
   bool clipped0, clipped1;
-  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0), r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1);
+  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM);
+  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM);
+  if (V::DIM > 4) {
+    __syncthreads();
+    constexpr int kVectors = kTileLanes * V::DIM / 4 / kBlockThreads;  // float4 per thread: 3 (D = 6) or 4 (D = 8)
+    const float4* staged = reinterpret_cast<const float4*>(staged_rows);
+    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kTileLanes * V::DIM / 4);
+#pragma unroll
+    for (int k = 0; k < kVectors; ++k) store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
+  }
   if ((blockIdx.x + 1u) * kTileLanes > P.n) {  // only the last tile can hold pad lanes: computed, never reported
     const bool real0 = lane0 < P.n, real1 = lane1 < P.n;
     r0 = real0 ? r0 : 0.0f;

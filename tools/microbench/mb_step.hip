@@ -60,9 +60,9 @@ __global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_tiles(const mb
     philox_pair_noise(pair, P.philox_step, P.key0, P.key1, nz0, nz1);
     LaneDraw d0 = make_draw<V>(nz0, P), d1 = make_draw<V>(nz1, P);
     tie_loads_to_draws(L0[t], L1[t], d0, d1);
-    r_sum += finish_lane<V>(B, P, lane0, L0[t], d0, c);
+    r_sum += finish_lane<V>(B, P, lane0, L0[t], d0, c, nullptr);  // (D = 4 only: no staging)
     clipped |= c;
-    r_sum += finish_lane<V>(B, P, lane1, L1[t], d1, c);
+    r_sum += finish_lane<V>(B, P, lane1, L1[t], d1, c, nullptr);
     clipped |= c;
   }
   if (__builtin_expect(clipped, 0)) atomicAdd(B.clip_count, 1ull);
