@@ -60,14 +60,28 @@ def build_env(n, rank, device):
 
 
 def run_steps(env, k, device, returns):
-    """k env.step() launches.  When an episode ends: all-reduce its [sum R, sum R^2, count] across ranks (the only
-    collective on the path, 3 doubles over RCCL) and restart it (reset kernel), like a VecEnv consumer would."""
-    from mbt_gym_amd.distributed import allreduce_return_sums
+    """k env.step() launches.  When an episode ends: reduce its [sum R, sum R^2, count] on the device, all-reduce the
+    three doubles across ranks (the only collective on the path, RCCL) and restart the episode (reset kernel), like a
+    VecEnv consumer would.  The boundary is pipelined - the device reduction is read back, and the collective waited
+    for, one episode later (and everything outstanding before this function returns) - so that 24 bytes of statistics
+    do not drain a stream that has a thousand launches in flight."""
+    from mbt_gym_amd.distributed import PendingReturnSums
 
+    reduction_in_flight, collective = False, None
     for _ in range(k):
         if env.step_device():
-            returns.append(allreduce_return_sums(env.episode_return_sums(), device=device))
+            if collective is not None:
+                returns.append(collective.result())
+                collective = None
+            if reduction_in_flight:
+                collective = PendingReturnSums(env.episode_return_sums_end(), device=device)
+            env.episode_return_sums_begin()
+            reduction_in_flight = True
             env.reset_device()
+    if collective is not None:
+        returns.append(collective.result())
+    if reduction_in_flight:
+        returns.append(PendingReturnSums(env.episode_return_sums_end(), device=device).result())
 
 
 def pmc_traffic(n):

@@ -244,6 +244,11 @@ int mbt_env_clip_count(mbt_env* env, uint64_t* count);
  * multi-GPU all-reduce carries. */
 int mbt_env_track_lane_returns(mbt_env* env, int enabled);
 int mbt_env_return_sums(mbt_env* env, double sums[3]);
+/* The same in two halves, so that an episode boundary does not drain the stream: _begin enqueues the reduction of the
+ * episode that just ended (then reset and keep stepping), _end waits for that reduction alone and returns the sums.
+ * One request in flight at a time. */
+int mbt_env_return_sums_begin(mbt_env* env);
+int mbt_env_return_sums_end(mbt_env* env, double sums[3]);
 
 /* ---- RewardFunction.calculate on caller-supplied matrices (RW:23-33, RW:96-109, RW:128-138) ---------------------
  * cur, nxt: (n, dim) row-major float64 state matrices; q_init, episode_length: (n) float64, only for MBT_REW_CJ_MM /

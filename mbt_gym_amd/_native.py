@@ -129,6 +129,8 @@ SIGNATURES = {
     "mbt_env_clip_count": (C.c_int, [_ENV, C.POINTER(C.c_uint64)]),
     "mbt_env_track_lane_returns": (C.c_int, [_ENV, C.c_int]),
     "mbt_env_return_sums": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
+    "mbt_env_return_sums_begin": (C.c_int, [_ENV]),
+    "mbt_env_return_sums_end": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),

@@ -178,6 +178,9 @@ struct mbt_env {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_sums = nullptr;   // mbt_env_return_sums_begin / _end
+  double* h_sums = nullptr;       // pinned: [sum of rewards, sum of squared per-lane returns]
+  bool sums_pending = false;
   // device buffers
   float* state[2] = {nullptr, nullptr};
   int cur = 0;  // state[cur] holds the current state
@@ -595,7 +598,9 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     return fail(MBT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
   }
   e->own_stream = true;
-  if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess) {
+  if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_sums, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&e->h_sums), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     mbt_env_destroy(e);
     return fail(MBT_ERR_HIP, "hipEventCreate failed");
   }
@@ -649,6 +654,8 @@ void mbt_env_destroy(mbt_env* e) {
   if (e->h_stage != nullptr) (void)hipHostFree(e->h_stage);
   if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);
   if (e->ev_end != nullptr) (void)hipEventDestroy(e->ev_end);
+  if (e->ev_sums != nullptr) (void)hipEventDestroy(e->ev_sums);
+  if (e->h_sums != nullptr) (void)hipHostFree(e->h_sums);
   if (e->own_stream && e->stream != nullptr) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -906,6 +913,30 @@ int mbt_env_return_sums(mbt_env* e, double sums[3]) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   sums[0] = host[0];
   sums[1] = e->track_returns ? host[1] : NAN;
+  sums[2] = static_cast<double>(e->n);
+  return MBT_OK;
+}
+
+int mbt_env_return_sums_begin(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (e->sums_pending) return fail(MBT_ERR_STATE, "a return-sums request is already in flight: call mbt_env_return_sums_end first");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(mbt::reduce_returns_kernel, dim3(1), dim3(256), 0, e->stream, e->wave_sums, e->n_waves,
+                     e->track_returns ? e->lane_returns : nullptr, e->n, e->reduce_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(e->h_sums, e->reduce_out, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipEventRecord(e->ev_sums, e->stream));
+  e->sums_pending = true;
+  return MBT_OK;
+}
+
+int mbt_env_return_sums_end(mbt_env* e, double sums[3]) {
+  if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!e->sums_pending) return fail(MBT_ERR_STATE, "no return-sums request in flight");
+  HIP_TRY(hipEventSynchronize(e->ev_sums));  // waits for the reduction only: later launches keep running
+  e->sums_pending = false;
+  sums[0] = e->h_sums[0];
+  sums[1] = e->track_returns ? e->h_sums[1] : NAN;
   sums[2] = static_cast<double>(e->n);
   return MBT_OK;
 }

@@ -43,6 +43,32 @@ def allreduce_return_sums(sums, device=None) -> np.ndarray:
     return out
 
 
+class PendingReturnSums:
+    """An all-reduce of [sum R, sum R^2, count] that has been started (`async_op=True`) but not waited for: the 24-byte
+    collective of one episode overlaps the stepping of the next.  `result()` waits and returns the global sums."""
+
+    def __init__(self, sums, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self._local = np.asarray(sums, dtype=np.float64)
+        self._work = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            nan = float(np.isnan(self._local[1]))  # a rank that does not track per-lane returns makes the second moment unknown
+            self._t = torch.tensor(list(np.nan_to_num(self._local, nan=0.0)) + [nan], dtype=torch.float64, device=device or "cpu")
+            self._work = dist.all_reduce(self._t, op=dist.ReduceOp.SUM, async_op=True)
+
+    def result(self) -> np.ndarray:
+        if self._work is None:
+            return self._local
+        self._work.wait()
+        out = self._t.cpu().numpy()
+        sums = out[:3].copy()
+        if out[3] > 0:
+            sums[1] = np.nan
+        return sums
+
+
 def return_statistics(sums) -> Tuple[float, float]:
     """(mean, population std) of the episode return from [sum R, sum R^2, count] (plotting.py:104-105)."""
     total, total_sq, count = (float(x) for x in sums)

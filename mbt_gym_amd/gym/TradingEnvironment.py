@@ -389,6 +389,17 @@ class TradingEnvironment(_EnvBase):
         _native.check(_native.load_library().mbt_env_return_sums(self._handle, out))
         return np.array(out[:], dtype=np.float64)
 
+    def episode_return_sums_begin(self):
+        """First half of `episode_return_sums()`: enqueue the reduction of the episode that just ended and return at
+        once - reset and keep stepping; nothing waits for the stream."""
+        _native.check(_native.load_library().mbt_env_return_sums_begin(self._handle))
+
+    def episode_return_sums_end(self) -> np.ndarray:
+        """Second half: wait for that reduction alone (not for the steps enqueued since) and return the three doubles."""
+        out = (C.c_double * 3)()
+        _native.check(_native.load_library().mbt_env_return_sums_end(self._handle, out))
+        return np.array(out[:], dtype=np.float64)
+
     # ---------------------------------------------------------------------------------------------------
     # state / normalisation helpers with the reference's names
     # ---------------------------------------------------------------------------------------------------
@@ -529,7 +540,11 @@ class TradingEnvironment(_EnvBase):
         The initial inventory and episode length CjMmCriterion captures at reset (RW:111-113) go with them."""
         start = self._get_start_time()
         q0 = self._get_initial_inventories()
-        _native.check(_native.load_library().mbt_env_reset_host(self._handle, start, _native.fptr(q0), _native.fptr(obs_out)))
+        lib = _native.load_library()
+        if obs_out is None:  # nothing to hand back: enqueue the reset without waiting for the stream
+            _native.check(lib.mbt_env_reset(self._handle, start, _native.fptr(q0)))
+        else:
+            _native.check(lib.mbt_env_reset_host(self._handle, start, _native.fptr(q0), _native.fptr(obs_out)))
 
     def _infos(self):
         if self._empty_infos is None:  # TE:320-321: one shared list of dicts, reused every step

@@ -7,7 +7,7 @@ import socket
 import numpy as np
 import pytest
 
-from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics, shard_bounds
+from mbt_gym_amd.distributed import PendingReturnSums, allreduce_return_sums, return_statistics, shard_bounds
 from oracle.mbt_oracle import OracleConfig, OracleEnv
 from oracle.philox_ref import PhiloxNoise
 
@@ -45,7 +45,12 @@ def _worker(rank, world, port, queue):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     offset, count = shard_bounds(N, rank, world)
     r = _returns(offset, count)
-    sums = allreduce_return_sums(np.array([r.sum(), (r * r).sum(), count]))
+    local = np.array([r.sum(), (r * r).sum(), count])
+    pending = PendingReturnSums(local)  # the pipelined form bench.py uses: started now, waited for later
+    sums = allreduce_return_sums(local)
+    np.testing.assert_array_equal(pending.result(), sums)
+    untracked = PendingReturnSums(np.array([r.sum(), np.nan if rank == 1 else (r * r).sum(), count])).result()
+    assert np.isnan(untracked[1]) and untracked[0] == sums[0] and untracked[2] == sums[2]
     queue.put((rank, sums.tolist(), r.tolist()))
     dist.barrier()
     dist.destroy_process_group()

@@ -172,3 +172,31 @@ def test_clip_counter_counts_every_clipped_lane_step():
     assert np.all(obs[:, 1] == -floor)
     assert env.clip_count == n * (10 - floor)
     env.close()
+
+
+def test_return_sums_in_two_halves_do_not_need_the_stream_to_drain():
+    """episode_return_sums_begin / _end: the reduction enqueued at an episode boundary is read back after the NEXT episode
+    has been enqueued, and equals the synchronous call made at the same point of a twin environment."""
+    cfg = _as_cfg(5000, n_steps=30)
+    env, twin = make_env(cfg), make_env(cfg)
+    action = np.tile(np.array([[0.7, 0.7]], np.float32), (5000, 1))
+    for e in (env, twin):
+        e.track_lane_returns(True)
+        e.reset_device()
+        e.set_action_host(action)
+    for _ in range(30):
+        env.step_device()
+        twin.step_device()
+    want = twin.episode_return_sums()
+    env.episode_return_sums_begin()
+    with pytest.raises(Exception):
+        env.episode_return_sums_begin()  # one request at a time
+    env.reset_device()
+    for _ in range(30):
+        env.step_device()  # the next episode is already in flight when the sums are collected
+    got = env.episode_return_sums_end()
+    np.testing.assert_array_equal(got, want)
+    with pytest.raises(Exception):
+        env.episode_return_sums_end()
+    env.close()
+    twin.close()
