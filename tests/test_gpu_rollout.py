@@ -155,26 +155,41 @@ def test_generate_trajectory_on_device_equals_the_host_version():
     env_d.close()
 
 
-@pytest.mark.parametrize("log2n", [20, 22])
-def test_back_to_back_launches_equal_the_fused_rollout_at_full_size(log2n):
-    """1000 dependent step launches enqueued without any host synchronisation (the benchmark's pattern; each reads what the
-    previous one wrote through the L2) must leave exactly the state the single fused rollout launch computes in registers:
-    any stale or torn read between launches would show up as a differing row."""
-    cfg, _ = load_case("as_limit_pnl")
-    cfg.num_trajectories, cfg.n_steps, cfg.seed, cfg.max_inventory = 1 << log2n, 1000, 31, 1000
+@pytest.mark.parametrize("name,log2n", [("as_limit_pnl", 20), ("as_limit_pnl", 22), ("hawkes_ou", 21), ("limit_and_market", 20),
+                                        ("default_normalised", 20), ("speed_temp_perm_cjoe", 20), ("speed_power_running", 20)])
+def test_back_to_back_launches_equal_the_fused_rollout_at_full_size(name, log2n):
+    """Hundreds of dependent step launches enqueued without any host synchronisation (the benchmark's pattern; each reads what
+    the previous one wrote through the L2, rows wider than 16 bytes via the LDS-assembled output) must leave exactly the state
+    the single fused rollout launch computes in registers: any stale or torn read between launches would show up as a
+    differing row."""
+    cfg, g = load_case(name)
+    steps = 1000 if name == "as_limit_pnl" else 300
+    cfg.num_trajectories, cfg.n_steps, cfg.seed = 1 << log2n, steps, 31
+    if isinstance(cfg.initial_inventory, tuple):
+        cfg.initial_inventory = 1
+    if cfg.dynamics == "speed":
+        cfg.impact_step_size = cfg.terminal_time / steps
+    fixed = {"limit_and_market": [0.7, 0.6, 0.0, 1.0], "default_normalised": [-0.5, -0.4]}.get(name, [0.5] if cfg.dynamics == "speed" else [0.7, 0.6])
     env_a, env_b = make_env(cfg), make_env(cfg)
-    agent = FixedActionAgent(np.array([0.7, 0.7], np.float32), env_a)
+    agent = FixedActionAgent(np.array(fixed, np.float32), env_a)
     env_a.reset_device()
-    steps, done = env_a.rollout_device(agent)
-    assert steps == 1000 and done
+    n_done, done = env_a.rollout_device(agent)
+    assert n_done == steps and done
     env_b.reset_device()
-    env_b.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (cfg.num_trajectories, 1)))
+    env_b.set_action_host(np.tile(np.array([fixed], np.float32), (cfg.num_trajectories, 1)))
     finished = False
-    for _ in range(1000):
+    for _ in range(steps):
         finished = env_b.step_device()
     assert finished
     state_a, state_b = env_a.state, env_b.state
     assert np.array_equal(state_a, state_b), f"{np.count_nonzero(np.any(state_a != state_b, axis=1))} rows differ"
+    if cfg.normalise_observation_space:
+        obs_a, obs_b = np.empty_like(state_a), np.empty_like(state_b)
+        from mbt_gym_amd import _native
+        lib = _native.load_library()
+        _native.check(lib.mbt_env_get_obs_host(env_a._handle, _native.fptr(obs_a)))
+        _native.check(lib.mbt_env_get_obs_host(env_b._handle, _native.fptr(obs_b)))
+        assert np.array_equal(obs_a, obs_b)
     np.testing.assert_allclose(env_a.episode_return_sums()[0], env_b.episode_return_sums()[0], rtol=1e-6)
     env_a.close()
     env_b.close()
