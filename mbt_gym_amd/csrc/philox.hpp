@@ -41,8 +41,10 @@ __device__ __forceinline__ PhiloxWords philox4x32_10(uint32_t c0, uint32_t c1, u
   for (int round = 0; round < MBT_PHILOX_ROUNDS; ++round) {
     const uint64_t p0 = static_cast<uint64_t>(M0) * c0;  // one v_mad_u64_u32 yields hi and lo
     const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;  // v_xor3_b32
-    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    // three-way XOR in ONE instruction: gfx950's v_bitop3_b32 with the parity truth table 0x96 (the compiler emits two
+    // v_xor_b32 for `a ^ b ^ c`); 40 VALU fewer per pair of lanes and step - the fused rollout is bound by exactly that
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, k1, 0x96);
     c1 = static_cast<uint32_t>(p1);
     c3 = static_cast<uint32_t>(p0);
     c0 = n0;
