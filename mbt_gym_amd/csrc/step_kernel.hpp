@@ -197,7 +197,7 @@ struct FillTest {
 
 __device__ __forceinline__ void fill_thresholds(float u, const StepParams& P, float& lo, float& hi) {
   const float t = __builtin_amdgcn_logf(u) * P.fill_depth_per_log2;  // -ln(u) / kappa  (v_log_f32 is log2)
-  const float band = __builtin_fmaf(__builtin_fabsf(t), 1e-6f, P.fill_band_abs);
+  const float band = __builtin_fmaf(t, 1e-6f, P.fill_band_abs);  // t >= 0 for u in [0, 1]
   lo = t - band;
   hi = t + band;
 }
