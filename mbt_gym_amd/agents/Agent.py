@@ -1,11 +1,14 @@
-import abc
+"""The policy interface of the reference (mbt_gym/agents/Agent.py:6-12): a batch of observations in, a batch of actions out.
 
-import numpy as np
+Agents of this package may additionally implement `device_policy()` and return an `mbt_gym_amd._native.MbtPolicy`
+describing themselves to the fused rollout kernel (closed forms and tables only); `get_action` stays the source of truth
+and the tests compare the two."""
+from abc import ABC, abstractmethod
+
+from numpy import ndarray
 
 
-class Agent(metaclass=abc.ABCMeta):
-    """A policy: observation matrix (N, D) -> action matrix (N, A) (reference: mbt_gym/agents/Agent.py:6-12)."""
-
-    @abc.abstractmethod
-    def get_action(self, state: np.ndarray) -> np.ndarray:
-        pass
+class Agent(ABC):
+    @abstractmethod
+    def get_action(self, state: ndarray) -> ndarray:
+        """(N, D) observations -> (N, A) actions."""

@@ -18,10 +18,10 @@ except Exception:  # noqa: BLE001
     HAVE_SB3 = False
 
     class _VecEnvBase:
+        """num_envs / observation_space / action_space and the step = step_async + step_wait split of SB3's VecEnv."""
+
         def __init__(self, num_envs, observation_space, action_space):
-            self.num_envs = num_envs
-            self.observation_space = observation_space
-            self.action_space = action_space
+            self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
 
         def step(self, actions):
             self.step_async(actions)
@@ -29,53 +29,60 @@ except Exception:  # noqa: BLE001
 
 
 class StableBaselinesTradingEnvironment(_VecEnvBase):
+    """All trajectories of one TradingEnvironment as the sub-environments of a VecEnv (they share the episode clock)."""
+
     def __init__(self, trading_env, store_terminal_observation_info: bool = True):
         self.env = trading_env
         self.store_terminal_observation_info = store_terminal_observation_info
-        self.actions: np.ndarray = self.env.action_space.sample()
-        super().__init__(self.env.num_trajectories, self.env.observation_space, self.env.action_space)
+        self.actions: np.ndarray = trading_env.action_space.sample()  # SBE:18: a placeholder until the first step_async
+        _VecEnvBase.__init__(self, trading_env.num_trajectories, trading_env.observation_space, trading_env.action_space)
 
+    # ---- the stepping protocol ----------------------------------------------------------------------------------
     def reset(self):
         return self.env.reset()
 
     def step_async(self, actions: np.ndarray) -> None:
-        self.actions = actions
+        self.actions = actions  # nothing is launched yet (SBE:25-26)
 
     def step_wait(self):
         obs, rewards, dones, infos = self.env.step(self.actions)
-        if dones.min():
-            if self.store_terminal_observation_info:
-                infos = infos.copy() if isinstance(infos, list) else [infos]
-                for lane, info in enumerate(infos):
-                    info["terminal_observation"] = obs[lane, :]
-            obs = self.env.reset()
-        return obs, rewards, dones, infos
-
-    def close(self) -> None:
-        self.env.close()
-
-    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
-        return [getattr(self.env, attr_name)] * self.env.num_trajectories
-
-    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
-        pass
-
-    def env_method(self, method_name: str, *method_args, indices=None, **method_kwargs) -> List[Any]:
-        pass
-
-    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
-        return [False for _ in range(self.env.num_trajectories)]
+        if not dones.min():
+            return obs, rewards, dones, infos
+        # episode over in every lane (the clock is shared): hand out the terminal observation, then auto-reset (SBE:28-37)
+        if self.store_terminal_observation_info:
+            infos = list(infos) if isinstance(infos, list) else [infos]
+            for lane in range(len(infos)):
+                infos[lane]["terminal_observation"] = obs[lane, :]
+        return self.env.reset(), rewards, dones, infos
 
     def seed(self, seed: Optional[int] = None):
         return self.env.seed(seed)
 
-    def get_images(self) -> Sequence[np.ndarray]:
-        pass
+    def close(self) -> None:
+        self.env.close()
 
+    # ---- the attribute / method plumbing SB3 expects of a VecEnv (SBE:39-58) ------------------------------------
+    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
+        value = getattr(self.env, attr_name)
+        return [value for _ in range(self.num_trajectories)]
+
+    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
+        return None  # not supported upstream either
+
+    def env_method(self, method_name: str, *method_args, indices=None, **method_kwargs) -> List[Any]:
+        return None
+
+    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
+        return [False] * self.num_trajectories
+
+    def get_images(self) -> Sequence[np.ndarray]:
+        return None
+
+    # ---- conveniences the reference's training scripts read -----------------------------------------------------
     @property
-    def num_trajectories(self):
+    def num_trajectories(self) -> int:
         return self.env.num_trajectories
 
     @property
-    def n_steps(self):
+    def n_steps(self) -> int:
         return self.env.n_steps
