@@ -52,53 +52,60 @@ except Exception:  # noqa: BLE001
             return close() if close is not None else None
 
 
-class ReduceStateSizeWrapper(Wrapper):
-    """Keeps the listed observation columns (default: inventory and time), wrappers.py:15-39."""
+class _ObservationView(Wrapper):
+    """Shared plumbing of the observation wrappers: `_on_reset` / `_on_step` map the observation the environment hands
+    back; rewards, dones and infos pass through untouched."""
 
-    def __init__(self, env, list_of_state_indices: list = [INVENTORY_INDEX, TIME_INDEX]):
-        super().__init__(env)
-        assert isinstance(env.observation_space, Box)
-        self.observation_space = Box(
-            low=env.observation_space.low[list_of_state_indices],
-            high=env.observation_space.high[list_of_state_indices],
-            dtype=np.float64,
-        )
-        self.list_of_state_indices = list_of_state_indices
+    def _on_reset(self, obs):
+        return obs
+
+    def _on_step(self, obs):
+        return obs
 
     def reset(self):
-        obs = self.env.reset()
-        return obs[:, self.list_of_state_indices]
+        return self._on_reset(self.env.reset())
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
-        return obs[:, self.list_of_state_indices], reward, done, info
+        return self._on_step(obs), reward, done, info
 
     @property
     def spec(self):
         return getattr(self.env, "spec", None)
 
 
-class NormaliseASObservation(Wrapper):
+class ReduceStateSizeWrapper(_ObservationView):
+    """Keeps the listed observation columns (default: inventory and time), wrappers.py:15-39."""
+
+    def __init__(self, env, list_of_state_indices: list = [INVENTORY_INDEX, TIME_INDEX]):
+        super().__init__(env)
+        assert isinstance(env.observation_space, Box)
+        self.list_of_state_indices = list_of_state_indices
+        box = env.observation_space
+        self.observation_space = Box(low=box.low[list_of_state_indices], high=box.high[list_of_state_indices], dtype=np.float64)
+
+    def _on_reset(self, obs):
+        return obs[:, self.list_of_state_indices]
+
+    _on_step = _on_reset
+
+
+class NormaliseASObservation(_ObservationView):
     """Affine map of the observation box onto [-1, 1]^D (wrappers.py:51-76), including the reference's step/reset asymmetry."""
 
     def __init__(self, env):
         super().__init__(env)
         assert isinstance(env.observation_space, Box)
-        self.normalisation_factor = 2 / (env.observation_space.high - env.observation_space.low)
-        self.normalisation_offset = (env.observation_space.high + env.observation_space.low) / 2
-        self.observation_space = Box(
-            low=-np.ones(env.observation_space.shape),
-            high=np.ones(env.observation_space.shape),
-            dtype=np.float64,
-        )
+        box = env.observation_space
+        self.normalisation_factor = 2 / (box.high - box.low)
+        self.normalisation_offset = (box.high + box.low) / 2
+        self.observation_space = Box(low=-np.ones(box.shape), high=np.ones(box.shape), dtype=np.float64)
 
-    def reset(self):
-        obs = self.env.reset()
-        return (obs - self.normalisation_offset) * self.normalisation_factor
+    def _on_reset(self, obs):
+        return (obs - self.normalisation_offset) * self.normalisation_factor  # wrappers.py:68
 
-    def step(self, action):
-        obs, reward, done, info = self.env.step(action)
-        return obs / self.normalisation_factor, reward, done, info
+    def _on_step(self, obs):
+        return obs / self.normalisation_factor  # wrappers.py:76 (sic)
 
 
 class RemoveTerminalRewards(Wrapper):
@@ -107,13 +114,9 @@ class RemoveTerminalRewards(Wrapper):
     def __init__(self, env, num_final_steps: int = 5):
         super().__init__(env)
 
-    def reset(self):
-        return self.env.reset()
-
     def step(self, action):
         state, reward, done, _ = self.env.step(action)
         if np.asarray(done).reshape(-1)[0]:
-            reward = reward * (
-                self.env.reward_function.per_step_inventory_aversion / self.env.reward_function.terminal_inventory_aversion
-            )
+            criterion = self.env.reward_function
+            reward = reward * (criterion.per_step_inventory_aversion / criterion.terminal_inventory_aversion)
         return state, reward, done, {}
