@@ -2,11 +2,26 @@
 path: they map the observation matrix to an action matrix on the host, once per step."""
 import warnings
 
+from copy import deepcopy
+
 import numpy as np
 
 from mbt_gym_amd import _native
 from mbt_gym_amd.agents.Agent import Agent
 from mbt_gym_amd.gym.index_names import ASSET_PRICE_INDEX, CASH_INDEX, INVENTORY_INDEX, TIME_INDEX
+
+
+class RandomAgent(Agent):
+    """One draw from a private copy of the action space, repeated for every trajectory (AG:15-22)."""
+
+    def __init__(self, env, seed: int = None):
+        self.action_space = deepcopy(env.action_space)
+        self.action_space.seed(seed)
+        self.num_trajectories = env.num_trajectories
+
+    def get_action(self, state: np.ndarray) -> np.ndarray:
+        one = np.asarray(self.action_space.sample(), dtype=np.float32).reshape(1, -1)
+        return np.repeat(one, self.num_trajectories, axis=0)
 
 
 class FixedActionAgent(Agent):

@@ -72,6 +72,12 @@ class ModelDynamics(metaclass=abc.ABCMeta):
         self._env.set_state(value)
 
     @property
+    def fill_multiplier(self) -> np.ndarray:
+        """(N, 2) signs [-1, +1]: a bid fill buys, an ask fill sells (MD:71-73; the kernel has them built in)."""
+        ones = np.ones((self.num_trajectories, 1))
+        return np.append(-ones, ones, axis=1)
+
+    @property
     def midprice(self) -> np.ndarray:
         return self.midprice_model.current_state[:, 0].reshape(-1, 1)
 

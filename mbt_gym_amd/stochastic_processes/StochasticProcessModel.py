@@ -42,6 +42,9 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         self.terminal_time = terminal_time
         self.num_trajectories = num_trajectories
         self.seed_ = seed
+        # API parity only (SP:27): the reference draws from this generator, the device draws from Philox keyed by the
+        # environment's seed - nothing on the path consumes it
+        self.rng = np.random.default_rng(seed)
         self._env = None  # set by TradingEnvironment: (env, first column, last column)
         self._columns = None
 
@@ -78,6 +81,7 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         # The reference gives process i its own generator seeded seed+i+1 (TE:345-348).  On the device all
         # processes read disjoint words of ONE Philox stream keyed by the environment seed; the per-process
         # number is kept for API parity only.
+        self.rng = np.random.default_rng(seed)
         self.seed_ = seed
 
     def update(self, arrivals, fills, action, state=None):

@@ -166,3 +166,24 @@ def test_sb3_adapter_auto_reset_and_terminal_observation():
     assert venv.env_is_wrapped(object) == [False, False, False]
     venv.seed(7)
     assert inner.seeded == 7
+
+
+@pytest.mark.parametrize("name", ["as_limit_pnl", "hawkes_ou", "exo_fill_hawkes_market", "speed_temp_transient_pnl", "cjp_cjmm"])
+def test_initial_state_and_small_api_surface(name, no_device):
+    """initial_state (TE:131-140) equals the reference's first observation; fill_multiplier, RandomAgent and the
+    processes' generators exist with the reference's shapes."""
+    from mbt_gym_amd.agents.BaselineAgents import RandomAgent
+
+    cfg, g = load_case(name)
+    env = make_env(cfg)
+    if not isinstance(cfg.initial_inventory, tuple):
+        np.testing.assert_array_equal(env.initial_state, g["obs0"])
+    else:  # random initial inventories: every call draws afresh from the environment's generator (TE:271-272)
+        first = env.initial_state
+        assert first.shape == g["obs0"].shape and np.all(first[:, 1] >= cfg.initial_inventory[0]) and np.all(first[:, 1] < cfg.initial_inventory[1])
+        np.testing.assert_array_equal(np.delete(first, 1, axis=1), np.delete(g["obs0"], 1, axis=1))
+    np.testing.assert_array_equal(env.model_dynamics.fill_multiplier, np.tile([-1.0, 1.0], (cfg.num_trajectories, 1)))
+    for proc in env.stochastic_processes.values():
+        assert isinstance(proc.rng, np.random.Generator)
+    action = RandomAgent(env, seed=3).get_action(None)
+    assert action.shape == (cfg.num_trajectories, env.action_space.shape[0]) and np.all(action == action[0])
