@@ -187,3 +187,31 @@ def test_initial_state_and_small_api_surface(name, no_device):
         assert isinstance(proc.rng, np.random.Generator)
     action = RandomAgent(env, seed=3).get_action(None)
     assert action.shape == (cfg.num_trajectories, env.action_space.shape[0]) and np.all(action == action[0])
+
+
+def test_sb_agent_wraps_any_predictor():
+    from mbt_gym_amd.agents.SbAgent import SbAgent
+    from mbt_gym_amd.spaces import Box
+
+    class Model:
+        action_space = Box(low=np.float32(0), high=np.float32(3), shape=(2,))
+
+        class env:
+            num_trajectories = 5
+
+        learned = 0
+
+        def predict(self, obs, deterministic=False):
+            assert deterministic
+            return np.stack([obs[:, 0], -obs[:, 0]], axis=1), None
+
+        def learn(self, total_timesteps):
+            self.learned += total_timesteps
+
+    model = Model()
+    obs = np.arange(20, dtype=np.float32).reshape(5, 4)
+    np.testing.assert_array_equal(SbAgent(model).get_action(obs), np.stack([obs[:, 0], -obs[:, 0]], axis=1))
+    np.testing.assert_array_equal(SbAgent(model, reduced_training_indices=[1, 2]).get_action(obs)[:, 0], obs[:, 1])
+    agent = SbAgent(model, num_trajectories=5)
+    agent.train(123)
+    assert model.learned == 123 and agent.num_actions == 2
