@@ -87,6 +87,8 @@ def test_full_episode_device_path_terminates_and_restarts():
 
 # notebooks/Test_1_-_replicate_AS_original_results.ipynb:219-231 / :338-350 (N = 1000, seed 50, numpy noise)
 PUBLISHED = {0.1: (1.49177, 64.872139, 6.692567, 0.201, 2.893544), 0.01: (1.349009, 68.754417, 8.720076, 0.23, 5.095989)}
+# the same agent on the finer grid of notebooks/Baseline_Agents.ipynb:189-214 (n_steps = 2000, max_inventory = n_steps): values :339-350, :475-486
+PUBLISHED_2000 = {0.1: (1.49087, 63.87827, 7.213852, 0.031, 3.318439), 0.01: (1.348919, 68.631525, 10.245411, -0.173, 6.085316)}
 
 
 @pytest.mark.parametrize("gamma", [0.1, 0.01])
@@ -200,3 +202,27 @@ def test_return_sums_in_two_halves_do_not_need_the_stream_to_drain():
         env.episode_return_sums_end()
     env.close()
     twin.close()
+
+
+@pytest.mark.parametrize("gamma", [0.1, 0.01])
+def test_avellaneda_stoikov_statistics_on_the_2000_step_grid(gamma):
+    """The second published Avellaneda-Stoikov table (Baseline_Agents notebook, n_steps = 2000, N = 1000): statistical
+    anchor for a long episode through the fused rollout, statistics reduced on the device."""
+    from mbt_gym_amd.agents.BaselineAgents import AvellanedaStoikovAgent
+    from mbt_gym_amd.gym.helpers.results import COLUMNS, episode_statistics
+    import warnings
+
+    cfg = _as_cfg(1 << 14, n_steps=2000, max_inventory=2000, seed=77)
+    env = make_env(cfg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        stats, totals = episode_statistics(env, AvellanedaStoikovAgent(risk_aversion=gamma, env=env))
+    spread, mean_pnl, std_pnl, mean_q, std_q = PUBLISHED_2000[gamma]
+    se = 1 / np.sqrt(1000)
+    assert stats["Mean spread"] == pytest.approx(spread, abs=4 * 0.35 * se)
+    assert stats["Mean PnL"] == pytest.approx(mean_pnl, abs=4 * std_pnl * se)
+    assert stats["Std PnL"] == pytest.approx(std_pnl, rel=4 * se)
+    assert stats["Mean terminal inventory"] == pytest.approx(mean_q, abs=4 * std_q * se)
+    assert stats["Std terminal inventory"] == pytest.approx(std_q, rel=4 * se)
+    assert totals.shape == (1 << 14,) and list(stats) == COLUMNS
+    env.close()
