@@ -186,8 +186,11 @@ enum {
                                          of (t, q) tabulated by the host, e.g. the Cartea-Jaimungal optimal quotes
                                          (agents/BaselineAgents.py:86-170).  table[(row * table_cols + col) * 2 + side], host
                                          memory, row = round(t / dt), col = clamp(q + table_q_offset, 0, table_cols - 1) */
-  MBT_POLICY_TIME_TABLE = 3           /* open-loop schedule: table[row * A + j], row = round(t / dt), table_cols = A; e.g. the
+  MBT_POLICY_TIME_TABLE = 3,          /* open-loop schedule: table[row * A + j], row = round(t / dt), table_cols = A; e.g. the
                                          Cartea-Jaimungal optimal-execution speed (agents/BaselineAgents.py:173-210) */
+  MBT_POLICY_ACTION_BUFFER = 4        /* every lane repeats ITS row of the (N, A) action buffer (mbt_env_action_ptr / set_action_host)
+                                         for max_steps steps: "action repeat" - k env.step(action) calls of a consumer that acts
+                                         every k-th step, in one launch */
 };
 typedef struct mbt_policy {
   int32_t kind;

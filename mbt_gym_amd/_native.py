@@ -52,7 +52,7 @@ class MbtConfig(C.Structure):
     ]
 
 
-POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE = 0, 1, 2, 3
+POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE, POLICY_ACTION_BUFFER = 0, 1, 2, 3, 4
 
 
 class MbtPolicy(C.Structure):

@@ -351,6 +351,8 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   if (policy->kind == MBT_POLICY_FIXED) {
     R.policy = mbt::kPolicyFixed;
     for (int j = 0; j < e->act_dim; ++j) R.action[j] = static_cast<float>(policy->params[j]);
+  } else if (policy->kind == MBT_POLICY_ACTION_BUFFER) {
+    R.policy = mbt::kPolicyBuffer;  // the kernel reads B.action (the library's action buffer) once per lane
   } else if (policy->kind == MBT_POLICY_TIME_TABLE) {
     if (policy->table == nullptr || policy->table_rows == 0 || policy->table_cols != static_cast<uint32_t>(e->act_dim))
       return fail(MBT_ERR_INVALID, "a time-table policy holds table_rows x action_dim (%d) floats", e->act_dim);
@@ -426,6 +428,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   std::memset(&B, 0, sizeof B);
   B.state_in = e->state[e->cur];
   B.state_out = e->state[e->cur ^ 1];
+  B.action = e->action;  // read by MBT_POLICY_ACTION_BUFFER only
   B.reward = e->reward;
   B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
   B.q_init = e->q_init_per_lane ? e->q_init : nullptr;

@@ -206,6 +206,11 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
     qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
     if (R.obs_traj != nullptr) store_speed_row<V, false>(R.obs_traj, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
   }
+  float held[4] = {0.f, 0.f, 0.f, 0.f};
+  if (R.policy == kPolicyBuffer) {  // action repeat: each lane keeps its entry of the action buffer
+#pragma unroll
+    for (int l = 0; l < 4; ++l) held[l] = B.action[lane0 + l * kBlockThreads];
+  }
   uint32_t clipped = 0;
   for (uint32_t k = 0; k < R.n_steps; ++k) {
     const QuadNoise nz = philox_quad_noise(quad, P.philox_step + k, P.key0, P.key1);
@@ -216,7 +221,8 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const uint32_t lane = lane0 + l * kBlockThreads;
-      const SpeedResult r = speed_lane<V>(s[l], speed, nz.z[l], qi[l], terminal, P);
+      const float v = R.policy == kPolicyBuffer ? held[l] : speed;
+      const SpeedResult r = speed_lane<V>(s[l], v, nz.z[l], qi[l], terminal, P);
       s[l] = r.next;
       rew[l] = r.reward;
       ev[l] = r.events;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
       clipped += (lane < P.n && r.events != 0u) ? 1u : 0u;
       if (R.obs_traj != nullptr)
         store_speed_row<V, false>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lane, s[l], static_cast<float>(t), V::NORM && P.norm_obs != 0, P);
-      if (R.act_traj != nullptr) R.act_traj[static_cast<size_t>(k) * n_pad + lane] = speed;
+      if (R.act_traj != nullptr) R.act_traj[static_cast<size_t>(k) * n_pad + lane] = v;
       if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lane] = r.reward;
     }
   }

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
 // rollout is bit-identical to the equivalent sequence of step() calls.  The caller's per-time-step Python loop
 // (generate_trajectory.py:21-34) disappears; HBM is touched only to record the trajectory (optional, time-major
 // so that every store is a coalesced float4) and once at the end for the final state.
-enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1, kPolicyTable = 2, kPolicyTimeTable = 3 };
+enum : int { kPolicyFixed = 0, kPolicyAvellanedaStoikov = 1, kPolicyTable = 2, kPolicyTimeTable = 3, kPolicyBuffer = 4 };
 
 struct RolloutParams {
   uint32_t n_steps;        // env-steps to run in this launch
@@ -676,6 +676,14 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     if (R.obs_traj != nullptr) store_row<V, false>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
   }
   load_initial_inventories<V>(B, lanes[0], lanes[1], qi[0], qi[1]);
+  float4 held[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (R.policy == kPolicyBuffer) {  // action repeat: each lane keeps the row of the action buffer it was given
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (A == 4) held[l] = reinterpret_cast<const float4*>(B.action)[lanes[l]];
+      else { const float2 a = reinterpret_cast<const float2*>(B.action)[lanes[l]]; held[l] = make_float4(a.x, a.y, 0.f, 0.f); }
+    }
+  }
   uint32_t clips = 0;
   double t = R.t_start;
   LaneResult last[2];
@@ -685,6 +693,9 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     float4 act[2];
     if (R.policy == kPolicyFixed) {
       act[0] = act[1] = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
+    } else if (R.policy == kPolicyBuffer) {
+      act[0] = held[0];
+      act[1] = held[1];
     } else if (R.policy == kPolicyTimeTable) {  // open-loop schedule over time steps
       const float* row = reinterpret_cast<const float*>(R.table) + static_cast<size_t>(min(R.table_row0 + k, R.table_rows - 1u)) * A;
       act[0] = act[1] = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);

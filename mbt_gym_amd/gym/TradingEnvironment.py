@@ -349,6 +349,13 @@ class TradingEnvironment(_EnvBase):
             self._handle, C.byref(pol), k, obs_ptr, act_ptr, rew_ptr, C.byref(steps), C.byref(done)))
         return int(steps.value), bool(done.value)
 
+    def step_repeat_device(self, repeats: int) -> Tuple[int, bool]:
+        """Action repeat: `repeats` environment steps with the action buffer held fixed, in ONE launch of the fused rollout
+        kernel (bit-identical to that many `step_device()` calls).  For consumers that act every k-th step - the
+        per-launch overhead, a third of a step at 2^20 trajectories, is paid once per k.  Returns (steps run, done)."""
+        pol = _native.MbtPolicy(kind=_native.POLICY_ACTION_BUFFER)
+        return self.rollout_device(pol, max_steps=repeats)
+
     @property
     def padded_lanes(self) -> int:
         return int(_native.load_library().mbt_env_padded_lanes(self._handle))

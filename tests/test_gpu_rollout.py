@@ -193,3 +193,30 @@ def test_back_to_back_launches_equal_the_fused_rollout_at_full_size(name, log2n)
     np.testing.assert_allclose(env_a.episode_return_sums()[0], env_b.episode_return_sums()[0], rtol=1e-6)
     env_a.close()
     env_b.close()
+
+
+@pytest.mark.parametrize("name", ["as_limit_pnl", "limit_and_market", "hawkes_ou", "default_normalised", "speed_temp_perm_cjoe"])
+def test_action_repeat_equals_repeated_steps(name):
+    """MBT_POLICY_ACTION_BUFFER: every lane holds ITS action for k steps in one launch = k step_device() calls."""
+    cfg, g = load_case(name)
+    cfg.num_trajectories, cfg.seed = 1300, 5
+    if isinstance(cfg.initial_inventory, tuple):
+        cfg.initial_inventory = 1
+    rng = np.random.default_rng(3)
+    per_lane = g["actions"][rng.integers(0, g["actions"].shape[0], size=1300), rng.integers(0, g["actions"].shape[1], size=1300)]
+    env_a, env_b = make_env(cfg), make_env(cfg)
+    for env in (env_a, env_b):
+        env.reset_device()
+        env.set_action_host(per_lane)
+    total = 0
+    for k in (1, 7, 16):
+        steps, done = env_a.step_repeat_device(k)
+        assert steps == k and not done
+        for _ in range(k):
+            env_b.step_device()
+        total += k
+        np.testing.assert_array_equal(env_a.state, env_b.state)
+        np.testing.assert_array_equal(np.asarray(env_a.clock), np.asarray(env_b.clock))
+    np.testing.assert_allclose(env_a.episode_return_sums()[0], env_b.episode_return_sums()[0], rtol=1e-6)
+    env_a.close()
+    env_b.close()
