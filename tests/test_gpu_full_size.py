@@ -109,3 +109,37 @@ def test_config4_limit_and_market_orders_at_2_to_21_lanes():
     lane_total = st[:, 0] + q * st[:, 3] - q0 * 100.0
     assert lane_total.mean() == pytest.approx(mean, abs=2e-3)
     env.close()
+
+
+def test_two_to_the_28_lanes_addressing():
+    """The largest batch tried: 2^28 trajectories (state rows beyond the 4 GB mark of their buffer - 64-bit addressing in
+    every kernel).  Seven back-to-back step launches equal the fused rollout of seven steps, row for row, on the device."""
+    torch = pytest.importorskip("torch")
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+
+    n = 1 << 28
+    cfg = OracleConfig(num_trajectories=n, n_steps=1000, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                       intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=1000, seed=50,
+                       normalise_action_space=False, normalise_observation_space=False)
+    env_a, env_b = make_env(cfg), make_env(cfg)
+    agent = FixedActionAgent(np.array([0.7, 0.7], np.float32), env_a)
+    act = torch.as_tensor(env_b.action_device, device="cuda")
+    act[:, 0] = 0.7
+    act[:, 1] = 0.7
+    torch.cuda.synchronize()
+    env_a.reset_device()
+    env_b.reset_device()
+    steps, done = env_a.rollout_device(agent, max_steps=7)
+    assert steps == 7 and not done
+    for _ in range(7):
+        env_b.step_device()
+    env_a.synchronize()
+    env_b.synchronize()
+    state_a, state_b = torch.as_tensor(env_a.obs_device, device="cuda"), torch.as_tensor(env_b.obs_device, device="cuda")
+    assert torch.equal(state_a, state_b)
+    q = state_a[:, 1]
+    assert float(q.abs().max()) <= 7 and bool(torch.all(q == torch.round(q)))
+    assert float(state_a[-1, 2]) == pytest.approx(7e-3, abs=1e-6)  # the very last row was stepped too
+    assert env_a.episode_return_sums()[0] == pytest.approx(env_b.episode_return_sums()[0], rel=1e-9)
+    env_a.close()
+    env_b.close()
