@@ -300,10 +300,12 @@ void key_from_seed(mbt_env* e) {
   e->params.key1 = static_cast<uint32_t>(e->seed >> 32);
 }
 
+// Zero-filled device buffer.  The fill is ordered on the environment's own stream: that stream is non-blocking, so a
+// fill on the null stream would not be ordered against the kernels that use the buffer next.
 template <typename T>
-int dev_alloc(T** p, size_t count) {
+int dev_alloc(T** p, size_t count, hipStream_t stream) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
-  HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+  HIP_TRY(hipMemsetAsync(*p, 0, count * sizeof(T), stream));
   return MBT_OK;
 }
 
@@ -611,22 +613,22 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     return fail(MBT_ERR_HIP, "hipEventCreate failed");
   }
   const size_t np = e->n_pad;
-  ENV_TRY(dev_alloc(&e->state[0], np * e->dim));
-  ENV_TRY(dev_alloc(&e->state[1], np * e->dim));
-  if (cfg->normalise_observation) ENV_TRY(dev_alloc(&e->obs, np * e->dim));
-  ENV_TRY(dev_alloc(&e->action, np * e->act_dim));
-  ENV_TRY(dev_alloc(&e->reward, np));
+  ENV_TRY(dev_alloc(&e->state[0], np * e->dim, e->stream));
+  ENV_TRY(dev_alloc(&e->state[1], np * e->dim, e->stream));
+  if (cfg->normalise_observation) ENV_TRY(dev_alloc(&e->obs, np * e->dim, e->stream));
+  ENV_TRY(dev_alloc(&e->action, np * e->act_dim, e->stream));
+  ENV_TRY(dev_alloc(&e->reward, np, e->stream));
   if (cfg->noise_mode == MBT_NOISE_INJECTED) {
     if (!speed) {
-      ENV_TRY(dev_alloc(&e->u_arr, np * 2));
-      ENV_TRY(dev_alloc(&e->u_fill, np * 2));
+      ENV_TRY(dev_alloc(&e->u_arr, np * 2, e->stream));
+      ENV_TRY(dev_alloc(&e->u_fill, np * 2, e->stream));
     }
-    ENV_TRY(dev_alloc(&e->z, np));
+    ENV_TRY(dev_alloc(&e->z, np, e->stream));
   }
-  ENV_TRY(dev_alloc(&e->q_init, np));
-  ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves));
-  ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots));
-  ENV_TRY(dev_alloc(&e->reduce_out, 2));
+  ENV_TRY(dev_alloc(&e->q_init, np, e->stream));
+  ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves, e->stream));
+  ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
+  ENV_TRY(dev_alloc(&e->reduce_out, 2, e->stream));
   uint32_t fast_path_lanes = kHostFastPathLanes;
   if (const char* env_override = std::getenv("MBT_HOST_FAST_PATH_LANES")) fast_path_lanes = static_cast<uint32_t>(std::strtoul(env_override, nullptr, 10));
   if (e->n <= fast_path_lanes) {  // see step_host: zero-copy staging instead of pageable DMA copies
@@ -646,6 +648,13 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     }
   }
 #undef ENV_TRY
+  // the zero fills above are ordered on e->stream; callers may touch the buffers from other streams (action_device,
+  // obs_device under PyTorch) as soon as this returns, so they must have landed
+  he = hipStreamSynchronize(e->stream);
+  if (he != hipSuccess) {
+    mbt_env_destroy(e);
+    return fail(MBT_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(he));
+  }
   *out = e;
   return MBT_OK;
 }
@@ -870,7 +879,7 @@ int mbt_env_record_events(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (enabled && e->events == nullptr) {
-    int rc = dev_alloc(&e->events, size_t(e->n_pad));
+    int rc = dev_alloc(&e->events, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;
   }
   e->record_events = enabled != 0;
@@ -903,7 +912,7 @@ int mbt_env_track_lane_returns(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (enabled && e->lane_returns == nullptr) {
-    int rc = dev_alloc(&e->lane_returns, size_t(e->n_pad));
+    int rc = dev_alloc(&e->lane_returns, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;
   }
   e->track_returns = enabled != 0;
