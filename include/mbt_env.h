@@ -146,7 +146,11 @@ int mbt_device_name(int device, char* buf, size_t buf_len);
  * allocates the (N, D) state and the output buffers in HBM, creates the stream. */
 int mbt_env_create(const mbt_config* cfg, mbt_env** out);
 void mbt_env_destroy(mbt_env* env);
-/* Use an existing hipStream_t (e.g. torch's current stream) instead of the environment's own. */
+/* Every launch and copy of an environment is ordered on ONE stream: its own (created non-blocking, so it does not
+ * synchronise with the null stream) until this call hands it another hipStream_t, e.g. torch's current stream.
+ * mbt_env_create returns with all buffers allocated, zero-filled and idle.  A caller that reads or writes the device
+ * buffers (mbt_env_*_device pointers) from a different stream orders the two itself - mbt_env_synchronize, or an
+ * event - or shares its stream through this call. */
 int mbt_env_set_stream(mbt_env* env, void* hip_stream);
 int mbt_env_synchronize(mbt_env* env);
 
