@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: env-steps/s of TradingEnvironment.step() on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,15 +11,26 @@ T=1, n_steps=1000, fp32 - with num_trajectories = 2^20 PER GPU (the trajectory a
 constant quote (0.7, 0.7) resident in HBM, in-kernel Philox noise keyed on the GLOBAL lane id.
 One "step" = one env.step() = one launch of the fused kernel over every lane of the rank; the episode restarts
 (reset kernel) whenever it ends, inside the timed region, exactly like a VecEnv consumer would.
-No data-path collective; the only RCCL traffic is the 3-double all-reduce of the episode-return sums.
+No data-path collective; the only RCCL traffic is the 3-double all-reduce of the episode-return sums, enqueued on the
+environment's stream through the C ABI (mbt_env_set_communicator), one per finished episode.
+
+Timed region: barrier; t0; ONE call into the library that enqueues the K launches (mbt_env_step_many_device); wait for the
+stream; torch.cuda.synchronize(); t1.  Nothing else is inside it.  Before the W warm-up steps the GPU's clocks are
+brought up with untimed steps (`prewarm_steps` in the output): the driver's W = 5 is 35 microseconds of work.
 
 Output: ONE JSON line on rank 0 (see README / the driver contract), including
-  roofline      - algorithmic bytes per launch / average launch duration from HIP events on the kernel's stream
-  cpu_baseline  - the NumPy restatement of the reference (oracle/, bit-matched to it) timed on this host
+  roofline      - algorithmic bytes per launch / average launch duration from HIP events on the kernel's stream, for the
+                  timed region, plus (N = 1) the same kernel measured at 2^24 lanes, where the working set (738 MB) no
+                  longer fits the 256 MB Infinity Cache: the HBM-resident regime
+  cpu_baseline  - the NumPy restatement of the reference (oracle/, bit-matched to it) timed on this host: one core (like
+                  the reference) and K processes x N/K lanes (the layout MultiprocessTradingEnv intended)
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,14 +41,16 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 LANES_PER_GPU = 1 << 20
+HBM_RESIDENT_LANES = 1 << 24
 N_STEPS = 1000
 BYTES_PER_ENV_STEP = 4 * (4 + 2 + 4 + 1)  # state read + action read + next-state write + reward write (D=4, A=2)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 50
 QUOTE = (0.7, 0.7)
+PREWARM_SECONDS = 0.05  # untimed: brings the clocks up before the warm-up the caller asked for
 
 
-def build_env(n, rank, device):
+def build_env(n, offset, device):
     """The environment through the public plugin API, one shard of the trajectory axis per rank."""
     from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
     from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
@@ -52,57 +65,85 @@ def build_env(n, rank, device):
         fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n),
         num_trajectories=n,
     )
-    return TradingEnvironment(
+    env = TradingEnvironment(
         terminal_time=1.0, n_steps=N_STEPS, model_dynamics=dynamics, initial_inventory=0, max_inventory=N_STEPS,
         seed=SEED, num_trajectories=n, normalise_action_space=False, normalise_observation_space=False,
-        device=device, trajectory_offset=rank * n,
+        device=device, trajectory_offset=offset,
     )
+    env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
+    env.reset_device()
+    return env
 
 
-def run_steps(env, k, device, returns):
-    """k env.step() launches.  When an episode ends: reduce its [sum R, sum R^2, count] on the device, all-reduce the
-    three doubles across ranks (the only collective on the path, RCCL) and restart the episode (reset kernel), like a
-    VecEnv consumer would.  The boundary is pipelined - the device reduction is read back, and the collective waited
-    for, one episode later (and everything outstanding before this function returns) - so that 24 bytes of statistics
-    do not drain a stream that has a thousand launches in flight."""
-    from mbt_gym_amd.distributed import PendingReturnSums
+def timed_steps(env, lib, k, sync_all):
+    """Exactly k env.step() launches between two synchronisation points.  Returns (wall seconds, HIP-event seconds)."""
+    import ctypes as C
 
-    reduction_in_flight, collective = False, None
-    for _ in range(k):
-        if env.step_device():
-            if collective is not None:
-                returns.append(collective.result())
-                collective = None
-            if reduction_in_flight:
-                collective = PendingReturnSums(env.episode_return_sums_end(), device=device)
-            env.episode_return_sums_begin()
-            reduction_in_flight = True
-            env.reset_device()
-    if collective is not None:
-        returns.append(collective.result())
-    if reduction_in_flight:
-        returns.append(PendingReturnSums(env.episode_return_sums_end(), device=device).result())
+    from mbt_gym_amd import _native
+
+    ms = C.c_float(0)
+    sync_all()
+    _native.check(lib.mbt_env_timer_begin(env._handle))  # HIP event on the kernel's stream
+    t0 = time.perf_counter()
+    steps, _ = env.step_many_device(k, auto_reset=True)
+    _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))  # records the closing event and waits for it (polling)
+    sync_all(barrier=False)
+    wall = time.perf_counter() - t0
+    assert steps == k
+    return wall, ms.value / 1e3
 
 
 def pmc_traffic(n):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    profiles/r01_pmc_summary.json, produced by tools/pmc_summary.py for this workload at 2^20 lanes); None for
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, the
+    newest profiles/r*_pmc_summary.json, produced by tools/pmc_summary.py for this workload at 2^20 lanes); None for
     other sizes.  Counters cannot be read from inside the benchmark process, so this is the profiled value."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if n != LANES_PER_GPU or not os.path.exists(path):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if n != LANES_PER_GPU or not paths:
         return None
-    for name, row in json.load(open(path)).items():
+    for name, row in json.load(open(paths[-1])).items():
         if "step_kernel" in name:
             return row["hbm_bytes_per_launch"]
     return None
 
 
-def cpu_baseline(budget_s=12.0):
-    """The reference's algorithm (oracle = NumPy restatement, bit-matched to the reference) on this host, one
-    process / one core like the reference, same model and N = 2^20 lanes, numpy PCG64 noise as the reference."""
-    from oracle.mbt_oracle import NumpyProtocolNoise, OracleConfig, OracleEnv  # the ONLY use of oracle/ in this file
+def _cpu_worker(args):
+    """One process of the CPU baseline: `steps` steps of the benchmark workload on `lanes` lanes of the oracle."""
+    lanes, seed, steps, start_at = args
+    from oracle.mbt_oracle import NumpyProtocolNoise, OracleConfig, OracleEnv  # cpu_baseline leg: the oracle is the thing timed here
+
+    cfg = OracleConfig(
+        num_trajectories=lanes, n_steps=N_STEPS, terminal_time=1.0, midprice="bm", drift=0.0, volatility=2.0,
+        initial_price=100.0, arrival="poisson", intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit",
+        reward="pnl", initial_inventory=0, max_inventory=N_STEPS, seed=seed,
+        normalise_action_space=False, normalise_observation_space=False,
+    )
+    env = OracleEnv(cfg, NumpyProtocolNoise(seed))
+    env.reset()
+    action = np.tile(np.array([QUOTE], dtype=np.float64), (lanes, 1))
+    env.step(action)  # warm
+    if start_at is not None:
+        while time.time() < start_at:  # the processes start together
+            pass
+    t0 = time.time()
+    done = 0
+    for _ in range(steps):
+        env.step(action)
+        done += 1
+    return t0, time.time(), done
+
+
+def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32)):
+    """The reference's algorithm (oracle = NumPy restatement, bit-matched to the reference, float64, PCG64 noise like the
+    reference) on this host, same model and N = 2^20 lanes: (i) one process / one core, like the reference itself;
+    (ii) K processes x N/K lanes - the sharding the reference's MultiprocessTradingEnv intended
+    (gym/MultiprocessTradingEnv.py:74-80).  A bounded sample: about 10 s + two times ~5 s."""
+    import multiprocessing as mp
 
     n = LANES_PER_GPU
+    # (i) one core
+    t0, steps = time.perf_counter(), 0
+    from oracle.mbt_oracle import NumpyProtocolNoise, OracleConfig, OracleEnv
+
     cfg = OracleConfig(
         num_trajectories=n, n_steps=N_STEPS, terminal_time=1.0, midprice="bm", drift=0.0, volatility=2.0,
         initial_price=100.0, arrival="poisson", intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit",
@@ -113,16 +154,101 @@ def cpu_baseline(budget_s=12.0):
     env.reset()
     action = np.tile(np.array([QUOTE], dtype=np.float64), (n, 1))
     env.step(action)  # warm
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and steps < N_STEPS - 2:
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < single_budget_s and steps < N_STEPS - 2:
         env.step(action)
         steps += 1
-    dt = time.perf_counter() - t0
-    return {
-        "value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    single = n * steps / (time.perf_counter() - t0)
+    del env
+    # (ii) K processes
+    cores = os.cpu_count() or 1
+    multi = {}
+    ctx = mp.get_context("spawn")
+    for k in process_counts:
+        if k > cores:
+            continue
+        lanes = n // k
+        try:
+            with ctx.Pool(k) as pool:
+                start = time.time() + 2.0 + 0.02 * k
+                spans = pool.map(_cpu_worker, [(lanes, SEED + i, multi_steps, start) for i in range(k)])
+            span = max(e for _, e, _ in spans) - min(s for s, _, _ in spans)
+            multi[k] = lanes * k * multi_steps / span
+        except Exception as exc:  # noqa: BLE001 - a host that cannot spawn still reports the one-core figure
+            multi[k] = f"failed: {exc}"
+    best_k = max((k for k, v in multi.items() if isinstance(v, float)), key=lambda k: multi[k], default=None)
+    out = {
+        "value": single, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{steps} steps x {n} lanes of the same workload, oracle/mbt_oracle.py (NumPy float64, PCG64 noise), "
-                  f"{os.cpu_count()} host cores present, 1 used",
+                  f"{cores} host cores present, 1 used",
     }
+    if best_k is not None:
+        out["multicore"] = {
+            "value": multi[best_k], "unit": "env-steps/s", "processes": best_k, "cores": best_k, "host_cores_present": cores,
+            "sample": f"{multi_steps} steps x {best_k} processes x {n // best_k} lanes (2^20 in total), the same oracle; "
+                      f"tried K = {list(multi)}: " + ", ".join(f"{k}: {v:.3g}" if isinstance(v, float) else f"{k}: {v}" for k, v in multi.items()),
+        }
+    return out
+
+
+def hbm_resident_measurement(lib, device, steps=600, warmup=100):
+    """The same kernel on 2^24 lanes: 738 MB of state + actions + rewards per launch, beyond the 256 MB Infinity Cache,
+    so every byte comes from / goes to HBM.  Reported beside the headline (cache-resident) figure, never instead of it."""
+    import torch
+
+    env = build_env(HBM_RESIDENT_LANES, 0, device)
+
+    def sync_all(barrier=True):
+        env.synchronize()
+        torch.cuda.synchronize()
+
+    try:
+        env.step_many_device(warmup, auto_reset=True)
+        wall, event_s = timed_steps(env, lib, steps, sync_all)
+    finally:
+        env.close()
+    launch_s = event_s / steps
+    achieved = BYTES_PER_ENV_STEP * HBM_RESIDENT_LANES / launch_s / 1e9
+    return {
+        "lanes": HBM_RESIDENT_LANES, "steps": steps, "bytes_per_launch": BYTES_PER_ENV_STEP * HBM_RESIDENT_LANES,
+        "avg_launch_us": launch_s * 1e6, "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
+        "env_steps_per_s": HBM_RESIDENT_LANES * steps / wall,
+        "note": "working set 738 MB per launch > 256 MB Infinity Cache: HBM-resident; the achievable copy rate of the chip "
+                "is ~6.3 TB/s (0.79 of the spec peak)",
+    }
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would set up, and pass rank 0's JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        deadline = time.time() + 1500
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    rc = rc or code
+            if rc != 0 or time.time() > deadline:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # a failed rank leaves the others waiting in a collective: stop exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+                rc = rc or 1
+    return rc
 
 
 def main():
@@ -132,80 +258,118 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--lanes", type=int, default=LANES_PER_GPU, help="trajectories per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for testing)")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch
 
+    from mbt_gym_amd import _native
+    from mbt_gym_amd.build import build_native
+    from mbt_gym_amd.distributed import RcclCommunicator, allreduce_return_sums, return_statistics, shard_bounds
+
+    if rank == 0:
+        build_native()  # no-op unless the library is missing or was built from other sources
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    visible = torch.cuda.device_count()
+    if world > 1 and not args.single_device and visible < world and args.backend == "nccl":
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, {visible} present (functional test on one GPU: --backend gloo --single-device)")
     # one process per GPU; a launcher that narrows each rank's visible devices leaves fewer ordinals than ranks
-    gpu = 0 if args.single_device else local_rank % max(1, torch.cuda.device_count())
+    gpu = 0 if args.single_device else local_rank % max(1, visible)
     torch.cuda.set_device(gpu)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend=args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.barrier()  # every rank waits for rank 0's build check before it loads the library
+    lib = _native.load_library()
 
     n = args.lanes
-    from mbt_gym_amd.distributed import shard_bounds
     offset, count = shard_bounds(n * world, rank, world)
     assert count == n and offset == rank * n
-    env = build_env(n, rank, gpu)
-    env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
-    env.reset()
+    env = build_env(n, offset, gpu)
 
-    def barrier():
+    # the one collective of the path: through the C ABI's RCCL binding when the launcher-side backend is RCCL too, else
+    # (gloo, single-device testing: RCCL refuses two ranks on one GPU) through torch.distributed after the fact
+    comm, transport = None, "none (1 rank)"
+    tdev = torch.device("cuda", gpu) if args.backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        transport = f"torch.distributed/{args.backend}"
+        if args.backend == "nccl":
+            ok = 1.0
+            try:
+                comm = RcclCommunicator(rank, world, gpu)
+                env.set_communicator(comm)
+            except Exception as exc:  # noqa: BLE001 - fall back to torch.distributed on EVERY rank, or on none
+                print(f"[rank {rank}] C-ABI RCCL communicator unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() < 1.0:
+                if comm is not None:
+                    env.set_communicator(None)
+                comm = None
+            else:
+                transport = "RCCL via mbt_env_set_communicator (C ABI), enqueued on the environment's stream"
+
+    def sync_all(barrier=True):
         env.synchronize()
         torch.cuda.synchronize()
-        if dist is not None:
+        if barrier and dist is not None:
             dist.barrier()
 
-    from mbt_gym_amd.distributed import allreduce_return_sums, return_statistics
+    def drain_log():
+        out = []
+        while True:
+            sums = env.episode_log_pop(wait=True)
+            if sums is None:
+                return out
+            out.append(sums if (comm is not None or world == 1) else allreduce_return_sums(sums, device=tdev))
 
-    device = torch.device("cuda", gpu) if args.backend == "nccl" else torch.device("cpu")
-    episode_returns = []
-    run_steps(env, args.warmup, device, episode_returns)
-    barrier()
-    from mbt_gym_amd import _native
-    import ctypes as C
+    # clocks up (untimed, not part of --warmup), then the warm-up the caller asked for
+    prewarm, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < PREWARM_SECONDS:
+        prewarm += env.step_many_device(256, auto_reset=True)[0]
+        env.synchronize()
+    if args.warmup > 0:
+        env.step_many_device(args.warmup, auto_reset=True)
+    sync_all()
+    drain_log()
 
-    lib = _native.load_library()
-    _native.check(lib.mbt_env_timer_begin(env._handle))
-    t0 = time.perf_counter()
-    episode_returns.clear()
-    run_steps(env, args.steps, device, episode_returns)
+    wall, event_s = timed_steps(env, lib, args.steps, sync_all)
+    episode_returns = drain_log()
     episodes = len(episode_returns)
-    ms = C.c_float(0)
-    _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))  # HIP events on the kernel's stream
-    env.synchronize()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([wall, ms.value / 1e3], dtype=torch.float64, device=device)
+        t = torch.tensor([wall, event_s], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, event_s = float(t[0]), float(t[1])
-    else:
-        event_s = ms.value / 1e3
 
     # mean return of the last finished episode over ALL shards (or of the partial episode if none finished)
-    sums = episode_returns[-1] if episode_returns else allreduce_return_sums(env.episode_return_sums(), device=device)
+    if episode_returns:
+        sums = episode_returns[-1]
+    else:
+        local = env.episode_return_sums()
+        sums = env.allreduce_return_sums(comm, local) if comm is not None else allreduce_return_sums(local, device=tdev)
 
     if rank == 0:
         total_lanes = n * world
         value = total_lanes * args.steps / wall
-        launch_us = event_s / args.steps * 1e6  # includes the reset launches of finished episodes (1 per 1000)
-        achieved = BYTES_PER_ENV_STEP * n / (event_s / args.steps) / 1e9
+        launch_s = event_s / args.steps  # includes the reset / reduction launches of finished episodes (2 per 1000 steps)
+        achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
         out = {
             "metric": "env-steps/s (num_trajectories x steps)", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -216,21 +380,35 @@ def main():
                 "num_trajectories_per_gpu": n, "num_trajectories_total": total_lanes, "n_steps": N_STEPS,
                 "action": "constant quote (0.7, 0.7) resident in HBM", "noise": "in-kernel Philox4x32-10",
                 "parallelism": f"trajectory axis sharded over {world} GPU(s), no data-path collective",
-                "episodes_finished_in_timed_region": episodes,
+                "return_allreduce": transport,
+                "episodes_finished_in_timed_region": episodes, "prewarm_steps": prewarm,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(n), "bytes_per_env_step": BYTES_PER_ENV_STEP, "avg_launch_us": launch_us,
-                "note": "algorithmic bytes (44 B/env-step x lanes per launch) / mean launch-to-launch time from HIP "
-                        "events on the kernel's stream; at 2^20 lanes the 44 MB working set is Infinity-Cache resident",
+                "traffic": pmc_traffic(n), "bytes_per_env_step": BYTES_PER_ENV_STEP, "avg_launch_us": launch_s * 1e6,
+                "regime": "Infinity-Cache resident" if n * BYTES_PER_ENV_STEP < (200 << 20) else "HBM resident",
+                "note": "algorithmic bytes (44 B/env-step x lanes per launch) / mean launch-to-launch time from HIP events on "
+                        "the kernel's stream over the timed region.  At 2^20 lanes the 46 MB a launch touches stay in the 256 MB "
+                        "Infinity Cache between launches, so this is NOT an HBM rate (it can exceed the ~6.3 TB/s HBM sustains); "
+                        "`hbm_resident` is the same kernel where every byte crosses HBM.",
             },
+            "event_env_steps_per_s": total_lanes * args.steps / event_s,
             "mean_episode_return": return_statistics(sums)[0],
         }
+    env.close()
+    if rank == 0:
+        if world == 1 and not args.no_hbm_resident:
+            try:
+                out["roofline"]["hbm_resident"] = hbm_resident_measurement(lib, gpu)
+            except Exception as exc:  # noqa: BLE001 - e.g. a smaller device: the headline stands on its own
+                out["roofline"]["hbm_resident"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    env.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 3u
+#define MBT_ABI_VERSION 4u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -47,7 +47,14 @@ typedef enum mbt_status {
  * (IMP = stochastic_processes/price_impact_models.py) */
 enum {
   MBT_MID_BROWNIAN = 0 /* MID:36-68 */, MBT_MID_OU = 1 /* MID:114-146 */, MBT_MID_GBM = 2 /* MID:71-111 */,
-  MBT_MID_BROWNIAN_JUMP = 3 /* MID:193-230 */, MBT_MID_OU_JUMP = 4 /* MID:233-273 */, MBT_MID_CONSTANT = 5 /* MID:12-33 */
+  MBT_MID_BROWNIAN_JUMP = 3 /* MID:193-230 */, MBT_MID_OU_JUMP = 4 /* MID:233-273 */, MBT_MID_CONSTANT = 5 /* MID:12-33 */,
+  /* The family all of the above are members of, for user-defined MidpriceModel subclasses (SP:8-53) that are linear
+   * SDEs - one Euler step of
+   *   dS = (mid_coef_add + mid_coef_mul * S) * (drift * dt + volatility * sqrt(dt) * Z) - ou_speed * (S - ou_level)
+   *        + jump_size * (ask fills - bid fills)
+   * e.g. CEV-free local-volatility mixtures, drifting OU, GBM with trade impact.  The built-in kinds are the rows
+   * (1,0,theta=0) BM, (1,0,theta) OU [drift forced to 0], (0,1) GBM, +jump_size for the jump variants, (0,0) constant. */
+  MBT_MID_LINEAR_SDE = 6
 };
 enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
@@ -129,6 +136,19 @@ typedef struct mbt_config {
    * columns and the depths of FILL:159-163 hold these values for the whole episode. */
   double exogenous_depth[2];
   double base_fill_probability;              /* FILL:132 */
+
+  /* ---- ABI 4 ---- */
+  double reward_terminal_time;               /* CjMmCriterion / CjOeCriterion keep their OWN terminal_time (RW:88, RW:74, RW:113); 0 = terminal_time */
+  double mid_coef_add, mid_coef_mul;         /* MBT_MID_LINEAR_SDE only */
+  /* 1 = keep cash and midprice as float32 PAIRS (value + residual, two more floats per lane in a side buffer, +16 B of
+   * traffic per env-step): the state follows the float64 reference to ~1e-12 instead of accumulating float32 roundings,
+   * so rewards stay within 1e-5 of it even on lane-steps where the clip of TE:283-289 turns the state's level into
+   * reward.  Observations are unchanged (the rounded float32 value).  Order-book dynamics only. */
+  int32_t precise_state;
+  /* The Hawkes intensity recursion lambda += speed (base - lambda) dt + jump (ARR:110-119) is a contraction only for
+   * hawkes_speed * arrival_step_size < 1; from 1 it oscillates and from 2 it diverges (in the float64 reference as well),
+   * and float32 state no longer tracks float64 state.  mbt_env_create rejects such a configuration unless this is 1. */
+  int32_t allow_stiff_hawkes;
 } mbt_config;
 
 typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
@@ -136,6 +156,9 @@ typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
 /* ---- library ---------------------------------------------------------------------------------- */
 uint32_t mbt_abi_version(void);
 size_t mbt_config_sizeof(void); /* sizeof(mbt_config) as compiled, for binding self-checks */
+/* sha256 (hex) of the sources this library was compiled from (every .hip / .hpp under csrc plus include/mbt_env.h, in
+ * name order), baked in at build time: lets a binding detect a stale prebuilt library next to newer sources. */
+const char* mbt_source_hash(void);
 const char* mbt_last_error(void);
 int mbt_device_count(void);
 /* Writes the device name ("gfx950...") into buf; returns MBT_OK or an error. */
@@ -152,7 +175,12 @@ void mbt_env_destroy(mbt_env* env);
  * buffers (mbt_env_*_device pointers) from a different stream orders the two itself - mbt_env_synchronize, or an
  * event - or shares its stream through this call. */
 int mbt_env_set_stream(mbt_env* env, void* hip_stream);
+/* Waits for everything enqueued on the environment's stream (polls for the first ~200 us, then blocks). */
 int mbt_env_synchronize(mbt_env* env);
+/* TradingEnvironment.step_size setter (TE:158-167): the clock, the done rule (TE:218-220) and EVERY process (each is
+ * given the new value, TE:161-163) continue with `step_size`; n_steps, terminal_time and max_cash are untouched, exactly
+ * like the reference.  Host-side parameters only: no reallocation, takes effect with the next step. */
+int mbt_env_set_step_size(mbt_env* env, double step_size);
 
 /* ---- seeding (TE:345-348, SP:37-39) ----------------------------------------------------------- */
 /* Re-keys the Philox generator and restarts its step counter.  Like the reference, reset() does not reseed:
@@ -174,6 +202,14 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
 int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);
 /* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
 int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);
+/* k consecutive mbt_env_step_device calls with the same action buffer in ONE host call (k launches; a consumer in an
+ * interpreted language pays its call overhead once).  With auto_reset, an episode that ends inside the batch is handled
+ * the way SB3's VecEnv contract prescribes (SBE:28-37) without draining the stream: the episode's return sums are
+ * reduced on the device (and all-reduced over the communicator of mbt_env_set_communicator, if any) into the episode
+ * log, and the lanes are reset with the start time and initial inventories of the last mbt_env_reset*.  Without
+ * auto_reset the batch stops at the end of the episode.  steps_done / episodes_ended may be NULL. */
+int mbt_env_step_many_device(mbt_env* env, uint32_t k, const float* action_device, int32_t auto_reset, uint32_t* steps_done,
+                             uint32_t* episodes_ended);
 
 /* ---- fused rollout: many steps in one launch with an on-device closed-form policy ---------------
  * Replaces the caller's per-time-step loop (gym/helpers/generate_trajectory.py:21-34) for policies that are closed
@@ -256,6 +292,27 @@ int mbt_env_return_sums(mbt_env* env, double sums[3]);
  * One request in flight at a time. */
 int mbt_env_return_sums_begin(mbt_env* env);
 int mbt_env_return_sums_end(mbt_env* env, double sums[3]);
+/* Episode log of mbt_env_step_many_device(auto_reset): pops the OLDEST finished episode's [sum R, sum R^2, lanes] (global
+ * over all ranks when a communicator is set).  Returns 1 and fills sums if one was popped, 0 if the log is empty - or,
+ * with wait == 0, if the oldest entry's reduction has not completed yet.  At most 16 episodes are kept in flight; a
+ * 17th waits for the oldest. */
+int mbt_env_episode_log_pop(mbt_env* env, double sums[3], int32_t wait);
+
+/* ---- multi-GPU: the trajectory axis is sharded, one handle per GPU; this is the ONLY collective on the path -------
+ * (replaces the concatenation of MultiprocessTradingEnv workers, gym/MultiprocessTradingEnv.py:74-80,112-116, for the one
+ * statistic a run reports).  RCCL is bound at run time (dlopen of librccl.so.1 - the copy already loaded in the process,
+ * e.g. PyTorch's, if there is one), so the library has no link-time dependency on it. */
+/* In place, blocking: sums[3] (host; this rank's [sum R, sum R^2, count]) -> the sums over all ranks of `nccl_comm`
+ * (an ncclComm_t created on this environment's device).  One 24-byte ncclAllReduce on the environment's stream. */
+int mbt_env_allreduce_returns(mbt_env* env, void* nccl_comm, double sums[3]);
+/* Communicator used by the episode log of mbt_env_step_many_device (NULL = none: local sums). */
+int mbt_env_set_communicator(mbt_env* env, void* nccl_comm);
+/* Thin wrappers so that a binding needs no second FFI: ncclGetUniqueId (id_out: 128 bytes), ncclCommInitRank on
+ * `device`, ncclCommDestroy.  The id travels from rank 0 to the others by whatever the launcher offers. */
+#define MBT_COMM_ID_BYTES 128
+int mbt_comm_unique_id(void* id_out);
+int mbt_comm_init_rank(int device, int n_ranks, const void* id, int rank, void** comm_out);
+int mbt_comm_destroy(void* comm);
 
 /* ---- RewardFunction.calculate on caller-supplied matrices (RW:23-33, RW:96-109, RW:128-138) ---------------------
  * cur, nxt: (n, dim) row-major float64 state matrices; q_init, episode_length: (n) float64, only for MBT_REW_CJ_MM /

@@ -9,9 +9,9 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT = 0, 1, 2, 3, 4, 5
+MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE = 0, 1, 2, 3, 4, 5, 6
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE = 0, 1, 2, 3
 FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM = 0, 1, 2
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
@@ -49,6 +49,8 @@ class MbtConfig(C.Structure):
         ("transient_impact", C.c_double), ("resilience", C.c_double), ("initial_transient_impact", C.c_double),
         ("kernel_coefficient", C.c_double), ("impact_step_size", C.c_double),
         ("exogenous_depth", C.c_double * 2), ("base_fill_probability", C.c_double),
+        ("reward_terminal_time", C.c_double), ("mid_coef_add", C.c_double), ("mid_coef_mul", C.c_double),
+        ("precise_state", C.c_int32), ("allow_stiff_hawkes", C.c_int32),
     ]
 
 
@@ -97,6 +99,7 @@ _ENV = C.c_void_p
 SIGNATURES = {
     "mbt_abi_version": (C.c_uint32, []),
     "mbt_config_sizeof": (C.c_size_t, []),
+    "mbt_source_hash": (C.c_char_p, []),
     "mbt_last_error": (C.c_char_p, []),
     "mbt_device_count": (C.c_int, []),
     "mbt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
@@ -104,11 +107,13 @@ SIGNATURES = {
     "mbt_env_destroy": (None, [_ENV]),
     "mbt_env_set_stream": (C.c_int, [_ENV, C.c_void_p]),
     "mbt_env_synchronize": (C.c_int, [_ENV]),
+    "mbt_env_set_step_size": (C.c_int, [_ENV, C.c_double]),
     "mbt_env_seed": (C.c_int, [_ENV, C.c_uint64]),
     "mbt_env_reset": (C.c_int, [_ENV, C.c_double, _F]),
     "mbt_env_reset_host": (C.c_int, [_ENV, C.c_double, _F, _F]),
     "mbt_env_step_host": (C.c_int, [_ENV, _F, _F, _F, C.POINTER(C.c_int32)]),
     "mbt_env_step_device": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_int32)]),
+    "mbt_env_step_many_device": (C.c_int, [_ENV, C.c_uint32, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "mbt_env_rollout_host": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, _F, _F, _F, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
@@ -131,6 +136,12 @@ SIGNATURES = {
     "mbt_env_return_sums": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_return_sums_begin": (C.c_int, [_ENV]),
     "mbt_env_return_sums_end": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
+    "mbt_env_episode_log_pop": (C.c_int, [_ENV, C.POINTER(C.c_double), C.c_int32]),
+    "mbt_env_allreduce_returns": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_double)]),
+    "mbt_env_set_communicator": (C.c_int, [_ENV, C.c_void_p]),
+    "mbt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mbt_comm_init_rank": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mbt_comm_destroy": (C.c_int, [C.c_void_p]),
     "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),
@@ -142,6 +153,33 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+COMM_ID_BYTES = 128
+
+
+def _torch_lib(name):
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+    return path if os.path.exists(path) else None
+
+
+def preload_torch_rccl():
+    """Same reasoning as for the HIP runtime below, for RCCL: PyTorch bundles its own librccl.so; libmbtenv binds RCCL with
+    dlopen at first use and must find THAT copy when torch is installed (two RCCL copies over one HIP runtime do not mix).
+    Called before the first communicator is made; harmless without torch (the system's /opt/rocm copy is used)."""
+    path = _torch_lib("librccl.so")
+    if path is None:
+        return None
+    os.environ.setdefault("MBT_RCCL_LIBRARY", path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def _preload_torch_hip_runtime():
@@ -183,6 +221,14 @@ def load_library():
         raise RuntimeError(f"libmbtenv ABI {lib.mbt_abi_version()} != binding {ABI_VERSION}")
     if lib.mbt_config_sizeof() != C.sizeof(MbtConfig):
         raise RuntimeError(f"struct mbt_config is {lib.mbt_config_sizeof()} bytes in the library, {C.sizeof(MbtConfig)} in the binding")
+    from mbt_gym_amd import build as _build
+
+    if os.path.isdir(_build.CSRC):  # sources present (a checkout, not an installed wheel): the library must be THEIR build
+        built_from, present = lib.mbt_source_hash().decode(), _build.source_hash()
+        if built_from != present:
+            raise RuntimeError(
+                f"{LIB_PATH} is stale: built from sources {built_from[:12]}..., the tree holds {present[:12]}...  "
+                "Rebuild it (python -m mbt_gym_amd.build); a stale library is refused rather than silently used.")
     _lib = lib
     return lib
 

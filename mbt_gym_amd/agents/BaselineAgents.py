@@ -140,7 +140,10 @@ class CarteaJaimungalMmAgent(Agent):
         return np.log(self._calculate_omega(current_time)) / self.kappa
 
     def h_table(self) -> np.ndarray:
-        """h(t_k, q) for k = 0..n_steps on the environment's time grid; columns ordered q = -Q..Q."""
+        """h(t_k, .) for k = 0..n_steps on the environment's time grid; column j is what the reference reads for inventory
+        q = j - Q.  The matrix of `_calculate_a_and_z` is laid out with row i <-> inventory Q - i, but the reference indexes
+        the resulting vector with Q + q WITHOUT flipping it (AG:117-136); for symmetric intensities h is even and the two
+        conventions coincide, for asymmetric ones they do not - the reference's indexing is reproduced here."""
         if self._h is None:
             from scipy.linalg import expm
 
@@ -150,7 +153,7 @@ class CarteaJaimungalMmAgent(Agent):
             omega[n] = self.z_vector[:, 0]
             for k in range(n - 1, -1, -1):
                 omega[k] = step @ omega[k + 1]
-            self._h = (np.log(omega) / self.kappa)[:, ::-1].copy()  # flip to ascending inventory
+            self._h = np.log(omega) / self.kappa  # NOT flipped: indexed with Q + q like the reference (AG:117-119)
         return self._h
 
     def depth_table(self) -> np.ndarray:
@@ -172,7 +175,7 @@ class CarteaJaimungalMmAgent(Agent):
 
     def calculate_true_value_function(self, state: np.ndarray) -> np.ndarray:
         """h(t, q) + cash + q S: the closed-form value the Monte-Carlo mean of the total reward must match."""
-        h_t = self._calculate_ht(float(state[0, TIME_INDEX]))[::-1, 0]
+        h_t = self._calculate_ht(float(state[0, TIME_INDEX]))[:, 0]  # indexed with Q + q, un-flipped (AG:160-167)
         cols = np.clip(self.max_inventory + state[:, INVENTORY_INDEX], 0, 2 * self.max_inventory).astype(int)
         return h_t[cols] + state[:, CASH_INDEX] + state[:, INVENTORY_INDEX] * state[:, ASSET_PRICE_INDEX]
 

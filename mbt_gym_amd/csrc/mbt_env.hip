@@ -5,7 +5,11 @@
 // No CPU fallback exists in this file or anywhere in the product path: without a gfx950 device every entry
 // point that needs one fails with MBT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen (see rccl_api below), never linked
 
+#include <dlfcn.h>
+
+#include <chrono>
 #include <vector>
 
 #include <cmath>
@@ -214,6 +218,17 @@ struct mbt_env {
   StepKernel kernel = nullptr;
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
+  bool q0_per_lane_reset = false;  // the last explicit reset passed per-lane initial inventories (kept in q_init for auto-reset)
+  // episode log of mbt_env_step_many_device: a ring of reductions in flight
+  static constexpr uint32_t kLogSlots = 16;
+  double* log_dev = nullptr;       // kLogSlots x 3 doubles, device
+  double* log_host = nullptr;      // the same, pinned host
+  hipEvent_t log_event[kLogSlots] = {};
+  uint32_t log_head = 0, log_count = 0;  // oldest entry, entries in flight
+  void* comm = nullptr;            // ncclComm_t of the episode log (mbt_env_set_communicator)
+  // staging of mbt_env_rollout_host trajectories (grow-only)
+  float* traj_stage[3] = {nullptr, nullptr, nullptr};
+  size_t traj_stage_floats[3] = {0, 0, 0};
 };
 
 namespace {
@@ -228,14 +243,15 @@ void fill_static_params(mbt_env* e) {
   P.dt = static_cast<float>(e->dt);
   // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
   const int mk = c.midprice_kind;
+  const bool sde = mk == MBT_MID_LINEAR_SDE;  // the family itself: every coefficient comes from the caller
   const bool ou = mk == MBT_MID_OU || mk == MBT_MID_OU_JUMP, jump = mk == MBT_MID_BROWNIAN_JUMP || mk == MBT_MID_OU_JUMP;
-  P.mid_add = (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0f : 1.0f;
-  P.mid_mul = mk == MBT_MID_GBM ? 1.0f : 0.0f;
+  P.mid_add = sde ? static_cast<float>(c.mid_coef_add) : (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0f : 1.0f;
+  P.mid_mul = sde ? static_cast<float>(c.mid_coef_mul) : mk == MBT_MID_GBM ? 1.0f : 0.0f;
   P.drift_dt = (ou || mk == MBT_MID_CONSTANT) ? 0.0f : static_cast<float>(c.drift * e->mid_dt);
   P.vol_sqrt_dt = mk == MBT_MID_CONSTANT ? 0.0f : static_cast<float>(c.volatility * std::sqrt(e->mid_dt));
-  P.ou_speed = ou ? static_cast<float>(c.ou_speed) : 0.0f;
-  P.ou_level = ou ? static_cast<float>(c.ou_level) : 0.0f;
-  P.jump_size = jump ? static_cast<float>(c.jump_size) : 0.0f;
+  P.ou_speed = (ou || sde) ? static_cast<float>(c.ou_speed) : 0.0f;
+  P.ou_level = (ou || sde) ? static_cast<float>(c.ou_level) : 0.0f;
+  P.jump_size = (jump || sde) ? static_cast<float>(c.jump_size) : 0.0f;
   if (c.arrival_kind == MBT_ARR_POISSON_NONLINEAR) {  // ARR:83
     P.arr_thr_bid = round_up_f32(1.0 - std::exp(-c.intensity[0] * e->arr_dt));
     P.arr_thr_ask = round_up_f32(1.0 - std::exp(-c.intensity[1] * e->arr_dt));
@@ -295,6 +311,19 @@ void fill_static_params(mbt_env* e) {
   }
 }
 
+// What the reward functions capture at reset (RW:72-74, RW:111-113): they measure the episode against THEIR OWN
+// terminal_time constructor argument, which need not be the environment's.
+void fill_episode_params(mbt_env* e) {
+  const mbt_config& c = e->cfg;
+  mbt::StepParams& P = e->params;
+  const double reward_T = c.reward_terminal_time > 0.0 ? c.reward_terminal_time : c.terminal_time;
+  const double length = reward_T - e->start_time;
+  P.q_init_scalar = static_cast<float>(c.initial_inventory);
+  P.dt_over_episode = static_cast<float>(e->dt / length);  // RW:106, RW:113
+  P.quad_init = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha * e->dt / length) : 0.0f;
+  P.episode_length = static_cast<float>(length);  // RW:67, RW:74
+}
+
 void key_from_seed(mbt_env* e) {
   e->params.key0 = static_cast<uint32_t>(e->seed);
   e->params.key1 = static_cast<uint32_t>(e->seed >> 32);
@@ -313,13 +342,13 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
   const bool inject = e->cfg.noise_mode == MBT_NOISE_INJECTED;
   if (inject && !e->noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: set_noise() must precede every step()");
-  // host clock: t += dt (TE:216); done = t >= T - dt/2 (TE:218-220)
-  e->time += e->dt;
-  const bool terminal = e->time >= e->cfg.terminal_time - e->dt / 2;
+  // host clock: t += dt (TE:216); done = t >= T - dt/2 (TE:218-220).  Committed only once the launch is known to be queued.
+  const double t_next = e->time + e->dt;
+  const bool terminal = t_next >= e->cfg.terminal_time - e->dt / 2;
   mbt::StepParams& P = e->params;
   P.philox_step = e->philox_step;
   P.is_terminal = terminal ? 1 : 0;
-  P.t_next = static_cast<float>(e->time);
+  P.t_next = static_cast<float>(t_next);
 
   mbt::StepBuffers B;
   B.state_in = e->state[e->cur];
@@ -337,6 +366,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   B.clip_count = e->clip_count;
   hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P);
   HIP_TRY(hipGetLastError());
+  e->time = t_next;
   e->cur ^= 1;
   e->philox_step += 1;
   e->episode_step += 1;
@@ -452,23 +482,25 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   return MBT_OK;
 }
 
-int do_reset(mbt_env* e, double start_time, const float* q0_host) {
+// reuse_q0: an automatic reset (mbt_env_step_many_device) restarts from the initial inventories of the last explicit one
+int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 = false) {
   const mbt_config& c = e->cfg;
   if (!(start_time >= 0.0 && start_time < c.terminal_time))
     return fail(MBT_ERR_INVALID, "start time %g is not within [0, terminal_time)", start_time);  // TE:267
-  e->q_init_per_lane = false;
-  if (q0_host != nullptr) {
-    HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM || c.reward_kind == MBT_REW_CJ_OE;
+  if (!reuse_q0) {
+    e->q_init_per_lane = false;
+    e->q0_per_lane_reset = q0_host != nullptr;
+    if (q0_host != nullptr) {
+      HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+      e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM || c.reward_kind == MBT_REW_CJ_OE;
+    }
   }
+  const bool per_lane_q0 = reuse_q0 ? e->q0_per_lane_reset : q0_host != nullptr;
   e->time = e->start_time = start_time;
   e->episode_step = 0;
   e->cur = 0;
   mbt::StepParams& P = e->params;
-  P.q_init_scalar = static_cast<float>(c.initial_inventory);
-  P.dt_over_episode = static_cast<float>(e->dt / (c.terminal_time - start_time));  // RW:106, RW:113
-  P.quad_init = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha * e->dt / (c.terminal_time - start_time)) : 0.0f;
-  P.episode_length = static_cast<float>(c.terminal_time - start_time);              // RW:67, RW:74
+  fill_episode_params(e);
   const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
   mbt::ResetRow row0{static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
                      static_cast<float>(c.initial_inventory), {0.f, 0.f, 0.f, 0.f}};
@@ -487,7 +519,7 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
   }
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
-                     q0_host != nullptr ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P);
+                     per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P);
   HIP_TRY(hipGetLastError());
   if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
   e->was_reset = true;
@@ -496,10 +528,101 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host) {
 
 float* current_obs(mbt_env* e) { return e->cfg.normalise_observation ? e->obs : e->state[e->cur]; }
 
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------------
+// The trajectory axis shards with no data-path collective; the one exchange is 24 bytes per episode.  libmbtenv therefore
+// does not link librccl: the symbols are looked up in the copy the process already has (PyTorch bundles its own; two
+// copies of RCCL - like two copies of the HIP runtime - must not meet in one process) or, failing that, in the system's.
+struct RcclApi {
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+const RcclApi& rccl() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = nullptr;
+    const char* override_path = std::getenv("MBT_RCCL_LIBRARY");
+    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* name : names)  // already in the process?
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : names)
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) {
+      const char* err = dlerror();
+      a.why = std::string("librccl.so.1 could not be loaded: ") + (err != nullptr ? err : "unknown error");
+      return a;
+    }
+    a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(h, "ncclAllReduce"));
+    a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
+    a.ok = a.all_reduce != nullptr && a.get_unique_id != nullptr && a.comm_init_rank != nullptr && a.comm_destroy != nullptr;
+    if (!a.ok) a.why = "librccl is loaded but lacks ncclAllReduce / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy";
+    return a;
+  }();
+  return api;
+}
+
+int rccl_fail(ncclResult_t r, const char* what) {
+  const RcclApi& api = rccl();
+  return fail(MBT_ERR_HIP, "%s failed: %s", what, api.error_string != nullptr ? api.error_string(r) : "RCCL error");
+}
+static_assert(sizeof(ncclUniqueId) == MBT_COMM_ID_BYTES, "ncclUniqueId size");
+
+// Enqueue "this episode's [sum R, sum R^2, lanes], over all ranks, into the next slot of the episode log": one reduction
+// launch, one in-place 24-byte all-reduce when a communicator is set, one copy to pinned memory, one event - all on the
+// environment's stream, nothing waits.
+int log_wait_oldest(mbt_env* e, double sums[3]);
+int log_push(mbt_env* e) {
+  if (e->log_count == mbt_env::kLogSlots) {
+    double dropped[3];
+    int rc = log_wait_oldest(e, dropped);  // the ring is full: the oldest entry is lost to the log (documented in the header)
+    if (rc < 0) return rc;
+  }
+  const uint32_t slot = (e->log_head + e->log_count) % mbt_env::kLogSlots;
+  double* dev = e->log_dev + 3 * slot;
+  hipLaunchKernelGGL(mbt::reduce_returns_kernel, dim3(1), dim3(256), 0, e->stream, e->wave_sums, e->n_waves,
+                     e->track_returns ? e->lane_returns : nullptr, e->n, dev);
+  HIP_TRY(hipGetLastError());
+  if (e->comm != nullptr) {
+    const RcclApi& api = rccl();
+    if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+    ncclResult_t r = api.all_reduce(dev, dev, 3, ncclDouble, ncclSum, static_cast<ncclComm_t>(e->comm), e->stream);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+  }
+  HIP_TRY(hipMemcpyAsync(e->log_host + 3 * slot, dev, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipEventRecord(e->log_event[slot], e->stream));
+  e->log_count += 1;
+  return MBT_OK;
+}
+
+int log_wait_oldest(mbt_env* e, double sums[3]) {
+  const uint32_t slot = e->log_head;
+  HIP_TRY(hipEventSynchronize(e->log_event[slot]));
+  for (int j = 0; j < 3; ++j) sums[j] = e->log_host[3 * slot + j];
+  e->log_head = (e->log_head + 1) % mbt_env::kLogSlots;
+  e->log_count -= 1;
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
 
+#ifndef MBT_SOURCE_HASH
+#define MBT_SOURCE_HASH "unknown"
+#endif
+// the marker lets build.py read the hash out of the file without loading the library
+static const char kSourceHash[] = "mbt-source-hash:" MBT_SOURCE_HASH;
+const char* mbt_source_hash(void) { return kSourceHash + 16; }
 uint32_t mbt_abi_version(void) { return MBT_ABI_VERSION; }
 size_t mbt_config_sizeof(void) { return sizeof(mbt_config); }
 const char* mbt_last_error(void) { return g_error.c_str(); }
@@ -529,8 +652,9 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
   if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
   const bool speed = cfg->dynamics_kind == MBT_DYN_SPEED;
-  if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_CONSTANT)
+  if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_LINEAR_SDE)
     return fail(MBT_ERR_INVALID, "midprice kind %d has no device implementation", cfg->midprice_kind);
+  if (cfg->reward_terminal_time != 0.0 && !(cfg->reward_terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "reward_terminal_time must be positive (or 0 = terminal_time)");
   if (cfg->dynamics_kind < MBT_DYN_LIMIT || cfg->dynamics_kind > MBT_DYN_SPEED)
     return fail(MBT_ERR_INVALID, "dynamics kind %d has no device implementation", cfg->dynamics_kind);
   if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_CJ_OE)
@@ -540,8 +664,10 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
       return fail(MBT_ERR_INVALID, "speed dynamics take no arrival or fill model (MD:273-275)");
     if (cfg->impact_kind < MBT_IMPACT_TEMPORARY_POWER || cfg->impact_kind > MBT_IMPACT_TRANSIENT)
       return fail(MBT_ERR_INVALID, "speed dynamics need a price impact model (impact kind %d)", cfg->impact_kind);
-    if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP)
+    if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP ||
+        (cfg->midprice_kind == MBT_MID_LINEAR_SDE && cfg->jump_size != 0.0))
       return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
+    if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state applies to order-book dynamics");
     if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
       return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
   } else {
@@ -556,6 +682,12 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
         return fail(MBT_ERR_INVALID, "base_fill_probability %g is not a probability", cfg->base_fill_probability);
     } else if (cfg->fill_kind != MBT_FILL_EXPONENTIAL) {
       return fail(MBT_ERR_INVALID, "fill kind %d has no device implementation", cfg->fill_kind);
+    }
+    if (cfg->arrival_kind == MBT_ARR_HAWKES && !cfg->allow_stiff_hawkes) {
+      const double dt_arr = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : cfg->terminal_time / cfg->n_steps;
+      if (!(cfg->hawkes_speed * dt_arr < 1.0))
+        return fail(MBT_ERR_INVALID, "Hawkes mean_reversion_speed * step_size = %g >= 1: the intensity recursion (ARR:110-119) oscillates (>= 2: diverges) "
+                    "and float32 state stops tracking the float64 reference; set allow_stiff_hawkes to run it anyway", cfg->hawkes_speed * dt_arr);
     }
     if (cfg->reward_kind == MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the one-dimensional action of speed dynamics (RW:65)");
     if (cfg->impact_kind != MBT_IMPACT_NONE) return fail(MBT_ERR_INVALID, "price impact models belong to speed dynamics");
@@ -608,7 +740,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->own_stream = true;
   if (hipEventCreate(&e->ev_begin) != hipSuccess || hipEventCreate(&e->ev_end) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_sums, hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&e->h_sums), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc(reinterpret_cast<void**>(&e->h_sums), 3 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     mbt_env_destroy(e);
     return fail(MBT_ERR_HIP, "hipEventCreate failed");
   }
@@ -628,7 +760,17 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   ENV_TRY(dev_alloc(&e->q_init, np, e->stream));
   ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves, e->stream));
   ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
-  ENV_TRY(dev_alloc(&e->reduce_out, 2, e->stream));
+  ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
+  ENV_TRY(dev_alloc(&e->log_dev, 3 * mbt_env::kLogSlots, e->stream));
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->log_host), 3 * mbt_env::kLogSlots * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    mbt_env_destroy(e);
+    return fail(MBT_ERR_HIP, "hipHostMalloc failed");
+  }
+  for (uint32_t k = 0; k < mbt_env::kLogSlots; ++k)
+    if (hipEventCreateWithFlags(&e->log_event[k], hipEventDisableTiming) != hipSuccess) {
+      mbt_env_destroy(e);
+      return fail(MBT_ERR_HIP, "hipEventCreate failed");
+    }
   uint32_t fast_path_lanes = kHostFastPathLanes;
   if (const char* env_override = std::getenv("MBT_HOST_FAST_PATH_LANES")) fast_path_lanes = static_cast<uint32_t>(std::strtoul(env_override, nullptr, 10));
   if (e->n <= fast_path_lanes) {  // see step_host: zero-copy staging instead of pageable DMA copies
@@ -665,9 +807,12 @@ void mbt_env_destroy(mbt_env* e) {
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
   void* bufs[] = {e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
                   e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
-                  e->policy_table};
+                  e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2]};
   for (void* b : bufs)
     if (b != nullptr) (void)hipFree(b);
+  if (e->log_host != nullptr) (void)hipHostFree(e->log_host);
+  for (hipEvent_t ev : e->log_event)
+    if (ev != nullptr) (void)hipEventDestroy(ev);
   if (e->h_stage != nullptr) (void)hipHostFree(e->h_stage);
   if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);
   if (e->ev_end != nullptr) (void)hipEventDestroy(e->ev_end);
@@ -679,6 +824,7 @@ void mbt_env_destroy(mbt_env* e) {
 
 int mbt_env_set_stream(mbt_env* e, void* hip_stream) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->own_stream && e->stream != nullptr) (void)hipStreamDestroy(e->stream);
   e->stream = static_cast<hipStream_t>(hip_stream);
@@ -688,7 +834,30 @@ int mbt_env_set_stream(mbt_env* e, void* hip_stream) {
 
 int mbt_env_synchronize(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  // A blocking wait costs a wake-up (an interrupt round trip, tens of microseconds) - more than a step at 2^20 lanes.
+  // Poll first: short waits, the common case between a consumer's launches, end within a microsecond of the stream.
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(e->stream);
+    if (q == hipSuccess) return MBT_OK;
+    if (q != hipErrorNotReady) return fail(MBT_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_set_step_size(mbt_env* e, double step_size) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (!(step_size > 0.0)) return fail(MBT_ERR_INVALID, "step_size must be positive");
+  // TE:158-167: the environment's clock and every process continue with the new value; like the reference, nothing else
+  // (n_steps, terminal_time, max_cash, Box bounds) is re-derived.  The kernel parameters are host-side data.
+  e->dt = e->mid_dt = e->arr_dt = e->imp_dt = step_size;
+  e->cfg.midprice_step_size = e->cfg.arrival_step_size = e->cfg.impact_step_size = step_size;
+  fill_static_params(e);
+  key_from_seed(e);
+  fill_episode_params(e);
   return MBT_OK;
 }
 
@@ -749,8 +918,111 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
   return MBT_OK;
 }
 
+int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device, int32_t auto_reset, uint32_t* steps_done,
+                             uint32_t* episodes_ended) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "injected noise is consumed one step at a time: use mbt_env_step_device");
+  if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows, once
+    HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    action_device = nullptr;
+  }
+  uint32_t steps = 0, episodes = 0;
+  int rc = MBT_OK;
+  while (steps < k) {
+    int32_t done = 0;
+    rc = launch_step(e, action_device, &done);
+    if (rc != MBT_OK) break;
+    ++steps;
+    if (done) {
+      ++episodes;
+      if (!auto_reset) break;
+      rc = log_push(e);
+      if (rc != MBT_OK) break;
+      rc = do_reset(e, e->start_time, nullptr, /*reuse_q0=*/true);
+      if (rc != MBT_OK) break;
+    }
+  }
+  if (steps_done != nullptr) *steps_done = steps;
+  if (episodes_ended != nullptr) *episodes_ended = episodes;
+  return rc;
+}
+
+int mbt_env_episode_log_pop(mbt_env* e, double sums[3], int32_t wait) {
+  if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (e->log_count == 0) return 0;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (!wait) {
+    const hipError_t q = hipEventQuery(e->log_event[e->log_head]);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return fail(MBT_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+  }
+  return log_wait_oldest(e, sums);
+}
+
+int mbt_env_set_communicator(mbt_env* e, void* nccl_comm) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (nccl_comm != nullptr && !rccl().ok) return fail(MBT_ERR_HIP, "%s", rccl().why.c_str());
+  e->comm = nccl_comm;
+  return MBT_OK;
+}
+
+int mbt_env_allreduce_returns(mbt_env* e, void* nccl_comm, double sums[3]) {
+  if (e == nullptr || nccl_comm == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  const RcclApi& api = rccl();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  // h_sums (pinned) -> reduce_out (device) -> all-reduce in place -> h_sums; ordered on the environment's stream
+  if (e->sums_pending) return fail(MBT_ERR_STATE, "a return-sums request is in flight: call mbt_env_return_sums_end first");
+  for (int j = 0; j < 3; ++j) e->h_sums[j] = sums[j];
+  HIP_TRY(hipMemcpyAsync(e->reduce_out, e->h_sums, 3 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  ncclResult_t r = api.all_reduce(e->reduce_out, e->reduce_out, 3, ncclDouble, ncclSum, static_cast<ncclComm_t>(nccl_comm), e->stream);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+  HIP_TRY(hipMemcpyAsync(e->h_sums, e->reduce_out, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int j = 0; j < 3; ++j) sums[j] = e->h_sums[j];  // an untracked second moment is NaN on its rank and stays NaN in the sum
+  return MBT_OK;
+}
+
+int mbt_comm_unique_id(void* id_out) {
+  if (id_out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  const RcclApi& api = rccl();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  ncclUniqueId id;
+  ncclResult_t r = api.get_unique_id(&id);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclGetUniqueId");
+  std::memcpy(id_out, &id, sizeof id);
+  return MBT_OK;
+}
+
+int mbt_comm_init_rank(int device, int n_ranks, const void* id_bytes, int rank, void** comm_out) {
+  if (id_bytes == nullptr || comm_out == nullptr || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(MBT_ERR_INVALID, "bad argument");
+  const RcclApi& api = rccl();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = api.comm_init_rank(&comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
+  *comm_out = comm;
+  return MBT_OK;
+}
+
+int mbt_comm_destroy(void* comm) {
+  if (comm == nullptr) return MBT_OK;
+  const RcclApi& api = rccl();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  ncclResult_t r = api.comm_destroy(static_cast<ncclComm_t>(comm));
+  if (r != ncclSuccess) return rccl_fail(r, "ncclCommDestroy");
+  return MBT_OK;
+}
+
 int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   if (action_device != nullptr && e->n != e->n_pad) {
     // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -772,21 +1044,30 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
                          float* rew_traj, uint32_t* steps_done, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends)
+  // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends); the buffers
+  // are kept by the environment (grow-only, up to 1 GiB each), so a consumer that records every episode allocates once
   const uint32_t remaining = static_cast<uint32_t>(std::ceil((e->cfg.terminal_time - e->time) / e->dt)) + 1;
   const size_t k_max = max_steps < remaining ? max_steps : remaining;
   const size_t np = e->n_pad;
-  float *d_obs = nullptr, *d_act = nullptr, *d_rew = nullptr;
-  int rc = MBT_OK;
-  if (obs_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_obs), (k_max + 1) * np * e->dim * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
-  if (rc == MBT_OK && act_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_act), k_max * np * e->act_dim * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
-  if (rc == MBT_OK && rew_traj != nullptr && hipMalloc(reinterpret_cast<void**>(&d_rew), k_max * np * sizeof(float)) != hipSuccess) rc = MBT_ERR_HIP;
-  uint32_t steps = 0;
-  if (rc != MBT_OK) {
-    fail(MBT_ERR_HIP, "out of device memory for the trajectory staging buffers");
-  } else {
-    rc = launch_rollout(e, policy, max_steps, d_obs, d_act, d_rew, &steps, done);
+  const size_t want[3] = {obs_traj != nullptr ? (k_max + 1) * np * e->dim : 0, act_traj != nullptr ? k_max * np * e->act_dim : 0,
+                          rew_traj != nullptr ? k_max * np : 0};
+  for (int j = 0; j < 3; ++j) {
+    if (want[j] <= e->traj_stage_floats[j]) continue;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->traj_stage[j] != nullptr) (void)hipFree(e->traj_stage[j]);
+    e->traj_stage[j] = nullptr;
+    e->traj_stage_floats[j] = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&e->traj_stage[j]), want[j] * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(MBT_ERR_HIP, "out of device memory for the trajectory staging buffers (%zu MB)", want[j] * sizeof(float) >> 20);
+    }
+    e->traj_stage_floats[j] = want[j];
   }
+  float* d_obs = obs_traj != nullptr ? e->traj_stage[0] : nullptr;
+  float* d_act = act_traj != nullptr ? e->traj_stage[1] : nullptr;
+  float* d_rew = rew_traj != nullptr ? e->traj_stage[2] : nullptr;
+  uint32_t steps = 0;
+  int rc = launch_rollout(e, policy, max_steps, d_obs, d_act, d_rew, &steps, done);
   if (rc == MBT_OK) {
     // compact the padded time slices (n_pad lanes) into the caller's (n lanes) with strided copies
     const size_t n = e->n;
@@ -797,10 +1078,13 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) rc = fail(MBT_ERR_HIP, "trajectory copy failed: %s", hipGetErrorString(he));
   }
-  (void)hipStreamSynchronize(e->stream);
-  if (d_obs != nullptr) (void)hipFree(d_obs);
-  if (d_act != nullptr) (void)hipFree(d_act);
-  if (d_rew != nullptr) (void)hipFree(d_rew);
+  for (int j = 0; j < 3; ++j)  // what is kept between calls is bounded: a recording of gigabytes is released again
+    if (e->traj_stage_floats[j] * sizeof(float) > (size_t(1) << 30)) {
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipFree(e->traj_stage[j]);
+      e->traj_stage[j] = nullptr;
+      e->traj_stage_floats[j] = 0;
+    }
   if (steps_done != nullptr) *steps_done = steps;
   return rc;
 }
@@ -950,6 +1234,7 @@ int mbt_env_return_sums_begin(mbt_env* e) {
 int mbt_env_return_sums_end(mbt_env* e, double sums[3]) {
   if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!e->sums_pending) return fail(MBT_ERR_STATE, "no return-sums request in flight");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipEventSynchronize(e->ev_sums));  // waits for the reduction only: later launches keep running
   e->sums_pending = false;
   sums[0] = e->h_sums[0];
@@ -1050,13 +1335,18 @@ int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key
 
 int mbt_env_timer_begin(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
   return MBT_OK;
 }
 
 int mbt_env_timer_end(mbt_env* e, float* elapsed_ms) {
   if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipEventRecord(e->ev_end, e->stream));
+  const auto t0 = std::chrono::steady_clock::now();  // poll before blocking, like mbt_env_synchronize
+  while (hipEventQuery(e->ev_end) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {
+  }
   HIP_TRY(hipEventSynchronize(e->ev_end));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev_begin, e->ev_end));
   return MBT_OK;

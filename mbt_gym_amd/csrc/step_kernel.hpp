@@ -799,7 +799,7 @@ __global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n
   for (int j = 0; j < dim; ++j) o[j] = P.norm_obs ? normalise_column(r[j], j, P) : r[j];
 }
 
-// [sum of wave_sums, sum of lane_returns^2] -> out[0], out[1]; one block.
+// [sum of wave_sums, sum of lane_returns^2 (NaN when per-lane returns are not tracked), lane count] -> out[0..2]; one block.
 __global__ void reduce_returns_kernel(const double* wave_sums, uint32_t n_waves, const float* lane_returns, uint32_t n,
                                       double* out) {
   __shared__ double s_sum[256], s_sq[256];
@@ -819,7 +819,8 @@ __global__ void reduce_returns_kernel(const double* wave_sums, uint32_t n_waves,
   }
   if (threadIdx.x == 0) {
     out[0] = s_sum[0];
-    out[1] = s_sq[0];
+    out[1] = lane_returns != nullptr ? s_sq[0] : __builtin_nan("");
+    out[2] = static_cast<double>(n);
   }
 }
 

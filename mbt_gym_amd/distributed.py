@@ -5,7 +5,10 @@ lane-invariant time and done flag, TradingEnvironment.py:218-220), so each rank 
 lane ids and steps it with no communication at all.  Noise is a function of the global lane id, so results do
 not depend on the number of ranks.  What a run reports - the mean (and spread) of the episode return - needs three
 doubles per rank, [sum R, sum R^2, count]: ONE all-reduce over RCCL/xGMI per episode, 24 bytes, latency bound
-(never inside the step loop).  `torch.distributed` is the transport (backend "nccl" = RCCL on ROCm, "gloo" on CPU).
+(never inside the step loop).  Two transports: the C ABI's own RCCL binding (`RcclCommunicator` +
+`TradingEnvironment.set_communicator` / `allreduce_return_sums`: the reduction is enqueued on the environment's stream
+and never touches Python) and `torch.distributed` (`allreduce_return_sums` / `PendingReturnSums` below; backend "nccl" =
+RCCL on ROCm, "gloo" on CPU - the route the CPU tests and single-device multi-rank tests take).
 """
 from typing import Tuple
 
@@ -23,6 +26,44 @@ def shard_bounds(total_lanes: int, rank: int, world_size: int) -> Tuple[int, int
     per = -(-per // SHARD_ALIGN) * SHARD_ALIGN
     offset = rank * per  # an empty shard (count 0) still sits on a tile boundary
     return offset, max(0, min(per, total_lanes - offset))
+
+
+class RcclCommunicator:
+    """An RCCL communicator created through the C ABI (mbt_comm_*), one rank per GPU.  The 128-byte unique id is made on
+    rank 0 and handed to the others by `exchange` - any callable bytes -> bytes that broadcasts rank 0's value (the
+    default uses the torch.distributed process group the launcher already set up; the collective itself never goes
+    through torch).  `handle` is the ncclComm_t for mbt_env_allreduce_returns / mbt_env_set_communicator."""
+
+    def __init__(self, rank: int, world_size: int, device: int, exchange=None):
+        import ctypes as C
+
+        from mbt_gym_amd import _native
+
+        _native.preload_torch_rccl()
+        lib = _native.load_library()
+        ident = C.create_string_buffer(_native.COMM_ID_BYTES)
+        if rank == 0:
+            _native.check(lib.mbt_comm_unique_id(ident))
+        raw = (exchange or _broadcast_bytes)(ident.raw)
+        assert len(raw) == _native.COMM_ID_BYTES
+        handle = C.c_void_p()
+        _native.check(lib.mbt_comm_init_rank(int(device), int(world_size), C.create_string_buffer(raw, _native.COMM_ID_BYTES), int(rank), C.byref(handle)))
+        self.handle, self.rank, self.world_size, self._lib = handle, rank, world_size, lib
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.mbt_comm_destroy(self.handle)
+            self.handle = None
+
+
+def _broadcast_bytes(payload: bytes) -> bytes:
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return payload
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def allreduce_return_sums(sums, device=None) -> np.ndarray:

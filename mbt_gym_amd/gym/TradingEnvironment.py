@@ -8,7 +8,9 @@ include/mbt_env.h.  This module holds host logic only (argument handling, spaces
 no numerics of the step are evaluated here, and there is no CPU fallback.
 
 Extra keyword arguments (after the reference's): `device`, `trajectory_offset` (global id of lane 0 when the
-trajectory axis is sharded over GPUs), `noise` ("philox" | "injected").
+trajectory axis is sharded over GPUs), `noise` ("philox" | "injected"), `precise_state` (cash and midprice kept as
+float32 pairs: rewards within 1e-5 of the float64 reference on every lane, +16 B of traffic per env-step),
+`allow_stiff_hawkes` (accept mean_reversion_speed * step_size >= 1, see include/mbt_env.h).
 Extra methods: `step_device()` / `obs_device` / `reward_device` (zero-copy, asynchronous), `set_noise()`,
 `record_events()`, `episode_return_sums()`.
 
@@ -72,6 +74,8 @@ class TradingEnvironment(_EnvBase):
         device: int = 0,
         trajectory_offset: int = 0,
         noise: str = "philox",
+        precise_state: bool = False,
+        allow_stiff_hawkes: bool = False,
     ):
         if _EnvBase is not object:
             super().__init__()
@@ -106,6 +110,8 @@ class TradingEnvironment(_EnvBase):
         self.device = device
         self.trajectory_offset = trajectory_offset
         self.noise = noise
+        self.precise_state = precise_state
+        self.allow_stiff_hawkes = allow_stiff_hawkes
         # Seeding protocol of the reference: `if seed:` - seed=0 or None leaves the processes unseeded (TE:70);
         # the environment-level generator (initial inventories) is always default_rng(seed) (TE:72).
         self.seed_ = seed
@@ -190,6 +196,10 @@ class TradingEnvironment(_EnvBase):
         cfg.max_cash = self.max_cash
         cfg.reward_scale = reward_scale
         cfg.seed = self._philox_key
+        # CjMmCriterion / CjOeCriterion measure the episode against their OWN terminal_time (RW:74, RW:113)
+        cfg.reward_terminal_time = float(getattr(self.reward_function, "terminal_time", 0.0) or 0.0)
+        cfg.precise_state = int(self.precise_state)
+        cfg.allow_stiff_hawkes = int(self.allow_stiff_hawkes)
         cfg.normalise_observation = int(self.normalise_observation_space_)
         cfg.normalise_action = int(self.normalise_action_space_)
         lo, hi = self.original_observation_space.low, self.original_observation_space.high
@@ -206,6 +216,16 @@ class TradingEnvironment(_EnvBase):
         cfg = self._device_config(num_trajectories, reward_scale, trajectory_offset)
         handle = C.c_void_p()
         _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        # the host derives the row widths from the descriptors (TE:311-318), the library from the plugin kinds: a
+        # disagreement would hand back misaligned rows, so it is an error, not a warning
+        dims = (lib.mbt_env_obs_dim(handle), lib.mbt_env_action_dim(handle))
+        if dims != (self.observation_dim, self.action_dim):
+            lib.mbt_env_destroy(handle)
+            raise UnsupportedOnDevice(
+                f"the device lays this plugin combination out as (D, A) = {dims}, the descriptors as "
+                f"({self.observation_dim}, {self.action_dim}): no HIP implementation for this combination")
+        if self._step_size != self.terminal_time / self.n_steps:  # a step_size set earlier (TE:158-167) survives a re-allocation
+            _native.check(lib.mbt_env_set_step_size(handle, float(self._step_size)))
         return handle
 
     def close(self):
@@ -281,6 +301,36 @@ class TradingEnvironment(_EnvBase):
         done = C.c_int32(0)
         _native.check(_native.load_library().mbt_env_step_device(self._handle, action_ptr, C.byref(done)))
         return bool(done.value)
+
+    def step_many_device(self, k: int, action_ptr: int = None, auto_reset: bool = True):
+        """`k` consecutive `step_device()` launches in ONE call into the library (the interpreter's per-call overhead is paid
+        once).  With `auto_reset`, an episode that ends inside the batch is logged - its return sums are reduced on the
+        device, all-reduced over `set_communicator()`'s communicator if there is one, and read with
+        `episode_log_pop()` - and the lanes restart from the last reset's start time and initial inventories, all
+        enqueued without waiting for the stream.  Returns (steps run, episodes ended)."""
+        steps, episodes = C.c_uint32(0), C.c_uint32(0)
+        _native.check(_native.load_library().mbt_env_step_many_device(
+            self._handle, int(k), action_ptr, int(bool(auto_reset)), C.byref(steps), C.byref(episodes)))
+        return int(steps.value), int(episodes.value)
+
+    def episode_log_pop(self, wait: bool = True):
+        """Oldest finished episode's [sum R, sum R^2, lanes] (global when a communicator is set), or None when the log is
+        empty (or, with wait=False, not ready yet)."""
+        out = (C.c_double * 3)()
+        got = _native.check(_native.load_library().mbt_env_episode_log_pop(self._handle, out, int(bool(wait))))
+        return np.array(out[:], dtype=np.float64) if got == 1 else None
+
+    def set_communicator(self, comm):
+        """`comm`: an `mbt_gym_amd.distributed.RcclCommunicator` (or None): episode logs become sums over all ranks."""
+        self._comm = comm  # keep it alive as long as the environment uses it
+        _native.check(_native.load_library().mbt_env_set_communicator(self._handle, None if comm is None else comm.handle))
+
+    def allreduce_return_sums(self, comm, sums) -> np.ndarray:
+        """[sum R, sum R^2, count] of this rank -> the sums over all ranks: one 24-byte RCCL all-reduce on the
+        environment's stream (mbt_env_allreduce_returns)."""
+        buf = (C.c_double * 3)(*[float(x) for x in sums])
+        _native.check(_native.load_library().mbt_env_allreduce_returns(self._handle, comm.handle, buf))
+        return np.array(buf[:], dtype=np.float64)
 
     @property
     def action_device(self):
@@ -491,10 +541,17 @@ class TradingEnvironment(_EnvBase):
 
     @step_size.setter
     def step_size(self, step_size: float):
-        # TE:158-167 lets step_size drift away from terminal_time / n_steps; the device clock is defined by
-        # (terminal_time, n_steps), so only a consistent value is accepted
-        if abs(step_size - self.terminal_time / self.n_steps) > 1e-15:
-            raise ValueError("step_size is terminal_time / n_steps on the device; construct a new environment to change it")
+        """TE:158-167: the environment's clock and done rule, every process and (if it has the attribute) the reward
+        function continue with the new step size; n_steps / terminal_time / max_cash are NOT re-derived, like the
+        reference.  On the device this replaces host-side kernel parameters: no reallocation."""
+        self._step_size = step_size
+        for process in self.stochastic_processes.values():
+            if process.step_size != step_size:
+                process.step_size = step_size
+        if hasattr(self.reward_function, "step_size"):
+            self.reward_function.step_size = step_size
+        if getattr(self, "_handle", None) is not None:
+            _native.check(_native.load_library().mbt_env_set_step_size(self._handle, float(step_size)))
 
     @property
     def num_trajectories(self):
@@ -600,21 +657,30 @@ class TradingEnvironment(_EnvBase):
         return spans
 
     def _get_inventory_neutral_rewards(self, num_total_trajectories=100_000):
-        """Mean episode return of the constant quote 1/kappa from t=0 over 100k lanes (TE:329-343), rolled out on
-        the device with a throw-away handle."""
+        """Mean episode return of the constant action 1/kappa from t=0 over 100k lanes (TE:329-343), rolled out on the
+        device with a throw-away handle.  Like the reference's deep copy, the calibration environment keeps the action
+        normalisation of this one - with `normalise_action_space=True` (the default) the fixed action 1/kappa is a
+        NORMALISED action and the quoted depth is (1/kappa + 1) * max_depth / 2 (TE:124) - and keeps tuple / callable
+        initial inventories (drawn from a copy of the environment generator, so this environment's stream is not
+        advanced).  Its Philox key is derived from, and different from, this environment's."""
+        import copy
+
         lib = _native.load_library()
-        saved = (self.start_time, self.normalise_action_space_, self.normalise_observation_space_)
-        self.normalise_action_space_, self.normalise_observation_space_ = False, False
         n = num_total_trajectories
+        saved = (self.normalise_observation_space_, self._philox_key, self._num_trajectories, self.rng)
         try:
+            self.normalise_observation_space_ = False  # observations are not read; rewards do not depend on it
+            self._philox_key = (self._philox_key ^ 0x9E3779B97F4A7C15) & (2**64 - 1)
             cfg = self._device_config(n, 1.0, trajectory_offset=0)
+            self._num_trajectories, self.rng = n, copy.deepcopy(self.rng)
+            q0 = self._get_initial_inventories()
         finally:
-            self.start_time, self.normalise_action_space_, self.normalise_observation_space_ = saved
+            self.normalise_observation_space_, self._philox_key, self._num_trajectories, self.rng = saved
         handle = C.c_void_p()
         _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
         try:
-            _native.check(lib.mbt_env_reset(handle, 0.0, None))
-            policy = _native.MbtPolicy(kind=_native.POLICY_FIXED)  # the constant quote 1/kappa on both sides (TE:330)
+            _native.check(lib.mbt_env_reset(handle, 0.0, _native.fptr(q0)))
+            policy = _native.MbtPolicy(kind=_native.POLICY_FIXED)  # the constant action 1/kappa on both sides (TE:330)
             policy.params[0] = policy.params[1] = 1.0 / self.model_dynamics.fill_probability_model.fill_exponent
             steps, done = C.c_uint32(0), C.c_int32(0)
             _native.check(lib.mbt_env_rollout_device(handle, C.byref(policy), self.n_steps, None, None, None, C.byref(steps), C.byref(done)))

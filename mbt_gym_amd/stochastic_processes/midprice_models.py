@@ -186,3 +186,59 @@ class ConstantMidpriceModel(_SymmetricBandMidprice):
 
     def device_params(self):
         return dict(midprice_kind=self.device_kind, initial_price=self.initial_price, midprice_step_size=self.step_size)
+
+
+class LinearSdeMidpriceModel(MidpriceModel):
+    """The device route for USER-DEFINED midprice models (the reference's plugin contract, SP:8-53, MID:12-273).
+
+    Every built-in midprice above is one member of the family the step kernel actually evaluates
+    (csrc/step_kernel.hpp: midprice_increment) - one Euler step of
+
+        S <- S + (scale_constant + scale_proportional * S) * (drift * dt + volatility * sqrt(dt) * Z)
+               - mean_reversion_speed * (S - mean_reversion_level)          [not scaled by dt, like MID:140-143]
+               + jump_size * (own ask fills - own bid fills)
+
+    with Z ~ N(0, 1) per lane and step.  A subclass of the reference's MidpriceModel whose `update` is of this form
+    (a drifting OU process, a mixture of arithmetic and geometric noise, GBM with jumps on the agent's trades, ...) runs on
+    the device by deriving from - or being replaced by - this class and naming its coefficients; what is NOT of this form
+    (stochastic volatility, extra state columns) has no device route and raises at construction of the environment.
+
+    min_value / max_value are the observation bounds of the midprice column (TE:232-241); the default is the OU band
+    initial_price -/+ 4 * volatility * terminal_time of MID:145-146 scaled by the noise level at the initial price."""
+
+    device_kind = _native.MID_LINEAR_SDE
+
+    def __init__(
+        self,
+        drift: float = 0.0,
+        volatility: float = 2.0,
+        scale_constant: float = 1.0,
+        scale_proportional: float = 0.0,
+        mean_reversion_level: float = 0.0,
+        mean_reversion_speed: float = 0.0,
+        jump_size: float = 0.0,
+        initial_price: float = 100.0,
+        terminal_time: float = 1.0,
+        step_size: float = 0.01,
+        num_trajectories: int = 1,
+        seed: Optional[int] = None,
+        min_value: Optional[float] = None,
+        max_value: Optional[float] = None,
+    ):
+        self.drift, self.volatility = drift, volatility
+        self.scale_constant, self.scale_proportional = scale_constant, scale_proportional
+        self.mean_reversion_level, self.mean_reversion_speed = mean_reversion_level, mean_reversion_speed
+        self.jump_size = jump_size
+        half = 4 * volatility * abs(scale_constant + scale_proportional * initial_price) * terminal_time
+        lo = initial_price - half if min_value is None else min_value
+        hi = initial_price + half if max_value is None else max_value
+        super().__init__(np.array([[lo]]), np.array([[hi]]), step_size, terminal_time, np.array([[initial_price]]), num_trajectories, seed)
+
+    @property
+    def initial_price(self) -> float:
+        return float(self.initial_state[0, 0])
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, mid_coef_add=self.scale_constant,
+                    mid_coef_mul=self.scale_proportional, ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed,
+                    jump_size=self.jump_size, initial_price=self.initial_price, midprice_step_size=self.step_size)

@@ -12,6 +12,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+def pytest_sessionstart(session):
+    """The tests exercise the in-tree libmbtenv.so: (re)build it when it is missing or was built from other sources
+    (content hash, mbt_gym_amd/build.py) - hipcc cross-compiles without a GPU.  Without hipcc the loader's own staleness
+    check decides."""
+    import shutil
+
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        from mbt_gym_amd.build import build_native
+
+        build_native()
+
+
+def _gfx950_visible() -> bool:
+    try:
+        from mbt_gym_amd import _native
+
+        return _native.device_count() > 0 and _native.device_name(0).startswith("gfx950")
+    except Exception:  # noqa: BLE001 - no library, no runtime, no device
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped - not errored - on a box without a gfx950 device (a plain `pytest` on the build container)."""
+    gpu_items = [item for item in items if "gpu" in item.keywords]
+    if not gpu_items or _gfx950_visible():
+        return
+    skip = pytest.mark.skip(reason="needs a gfx950 (MI355X) device: run through gpurun")
+    for item in gpu_items:
+        item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT

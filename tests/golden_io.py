@@ -8,7 +8,9 @@ import numpy as np
 from oracle.mbt_oracle import OracleConfig
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+# environment trajectories; `agents_*.npz` (tools/refgen/make_agent_golden.py) hold agent outputs and are loaded by their own tests
+CASES = sorted(name for name in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+               if not name.startswith("agents_"))
 
 
 def load_case(name):

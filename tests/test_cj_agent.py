@@ -82,3 +82,29 @@ def test_discrete_expectation_of_the_cj_policy_is_close_to_the_closed_form(no_de
     table = agent.depth_table()
     exact, _ = expected_episode_return(cfg, lambda k, q: (table[k, q + 100, 0], table[k, q + 100, 1]))
     assert exact == pytest.approx(68.25583476, abs=0.25)  # discretisation bias of dt = 1e-3 only
+
+
+def test_asymmetric_intensities_match_the_reference_agent(no_device, repo_root):
+    """Fixture: the reference's CarteaJaimungalMmAgent with intensity (140, 60) (tools/refgen/make_agent_golden.py).  For
+    symmetric intensities h is even in q and a mirrored inventory index goes unnoticed; here bid and ask differ."""
+    import os
+
+    g = np.load(os.path.join(repo_root, "tests", "golden", "agents_cj_asymmetric.npz"))
+    q_max, ns = int(g["max_inventory"]), int(g["n_steps"])
+    inventories = g["inventories"]
+    n = len(inventories)
+    cfg = OracleConfig(
+        num_trajectories=n, n_steps=ns, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+        intensity=tuple(g["intensity"]), fill_exponent=float(g["kappa"]), dynamics="limit", reward="cjmm", phi=float(g["phi"]),
+        alpha=float(g["alpha"]), initial_inventory=0, max_inventory=q_max, seed=3, normalise_action_space=False,
+        normalise_observation_space=False)
+    agent = CarteaJaimungalMmAgent(env=make_env(cfg))
+    for row, k in enumerate(g["time_steps"]):
+        state = np.zeros((n, 4))
+        state[:, 1], state[:, 2], state[:, 3] = inventories, k / ns, 100.0
+        np.testing.assert_allclose(agent.get_action(state), g["actions"][row], rtol=2e-6, atol=1e-6)  # float32 actions
+        np.testing.assert_allclose(agent.h_table()[k], g["h"][row], rtol=1e-9, atol=1e-12)
+        value = agent.calculate_true_value_function(state)
+        np.testing.assert_allclose(value, g["h"][row][np.clip(q_max + inventories, 0, 2 * q_max).astype(int)] + inventories * 100.0, rtol=1e-9)
+    a0 = agent.get_action(np.array([[0.0, 0.0, 0.0, 100.0]] * n))[0]
+    assert a0[0] > a0[1] + 0.3  # more buyers hitting the bid side's queue than sellers: the reference quotes (0.97, 0.41) at q = 0
