@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--lanes", type=int, default=LANES_PER_GPU, help="trajectories per GPU (default 2^20)")
+    ap.add_argument("--prewarm-steps", type=int, default=-1, help="untimed clock warm-up before --warmup; -1 = ~50 ms worth (default), 0 = none (reproducible episode count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
@@ -341,8 +342,8 @@ def main():
 
     # clocks up (untimed, not part of --warmup), then the warm-up the caller asked for
     prewarm, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < PREWARM_SECONDS:
-        prewarm += env.step_many_device(256, auto_reset=True)[0]
+    while (time.perf_counter() - t0 < PREWARM_SECONDS) if args.prewarm_steps < 0 else (prewarm < args.prewarm_steps):
+        prewarm += env.step_many_device(256 if args.prewarm_steps < 0 else min(256, args.prewarm_steps - prewarm), auto_reset=True)[0]
         env.synchronize()
     if args.warmup > 0:
         env.step_many_device(args.warmup, auto_reset=True)

@@ -79,29 +79,34 @@ int reward_weight(const mbt_config& c) {
   const bool quadratic = (c.reward_kind == MBT_REW_RUNNING_PENALTY || c.reward_kind == MBT_REW_CJ_MM) && c.inventory_exponent == 2.0;
   return quadratic ? mbt::kRewardQuadratic : mbt::kRewardGeneral;
 }
+// `stream` = the non-temporal-load instantiation (production noise only; see step_kernel and tune_for_size)
+template <int ARR, int DYN, bool BM, int REW, bool NORM>
+StepKernel pick_noise(bool inject, bool stream) {
+  if (inject) return mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, true>>;
+  return stream ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, false>, true> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, false>, false>;
+}
 template <int ARR, int DYN, bool BM, int REW>
-StepKernel pick_flags(bool norm, bool inject) {
-  if (norm) return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, true, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, true, false>>;
-  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, false, true>> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, false, false>>;
+StepKernel pick_flags(bool norm, bool inject, bool stream) {
+  return norm ? pick_noise<ARR, DYN, BM, REW, true>(inject, stream) : pick_noise<ARR, DYN, BM, REW, false>(inject, stream);
 }
 template <int ARR, int DYN, bool BM>
-StepKernel pick_rew(int rew, bool norm, bool inject) {
+StepKernel pick_rew(int rew, bool norm, bool inject, bool stream) {
   switch (rew) {
-    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject);
-    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject);
-    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject);
+    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject, stream);
+    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject, stream);
+    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject, stream);
   }
 }
 template <int ARR, int DYN>
-StepKernel pick_pen(bool bm, int rew, bool norm, bool inject) {
-  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject) : pick_rew<ARR, DYN, false>(rew, norm, inject);
+StepKernel pick_pen(bool bm, int rew, bool norm, bool inject, bool stream) {
+  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject, stream) : pick_rew<ARR, DYN, false>(rew, norm, inject, stream);
 }
 template <int ARR>
-StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject) {
+StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, bool stream) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject);
-    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject);
-    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject);
+    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject, stream);
+    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject, stream);
+    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, stream);
   }
 }
 template <bool STATE>
@@ -122,7 +127,7 @@ StepKernel pick_exogenous(bool inject) {
                 : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>>;
 }
 
-StepKernel pick_kernel(const mbt_config& c) {
+StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject) : pick_speed<false>(norm, inject);
@@ -133,8 +138,8 @@ StepKernel pick_kernel(const mbt_config& c) {
   }
   const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
   const int rew = reward_weight(c);
-  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject)
-                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject);
+  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject, stream)
+                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject, stream);
 }
 
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
@@ -218,6 +223,8 @@ struct mbt_env {
   StepKernel kernel = nullptr;
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
+  uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
+  bool stream_loads = false;       // the non-temporal-load instantiation of the step kernel, see tune_for_size()
   bool q0_per_lane_reset = false;  // the last explicit reset passed per-lane initial inventories (kept in q_init for auto-reset)
   // episode log of mbt_env_step_many_device: a ring of reductions in flight
   static constexpr uint32_t kLogSlots = 16;
@@ -311,6 +318,22 @@ void fill_static_params(mbt_env* e) {
   }
 }
 
+// Two regimes, chosen by how many bytes ONE launch touches.  Up to ~200 MB (2^22 lanes of the 44-byte step) the state the
+// next step reads is still in the 256 MB Infinity Cache: default-policy loads, full occupancy (8 workgroups per CU hide the
+// generator behind the loads).  Beyond that every byte crosses HBM and nothing is re-used: the step kernel's STREAM
+// instantiation is used, whose loads carry the non-temporal bit (they do not displace lines on the way in) and occupancy is capped at 5 workgroups per CU through a
+// dynamic LDS allocation - fewer, longer-lived streams per channel (129.9 -> 124.3 us at 2^24 lanes for occupancy alone,
+// profiles/r01_microbench.txt; the non-temporal loads: 128.3 -> 118.7 us on the copy kernel).  MBT_STREAM_LOADS = 0 / 1 and
+// MBT_STEP_DYNAMIC_LDS = bytes override the choice (measurement knobs).
+void tune_for_size(mbt_env* e) {
+  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u);
+  const bool hbm_resident = bytes_per_launch > (size_t(200) << 20);
+  e->stream_loads = hbm_resident;
+  e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;
+  if (const char* v = std::getenv("MBT_STREAM_LOADS")) e->stream_loads = std::atoi(v) != 0;
+  if (const char* v = std::getenv("MBT_STEP_DYNAMIC_LDS")) e->step_dynamic_lds = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
+}
+
 // What the reward functions capture at reset (RW:72-74, RW:111-113): they measure the episode against THEIR OWN
 // terminal_time constructor argument, which need not be the environment's.
 void fill_episode_params(mbt_env* e) {
@@ -364,7 +387,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
   B.clip_count = e->clip_count;
-  hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P);
+  hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P);
   HIP_TRY(hipGetLastError());
   e->time = t_next;
   e->cur ^= 1;
@@ -719,7 +742,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
-  e->kernel = pick_kernel(*cfg);
+  tune_for_size(e);
+  e->kernel = pick_kernel(*cfg, e->stream_loads);
   e->rollout = pick_rollout_kernel(*cfg);
   fill_static_params(e);
   key_from_seed(e);

@@ -77,6 +77,7 @@ struct StepParams {
   uint32_t key0, key1;   // Philox key (seed)
   uint32_t philox_step;  // Philox counter word 2
   int32_t is_terminal;   // this step ends the episode (TE:218-220), decided on the host
+  int32_t reserved_pad;
   float t_next;          // time written into the next state (TE:216)
   float dt;              // terminal_time / n_steps (TE:49): the clock and the reward penalties
   // midprice (each process scales with ITS OWN step size, SP:21; the environment never synchronises them)
@@ -454,25 +455,38 @@ struct LaneLoads {
   float qi;     // per-lane initial inventory (CjMm)
 };
 
-template <class V>
+typedef float ld4_t __attribute__((ext_vector_type(4)));
+typedef float ld2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float4 load4(const float* p) {
+  const ld4_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ld4_t*>(p)) : *reinterpret_cast<const ld4_t*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ float2 load2(const float* p) {
+  const ld2_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ld2_t*>(p)) : *reinterpret_cast<const ld2_t*>(p);
+  return make_float2(v.x, v.y);
+}
+
+template <class V, bool NT = false>
 __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepParams& P, uint32_t lane) {
   LaneLoads L;
   if (V::DIM == 8) {  // Hawkes + exogenous depths: 32-byte rows, the (constant) depth columns are not read
-    L.core = reinterpret_cast<const float4*>(B.state_in)[static_cast<size_t>(lane) * 2];
-    L.lam = reinterpret_cast<const float2*>(B.state_in)[static_cast<size_t>(lane) * 4 + 2];
+    L.core = load4<NT>(B.state_in + static_cast<size_t>(lane) * 8);
+    L.lam = load2<NT>(B.state_in + static_cast<size_t>(lane) * 8 + 4);
   } else if (V::DIM == 6) {  // rows of 6 floats: 8-byte aligned
-    const float2* row = reinterpret_cast<const float2*>(B.state_in) + static_cast<size_t>(lane) * 3;
-    const float2 a = row[0], b = row[1];
+    const float* row = B.state_in + static_cast<size_t>(lane) * 6;
+    const float2 a = load2<NT>(row), b = load2<NT>(row + 2);
     L.core = make_float4(a.x, a.y, b.x, b.y);
-    L.lam = V::ARR == kArrHawkes ? row[2] : make_float2(0.f, 0.f);
+    L.lam = V::ARR == kArrHawkes ? load2<NT>(row + 4) : make_float2(0.f, 0.f);
   } else {
-    L.core = reinterpret_cast<const float4*>(B.state_in)[lane];
+    L.core = load4<NT>(B.state_in + static_cast<size_t>(lane) * 4);
     L.lam = make_float2(0.f, 0.f);
   }
   if (V::DYN == kDynLimitAndMarket) {
-    L.act = reinterpret_cast<const float4*>(B.action)[lane];
+    L.act = load4<NT>(B.action + static_cast<size_t>(lane) * 4);
   } else {
-    const float2 a = reinterpret_cast<const float2*>(B.action)[lane];
+    const float2 a = load2<NT>(B.action + static_cast<size_t>(lane) * 2);
     L.act = make_float4(a.x, a.y, 0.f, 0.f);
   }
   if (V::INJECT) {
@@ -580,11 +594,17 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   return r.reward;
 }
 
-template <class V>
+// STREAM: the state / action loads carry the non-temporal bit.  Chosen by the host (mbt_env.hip: tune_for_size) when one
+// launch's working set exceeds the Infinity Cache - nothing read now is still cached at the next step, so it should not
+// displace lines on its way in: 128.3 -> 118.7 us for the 44-byte copy kernel at 2^24 lanes (profiles/r01_microbench.txt) -
+// and a LOSS where the working set does fit (2^20..2^22 lanes), hence two instantiations rather than one policy.  (A
+// run-time branch around the two load sequences does not survive the optimiser: it merges the branches' loads and drops
+// the hint.)
+template <class V, bool STREAM = false>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
   const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
-  LaneLoads L0 = load_lane<V>(B, P, lane0), L1 = load_lane<V>(B, P, lane1);  // issue every load ...
+  LaneLoads L0 = load_lane<V, STREAM>(B, P, lane0), L1 = load_lane<V, STREAM>(B, P, lane1);  // issue every load ...
   load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
   LaneNoise nz0, nz1;
   LaneDraw d0, d1;

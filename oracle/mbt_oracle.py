@@ -49,7 +49,14 @@ class OracleConfig:
     terminal_time: float = 1.0  # TE:29
     # midprice: "bm" (MID:36-68), "ou" (MID:114-146), "gbm" (MID:71-111), "bm_jump" (MID:193-230),
     # "ou_jump" (MID:233-273), "constant" (MID:12-33)
+    # "linear_sde": a USER-DEFINED MidpriceModel subclass (the plugin contract SP:8-53) of the form
+    #   S <- S + (mid_coef_add + mid_coef_mul S) (drift dt + volatility sqrt(dt) Z) - ou_speed (S - ou_level) + jump terms
+    # with its own observation bounds (midprice_lo, midprice_hi); the family every built-in midprice is a member of
     midprice: str = "bm"
+    mid_coef_add: float = 1.0
+    mid_coef_mul: float = 0.0
+    midprice_lo: Optional[float] = None
+    midprice_hi: Optional[float] = None
     drift: float = 0.0
     volatility: float = 2.0
     initial_price: float = 100.0
@@ -158,6 +165,8 @@ def midprice_bounds(cfg: OracleConfig) -> Tuple[float, float]:
         hi = cfg.initial_price * np.exp(cfg.drift * cfg.terminal_time) + 4 * stdev
     elif cfg.midprice == "constant":  # MID:21-23
         return float(cfg.initial_price), float(cfg.initial_price)
+    elif cfg.midprice == "linear_sde":  # the user's class states its own min_value / max_value (SP:11-12)
+        return float(cfg.midprice_lo), float(cfg.midprice_hi)
     else:
         raise ValueError(cfg.midprice)
     lo = cfg.initial_price - (hi - cfg.initial_price)
@@ -317,6 +326,14 @@ class OracleEnv:
         self.episode_length = self.cfg.terminal_time - self.state[:, TIME]
         return self.normalise_observation(self.state.copy())
 
+    def set_step_size(self, step_size: float):
+        """The step_size setter (TE:158-167): the clock / done rule and EVERY process continue with the new value;
+        n_steps, terminal_time, max_cash and the Box bounds are not re-derived."""
+        import dataclasses
+
+        self.dt = step_size
+        self.cfg = dataclasses.replace(self.cfg, midprice_step_size=step_size, arrival_step_size=step_size, impact_step_size=step_size)
+
     # -- normalisation (TE:112-129, TE:180-194) -------------------------------------------------
     def normalise_observation(self, obs: np.ndarray) -> np.ndarray:
         if not self.cfg.normalise_observation_space:
@@ -405,7 +422,8 @@ class OracleEnv:
         s_old = prev[:, PRICE].reshape(-1, 1)
         mdt = cfg.midprice_step_size or dt
         noise_term = cfg.volatility * math.sqrt(mdt) * z
-        if cfg.midprice in ("bm_jump", "ou_jump"):  # MID:220-221, MID:262-263
+        if cfg.midprice in ("bm_jump", "ou_jump", "linear_sde"):  # MID:220-221, MID:262-263
+            assert cfg.dynamics != "speed", "jump midprice models move on the agent's fills; speed dynamics have none"
             fills_bid = fills[:, 0] * arrivals[:, 0]
             fills_ask = fills[:, 1] * arrivals[:, 1]
             jump = (cfg.jump_size * fills_ask - cfg.jump_size * fills_bid).reshape(-1, 1)
@@ -419,6 +437,9 @@ class OracleEnv:
             s_new = s_old + cfg.drift * mdt * np.ones((n, 1)) + noise_term + jump
         elif cfg.midprice == "ou_jump":  # MID:264-270
             s_new = s_old - cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + noise_term + jump
+        elif cfg.midprice == "linear_sde":  # user plugin: same structure as MID:222-227 / MID:264-270 with a state-dependent scale
+            scale = cfg.mid_coef_add + cfg.mid_coef_mul * s_old
+            s_new = s_old + scale * (cfg.drift * mdt * np.ones((n, 1)) + noise_term) - cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + jump
         else:  # constant, MID:32-33
             s_new = s_old
         st[:, PRICE] = s_new[:, 0]

@@ -33,6 +33,11 @@ def make_env(cfg, noise="philox", **overrides):
         "ou_jump": lambda: mid_m.OuJumpMidpriceModel(mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, volatility=cfg.volatility,
                                                      jump_size=cfg.jump_size, initial_price=cfg.initial_price, **common),
         "constant": lambda: mid_m.ConstantMidpriceModel(initial_price=cfg.initial_price, **common),
+        # a user-defined midprice of the reference's plugin API, through the public device route for such classes
+        "linear_sde": lambda: mid_m.LinearSdeMidpriceModel(
+            drift=cfg.drift, volatility=cfg.volatility, scale_constant=cfg.mid_coef_add, scale_proportional=cfg.mid_coef_mul,
+            mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, jump_size=cfg.jump_size, initial_price=cfg.initial_price,
+            min_value=cfg.midprice_lo, max_value=cfg.midprice_hi, **common),
     }[cfg.midprice]()
     arr = {
         "poisson": lambda: arr_m.PoissonArrivalModel(intensity=np.array(cfg.intensity), step_size=arr_dt, num_trajectories=n),

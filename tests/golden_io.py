@@ -19,3 +19,10 @@ def load_case(name):
     if isinstance(raw.get("initial_inventory"), list):
         raw["initial_inventory"] = tuple(raw["initial_inventory"])
     return OracleConfig(**raw), data
+
+
+def step_size_changes(g):
+    """{step index: new step size} of fixtures that use the step_size setter in mid-episode (TE:158-167)."""
+    if "step_size_at" not in g:
+        return {}
+    return {int(k): float(v) for k, v in zip(g["step_size_at"], g["step_size_to"])}

@@ -21,7 +21,7 @@ import pytest
 
 from oracle.mbt_oracle import InjectedNoise, OracleEnv
 from tests.env_factory import make_env
-from tests.golden_io import CASES, load_case
+from tests.golden_io import CASES, load_case, step_size_changes
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ STATE_DEPENDENT_DIFFUSION = {"gbm_nonlinear_touch": 5e-5}
 
 
 def _is_speed(name):
-    return name.startswith("speed_")
+    return name.startswith("speed_") or name.endswith("_speed")
 
 
 def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
@@ -70,7 +70,11 @@ def test_step_matches_reference_fixture(name, record):
     assert obs0.dtype == np.float32 and obs0.shape == g["obs0"].shape
     _check_obs(name, -1, obs0, g["obs0"], cfg.normalise_observation_space, cfg.max_inventory)
     cash_scale = np.abs(g["obs0"][:, 0]) if not cfg.normalise_observation_space else None
+    changes = step_size_changes(g)
     for k in range(g["actions"].shape[0]):
+        if k in changes:  # the step_size setter in mid-episode (TE:158-167): host-side kernel parameters only
+            env.step_size = changes[k]
+            oracle.set_step_size(changes[k])
         env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
         obs, rew, dones, infos = env.step(g["actions"][k])
         o_obs, o_rew, o_done = oracle.step(g["actions"][k].astype(np.float64))

@@ -154,8 +154,13 @@ def test_normalise_rewards_scale_and_batch_resize():
     assert plain.reset().shape == (1000, 4) and plain.model_dynamics.midprice_model.num_trajectories == 1000
     obs, rew, dones, infos = plain.step(np.tile(np.array([[0.5, 0.5]], np.float32), (1000, 1)))
     assert obs.shape == (1000, 4) and rew.shape == (1000,) and len(infos) == 1000
-    with pytest.raises(ValueError):
-        plain.step_size = 0.1
+    plain.step_size = 0.01  # the setter (TE:158-167) is host-side parameters only; every process follows
+    assert plain.step_size == 0.01 and plain.model_dynamics.arrival_model.step_size == 0.01
+    obs2, _, _, _ = plain.step(np.tile(np.array([[0.5, 0.5]], np.float32), (1000, 1)))
+    assert obs2[0, 2] == pytest.approx(obs[0, 2] + 0.01, abs=1e-6)
+    plain.num_trajectories = 512  # a re-allocation keeps the step size that was set
+    plain.reset()
+    assert plain.step(np.tile(np.array([[0.5, 0.5]], np.float32), (512, 1)))[0][0, 2] == pytest.approx(0.01, abs=1e-7)
     env.close()
     plain.close()
 

@@ -1,0 +1,209 @@
+"""Round-2 entry points of the C ABI on the GPU: k steps per host call with the episode log, the RCCL all-reduce
+(world size 1 here - one GPU box; the N-rank path is the same code with N > 1), bench.py's self-spawned ranks, the
+calibration of normalise_rewards against the reference, and the refusals that replaced silent misbehaviour."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.mbt_oracle import OracleConfig
+from tests.env_factory import make_env
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(n, **kw):
+    base = dict(num_trajectories=n, n_steps=40, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=40, seed=9,
+                normalise_action_space=False, normalise_observation_space=False)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(reward="cjmm", phi=0.01, alpha=0.02, initial_inventory=(-3, 4), max_inventory=6),
+                                dict(arrival="hawkes", intensity=(10.0, 10.0), hawkes_speed=20.0, midprice="ou", ou_level=100.0, ou_speed=0.02)])
+def test_step_many_equals_the_step_loop_and_logs_every_episode(kw):
+    """mbt_env_step_many_device(k, auto_reset) == k x mbt_env_step_device with the consumer's own episode handling:
+    bit-identical state, and the episode log holds each finished episode's sums in order."""
+    n, k = 5000, 40 * 2 + 17
+    cfg = _cfg(n, **kw)
+    many, loop = make_env(cfg), make_env(cfg)
+    action = np.tile(np.array([[0.6, 0.8]], np.float32), (n, 1))
+    want = []
+    for e in (many, loop):
+        e.track_lane_returns(True)
+        e.reset()
+        e.set_action_host(action)
+    for _ in range(k):
+        if loop.step_device():
+            want.append(loop.episode_return_sums())
+            explicit_reset_like_auto_reset(loop)
+    steps, episodes = many.step_many_device(k)
+    assert (steps, episodes) == (k, 2)
+    got = [many.episode_log_pop() for _ in range(2)]
+    assert many.episode_log_pop() is None and many.episode_log_pop(wait=False) is None
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    np.testing.assert_array_equal(many.state, loop.state)
+    np.testing.assert_array_equal(many.episode_return_sums(), loop.episode_return_sums())
+    assert many.clock == loop.clock
+    many.close(), loop.close()
+
+
+def explicit_reset_like_auto_reset(env):
+    """What auto_reset does, spelled out through the public ABI: the start time and the per-lane initial inventories of the
+    last explicit reset (a fresh draw of random inventories is a HOST decision, TE:270-281, so auto_reset cannot make it)."""
+    from mbt_gym_amd import _native
+
+    _native.check(_native.load_library().mbt_env_reset(env._handle, env._get_start_time(), _native.fptr(env._q0_first)))
+
+
+@pytest.fixture(autouse=True)
+def _remember_first_q0(monkeypatch):
+    """Record the per-lane initial inventories of every environment's explicit resets (host decision, TE:270-281)."""
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
+
+    original = TradingEnvironment._get_initial_inventories
+
+    def remembering(self):
+        q0 = original(self)
+        self._q0_first = q0
+        return q0
+
+    monkeypatch.setattr(TradingEnvironment, "_get_initial_inventories", remembering)
+
+
+def test_step_many_without_auto_reset_stops_at_the_end_of_the_episode():
+    env = make_env(_cfg(2000))
+    env.reset()
+    env.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (2000, 1)))
+    assert env.step_many_device(25, auto_reset=False) == (25, 0)
+    assert env.step_many_device(100, auto_reset=False) == (15, 1)
+    assert env.episode_log_pop() is None  # nothing is logged without auto_reset
+    env.close()
+
+
+def test_episode_log_ring_keeps_the_newest_sixteen():
+    n = 1024
+    env = make_env(_cfg(n, n_steps=5))
+    env.reset()
+    env.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (n, 1)))
+    assert env.step_many_device(5 * 20) == (100, 20)
+    popped = 0
+    while env.episode_log_pop() is not None:
+        popped += 1
+    assert popped == 16
+    env.close()
+
+
+def test_rccl_allreduce_through_the_c_abi_world_size_one():
+    """mbt_comm_* + mbt_env_allreduce_returns + mbt_env_set_communicator on a one-rank RCCL communicator: the symbols
+    resolve (dlopen of the process's RCCL), the collective runs on the environment's stream, sums come back unchanged -
+    including the NaN of an untracked second moment."""
+    from mbt_gym_amd.distributed import RcclCommunicator
+
+    n = 4096
+    env = make_env(_cfg(n))
+    comm = RcclCommunicator(rank=0, world_size=1, device=0)
+    env.reset()
+    env.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (n, 1)))
+    env.step_many_device(10)
+    local = env.episode_return_sums()
+    assert np.isnan(local[1]) and local[2] == n
+    np.testing.assert_array_equal(env.allreduce_return_sums(comm, local), local)
+    np.testing.assert_array_equal(env.allreduce_return_sums(comm, [1.5, 2.5, 3.0]), [1.5, 2.5, 3.0])
+    env.set_communicator(comm)
+    twin = make_env(_cfg(n))
+    twin.reset()
+    twin.set_action_host(np.tile(np.array([[0.7, 0.7]], np.float32), (n, 1)))
+    twin.step_many_device(10)
+    assert env.step_many_device(70) == twin.step_many_device(70) == (70, 2)
+    for _ in range(2):
+        np.testing.assert_array_equal(env.episode_log_pop(), twin.episode_log_pop())
+    env.set_communicator(None)
+    env.close(), twin.close()
+    comm.close()
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-resident", *args],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks_and_sharding_is_invisible_in_the_result():
+    """`python bench.py --gpus 2` with no launcher: the script starts two ranks (here both on GPU 0, gloo transport - RCCL
+    refuses two ranks on one device), each steps its shard of the trajectory axis, the 24-byte all-reduce merges the
+    episode sums; the mean episode return equals that of ONE rank stepping all 2^21 lanes (Philox keyed on global ids)."""
+    common = ("--steps", "1100", "--warmup", "0", "--prewarm-steps", "0")
+    two = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--lanes", str(1 << 20), *common)
+    one = _bench("--gpus", "1", "--lanes", str(1 << 21), *common)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["num_trajectories_total"] == one["config"]["num_trajectories_total"] == 1 << 21
+    assert two["config"]["episodes_finished_in_timed_region"] == one["config"]["episodes_finished_in_timed_region"] == 1
+    assert two["mean_episode_return"] == pytest.approx(one["mean_episode_return"], rel=1e-12)
+    assert 60.0 < one["mean_episode_return"] < 75.0  # Avellaneda-Stoikov market, constant quote 0.7: about 67
+    for line in (one, two):
+        assert line["value"] == pytest.approx(line["config"]["num_trajectories_total"] * 1100 / (line["ms_per_step"] * 1e-3 * 1100), rel=1e-9)
+
+
+@pytest.mark.timeout(600)
+def test_bench_at_the_drivers_arguments_is_not_dominated_by_fixed_costs():
+    """--steps 20 --warmup 5 (what the driver runs): the wall clock per step stays within 2x of the kernel's own
+    launch-to-launch time (it was 9x when the timed region held event creation, two device syncs and cold clocks)."""
+    line = _bench("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert line["steps"] == 20 and line["warmup"] == 5
+    assert line["ms_per_step"] * 1e3 <= 2.0 * line["roofline"]["avg_launch_us"], line
+    assert line["roofline"]["avg_launch_us"] < 12.0
+
+
+def test_reward_scaling_matches_the_reference_calibration(repo_root):
+    """normalise_rewards=True: 1 / (mean episode return of the fixed action 1/kappa), TE:329-343 - including the reference's
+    behaviour that with normalise_action_space=True (the default) that fixed action is a NORMALISED action."""
+    g = np.load(os.path.join(repo_root, "tests", "golden", "agents_reward_scaling.npz"))
+    ns = int(g["n_steps"])
+    for tag, norm in (("default", True), ("raw_actions", False)):
+        cfg = OracleConfig(num_trajectories=64, n_steps=ns, terminal_time=1.0, midprice="bm", volatility=float(g["sigma"]), initial_price=100.0,
+                           arrival="poisson", intensity=tuple(g["intensity"]), fill_exponent=float(g["kappa"]), dynamics="limit", reward="pnl",
+                           initial_inventory=0, max_inventory=int(g["max_inventory"]), seed=7, normalise_action_space=norm,
+                           normalise_observation_space=norm)
+        env = make_env(cfg, normalise_rewards=True)
+        # Monte-Carlo over 100 000 lanes on both sides (std of an episode return ~ 4): relative standard error ~ 3e-3
+        assert env.reward_scaling == pytest.approx(float(g[tag]), rel=0.015), tag
+        env.close()
+
+
+def test_row_width_disagreements_and_stiff_hawkes_are_refused():
+    from mbt_gym_amd._native import NativeError
+    from mbt_gym_amd.gym.ModelDynamics import AtTheTouchModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment, UnsupportedOnDevice
+    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExogenousMmFillProbabilityModel
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+    from tests.env_factory import _FixedBoundsProcess
+
+    n, dt = 64, 0.01
+    # the host would count 6 columns (the fill model's two depths), the device lays at-the-touch out with 4: refused
+    best = tuple(_FixedBoundsProcess(0.2, 0.0, 1.0, dt, n) for _ in range(2))
+    md = AtTheTouchModelDynamics(
+        midprice_model=BrownianMotionMidpriceModel(step_size=dt, num_trajectories=n),
+        arrival_model=PoissonArrivalModel(intensity=np.array([50.0, 50.0]), step_size=dt, num_trajectories=n), num_trajectories=n)
+    md.fill_probability_model = ExogenousMmFillProbabilityModel(best, step_size=dt, num_trajectories=n)
+    with pytest.raises((UnsupportedOnDevice, NativeError)):
+        TradingEnvironment(n_steps=100, model_dynamics=md, num_trajectories=n, normalise_action_space=False, normalise_observation_space=False)
+    # Hawkes with mean_reversion_speed * step_size >= 1: refused unless explicitly allowed
+    stiff = _cfg(n, arrival="hawkes", intensity=(10.0, 10.0), hawkes_speed=60.0)  # 60 * (1/40) = 1.5
+    with pytest.raises(NativeError, match="Hawkes"):
+        make_env(stiff)
+    make_env(stiff, allow_stiff_hawkes=True).close()

@@ -15,7 +15,7 @@ from oracle.mbt_oracle import (
     results_table,
     rollout,
 )
-from tests.golden_io import CASES, load_case
+from tests.golden_io import CASES, load_case, step_size_changes
 
 
 def test_fixture_set_is_complete():
@@ -23,6 +23,7 @@ def test_fixture_set_is_complete():
         "as_limit_pnl", "cjp_running", "cjp_cjmm", "hawkes_ou", "limit_and_market", "default_normalised", "clip_cash",
         "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice",
         "speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transient_pnl", "speed_transient_pnl",
+        "step_size_change_hawkes", "step_size_change_speed", "user_linear_sde_midprice",
     }
 
 
@@ -40,7 +41,10 @@ def test_oracle_reproduces_reference_bit_for_bit(name):
     np.testing.assert_array_equal(env.state[:, 1], g["q0"])
     assert float(env.state[0, 2]) == float(g["t0"])
     np.testing.assert_array_equal(obs0, g["obs0"])
+    changes = step_size_changes(g)
     for k in range(g["actions"].shape[0]):
+        if k in changes:
+            env.set_step_size(changes[k])
         obs, rew, done = env.step(g["actions"][k].astype(np.float64))
         if env.last_arrivals is not None:  # speed dynamics have neither arrivals nor fills (MD:47-48)
             np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"arrivals step {k}")

@@ -120,7 +120,8 @@ def draw_actions(rng, k, n, a_dim, max_depth, normalised, kind="depths", max_spe
 
 
 def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None, action_kind="depths",
-             fill_prob=None, action_hook=None):
+             fill_prob=None, action_hook=None, step_size_changes=None):
+    """step_size_changes: {step index: new step size} - `env.step_size = value` (TE:158-167) before that step."""
     rng = np.random.default_rng(1000 + seed)
     with contextlib.redirect_stdout(io.StringIO()):
         env = build_env()
@@ -172,6 +173,8 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         t0 = float(env.model_dynamics.state[0, 2])
         obs, rew, done = [], [], []
         for k in range(k_steps):
+            if step_size_changes and k in step_size_changes:
+                env.step_size = step_size_changes[k]
             o, r, d, _ = env.step(actions[k].astype(np.float64))
             obs.append(np.array(o, dtype=np.float64))
             rew.append(np.array(np.broadcast_to(np.asarray(r, dtype=np.float64), (n,))))  # ExponentialUtility returns the scalar 0
@@ -191,6 +194,8 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         obs_lo=lo, obs_hi=hi, act_lo=np.float32(alo), act_hi=np.float32(ahi), max_cash=float(env.max_cash),
         process_indices=np.array([v for v in env.stochastic_process_indices.values()]),
         config_json=json.dumps(dict(cfg, num_trajectories=n)),
+        **({"step_size_at": np.array(sorted(step_size_changes)), "step_size_to": np.array([step_size_changes[k] for k in sorted(step_size_changes)])}
+           if step_size_changes else {}),
     )
     fills_total = int(np.sum(np.stack(rec["arr"]) * np.stack(rec["fill"])))
     print(f"{name}: N={n} steps={k_steps} D={obs[0].shape[1]} trades={fills_total} "
@@ -500,8 +505,98 @@ def exogenous_fill_cases():
         normalised=True)
 
 
+def round2_cases():
+    """Round 2: the step_size setter (TE:158-167) used in mid-episode, and a USER-DEFINED midprice plugin."""
+    from mbt_gym.gym.index_names import ASK_INDEX, BID_INDEX
+    from mbt_gym.stochastic_processes.midprice_models import MidpriceModel
+
+    common = dict(normalise_action_space=False, normalise_observation_space=False)
+
+    # R. step size doubled after 30 of 100 steps, halved again 10 steps later: drift + volatility scaling (MID:63-64), Hawkes
+    #    thresholds and decay (ARR:115-123), the reward's dt (RW:131), the clock and the done rule (TE:216-220) all follow
+    n, ns = 32, 100
+    changes = {30: 0.02, 40: 0.005}
+    steps = 30 + 10 + int(round((1.0 - 0.3 - 0.2) / 0.005))
+    run_case(
+        "step_size_change_hawkes",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=51, initial_inventory=0, max_inventory=20, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.02, 0.1),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(drift=0.5, volatility=2.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                HawkesArrivalModel(baseline_arrival_rate=np.array([[12.0, 9.0]]), step_size=1 / ns, jump_size=25.0, mean_reversion_speed=30.0, terminal_time=1.0, num_trajectories=n)),
+            **common),
+        steps, n, 2, 51,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.5, volatility=2.0, initial_price=100.0, arrival="hawkes", intensity=[12.0, 9.0],
+             hawkes_jump=25.0, hawkes_speed=30.0, fill_exponent=1.5, dynamics="limit", reward="running", phi=0.02, alpha=0.1, initial_inventory=0,
+             max_inventory=20, seed=51, **common),
+        step_size_changes=changes)
+
+    # S. the same setter under trading-with-speed dynamics: traded volume (MD:265) and the impact model's step (IMP:87-88)
+    n, ns = 32, 80
+    changes = {20: 0.025}
+    steps = 20 + int(round((1.0 - 20 / ns) / 0.025))
+    run_case(
+        "step_size_change_speed",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=52, initial_inventory=10, max_inventory=1000, num_trajectories=n,
+            reward_function=CjOeCriterion(per_step_inventory_aversion=0.01, terminal_inventory_aversion=0.05, terminal_time=1.0),
+            model_dynamics=TradinghWithSpeedModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(drift=0.02, volatility=1.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                price_impact_model=TemporaryAndPermanentPriceImpact(temporary_impact_coefficient=0.02, permanent_impact_coefficient=0.015, n_steps=ns, terminal_time=1.0, num_trajectories=n),
+                num_trajectories=n),
+            **common),
+        steps, n, 1, 52,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.02, volatility=1.0, initial_price=100.0, arrival="none", dynamics="speed",
+             midprice_step_size=1 / ns, impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, impact_step_size=1.0 / ns, reward="cjoe",
+             phi=0.01, alpha=0.05, initial_inventory=10, max_inventory=1000, seed=52, **common),
+        action_kind="speed", step_size_changes=changes)
+
+    # T. a user-defined MidpriceModel written against the reference's plugin API (SP:8-53): a drifting mean-reverting price
+    #    whose noise has an arithmetic and a geometric part and which jumps on the agent's own fills
+    class UserMixedNoiseOuJumpMidprice(MidpriceModel):
+        def __init__(self, drift, volatility, scale_constant, scale_proportional, level, speed, jump_size, initial_price, lo, hi,
+                     terminal_time, step_size, num_trajectories, seed=None):
+            self.drift, self.volatility, self.a, self.b = drift, volatility, scale_constant, scale_proportional
+            self.level, self.speed, self.jump_size = level, speed, jump_size
+            super().__init__(min_value=np.array([[lo]]), max_value=np.array([[hi]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[initial_price]]), num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            ones = np.ones((self.num_trajectories, 1))
+            fills_bid = fills[:, BID_INDEX] * arrivals[:, BID_INDEX]
+            fills_ask = fills[:, ASK_INDEX] * arrivals[:, ASK_INDEX]
+            jump = (self.jump_size * fills_ask - self.jump_size * fills_bid).reshape(-1, 1)
+            s = self.current_state
+            scale = self.a + self.b * s
+            noise = self.volatility * np.sqrt(self.step_size) * self.rng.normal(size=(self.num_trajectories, 1))
+            self.current_state = s + scale * (self.drift * self.step_size * ones + noise) - self.speed * (s - self.level * ones) + jump
+
+    n, ns = 32, 90
+    sde = dict(drift=0.3, volatility=0.4, mid_coef_add=1.5, mid_coef_mul=0.02, ou_level=101.0, ou_speed=0.03, jump_size=0.125,
+               initial_price=100.0, midprice_lo=80.0, midprice_hi=120.0)
+    run_case(
+        "user_linear_sde_midprice",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=53, initial_inventory=(-2, 3), max_inventory=4, num_trajectories=n,
+            reward_function=CjMmCriterion(0.02, 0.05, terminal_time=1.0),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                UserMixedNoiseOuJumpMidprice(0.3, 0.4, 1.5, 0.02, 101.0, 0.03, 0.125, 100.0, 80.0, 120.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([70.0, 55.0]), step_size=1 / ns, num_trajectories=n)),
+            **common),
+        ns, n, 2, 53,
+        dict(n_steps=ns, terminal_time=1.0, midprice="linear_sde", arrival="poisson", intensity=[70.0, 55.0], fill_exponent=1.5, dynamics="limit",
+             reward="cjmm", phi=0.02, alpha=0.05, initial_inventory=[-2, 3], max_inventory=4, seed=53, **sde, **common),
+        poisson_thr=55.0 / ns)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
         exogenous_fill_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--only-round2":
+        round2_cases()
     else:
         main()
+        round2_cases()
