@@ -85,12 +85,12 @@ def timed_steps(env, lib, k, sync_all):
     sync_all()
     _native.check(lib.mbt_env_timer_begin(env._handle))  # HIP event on the kernel's stream
     t0 = time.perf_counter()
-    steps, _ = env.step_many_device(k, auto_reset=True)
+    steps, episodes = env.step_many_device(k, auto_reset=True)
     _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))  # records the closing event and waits for it (polling)
     sync_all(barrier=False)
     wall = time.perf_counter() - t0
     assert steps == k
-    return wall, ms.value / 1e3
+    return wall, ms.value / 1e3, episodes
 
 
 def pmc_traffic(n):
@@ -204,7 +204,7 @@ def hbm_resident_measurement(lib, device, steps=600, warmup=100):
 
     try:
         env.step_many_device(warmup, auto_reset=True)
-        wall, event_s = timed_steps(env, lib, steps, sync_all)
+        wall, event_s, _ = timed_steps(env, lib, steps, sync_all)
     finally:
         env.close()
     launch_s = event_s / steps
@@ -350,9 +350,8 @@ def main():
     sync_all()
     drain_log()
 
-    wall, event_s = timed_steps(env, lib, args.steps, sync_all)
-    episode_returns = drain_log()
-    episodes = len(episode_returns)
+    wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
+    episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([wall, event_s], dtype=torch.float64, device=tdev)

@@ -109,10 +109,12 @@ StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, bool stre
     default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, stream);
   }
 }
+// `staged` = the instantiation that loads 20-byte rows through LDS (see speed_step_kernel; only with an impact state)
 template <bool STATE>
-StepKernel pick_speed(bool norm, bool inject) {
-  if (norm) return inject ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>>;
-  return inject ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>>;
+StepKernel pick_speed(bool norm, bool inject, bool staged) {
+  if (inject) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true>>;
+  if (STATE && staged) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, true>;
+  return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>>;
 }
 bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
 
@@ -127,10 +129,28 @@ StepKernel pick_exogenous(bool inject) {
                 : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>>;
 }
 
+// precise_state: the general tier again (runtime midprice coefficients, every reward, runtime normalisation flags) with
+// cash and midprice as float32 pairs: 12 step + 6 rollout kernels.
+template <int ARR, int DYN>
+StepKernel pick_precise(bool inject) {
+  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, false, true>>
+                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, false, true>>;
+}
+template <int ARR>
+StepKernel pick_precise_dyn(int dyn, bool inject) {
+  switch (dyn) {
+    case MBT_DYN_LIMIT: return pick_precise<ARR, mbt::kDynLimit>(inject);
+    case MBT_DYN_LIMIT_AND_MARKET: return pick_precise<ARR, mbt::kDynLimitAndMarket>(inject);
+    default: return pick_precise<ARR, mbt::kDynTouch>(inject);
+  }
+}
+
 StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
-  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject) : pick_speed<false>(norm, inject);
+  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject, !stream) : pick_speed<false>(norm, inject, false);
+  if (c.precise_state)
+    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, inject) : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, inject);
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
     if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject);
@@ -160,12 +180,21 @@ RolloutKernel rpick_dyn(int dyn, bool bm, int rew, bool norm) {
     default: return bm ? rpick_rew<ARR, mbt::kDynTouch, true>(rew, norm) : rpick_rew<ARR, mbt::kDynTouch, false>(rew, norm);
   }
 }
+template <int ARR>
+RolloutKernel rpick_precise(int dyn) {
+  switch (dyn) {
+    case MBT_DYN_LIMIT: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
+    case MBT_DYN_LIMIT_AND_MARKET: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
+    default: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynTouch, false, mbt::kRewardGeneral, true, false, false, true>>;
+  }
+}
 RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
     if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
     return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
   }
+  if (c.precise_state) return c.arrival_kind == MBT_ARR_HAWKES ? rpick_precise<mbt::kArrHawkes>(c.dynamics_kind) : rpick_precise<mbt::kArrPoisson>(c.dynamics_kind);
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
     if (c.arrival_kind == MBT_ARR_HAWKES)
@@ -207,6 +236,7 @@ struct mbt_env {
   float* u_fill = nullptr;
   float* z = nullptr;
   float* q_init = nullptr;
+  float* resid = nullptr;      // precise_state: (n_pad, 2) residuals of (cash, midprice)
   uint8_t* events = nullptr;
   float* lane_returns = nullptr;
   double* wave_sums = nullptr;
@@ -306,6 +336,22 @@ void fill_static_params(mbt_env* e) {
   P.trans_coef = static_cast<float>(c.transient_impact);
   P.resilience = static_cast<float>(c.resilience);
   P.kernel_coef = static_cast<float>(c.kernel_coefficient);
+  mbt::PreciseParams& X = P.X;  // the same quantities in double, for the precise_state tier
+  X.drift_dt = (ou || mk == MBT_MID_CONSTANT) ? 0.0 : c.drift * e->mid_dt;
+  X.vol_sqrt_dt = mk == MBT_MID_CONSTANT ? 0.0 : c.volatility * std::sqrt(e->mid_dt);
+  X.mid_add = sde ? c.mid_coef_add : (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0 : 1.0;
+  X.mid_mul = sde ? c.mid_coef_mul : mk == MBT_MID_GBM ? 1.0 : 0.0;
+  X.ou_speed = (ou || sde) ? c.ou_speed : 0.0;
+  X.ou_level = (ou || sde) ? c.ou_level : 0.0;
+  X.jump_size = (jump || sde) ? c.jump_size : 0.0;
+  X.half_spread = c.market_half_spread;
+  X.c_max = c.max_cash;
+  X.dt = e->dt;
+  X.phi = c.phi;
+  X.alpha = c.alpha;
+  X.exponent = c.inventory_exponent;
+  X.risk_aversion = c.risk_aversion;
+  X.reward_scale = c.reward_scale;
   P.norm_act = c.normalise_action;
   P.norm_obs = c.normalise_observation;
   for (int j = 0; j < 4; ++j) {
@@ -318,18 +364,20 @@ void fill_static_params(mbt_env* e) {
   }
 }
 
-// Two regimes, chosen by how many bytes ONE launch touches.  Up to ~200 MB (2^22 lanes of the 44-byte step) the state the
-// next step reads is still in the 256 MB Infinity Cache: default-policy loads, full occupancy (8 workgroups per CU hide the
-// generator behind the loads).  Beyond that every byte crosses HBM and nothing is re-used: the step kernel's STREAM
+// Two regimes, chosen by how many bytes ONE launch touches.  While that is about the size of the 256 MB Infinity Cache or
+// less, the state the next step reads is still cached: default-policy loads, full occupancy (8 workgroups per CU hide the
+// generator behind the loads).  Measured (profiles/r02_regimes.json): at 184 MB (AS, 2^22 lanes) and 252 MB (Hawkes + OU,
+// 2^22 lanes) default loads win (26.9 vs 28.2 us, 36.7 vs 45.1 us), at 369 MB (AS, 2^23 lanes) streaming loads win
+// (53.4 vs 63.5 us); the switch sits at 320 MB.  Beyond that every byte crosses HBM and nothing is re-used: the step kernel's STREAM
 // instantiation is used, whose loads carry the non-temporal bit (they do not displace lines on the way in) and occupancy is capped at 5 workgroups per CU through a
 // dynamic LDS allocation - fewer, longer-lived streams per channel (129.9 -> 124.3 us at 2^24 lanes for occupancy alone,
 // profiles/r01_microbench.txt; the non-temporal loads: 128.3 -> 118.7 us on the copy kernel).  MBT_STREAM_LOADS = 0 / 1 and
 // MBT_STEP_DYNAMIC_LDS = bytes override the choice (measurement knobs).
 void tune_for_size(mbt_env* e) {
-  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u);
-  const bool hbm_resident = bytes_per_launch > (size_t(200) << 20);
+  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + (e->cfg.precise_state ? 4u : 0u));
+  const bool hbm_resident = bytes_per_launch > (size_t(320) << 20);
   e->stream_loads = hbm_resident;
-  e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;
+  e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;  // AS 2^24: 115.7 -> 114.2 us; Hawkes (D = 6) loses with it
   if (const char* v = std::getenv("MBT_STREAM_LOADS")) e->stream_loads = std::atoi(v) != 0;
   if (const char* v = std::getenv("MBT_STEP_DYNAMIC_LDS")) e->step_dynamic_lds = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
 }
@@ -345,6 +393,7 @@ void fill_episode_params(mbt_env* e) {
   P.dt_over_episode = static_cast<float>(e->dt / length);  // RW:106, RW:113
   P.quad_init = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha * e->dt / length) : 0.0f;
   P.episode_length = static_cast<float>(length);  // RW:67, RW:74
+  P.X.dt_over_episode = e->dt / length;
 }
 
 void key_from_seed(mbt_env* e) {
@@ -383,6 +432,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   B.u_fill = e->u_fill;
   B.z = e->z;
   B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.resid = e->resid;
   B.events = e->record_events ? e->events : nullptr;
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
@@ -490,6 +540,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   B.reward = e->reward;
   B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
   B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.resid = e->resid;
   B.events = e->record_events ? e->events : nullptr;
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
@@ -542,7 +593,9 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
   }
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
-                     per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P);
+                     per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P, e->resid,
+                     make_float2(static_cast<float>(c.initial_cash - static_cast<double>(row0.cash0)),
+                                 static_cast<float>(c.initial_price - static_cast<double>(row0.s0))));
   HIP_TRY(hipGetLastError());
   if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
   e->was_reset = true;
@@ -714,6 +767,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     }
     if (cfg->reward_kind == MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the one-dimensional action of speed dynamics (RW:65)");
     if (cfg->impact_kind != MBT_IMPACT_NONE) return fail(MBT_ERR_INVALID, "price impact models belong to speed dynamics");
+    if (cfg->precise_state && exogenous_fill(*cfg)) return fail(MBT_ERR_INVALID, "precise_state has no kernel for the exogenous-depth fill model");
     if (cfg->trajectory_offset % mbt::kTileLanes != 0)
       return fail(MBT_ERR_INVALID, "order-book dynamics draw noise per 512-lane tile: trajectory_offset must be a multiple of 512");
   }
@@ -782,6 +836,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
     ENV_TRY(dev_alloc(&e->z, np, e->stream));
   }
   ENV_TRY(dev_alloc(&e->q_init, np, e->stream));
+  if (cfg->precise_state) ENV_TRY(dev_alloc(&e->resid, np * 2, e->stream));
   ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves, e->stream));
   ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
   ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
@@ -829,7 +884,7 @@ void mbt_env_destroy(mbt_env* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = {e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
+  void* bufs[] = {e->resid, e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
                   e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
                   e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2]};
   for (void* b : bufs)
@@ -1161,6 +1216,7 @@ int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uin
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->state[e->cur], state_host, size_t(e->n) * e->dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  if (e->resid != nullptr) HIP_TRY(hipMemsetAsync(e->resid, 0, size_t(e->n_pad) * 2 * sizeof(float), e->stream));  // a float32 state has no residual
   if (e->cfg.normalise_observation) {
     const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
     hipLaunchKernelGGL(mbt::normalise_rows_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->state[e->cur], e->obs,

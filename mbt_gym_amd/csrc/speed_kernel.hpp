@@ -122,16 +122,33 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
   }
 }
 
-template <class V>
+// STAGED (D = 5 only): the tile's 1024 twenty-byte rows are LOADED as 1280 whole-line float4 into LDS and read from there,
+// instead of five dword loads per lane that walk the same cache lines.  Measured with the traffic-only kernels of
+// tools/microbench/mb_floor.hip (48 B/lane, 2^20 lanes): 7.94 us for the dword loads, 7.50 us staged - but at 2^24 lanes,
+// where every byte crosses HBM, 134.9 vs 144.3 us the other way round.  The host picks the instantiation by size
+// (mbt_env.hip: tune_for_size).
+template <class V, bool STAGED = false>
 __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuffers B, const StepParams P) {
+  constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
   const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
+  // 20-byte rows (D = 5) would leave the thread as five 4-byte stores per lane, each covering part of a cache line: such
+  // stores cannot be written through the L2 (step_kernel.hpp: store_through).  The workgroup therefore assembles its
+  // 1024 x 5 floats in LDS (20 KB; consecutive threads write at a stride of 5 words: no bank conflicts) and writes them
+  // out as 1280 contiguous, whole-line float4 - through the L2.
+  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];
   SpeedLane s[4];
   float act[4], qi[4], z[4];
+  float4 tile_in[kStaged ? 5 : 1];
+  if (kStaged) {
+    const float4* in4 = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tile_in[k] = in4[threadIdx.x + k * kBlockThreads];
+  }
 #pragma unroll
   for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
     const uint32_t lane = lane0 + l * kBlockThreads;
-    s[l] = load_speed_row<V>(B.state_in, lane);
+    if (!kStaged) s[l] = load_speed_row<V>(B.state_in, lane);
     act[l] = B.action[lane];
     if (V::INJECT) z[l] = B.z[lane];
     qi[l] = P.q_init_scalar;
@@ -145,11 +162,18 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
 #pragma unroll
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
   }
-  // 20-byte rows (D = 5) would leave the thread as five 4-byte stores per lane, each covering part of a cache line: such
-  // stores cannot be written through the L2 (step_kernel.hpp: store_through).  The workgroup therefore assembles its
-  // 1024 x 5 floats in LDS (20 KB; consecutive threads write at a stride of 5 words: no bank conflicts) and writes them
-  // out as 1280 contiguous, whole-line float4 - through the L2.
-  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];
+  if (kStaged) {
+    float4* staged4 = reinterpret_cast<float4*>(staged_rows);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) staged4[threadIdx.x + k * kBlockThreads] = tile_in[k];
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const float* row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
+      s[l] = SpeedLane{row[0], row[1], row[3], row[4]};
+    }
+    __syncthreads();  // every row has been read before results overwrite the tile
+  }
   float r_sum = 0.0f;
   bool clipped = false;
   uint32_t n_clipped = 0;

@@ -51,7 +51,7 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
-template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false>
+template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -65,11 +65,23 @@ struct Variant {
   // reference never advances (FILL:168-170) - the kernel does not load them, it writes the constants.  Instantiated
   // only on the general tier (BROWNIAN false, kRewardGeneral, NORM true: each a superset of the specialised code).
   static constexpr bool EXO = EXO_;
+  // precise_state (mbt_config): cash and midprice are float32 PAIRS - the row holds the rounded value the observation
+  // shows, a side buffer its residual - advanced and rewarded in double, in the reference's own formulation (RW:27-33).
+  // Instantiated on the general tier only, like EXO.
+  static constexpr bool PRECISE = PRECISE_;
+  static_assert(!(EXO_ && PRECISE_), "precise_state is not instantiated for the exogenous-depth fill model");
   static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
   static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
 };
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
+// float64 copies of what the precise_state tier computes with (everything else it shares with the float32 tiers)
+struct PreciseParams {
+  double drift_dt, vol_sqrt_dt, mid_add, mid_mul, ou_speed, ou_level, jump_size;  // midprice_increment() in double
+  double half_spread, c_max;
+  double dt, phi, alpha, exponent, risk_aversion, dt_over_episode, reward_scale;  // finish_reward() in double
+};
+
 struct StepParams {
   uint32_t n;            // lanes of this shard
   uint32_t n_pairs;      // padded lanes / 2 (a whole number of 512-lane tiles for order-book dynamics)
@@ -122,6 +134,7 @@ struct StepParams {
   int32_t norm_act, norm_obs;
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
+  PreciseParams X;
 };
 
 struct StepBuffers {
@@ -134,6 +147,7 @@ struct StepBuffers {
   const float* u_fill;
   const float* z;
   const float* q_init;     // CjMm per-lane initial inventory or nullptr
+  float* resid;            // precise_state: (n_pad, 2) [cash residual, midprice residual], updated in place; else nullptr
   uint8_t* events;         // nullptr unless recording
   float* lane_returns;     // nullptr unless tracking
   double* wave_sums;       // one slot per wave: running sum of rewards since reset
@@ -290,9 +304,31 @@ __device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_n
   return reward * P.reward_scale;
 }
 
+// The same in double and in the reference's order of operations, for the precise_state tier (order-book rewards only).
+__device__ __forceinline__ double finish_reward_f64(double pnl, double q_old, double q_new, double wealth_new, double q_init, bool is_terminal,
+                                                    const StepParams& P) {
+  const PreciseParams& X = P.X;
+  double reward = pnl;
+  if (P.reward_kind == kRewExpUtility) {
+    reward = is_terminal ? -exp(-X.risk_aversion * wealth_new) : 0.0;
+  } else if (P.reward_kind != kRewPnl) {
+    const bool two = P.exponent_is_two != 0;
+    const double qp = two ? q_new * q_new : pow(q_new, X.exponent);
+    reward -= X.dt * X.phi * qp;
+    if (P.reward_kind == kRewRunning) {
+      reward -= is_terminal ? X.alpha * qp : 0.0;
+    } else {
+      const double qp_old = two ? q_old * q_old : pow(q_old, X.exponent), qp_init = two ? q_init * q_init : pow(q_init, X.exponent);
+      reward -= X.alpha * ((qp - qp_old) + X.dt_over_episode * qp_init);
+    }
+  }
+  return reward * X.reward_scale;
+}
+
 struct LaneResult {
   float4 core;
   float2 lam;
+  float2 resid;  // precise_state: residuals of (cash, midprice) after the step
   float reward;
   // what happened, kept as predicates (scalar masks); turned into the event byte only when someone asks for it
   bool arr_bid, arr_ask, fill_bid, fill_ask, mo_buy, mo_sell, clipped_q, clipped_c;
@@ -307,9 +343,10 @@ __device__ __forceinline__ uint32_t event_byte(const LaneResult& r) {
 template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
-                                                const StepParams& P) {
+                                                const StepParams& P, const float2 resid = make_float2(0.f, 0.f), const float z = 0.f) {
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
+  r.resid = resid;
   const bool norm_act = V::NORM && P.norm_act;
 
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
@@ -372,6 +409,41 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
     gain = __builtin_fmaf(-P.half_spread, mb + ms, gain);
   }
   const float q_new = q + dq;
+  if (V::PRECISE) {
+    // ---- precise_state: the decisions above stand (they never depended on the state's low bits); cash, midprice and the
+    //      reward are re-done in double on (value + residual), in the reference's formulation ----------------------
+    const PreciseParams& X = P.X;
+    const double cash64 = static_cast<double>(cash) + static_cast<double>(resid.x), mid64 = static_cast<double>(mid) + static_cast<double>(resid.y);
+    double depth_b = act.x, depth_a = act.y;  // the float32 action IS the reference's float64 action (TE:104 de-normalises in double)
+    if (V::DYN == kDynTouch) {
+      depth_b = depth_a = X.half_spread;
+    } else if (norm_act) {
+      depth_b = (static_cast<double>(act.x) + 1.0) * P.act_grad[0] + P.act_lo[0];
+      depth_a = (static_cast<double>(act.y) + 1.0) * P.act_grad[1] + P.act_lo[1];
+    }
+    double gain64 = static_cast<double>(n_ask) * depth_a + static_cast<double>(n_bid) * depth_b;
+    if (V::DYN == kDynLimitAndMarket) gain64 -= X.half_spread * ((r.mo_buy ? 1.0 : 0.0) + (r.mo_sell ? 1.0 : 0.0));
+    const double cash_new64 = cash64 + gain64 - static_cast<double>(dq) * mid64;  // MD:108-116, MD:208-222 with the OLD midprice
+    const float q_clip = __builtin_amdgcn_fmed3f(q_new, -P.q_max, P.q_max);       // TE:283-289
+    const double c_clip64 = fmin(fmax(cash_new64, -X.c_max), X.c_max);
+    r.clipped_q = q_clip != q_new;
+    r.clipped_c = c_clip64 != cash_new64;
+    const double dz64 = X.drift_dt + X.vol_sqrt_dt * static_cast<double>(z);
+    const double mid_new64 = mid64 + ((X.mid_add + X.mid_mul * mid64) * dz64 - X.ou_speed * (mid64 - X.ou_level) +
+                                      X.jump_size * static_cast<double>(n_ask - n_bid));
+    r.lam = lam;
+    if (V::ARR == kArrHawkes) {
+      r.lam.x = __builtin_fmaf(P.hawkes_jump, arr_bid, lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.arr_dt);
+      r.lam.y = __builtin_fmaf(P.hawkes_jump, arr_ask, lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.arr_dt);
+    }
+    const double wealth_new = c_clip64 + static_cast<double>(q_clip) * mid_new64;
+    const double pnl64 = wealth_new - (cash64 + static_cast<double>(q) * mid64);  // RW:27-33, literally
+    r.reward = static_cast<float>(finish_reward_f64(pnl64, q, q_clip, wealth_new, q_init, is_terminal, P));
+    const float c_hi = static_cast<float>(c_clip64), m_hi = static_cast<float>(mid_new64);
+    r.core = make_float4(c_hi, q_clip, t_next, m_hi);
+    r.resid = make_float2(static_cast<float>(c_clip64 - static_cast<double>(c_hi)), static_cast<float>(mid_new64 - static_cast<double>(m_hi)));
+    return r;
+  }
   const float cash_new = __builtin_fmaf(-dq, mid, cash + gain);
 
   // -- clip (TE:283-289): v_med3_f32
@@ -453,6 +525,7 @@ struct LaneLoads {
   float2 ua, uf;  // injected noise
   float z;
   float qi;     // per-lane initial inventory (CjMm)
+  float2 resid; // precise_state residuals
 };
 
 typedef float ld4_t __attribute__((ext_vector_type(4)));
@@ -495,6 +568,7 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
     L.z = B.z[lane];
   }
   L.qi = P.q_init_scalar;
+  L.resid = V::PRECISE ? load2<NT>(B.resid + static_cast<size_t>(lane) * 2) : make_float2(0.f, 0.f);
   return L;
 }
 
@@ -570,8 +644,9 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
-                                             const LaneDraw& d, bool& clipped, float* staged_row) {
-  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P);
+                                             const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f) {
+  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, L.resid, z);
+  if (V::PRECISE) store_through(reinterpret_cast<float2*>(B.resid) + lane, r.resid);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
   } else {  // rows wider than 16 bytes go through LDS (see step_kernel): this lane's row, 8-byte pieces
@@ -624,8 +699,8 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
   // in LDS instead (12 / 16 KB) and writes them out as contiguous whole-line float4 - through the L2.
   __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM > 4 ? kTileLanes * V::DIM : 4];
   bool clipped0, clipped1;
-  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM);
-  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM);
+  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM, nz0.z);
+  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM, nz1.z);
   if (V::DIM > 4) {
     __syncthreads();
     constexpr int kVectors = kTileLanes * V::DIM / 4 / kBlockThreads;  // float4 per thread: 3 (D = 6) or 4 (D = 8)
@@ -686,6 +761,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
   const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
   float4 core[2];
   float2 lam[2];
+  float2 resid[2];
   float qi[2], ret[2] = {0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -693,6 +769,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     core[l] = L.core;
     lam[l] = L.lam;
     qi[l] = L.qi;
+    resid[l] = L.resid;
     if (R.obs_traj != nullptr) store_row<V, false>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
   }
   load_initial_inventories<V>(B, lanes[0], lanes[1], qi[0], qi[1]);
@@ -740,9 +817,10 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
     const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P);
+      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, resid[l], nz[l].z);
       core[l] = r.core;
       lam[l] = r.lam;
+      resid[l] = r.resid;
       ret[l] += r.reward;
       clips += (lanes[l] < P.n && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
       last[l] = r;
@@ -759,6 +837,7 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
 #pragma unroll
   for (int l = 0; l < 2; ++l) {  // what step() leaves behind: final state, last rewards (and events) of the final step
     store_row<V>(B.state_out, lanes[l], core[l], lam[l], false, P);
+    if (V::PRECISE) reinterpret_cast<float2*>(B.resid)[lanes[l]] = resid[l];
     if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
     if (R.n_steps > 0) {
       B.reward[lanes[l]] = last[l].reward;
@@ -784,10 +863,11 @@ struct ResetRow {
 };
 
 __global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0, const ResetRow row0,
-                             uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P) {
+                             uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P, float* resid, float2 resid0) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
+  if (resid != nullptr) reinterpret_cast<float2*>(resid)[i] = resid0;  // what float32 lost of the initial cash / price
   float* row = state + static_cast<size_t>(i) * dim;
   float* orow = obs != nullptr ? obs + static_cast<size_t>(i) * dim : nullptr;
   for (int j = 0; j < dim; ++j) {

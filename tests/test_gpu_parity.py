@@ -10,7 +10,7 @@ and, redundantly, the float64 oracle run live on the same inputs.  Stated tolera
                                                                            has held this episode) + 1e-4
   midprice ............................................................... |err| <= 3e-4   (S ~ 100: ulp = 7.6e-6,
                                                                            random-walk of the per-step rounding)
-  Hawkes intensities ..................................................... |err| <= 2e-5
+  Hawkes intensities ..................................................... |err| <= 2e-5 + 3e-7 |lambda|
   time ................................................................... 1e-6 abs
   normalised observations ................................................ 5e-5 abs (midprice drift / half-width 8)
 The state is float32 in HBM (it IS the float32 observation the API returns), so cash and midprice carry the
@@ -54,7 +54,9 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
     assert np.all(np.abs(got[:, 0] - want[:, 0]) <= cash_tol), f"{name} step {k}: cash {np.max(np.abs(got[:, 0] - want[:, 0]))}"
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=3e-4, err_msg=f"{name} step {k}: midprice")
     if want.shape[1] > 5:
-        np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=0, atol=2e-5, err_msg=f"{name} step {k}: intensities")
+        # float32 state: 2e-5 absolute around the baselines (10..50), float32 relative accuracy where arrivals have driven an
+        # intensity to ~150 (ulp 1.5e-5 there)
+        np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=3e-7, atol=2e-5, err_msg=f"{name} step {k}: intensities")
 
 
 @pytest.mark.parametrize("record", [True, False])

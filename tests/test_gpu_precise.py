@@ -1,0 +1,95 @@
+"""precise_state=True: cash and midprice kept as float32 pairs, advanced and rewarded in double.
+
+The float32 tiers carry an episode's accumulated rounding of cash (~1e-4 at |cash| ~ 1e3) and midprice (~1e-4 at S ~ 100)
+in their state; where the clip of TE:283-289 fires, or the midprice increment is proportional to the price (GBM), that
+level error becomes reward error (measured up to 5.8e-5, profiles/r01_parity_report.txt).  With precise_state the state
+follows the float64 reference to ~1e-12, so the north star's "fp32 rewards within 1e-5 of reference" holds on EVERY
+lane-step of every order-book fixture - clipped lanes included - and observations are the correctly rounded float32 of the
+reference's float64 state."""
+import numpy as np
+import pytest
+
+from oracle.mbt_oracle import InjectedNoise, OracleEnv
+from tests.env_factory import make_env
+from tests.golden_io import CASES, load_case, step_size_changes
+
+pytestmark = pytest.mark.gpu
+
+ORDER_BOOK = [c for c in CASES if not (c.startswith("speed_") or c.endswith("_speed") or c.startswith("exo_fill"))]
+HALF_ULP = 2.0 ** -24  # relative half-spacing of float32
+
+
+@pytest.mark.parametrize("name", ORDER_BOOK)
+def test_precise_state_rewards_within_1e5_on_every_lane(name):
+    cfg, g = load_case(name)
+    env = make_env(cfg, noise="injected", precise_state=True)
+    env.record_events(True)
+    obs0 = env.reset()
+    changes = step_size_changes(g)
+    worst = 0.0
+    for k in range(g["actions"].shape[0]):
+        if k in changes:
+            env.step_size = changes[k]
+        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        obs, rew, dones, _ = env.step(g["actions"][k])
+        want_obs, want_rew = g["obs"][k], g["rewards"][k]
+        np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"{name} step {k}: arrivals")
+        np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"{name} step {k}: fills")
+        err = np.abs(rew.astype(np.float64) - want_rew)
+        tol = 1e-5 + HALF_ULP * np.abs(want_rew)  # the float32 output itself rounds a reward of magnitude >> 1
+        assert np.all(err <= tol), f"{name} step {k}: reward off by {err.max()} (clipped lanes included)"
+        worst = max(worst, float(err.max()))
+        if cfg.normalise_observation_space:
+            np.testing.assert_allclose(obs, want_obs, rtol=0, atol=2e-6, err_msg=f"{name} step {k}: normalised obs")
+        else:
+            np.testing.assert_array_equal(obs[:, 1].astype(np.float64), want_obs[:, 1], err_msg=f"{name} step {k}: inventory")
+            # cash and midprice: the float32 NEAREST the reference's float64 value (state error ~1e-12, then one rounding)
+            for col, label in ((0, "cash"), (3, "midprice")):
+                bound = 1.001 * HALF_ULP * np.maximum(np.abs(want_obs[:, col]), 1e-30) + 1e-9
+                assert np.all(np.abs(obs[:, col] - want_obs[:, col]) <= bound), f"{name} step {k}: {label}"
+        assert bool(dones[0]) == bool(g["done"][k])
+    assert worst <= 1e-5 + HALF_ULP * float(np.abs(g["rewards"]).max())
+    env.close()
+
+
+def test_precise_state_philox_rollout_equals_step_loop_and_tracks_the_float64_oracle():
+    """Production noise: the fused rollout is bit-identical to the step loop in the precise tier too, and the oracle fed
+    with the kernel's own draws agrees to 1e-5 on every lane for a limit+market configuration that clips every few steps
+    (BASELINE configs[4]'s dynamics)."""
+    from mbt_gym_amd import _native
+    from oracle.mbt_oracle import OracleConfig
+
+    n, steps, seed = 4096, 60, 77
+    cfg = OracleConfig(num_trajectories=n, n_steps=steps, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                       intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit_and_market", market_half_spread=0.5, reward="running", phi=0.01,
+                       alpha=0.1, initial_inventory=2, max_inventory=3, seed=seed, normalise_action_space=False, normalise_observation_space=False)
+    action = np.tile(np.array([[0.4, 0.9, 1.0, 0.0]], np.float32), (n, 1))  # buys at market every step: the inventory clip fires constantly
+    loop, fused = make_env(cfg, precise_state=True), make_env(cfg, precise_state=True)
+    draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    loop.reset(), fused.reset(), oracle.reset()
+    total = np.zeros(n)
+    for k in range(steps):
+        obs, rew, _, _ = loop.step(action)
+        o_obs, o_rew, _ = oracle.step(action.astype(np.float64))
+        assert np.all(np.abs(rew - o_rew) <= 1e-5 + HALF_ULP * np.abs(o_rew)), f"step {k}: {np.abs(rew - o_rew).max()}"
+        np.testing.assert_array_equal(obs[:, 1], o_obs[:, 1])
+        total += o_rew
+    assert loop.clip_count > n * steps // 4
+    fused.set_action_host(action)
+    fused.step_repeat_device(steps)
+    np.testing.assert_array_equal(fused.state, loop.state)
+    assert fused.episode_return_sums()[0] == pytest.approx(loop.episode_return_sums()[0], rel=1e-6)
+    assert loop.episode_return_sums()[0] == pytest.approx(total.sum(), rel=1e-6)
+    loop.close(), fused.close()
+
+
+def test_precise_state_refusals():
+    from mbt_gym_amd._native import NativeError
+
+    cfg, _ = load_case("speed_temp_perm_cjoe")
+    with pytest.raises(NativeError, match="precise_state"):
+        make_env(cfg, precise_state=True)
+    cfg, _ = load_case("exo_fill_bm_poisson")
+    with pytest.raises(NativeError, match="precise_state"):
+        make_env(cfg, precise_state=True)
