@@ -62,7 +62,8 @@ enum {
 };
 enum {
   MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */,
-  MBT_FILL_EXOGENOUS_MM = 2 /* FILL:126-170: certain inside an exogenous best depth, exponential beyond; adds two state columns */
+  MBT_FILL_EXOGENOUS_MM = 2 /* FILL:126-170: certain inside an exogenous best depth, exponential beyond; adds two state columns */,
+  MBT_FILL_USER = 3 /* a user-defined FillProbabilityModel subclass (FILL:9-39): mbt_env_create_jit only */
 };
 enum {
   MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */, MBT_DYN_AT_THE_TOUCH = 2 /* MD:134-176 */,
@@ -70,7 +71,8 @@ enum {
 };
 enum {
   MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */,
-  MBT_REW_EXP_UTILITY = 3 /* RW:149-163 */, MBT_REW_CJ_OE = 4 /* RW:39-74, speed dynamics */
+  MBT_REW_EXP_UTILITY = 3 /* RW:149-163 */, MBT_REW_CJ_OE = 4 /* RW:39-74, speed dynamics */,
+  MBT_REW_USER = 5 /* a user-defined RewardFunction subclass (RW:8-17): mbt_env_create_jit only */
 };
 enum {
   MBT_IMPACT_NONE = -1, MBT_IMPACT_TEMPORARY_POWER = 0 /* IMP:34-61 */, MBT_IMPACT_TEMPORARY_AND_PERMANENT = 1 /* IMP:64-96 */,
@@ -169,6 +171,39 @@ int mbt_device_name(int device, char* buf, size_t buf_len);
  * allocates the (N, D) state and the output buffers in HBM, creates the stream. */
 int mbt_env_create(const mbt_config* cfg, mbt_env** out);
 void mbt_env_destroy(mbt_env* env);
+
+/* ---- user-defined plugins: the device route for subclasses of the reference's plugin contract -------------------
+ * The reference composes arbitrary StochasticProcessModel / RewardFunction subclasses (SP:8-53, FILL:9-39, RW:8-17).
+ * There is no CPU path to run their NumPy code, so a subclass states its numerics as a C++ device EXPRESSION and the
+ * library compiles the step (and fused rollout) kernel around it at run time with hiprtc - the same kernel source as
+ * the built-in tiers (general tier: any midprice kind incl. MBT_MID_LINEAR_SDE, Poisson / Hawkes arrivals, limit or
+ * limit + market dynamics, normalisation), with the user's function inlined where the built-in one would be:
+ *   fill_probability   replaces FillProbabilityModel._get_fill_probabilities (FILL:22-34) when cfg.fill_kind ==
+ *                      MBT_FILL_USER: an expression of type double in `depth` (double: the de-normalised quote depth),
+ *                      `side` (int: 0 bid, 1 ask) and the named parameters.  A fill happens when u < expression, with
+ *                      u the lane's uniform, compared in double.
+ *   reward             replaces RewardFunction.calculate (RW:10-13) when cfg.reward_kind == MBT_REW_USER: an expression of
+ *                      type double in  cash, q, t, mid  (current state)  cash_next, q_next, t_next, mid_next  (next state)
+ *                      a0, a1, a2, a3 (the action as given)  pnl (the mark-to-market change, from the step's increments)
+ *                      dt, is_terminal (1.0 on the terminal step), q0 (initial inventory), episode_length (T - t_start)
+ *                      and the named parameters.  The value is multiplied by cfg.reward_scale and rounded to float32.
+ * Parameter names are comma-separated C identifiers bound, in order, to the params arrays (at most 8 each).  Math
+ * functions are HIP's device library in double (exp, log, pow, sqrt, fabs, fmin, fmax, tanh, ...).  Compilation takes
+ * a few seconds per distinct (configuration, code) pair and is cached for the life of the process; diagnostics of a
+ * failed compilation are returned by mbt_jit_log().  Everything else about the handle is as mbt_env_create makes it. */
+typedef struct mbt_user_code {
+  const char* fill_probability;   /* NULL unless cfg.fill_kind == MBT_FILL_USER */
+  const char* fill_param_names;   /* e.g. "k,alpha"; NULL or "" = none */
+  double fill_params[8];
+  const char* reward;             /* NULL unless cfg.reward_kind == MBT_REW_USER */
+  const char* reward_param_names;
+  double reward_params[8];
+} mbt_user_code;
+int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out);
+const char* mbt_jit_log(void);    /* thread local; "" when the last compilation had nothing to say */
+/* Compiles the kernels for (cfg, code) and discards them: "do these expressions compile?" - needs no GPU (hiprtc
+ * cross-compiles), so a plugin can be checked where it is written. */
+int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
 /* Every launch and copy of an environment is ordered on ONE stream: its own (created non-blocking, so it does not
  * synchronise with the null stream) until this call hands it another hipStream_t, e.g. torch's current stream.
  * mbt_env_create returns with all buffers allocated, zero-filled and idle.  A caller that reads or writes the device

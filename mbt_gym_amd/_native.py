@@ -13,9 +13,9 @@ ABI_VERSION = 4
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE = 0, 1, 2, 3, 4, 5, 6
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE = 0, 1, 2, 3
-FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM = 0, 1, 2
+FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER = 0, 1, 2, 3
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
-REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE = 0, 1, 2, 3, 4
+REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE, REW_USER = 0, 1, 2, 3, 4, 5
 IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT = -1, 0, 1, 2, 3
 NOISE_PHILOX, NOISE_INJECTED = 0, 1
 
@@ -52,6 +52,29 @@ class MbtConfig(C.Structure):
         ("reward_terminal_time", C.c_double), ("mid_coef_add", C.c_double), ("mid_coef_mul", C.c_double),
         ("precise_state", C.c_int32), ("allow_stiff_hawkes", C.c_int32),
     ]
+
+
+class MbtUserCode(C.Structure):
+    """struct mbt_user_code (include/mbt_env.h): device expressions of user-defined plugins."""
+
+    _fields_ = [("fill_probability", C.c_char_p), ("fill_param_names", C.c_char_p), ("fill_params", C.c_double * 8),
+                ("reward", C.c_char_p), ("reward_param_names", C.c_char_p), ("reward_params", C.c_double * 8)]
+
+
+def user_code(fill=None, reward=None) -> MbtUserCode:
+    """(expression, {name: value}) pairs -> struct mbt_user_code."""
+    code = MbtUserCode()
+    for prefix, part in (("fill", fill), ("reward", reward)):
+        if part is None:
+            continue
+        expression, params = part
+        if len(params) > 8:
+            raise ValueError("a device expression takes at most 8 parameters")
+        setattr(code, "fill_probability" if prefix == "fill" else "reward", expression.encode())
+        setattr(code, prefix + "_param_names", ",".join(params).encode())
+        for j, value in enumerate(params.values()):
+            getattr(code, prefix + "_params")[j] = float(value)
+    return code
 
 
 POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE, POLICY_ACTION_BUFFER = 0, 1, 2, 3, 4
@@ -105,6 +128,9 @@ SIGNATURES = {
     "mbt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "mbt_env_create": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(_ENV)]),
     "mbt_env_destroy": (None, [_ENV]),
+    "mbt_env_create_jit": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(MbtUserCode), C.POINTER(_ENV)]),
+    "mbt_jit_log": (C.c_char_p, []),
+    "mbt_jit_check": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(MbtUserCode)]),
     "mbt_env_set_stream": (C.c_int, [_ENV, C.c_void_p]),
     "mbt_env_synchronize": (C.c_int, [_ENV]),
     "mbt_env_set_step_size": (C.c_int, [_ENV, C.c_double]),
@@ -235,7 +261,11 @@ def load_library():
 
 def check(code):
     if code < 0:
-        raise NativeError(code, load_library().mbt_last_error().decode("utf-8", "replace"))
+        lib = load_library()
+        message = lib.mbt_last_error().decode("utf-8", "replace")
+        if "mbt_jit_log" in message:  # a user expression that does not compile: show the compiler's diagnostics
+            message += "\n" + lib.mbt_jit_log().decode("utf-8", "replace")
+        raise NativeError(code, message)
     return code
 
 

@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include <cmath>
@@ -253,6 +255,8 @@ struct mbt_env {
   StepKernel kernel = nullptr;
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
+  hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
+  double user_fill_p[8] = {}, user_reward_p[8] = {};        // parameters of the user's device expressions
   uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
   bool stream_loads = false;       // the non-temporal-load instantiation of the step kernel, see tune_for_size()
   bool q0_per_lane_reset = false;  // the last explicit reset passed per-lane initial inventories (kept in q_init for auto-reset)
@@ -277,6 +281,10 @@ void fill_static_params(mbt_env* e) {
   P.n = e->n;
   P.n_pairs = e->n_pairs;
   P.pair_offset = c.trajectory_offset >> 1;
+  for (int j = 0; j < 8; ++j) {
+    P.user_fill_p[j] = e->user_fill_p[j];
+    P.user_reward_p[j] = e->user_reward_p[j];
+  }
   P.dt = static_cast<float>(e->dt);
   // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
   const int mk = c.midprice_kind;
@@ -437,8 +445,13 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
   B.clip_count = e->clip_count;
-  hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P);
-  HIP_TRY(hipGetLastError());
+  if (e->jit_step != nullptr) {
+    void* args[] = {&B, &P};
+    HIP_TRY(hipModuleLaunchKernel(e->jit_step, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, e->step_dynamic_lds, e->stream, args, nullptr));
+  } else {
+    hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P);
+    HIP_TRY(hipGetLastError());
+  }
   e->time = t_next;
   e->cur ^= 1;
   e->philox_step += 1;
@@ -545,8 +558,14 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
   B.clip_count = e->clip_count;
-  hipLaunchKernelGGL(e->rollout, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R);
-  HIP_TRY(hipGetLastError());
+  if (e->jit_rollout != nullptr) {
+    void* args[] = {&B, &P, &R};
+    HIP_TRY(hipModuleLaunchKernel(e->jit_rollout, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, 0, e->stream, args, nullptr));
+  } else {
+    if (e->rollout == nullptr) return fail(MBT_ERR_INVALID, "this environment has no fused rollout kernel");
+    hipLaunchKernelGGL(e->rollout, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R);
+    HIP_TRY(hipGetLastError());
+  }
   e->cur ^= 1;
   e->time = t;
   e->philox_step += steps;
@@ -603,6 +622,182 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
 }
 
 float* current_obs(mbt_env* e) { return e->cfg.normalise_observation ? e->obs : e->state[e->cur]; }
+
+// ---- run-time compilation of user plugins (mbt_env_create_jit) ----------------------------------------------------------
+// The kernel source IS this library's own: build.py embeds csrc/philox.hpp and csrc/step_kernel.hpp as string literals
+// (embedded_sources.inc), hiprtc compiles them with the user's two device functions in front of one instantiation of
+// step_body / rollout_body.  hiprtc is bound with dlopen like RCCL (PyTorch ships its own copy).
+extern const char* const kEmbeddedPhilox;
+extern const char* const kEmbeddedStepKernel;
+thread_local std::string g_jit_log;
+
+typedef struct _hiprtcProgram* rtc_program;
+struct HiprtcApi {
+  int (*create)(rtc_program*, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*compile)(rtc_program, int, const char**) = nullptr;
+  int (*log_size)(rtc_program, size_t*) = nullptr;
+  int (*log)(rtc_program, char*) = nullptr;
+  int (*code_size)(rtc_program, size_t*) = nullptr;
+  int (*code)(rtc_program, char*) = nullptr;
+  int (*destroy)(rtc_program*) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+const HiprtcApi& hiprtc() {
+  static const HiprtcApi api = [] {
+    HiprtcApi a;
+    void* h = nullptr;
+    const char* override_path = std::getenv("MBT_HIPRTC_LIBRARY");
+    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    const char* names[] = {"libhiprtc.so.7", "libhiprtc.so"};
+    for (const char* name : names)
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : names)
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) {
+      const char* err = dlerror();
+      a.why = std::string("libhiprtc.so could not be loaded: ") + (err != nullptr ? err : "unknown error");
+      return a;
+    }
+    a.create = reinterpret_cast<decltype(a.create)>(dlsym(h, "hiprtcCreateProgram"));
+    a.compile = reinterpret_cast<decltype(a.compile)>(dlsym(h, "hiprtcCompileProgram"));
+    a.log_size = reinterpret_cast<decltype(a.log_size)>(dlsym(h, "hiprtcGetProgramLogSize"));
+    a.log = reinterpret_cast<decltype(a.log)>(dlsym(h, "hiprtcGetProgramLog"));
+    a.code_size = reinterpret_cast<decltype(a.code_size)>(dlsym(h, "hiprtcGetCodeSize"));
+    a.code = reinterpret_cast<decltype(a.code)>(dlsym(h, "hiprtcGetCode"));
+    a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(h, "hiprtcDestroyProgram"));
+    a.ok = a.create && a.compile && a.log_size && a.log && a.code_size && a.code && a.destroy;
+    if (!a.ok) a.why = "libhiprtc is loaded but lacks part of the hiprtc API";
+    return a;
+  }();
+  return api;
+}
+
+bool valid_identifier(const std::string& name) {
+  if (name.empty() || !(std::isalpha(static_cast<unsigned char>(name[0])) || name[0] == '_')) return false;
+  for (char ch : name)
+    if (!(std::isalnum(static_cast<unsigned char>(ch)) || ch == '_')) return false;
+  return true;
+}
+
+// "k, alpha" -> "const double k = p[0]; const double alpha = p[1];"
+int param_declarations(const char* names, std::string& out) {
+  out.clear();
+  if (names == nullptr) return MBT_OK;
+  std::string token;
+  int index = 0;
+  const std::string all = std::string(names) + ",";
+  for (char ch : all) {
+    if (ch == ',') {
+      if (!token.empty()) {
+        if (!valid_identifier(token)) return fail(MBT_ERR_INVALID, "'%s' is not a C identifier (parameter names of a user expression)", token.c_str());
+        if (index >= 8) return fail(MBT_ERR_INVALID, "a user expression takes at most 8 parameters");
+        out += "  const double " + token + " = p[" + std::to_string(index++) + "];\n";
+        token.clear();
+      }
+    } else if (!std::isspace(static_cast<unsigned char>(ch))) {
+      token += ch;
+    }
+  }
+  return MBT_OK;
+}
+
+// source -> gfx950 code object (no device needed: hiprtc cross-compiles like hipcc does)
+int jit_compile(const std::string& source, std::vector<char>& code) {
+  g_jit_log.clear();
+  const HiprtcApi& api = hiprtc();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  rtc_program prog = nullptr;
+  const char* headers[] = {kEmbeddedPhilox, kEmbeddedStepKernel};
+  const char* header_names[] = {"philox.hpp", "step_kernel.hpp"};
+  if (api.create(&prog, source.c_str(), "mbt_user_plugins.hip", 2, headers, header_names) != 0) return fail(MBT_ERR_HIP, "hiprtcCreateProgram failed");
+  // the flags of the ahead-of-time build (mbt_gym_amd/build.py): in particular -ffp-contract=off, which keeps the step and
+  // the rollout instantiation bit-identical
+  const char* options[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};
+  const int rc = api.compile(prog, 5, options);
+  size_t log_bytes = 0;
+  if (api.log_size(prog, &log_bytes) == 0 && log_bytes > 1) {
+    g_jit_log.resize(log_bytes);
+    (void)api.log(prog, &g_jit_log[0]);
+    while (!g_jit_log.empty() && g_jit_log.back() == 0) g_jit_log.pop_back();
+  }
+  if (rc != 0) {
+    (void)api.destroy(&prog);
+    return fail(MBT_ERR_INVALID, "the user expression does not compile (hiprtc status %d): see mbt_jit_log()", rc);
+  }
+  size_t code_bytes = 0;
+  if (api.code_size(prog, &code_bytes) != 0 || code_bytes == 0) {
+    (void)api.destroy(&prog);
+    return fail(MBT_ERR_HIP, "hiprtcGetCodeSize failed");
+  }
+  code.resize(code_bytes);
+  const int got = api.code(prog, code.data());
+  (void)api.destroy(&prog);
+  if (got != 0) return fail(MBT_ERR_HIP, "hiprtcGetCode failed");
+  return MBT_OK;
+}
+
+struct JitKernels {
+  hipModule_t module = nullptr;
+  hipFunction_t step = nullptr, rollout = nullptr;
+};
+
+// One module per distinct (device, generated source): environments that share plugins share the compiled code.  Modules
+// live until the process exits (they are small and a handle may outlive the environment that first asked for them).
+int jit_build(int device, const std::string& source, bool with_rollout, JitKernels& out) {
+  static std::mutex mutex;
+  static std::map<std::pair<int, std::string>, JitKernels> cache;
+  std::lock_guard<std::mutex> guard(mutex);
+  g_jit_log.clear();  // a cache hit has nothing to say
+  const auto key = std::make_pair(device, source);
+  const auto hit = cache.find(key);
+  if (hit != cache.end()) {
+    out = hit->second;
+    return MBT_OK;
+  }
+  std::vector<char> code;
+  const int rc_compile = jit_compile(source, code);
+  if (rc_compile != MBT_OK) return rc_compile;
+  JitKernels k;
+  HIP_TRY(hipModuleLoadData(&k.module, code.data()));
+  HIP_TRY(hipModuleGetFunction(&k.step, k.module, "mbt_user_step"));
+  if (with_rollout) HIP_TRY(hipModuleGetFunction(&k.rollout, k.module, "mbt_user_rollout"));
+  cache.emplace(key, k);
+  out = k;
+  return MBT_OK;
+}
+
+// The translation unit: the library's own kernel source with the user's functions and ONE instantiation.
+int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
+  const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER;
+  std::string fill_decl, reward_decl;
+  int rc = param_declarations(u.fill_param_names, fill_decl);
+  if (rc != MBT_OK) return rc;
+  rc = param_declarations(u.reward_param_names, reward_decl);
+  if (rc != MBT_OK) return rc;
+  const int arr = c.arrival_kind == MBT_ARR_HAWKES ? mbt::kArrHawkes : mbt::kArrPoisson;
+  const int dyn = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? mbt::kDynLimitAndMarket : c.dynamics_kind == MBT_DYN_AT_THE_TOUCH ? mbt::kDynTouch : mbt::kDynLimit;
+  const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
+  src = "#define MBT_JIT_USER_CODE 1\n#include \"step_kernel.hpp\"\nnamespace mbt {\n";
+  src += "__device__ double mbt_user_fill_probability(double depth, int side, const double* p) {\n" + fill_decl + "  return static_cast<double>(" +
+         std::string(user_fill ? u.fill_probability : "0.0") + ");\n}\n";
+  src += "__device__ double mbt_user_reward(const UserRewardArgs& s_, const double* p) {\n"
+         "  const double cash = s_.cash, q = s_.q, t = s_.t, mid = s_.mid, cash_next = s_.cash_next, q_next = s_.q_next, t_next = s_.t_next,\n"
+         "               mid_next = s_.mid_next, a0 = s_.a0, a1 = s_.a1, a2 = s_.a2, a3 = s_.a3, pnl = s_.pnl, dt = s_.dt,\n"
+         "               is_terminal = s_.is_terminal, q0 = s_.q0, episode_length = s_.episode_length;\n"
+         "  (void)cash; (void)q; (void)t; (void)mid; (void)cash_next; (void)q_next; (void)t_next; (void)mid_next; (void)a0; (void)a1; (void)a2;\n"
+         "  (void)a3; (void)pnl; (void)dt; (void)is_terminal; (void)q0; (void)episode_length; (void)p;\n" +
+         reward_decl + "  return static_cast<double>(" + std::string(user_reward ? u.reward : "0.0") + ");\n}\n}  // namespace mbt\n";
+  src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
+         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ">;\n";
+  src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
+  if (!inject)
+    src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
+           "mbt::rollout_body<V>(B, P, R); }\n";
+  return MBT_OK;
+}
 
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------------------
 // The trajectory axis shards with no data-path collective; the one exchange is 24 bytes per episode.  libmbtenv therefore
@@ -719,9 +914,20 @@ int mbt_device_name(int device, char* buf, size_t buf_len) {
   return MBT_OK;
 }
 
-int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
+static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
   if (cfg == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   *out = nullptr;
+  const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
+  if ((user_fill || user_reward) && code == nullptr)
+    return fail(MBT_ERR_INVALID, "user-defined plugin kinds (MBT_FILL_USER / MBT_REW_USER) need their device expressions: use mbt_env_create_jit");
+  if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
+  if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
+  if (code != nullptr && !user_fill && !user_reward) return fail(MBT_ERR_INVALID, "mbt_env_create_jit: neither fill_kind nor reward_kind names a user-defined plugin");
+  if (user_fill || user_reward) {
+    if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill))
+      return fail(MBT_ERR_INVALID, "user-defined plugins run on the order-book kernels (a fill model needs limit or limit + market dynamics)");
+    if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state has no kernel for user-defined plugins");
+  }
   if (cfg->abi_version != MBT_ABI_VERSION)
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
   if (cfg->num_trajectories == 0 || cfg->num_trajectories > 0x7FFFF000ull)
@@ -733,7 +939,7 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   if (cfg->reward_terminal_time != 0.0 && !(cfg->reward_terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "reward_terminal_time must be positive (or 0 = terminal_time)");
   if (cfg->dynamics_kind < MBT_DYN_LIMIT || cfg->dynamics_kind > MBT_DYN_SPEED)
     return fail(MBT_ERR_INVALID, "dynamics kind %d has no device implementation", cfg->dynamics_kind);
-  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_CJ_OE)
+  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_USER)
     return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", cfg->reward_kind);
   if (speed) {
     if (cfg->arrival_kind != MBT_ARR_NONE || cfg->fill_kind != MBT_FILL_NONE)
@@ -751,6 +957,8 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
     if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
       if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
+    } else if (user_fill) {
+      // the expression is the model: no built-in parameter to validate
     } else if (!(cfg->fill_exponent > 0.0)) {
       return fail(MBT_ERR_INVALID, "fill_exponent must be positive (got %g)", cfg->fill_exponent);
     } else if (cfg->fill_kind == MBT_FILL_EXOGENOUS_MM) {
@@ -797,8 +1005,26 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
   tune_for_size(e);
-  e->kernel = pick_kernel(*cfg, e->stream_loads);
-  e->rollout = pick_rollout_kernel(*cfg);
+  if (user_fill || user_reward) {
+    for (int j = 0; j < 8; ++j) {
+      e->user_fill_p[j] = code->fill_params[j];
+      e->user_reward_p[j] = code->reward_params[j];
+    }
+    std::string source;
+    JitKernels kernels;
+    int jit_rc = jit_source(*cfg, *code, source);
+    if (jit_rc == MBT_OK) jit_rc = jit_build(cfg->device, source, cfg->noise_mode == MBT_NOISE_PHILOX, kernels);
+    if (jit_rc != MBT_OK) {
+      delete e;
+      return jit_rc;
+    }
+    e->jit_step = kernels.step;
+    e->jit_rollout = kernels.rollout;
+    e->stream_loads = false;  // one instantiation is compiled: default-policy loads
+  } else {
+    e->kernel = pick_kernel(*cfg, e->stream_loads);
+    e->rollout = pick_rollout_kernel(*cfg);
+  }
   fill_static_params(e);
   key_from_seed(e);
 
@@ -878,6 +1104,28 @@ int mbt_env_create(const mbt_config* cfg, mbt_env** out) {
   }
   *out = e;
   return MBT_OK;
+}
+
+int mbt_env_create(const mbt_config* cfg, mbt_env** out) { return create_env(cfg, nullptr, out); }
+
+int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
+  if (code == nullptr) return fail(MBT_ERR_INVALID, "null user code");
+  return create_env(cfg, code, out);
+}
+
+const char* mbt_jit_log(void) { return g_jit_log.c_str(); }
+
+int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
+  if (cfg == nullptr || code == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
+  if (!user_fill && !user_reward) return fail(MBT_ERR_INVALID, "neither fill_kind nor reward_kind names a user-defined plugin");
+  if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
+  if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
+  std::string source;
+  std::vector<char> object;
+  int rc = jit_source(*cfg, *code, source);
+  if (rc == MBT_OK) rc = jit_compile(source, object);
+  return rc;
 }
 
 void mbt_env_destroy(mbt_env* e) {
@@ -1433,3 +1681,7 @@ int mbt_env_timer_end(mbt_env* e, float* elapsed_ms) {
 }
 
 }  // extern "C"
+
+// ---- the kernel source, embedded for mbt_env_create_jit (generated by mbt_gym_amd/build.py from csrc/philox.hpp and
+//      csrc/step_kernel.hpp: the very files this library was compiled from) -------------------------------------------
+#include "embedded_sources.inc"

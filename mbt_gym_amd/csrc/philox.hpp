@@ -20,8 +20,15 @@
 // Uniforms are u = (w >> 8) * 2^-24 in [0,1): exactly representable in float32, which is what lets the
 // Bernoulli decisions of the step be bit-exact against a float64 evaluation of the same draws.
 #pragma once
+#ifndef __HIPCC_RTC__  // hiprtc (the run-time compiler of user plugins, mbt_env_create_jit) pre-includes the HIP runtime ...
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // ... and keeps the fixed-width integer types in a namespace of its own
+typedef __hip_internal::uint8_t uint8_t;
+typedef __hip_internal::uint32_t uint32_t;
+typedef __hip_internal::uint64_t uint64_t;
+typedef __hip_internal::int32_t int32_t;
+#endif
 
 #ifndef MBT_PHILOX_ROUNDS
 #define MBT_PHILOX_ROUNDS 10  // the standard Philox4x32-10; fewer rounds are for sensitivity experiments only

@@ -28,8 +28,10 @@
 //     reference's (c'+q'S') - (c+qS) (RW:27-33) with the S terms cancelled analytically.
 //   * cash / midprice: float32 state, a few ulps from the float64 reference.
 #pragma once
+#ifndef __HIPCC_RTC__  // (see philox.hpp)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "philox.hpp"
 
@@ -51,7 +53,8 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
-template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false>
+template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
+          bool USER_FILL_ = false, bool USER_REWARD_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -70,6 +73,10 @@ struct Variant {
   // Instantiated on the general tier only, like EXO.
   static constexpr bool PRECISE = PRECISE_;
   static_assert(!(EXO_ && PRECISE_), "precise_state is not instantiated for the exogenous-depth fill model");
+  // User-defined plugins (mbt_env_create_jit): this header is compiled at RUN TIME (hiprtc) together with the user's
+  // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
+  // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
+  static constexpr bool USER_FILL = USER_FILL_, USER_REWARD = USER_REWARD_;
   static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
   static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
 };
@@ -135,7 +142,21 @@ struct StepParams {
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
   PreciseParams X;
+  double user_fill_p[8], user_reward_p[8];  // parameters of the user's device expressions (mbt_user_code)
 };
+
+#ifdef MBT_JIT_USER_CODE
+// Defined by the translation unit mbt_env_create_jit generates in front of this header.
+__device__ double mbt_user_fill_probability(double depth, int side, const double* p);
+struct UserRewardArgs {
+  double cash, q, t, mid;                      // current state (before the step)
+  double cash_next, q_next, t_next, mid_next;  // next state
+  double a0, a1, a2, a3;                       // the action as the agent gave it
+  double pnl;                                  // mark-to-market change (c' + q' S') - (c + q S), from the step's increments
+  double dt, is_terminal, q0, episode_length;  // step size, 1.0 on the terminal step, initial inventory, T - t_start
+};
+__device__ double mbt_user_reward(const UserRewardArgs& s, const double* p);
+#endif
 
 struct StepBuffers {
   const float* state_in;   // (n_pad, D) row-major
@@ -187,7 +208,7 @@ __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepPar
   d.uf_bid = nz.uf_bid;
   d.uf_ask = nz.uf_ask;
   d.lo_bid = d.hi_bid = d.lo_ask = d.hi_ask = 0.0f;
-  if (!V::EXO && V::DYN != kDynTouch) {
+  if (!V::EXO && !V::USER_FILL && V::DYN != kDynTouch) {
     fill_thresholds(nz.uf_bid, P, d.lo_bid, d.hi_bid);
     fill_thresholds(nz.uf_ask, P, d.lo_ask, d.hi_ask);
   }
@@ -372,16 +393,28 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   } else {
     off_bid = depth_of(act.x, 0, norm_act, P);
     off_ask = depth_of(act.y, 1, norm_act, P);
-    const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(off_bid, dr.lo_bid, dr.hi_bid);
-    const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(off_ask, dr.lo_ask, dr.hi_ask);
-    bool fb = tb.fill, fa = ta.fill;
-    if (__builtin_expect(tb.near | ta.near, 0)) {
-      if (V::EXO) {
-        if (tb.near) fb = refine_fill_exogenous_f64(dr.uf_bid, act.x, 0, norm_act, P);
-        if (ta.near) fa = refine_fill_exogenous_f64(dr.uf_ask, act.y, 1, norm_act, P);
-      } else {
-        if (tb.near) fb = refine_fill_f64(dr.uf_bid, act.x, 0, norm_act, P);
-        if (ta.near) fa = refine_fill_f64(dr.uf_ask, act.y, 1, norm_act, P);
+    bool fb = false, fa = false;
+    if (V::USER_FILL) {
+#ifdef MBT_JIT_USER_CODE
+      // the user's _get_fill_probabilities (FILL:22-34), evaluated in double on the de-normalised depth: u < p(depth)
+      const double depth_b = norm_act ? (static_cast<double>(act.x) + 1.0) * P.act_grad[0] + P.act_lo[0] : static_cast<double>(act.x);
+      const double depth_a = norm_act ? (static_cast<double>(act.y) + 1.0) * P.act_grad[1] + P.act_lo[1] : static_cast<double>(act.y);
+      fb = static_cast<double>(dr.uf_bid) < mbt_user_fill_probability(depth_b, 0, P.user_fill_p);
+      fa = static_cast<double>(dr.uf_ask) < mbt_user_fill_probability(depth_a, 1, P.user_fill_p);
+#endif
+    } else {
+      const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(off_bid, dr.lo_bid, dr.hi_bid);
+      const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(off_ask, dr.lo_ask, dr.hi_ask);
+      fb = tb.fill;
+      fa = ta.fill;
+      if (__builtin_expect(tb.near | ta.near, 0)) {
+        if (V::EXO) {
+          if (tb.near) fb = refine_fill_exogenous_f64(dr.uf_bid, act.x, 0, norm_act, P);
+          if (ta.near) fa = refine_fill_exogenous_f64(dr.uf_ask, act.y, 1, norm_act, P);
+        } else {
+          if (tb.near) fb = refine_fill_f64(dr.uf_bid, act.x, 0, norm_act, P);
+          if (ta.near) fa = refine_fill_f64(dr.uf_ask, act.y, 1, norm_act, P);
+        }
       }
     }
     r.fill_bid = fb && open_bid;
@@ -477,6 +510,16 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
     const float c_new = P.quad_new + (is_terminal ? P.alpha_running : 0.0f);
     const float pen = __builtin_fmaf(-P.alpha_cjmm, q * q, __builtin_fmaf(c_new, q_clip * q_clip, P.quad_init * (q_init * q_init)));
     r.reward = (pnl - pen) * P.reward_scale;
+  } else if (V::USER_REWARD) {
+#ifdef MBT_JIT_USER_CODE
+    UserRewardArgs u;  // RewardFunction.calculate(current_state, action, next_state, is_terminal_step) (RW:10-13), in double
+    u.cash = cash; u.q = q; u.t = static_cast<double>(t_next) - static_cast<double>(P.dt); u.mid = mid;
+    u.cash_next = c_clip; u.q_next = q_clip; u.t_next = t_next; u.mid_next = mid_new;
+    u.a0 = act.x; u.a1 = act.y; u.a2 = act.z; u.a3 = act.w;
+    u.pnl = pnl;
+    u.dt = P.dt; u.is_terminal = is_terminal ? 1.0 : 0.0; u.q0 = q_init; u.episode_length = P.episode_length;
+    r.reward = static_cast<float>(mbt_user_reward(u, P.user_reward_p) * static_cast<double>(P.reward_scale));
+#endif
   } else {
     r.reward = finish_reward(pnl, q, q_clip, c_clip, mid_new, q_init, 0.0f, is_terminal, P);
   }
@@ -676,7 +719,7 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
 // run-time branch around the two load sequences does not survive the optimiser: it merges the branches' loads and drops
 // the hint.)
 template <class V, bool STREAM = false>
-__global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
+__device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {
   const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
   LaneLoads L0 = load_lane<V, STREAM>(B, P, lane0), L1 = load_lane<V, STREAM>(B, P, lane1);  // issue every load ...
@@ -729,6 +772,13 @@ __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B
   }
 }
 
+// (the body is a device function so that the run-time compiled kernels of mbt_env_create_jit - plain extern "C" entry
+// points around one instantiation - share it with the ahead-of-time instantiations)
+template <class V, bool STREAM = false>
+__global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
+  step_body<V, STREAM>(B, P);
+}
+
 // ---- fused rollout -----------------------------------------------------------------------
 // Many consecutive env-steps in ONE launch with an on-device closed-form policy: the pair's state stays in
 // registers, noise comes from the same Philox stream the step kernel would draw (philox step = first + k), so a
@@ -753,7 +803,7 @@ struct RolloutParams {
 };
 
 template <class V>
-__global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
+__device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepParams& P, const RolloutParams& R) {
   static_assert(!V::INJECT, "rollouts draw their own noise");
   constexpr int A = (V::DYN == kDynLimitAndMarket) ? 4 : 2;
   const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
@@ -854,6 +904,12 @@ __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffer
   }
 }
 
+template <class V>
+__global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
+  rollout_body<V>(B, P, R);
+}
+
+#ifndef MBT_JIT_USER_CODE  // the run-time compiled translation unit needs the step and rollout bodies only
 // ---- small helper kernels ----------------------------------------------------------------------------------
 
 // reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...], zeroed accumulators.
@@ -983,5 +1039,7 @@ __global__ void philox_kat_kernel(const uint32_t* ctr, const uint32_t* key, uint
   const PhiloxWords w = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
   out[0] = w.w0; out[1] = w.w1; out[2] = w.w2; out[3] = w.w3;
 }
+
+#endif  // MBT_JIT_USER_CODE
 
 }  // namespace mbt

@@ -215,7 +215,11 @@ class TradingEnvironment(_EnvBase):
         lib = _native.load_library()
         cfg = self._device_config(num_trajectories, reward_scale, trajectory_offset)
         handle = C.c_void_p()
-        _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        code = self._user_code()
+        if code is None:
+            _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        else:  # user-defined plugins: the kernels are compiled around their device expressions (hiprtc, cached per process)
+            _native.check(lib.mbt_env_create_jit(C.byref(cfg), C.byref(code), C.byref(handle)))
         # the host derives the row widths from the descriptors (TE:311-318), the library from the plugin kinds: a
         # disagreement would hand back misaligned rows, so it is an error, not a warning
         dims = (lib.mbt_env_obs_dim(handle), lib.mbt_env_action_dim(handle))
@@ -227,6 +231,23 @@ class TradingEnvironment(_EnvBase):
         if self._step_size != self.terminal_time / self.n_steps:  # a step_size set earlier (TE:158-167) survives a re-allocation
             _native.check(lib.mbt_env_set_step_size(handle, float(self._step_size)))
         return handle
+
+    def _user_code(self):
+        """struct mbt_user_code for the user-defined plugins of this environment (None when every plugin is built in)."""
+        fill, reward = self.model_dynamics.fill_probability_model, self.reward_function
+        fill_code = fill.device_code() if getattr(fill, "device_kind", None) == _native.FILL_USER else None
+        reward_code = reward.device_code() if getattr(reward, "device_kind", None) == _native.REW_USER else None
+        if fill_code is None and reward_code is None:
+            return None
+        return _native.user_code(fill_code, reward_code)
+
+    def check_device_expressions(self):
+        """Compile the user-defined plugins' device expressions without creating anything (needs no GPU); raises
+        NativeError with the compiler's diagnostics if they do not compile."""
+        code = self._user_code()
+        if code is not None:
+            cfg = self._device_config(self.num_trajectories, self.reward_scaling)
+            _native.check(_native.load_library().mbt_jit_check(C.byref(cfg), C.byref(code)))
 
     def close(self):
         if getattr(self, "_handle", None) is not None:

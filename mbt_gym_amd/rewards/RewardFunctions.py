@@ -136,3 +136,46 @@ class ExponentialUtility(RewardFunction):
 
     def device_params(self):
         return dict(reward_kind=self.device_kind, risk_aversion=self.risk_aversion)
+
+
+class DeviceExpressionReward(RewardFunction):
+    """The device route for USER-DEFINED reward functions (the reference's plugin contract, RW:8-17).
+
+    The reference asks a subclass for `calculate(current_state, action, next_state, is_terminal_step)` in NumPy; there is
+    no CPU path here to run NumPy code in the step, so a subclass states the same function as a C++ device expression in
+        cash, q, t, mid                         the current state's [cash, inventory, time, midprice]
+        cash_next, q_next, t_next, mid_next     the next state's
+        a0, a1, a2, a3                          the action as the agent gave it
+        pnl                                     (c' + q' S') - (c + q S), computed from the step's increments
+        dt, is_terminal, q0, episode_length     step size, 1.0 on the terminal step, inventory at reset, T - t_start
+    and its own named parameters (`device_expression_params()`, at most 8):
+
+        class ExponentialInventoryCost(DeviceExpressionReward):
+            device_expression = "pnl - dt * phi * (exp(eta * fabs(q_next)) - 1.0) - is_terminal * alpha * q_next * q_next"
+            def device_expression_params(self):
+                return {"phi": self.phi, "eta": self.eta, "alpha": self.alpha}
+
+    Evaluated in double inside the fused step / rollout kernels, which the library compiles around the expression at run
+    time (include/mbt_env.h, mbt_env_create_jit).  `calculate()` on host matrices is not available for such a class (the
+    expression only exists on the device); the reference-API method can still be defined by the subclass for host use."""
+
+    device_kind = _native.REW_USER
+    device_expression: str = None
+
+    def __init__(self):
+        if not self.device_expression:
+            raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of calculate)")
+
+    def device_expression_params(self) -> dict:
+        return {}
+
+    def calculate(self, current_state, action, next_state, is_terminal_step: bool = False):
+        from mbt_gym_amd.stochastic_processes.StochasticProcessModel import DeviceResidentError
+
+        raise DeviceResidentError(f"{type(self).__name__}.calculate exists as a device expression only; rewards come from TradingEnvironment.step().")
+
+    def reset(self, initial_state):
+        pass
+
+    def device_code(self):
+        return self.device_expression, dict(self.device_expression_params())

@@ -30,6 +30,47 @@ class FillProbabilityModel(StochasticProcessModel):
         raise NotImplementedError
 
 
+class DeviceExpressionFillModel(FillProbabilityModel):
+    """The device route for USER-DEFINED fill-probability models (the reference's plugin contract, FILL:9-39).
+
+    The reference asks a subclass for `_get_fill_probabilities(depths)` in NumPy and `max_depth`; there is no CPU path
+    here to run NumPy code in the step, so a subclass ALSO states the same function as a C++ device expression:
+
+        class PowerLawFill(DeviceExpressionFillModel):
+            device_expression = "1.0 / (1.0 + pow(scale * depth, exponent))"     # in `depth` (double), `side` (0 bid / 1 ask)
+            def __init__(self, scale, exponent, **kw):
+                self.scale, self.exponent = scale, exponent
+                super().__init__(**kw)
+            def device_expression_params(self):
+                return {"scale": self.scale, "exponent": self.exponent}           # at most 8, bound by name
+            def _get_fill_probabilities(self, depths):                            # the reference's method (host utility)
+                return 1.0 / (1.0 + (self.scale * depths) ** self.exponent)
+            @property
+            def max_depth(self):
+                return 99.0 ** (1.0 / self.exponent) / self.scale                 # where the probability is 1 %
+
+    The library compiles the step and rollout kernels around the expression at run time (hiprtc, a few seconds, cached
+    per process: include/mbt_env.h, mbt_env_create_jit); a fill happens when the lane's uniform u < expression, compared
+    in double on the de-normalised depth.  `check_device_expression()` compiles without a GPU."""
+
+    device_kind = _native.FILL_USER
+    device_expression: str = None
+
+    def __init__(self, step_size: float = 0.1, num_trajectories: int = 1, seed: Optional[int] = None):
+        if not self.device_expression:
+            raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of _get_fill_probabilities)")
+        super().__init__(_EMPTY, _EMPTY, step_size, 0.0, _EMPTY, num_trajectories, seed)
+
+    def device_expression_params(self) -> dict:
+        return {}
+
+    def device_params(self):
+        return dict(fill_kind=self.device_kind)
+
+    def device_code(self):
+        return self.device_expression, dict(self.device_expression_params())
+
+
 class ExponentialFillFunction(FillProbabilityModel):
     device_kind = _native.FILL_EXPONENTIAL
 

@@ -72,7 +72,12 @@ class OracleConfig:
     # The reference's ExogenousMmFillProbabilityModel.update advances its two depth processes but never copies their
     # state into its own current_state (FILL:168-170), so the best depths the environment sees - the two state
     # columns and the depths in FILL:159-163 - stay at the processes' initial values for the whole episode.
+    # "user_power_law": a USER-DEFINED FillProbabilityModel subclass (plugin contract FILL:9-39; the reference's own
+    # PowerFillFunction, FILL:96-123, is not per-trajectory): p(depth) = 1 / (1 + (fill_scale depth)^fill_power),
+    # max_depth = 99^(1/fill_power) / fill_scale (where p = 1 %)
     fill: str = "exponential"
+    fill_scale: float = 1.0
+    fill_power: float = 1.5
     fill_exponent: float = 1.5
     base_fill_probability: float = 1.0  # FILL:132
     exo_depth: Sequence[float] = (0.0, 0.0)  # initial states of the (bid, ask) best-depth processes (FILL:148-154)
@@ -99,7 +104,10 @@ class OracleConfig:
     midprice_step_size: Optional[float] = None
     arrival_step_size: Optional[float] = None
     # reward: "pnl" (RW:20-36), "running" (RW:116-143), "cjmm" (RW:77-113), "cjoe" (RW:39-74), "exp_utility" (RW:149-163)
+    # "user_exp_inventory_cost": a USER-DEFINED RewardFunction subclass (plugin contract RW:8-17):
+    #   PnL - dt phi (exp(eta |q'|) - 1) - alpha [terminal] q'^2
     reward: str = "pnl"
+    eta: float = 0.1
     risk_aversion: float = 0.1  # RW:150
     phi: float = 0.01  # per_step_inventory_aversion
     alpha: float = 0.0  # terminal_inventory_aversion
@@ -177,6 +185,8 @@ def resolved_max_depth(cfg: OracleConfig) -> float:
     """-ln(0.01)/kappa unless given (FILL:60-62, MD:103); the exogenous model adds the bid process' upper bound (FILL:164-166)."""
     if cfg.max_depth:
         return cfg.max_depth
+    if cfg.fill == "user_power_law":
+        return float(99.0 ** (1.0 / cfg.fill_power) / cfg.fill_scale)
     if cfg.has_exogenous_fill:
         return float(-np.log(0.01) / cfg.fill_exponent + np.max(np.asarray(cfg.exo_depth_hi, dtype=np.float64)[0]))
     return float(-np.log(0.01) / cfg.fill_exponent)
@@ -390,6 +400,8 @@ class OracleEnv:
                 best = np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0)
                 prob = (depths > best) * cfg.base_fill_probability * np.exp(-cfg.fill_exponent * (depths - best)) + (depths <= best)
                 fills = u_fill < prob
+            elif cfg.fill == "user_power_law":  # the user's _get_fill_probabilities behind FILL:28-34
+                fills = u_fill < 1.0 / (1.0 + (cfg.fill_scale * depths) ** cfg.fill_power)
             else:
                 fills = u_fill < np.exp(-cfg.fill_exponent * depths)
             # no bid fill at +max inventory, no ask fill at -max inventory, pre-update q (TE:323-327)
@@ -480,6 +492,10 @@ class OracleEnv:
             return pnl
         if cfg.reward == "running":
             return running_inventory_penalty(cur, nxt, done, cfg.phi, cfg.alpha, cfg.inventory_exponent)
+        if cfg.reward == "user_exp_inventory_cost":  # the user's calculate()
+            dt = nxt[:, TIME] - cur[:, TIME]
+            q = nxt[:, INVENTORY]
+            return pnl - dt * cfg.phi * (np.exp(cfg.eta * np.abs(q)) - 1.0) - cfg.alpha * int(done) * q**2
         if cfg.reward == "cjmm":
             return cj_mm_criterion(
                 cur, nxt, cfg.phi, cfg.alpha, cfg.inventory_exponent, self.q_init, self.episode_length

@@ -50,6 +50,10 @@ def make_env(cfg, noise="philox", **overrides):
         best = [_FixedBoundsProcess(cfg.exo_depth[s], cfg.exo_depth_lo[s], cfg.exo_depth_hi[s], dt, n) for s in range(2)]
         fill = ExogenousMmFillProbabilityModel(tuple(best), fill_exponent=cfg.fill_exponent, base_fill_probability=cfg.base_fill_probability,
                                                step_size=dt, num_trajectories=n)
+    elif cfg.fill == "user_power_law":  # a user-defined plugin: compiled into the kernel at run time
+        from tests.user_plugins import PowerLawFill
+
+        fill = PowerLawFill(scale=cfg.fill_scale, power=cfg.fill_power, step_size=dt, num_trajectories=n)
     else:
         fill = ExponentialFillFunction(fill_exponent=cfg.fill_exponent, step_size=dt, num_trajectories=n)
     if cfg.dynamics == "limit":
@@ -76,6 +80,7 @@ def make_env(cfg, noise="philox", **overrides):
         "cjmm": lambda: rw.CjMmCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
         "cjoe": lambda: rw.CjOeCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
         "exp_utility": lambda: rw.ExponentialUtility(cfg.risk_aversion),
+        "user_exp_inventory_cost": lambda: __import__("tests.user_plugins", fromlist=["x"]).ExponentialInventoryCost(cfg.phi, cfg.eta, cfg.alpha),
     }[cfg.reward]()
     kwargs = dict(
         terminal_time=T, n_steps=cfg.n_steps, reward_function=rew, model_dynamics=md, initial_cash=cfg.initial_cash,

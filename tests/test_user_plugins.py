@@ -1,0 +1,111 @@
+"""The device route for user-defined plugins (include/mbt_env.h: mbt_env_create_jit, mbt_jit_check).
+
+CPU part: the expressions are compiled by hiprtc without a GPU (`check_device_expressions`), diagnostics surface as
+exceptions.  GPU part: the run-time compiled kernels against the oracle fed with the kernel's own Philox draws, the fused
+rollout against the step loop, and the refusals.  Parity with the REAL reference running the same user-defined classes
+is in test_gpu_parity.py (fixtures user_*)."""
+import numpy as np
+import pytest
+
+from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv
+from tests.env_factory import make_env
+
+
+def _cfg(n, **kw):
+    base = dict(num_trajectories=n, n_steps=50, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                intensity=(80.0, 60.0), fill="user_power_law", fill_scale=1.25, fill_power=1.5, dynamics="limit",
+                reward="user_exp_inventory_cost", phi=0.05, eta=0.3, alpha=0.02, initial_inventory=0, max_inventory=6, seed=17,
+                normalise_action_space=False, normalise_observation_space=False)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+def test_device_expressions_compile_without_a_gpu(no_device):
+    from mbt_gym_amd import _native
+    from tests.user_plugins import ExponentialInventoryCost
+
+    env = make_env(_cfg(64))
+    env.check_device_expressions()  # hiprtc cross-compiles: a plugin can be checked where it is written
+    assert env.action_space.high[0] == pytest.approx(99.0 ** (1 / 1.5) / 1.25, rel=1e-6)  # the user's max_depth bounds the action (MD:118-121)
+    good = ExponentialInventoryCost.device_expression
+    try:
+        ExponentialInventoryCost.device_expression = "pnl - undeclared_symbol * q_next"
+        with pytest.raises(_native.NativeError, match="undeclared_symbol"):
+            env.check_device_expressions()
+    finally:
+        ExponentialInventoryCost.device_expression = good
+    built_in = make_env(_cfg(64, fill="exponential", reward="pnl"))
+    built_in.check_device_expressions()  # nothing to compile: a no-op
+
+
+def test_a_plugin_class_without_a_device_form_is_refused(no_device):
+    """A subclass of the plugin base classes that only has NumPy code (what the reference accepts) cannot run: there is no
+    CPU fallback.  It is refused at construction with a message that names the device routes."""
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment, UnsupportedOnDevice
+    from mbt_gym_amd.rewards.RewardFunctions import DeviceExpressionReward, RewardFunction
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import DeviceExpressionFillModel
+
+    class NumpyOnlyReward(RewardFunction):
+        def calculate(self, current_state, action, next_state, is_terminal_step=False):
+            return np.zeros(len(current_state))
+
+        def reset(self, initial_state):
+            pass
+
+    env = make_env(_cfg(8, fill="exponential", reward="pnl"))
+    env.reward_function = NumpyOnlyReward()
+    with pytest.raises(UnsupportedOnDevice):
+        env._device_config(8, 1.0)
+    with pytest.raises(TypeError, match="device_expression"):
+        type("NoExpression", (DeviceExpressionReward,), {})()
+    with pytest.raises(TypeError, match="device_expression"):
+        type("NoExpression", (DeviceExpressionFillModel,), {})()
+    assert TradingEnvironment is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(dynamics="limit_and_market", market_half_spread=0.4, arrival="hawkes", intensity=(15.0, 10.0), hawkes_speed=20.0),
+                                dict(fill="exponential"), dict(reward="running")])
+def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw):
+    from mbt_gym_amd import _native
+
+    n, seed = 3000, 17
+    cfg = _cfg(n, **kw)
+    steps = cfg.n_steps
+    a_dim = 4 if cfg.dynamics == "limit_and_market" else 2
+    action = np.tile(np.array([[0.3, 0.5, 0.0, 1.0][:a_dim]], np.float32), (n, 1))
+    env, fused = make_env(cfg), make_env(cfg)
+    draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    env.reset(), fused.reset(), oracle.reset()
+    for k in range(steps):
+        obs, rew, dones, _ = env.step(action)
+        o_obs, o_rew, _ = oracle.step(action.astype(np.float64))
+        np.testing.assert_array_equal(obs[:, 1], o_obs[:, 1], err_msg=f"step {k}: inventory")
+        clipped = oracle.last_clipped
+        err = np.abs(rew - o_rew)
+        assert np.all(err[~clipped] <= 1e-5 + 1e-6 * np.abs(o_rew[~clipped])), f"step {k}: reward {err[~clipped].max()}"
+        assert np.all(err[clipped] <= 1e-3)
+    assert dones[0]
+    fused.set_action_host(action)
+    assert fused.step_repeat_device(steps) == (steps, True)
+    np.testing.assert_array_equal(fused.state, env.state)
+    assert fused.episode_return_sums()[0] == pytest.approx(env.episode_return_sums()[0], rel=1e-6)
+    env.close(), fused.close()
+
+
+@pytest.mark.gpu
+def test_user_plugin_refusals_and_cache():
+    import time
+
+    from mbt_gym_amd._native import NativeError
+
+    t0 = time.perf_counter()
+    first = make_env(_cfg(1024))
+    t1 = time.perf_counter()
+    second = make_env(_cfg(2048))  # same plugins, same kernels: served from the process-wide module cache
+    t2 = time.perf_counter()
+    assert (t2 - t1) < 0.5 * (t1 - t0) + 0.2
+    first.close(), second.close()
+    with pytest.raises(NativeError, match="precise_state"):
+        make_env(_cfg(64), precise_state=True)

@@ -1,0 +1,42 @@
+"""What a USER of the reference writes to bring their own plugins to the device: subclasses of the plugin base classes
+(the reference's contract: FILL:9-39, RW:8-17) that state their numerics as a device expression.  These two mirror, class
+for class, the reference-API plugins that tools/refgen/make_golden.py runs through the REAL reference to produce the
+`user_*` fixtures - so the parity tests compare a user-defined plugin on the device with the same user-defined plugin in
+the reference."""
+import numpy as np
+
+from mbt_gym_amd.rewards.RewardFunctions import DeviceExpressionReward
+from mbt_gym_amd.stochastic_processes.fill_probability_models import DeviceExpressionFillModel
+
+
+class PowerLawFill(DeviceExpressionFillModel):
+    """p(depth) = 1 / (1 + (scale depth)^power): a heavier tail than the exponential fill function."""
+
+    device_expression = "1.0 / (1.0 + pow(scale * depth, power))"
+
+    def __init__(self, scale: float = 1.0, power: float = 1.5, step_size: float = 0.1, num_trajectories: int = 1, seed=None):
+        self.scale, self.power = scale, power
+        super().__init__(step_size=step_size, num_trajectories=num_trajectories, seed=seed)
+
+    def device_expression_params(self):
+        return {"scale": self.scale, "power": self.power}
+
+    def _get_fill_probabilities(self, depths):  # the reference's abstract method: host utility (plots, agents)
+        return 1.0 / (1.0 + (self.scale * np.asarray(depths)) ** self.power)
+
+    @property
+    def max_depth(self) -> float:
+        return 99.0 ** (1.0 / self.power) / self.scale  # the depth whose fill probability is 1 %
+
+
+class ExponentialInventoryCost(DeviceExpressionReward):
+    """PnL - dt phi (exp(eta |q'|) - 1) - alpha [terminal] q'^2: an inventory cost that grows exponentially."""
+
+    device_expression = "pnl - dt * phi * (exp(eta * fabs(q_next)) - 1.0) - alpha * is_terminal * q_next * q_next"
+
+    def __init__(self, phi: float = 0.01, eta: float = 0.1, alpha: float = 0.0):
+        self.phi, self.eta, self.alpha = phi, eta, alpha
+        super().__init__()
+
+    def device_expression_params(self):
+        return {"phi": self.phi, "eta": self.eta, "alpha": self.alpha}

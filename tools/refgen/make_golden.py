@@ -592,11 +592,109 @@ def round2_cases():
         poisson_thr=55.0 / ns)
 
 
+def user_plugin_cases():
+    """User-defined FillProbabilityModel and RewardFunction subclasses written against the reference's plugin API."""
+    from mbt_gym.gym.index_names import CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX
+    from mbt_gym.rewards.RewardFunctions import RewardFunction
+    from mbt_gym.stochastic_processes.fill_probability_models import FillProbabilityModel
+
+    class UserPowerLawFill(FillProbabilityModel):
+        def __init__(self, scale, power, step_size, num_trajectories, seed=None):
+            self.scale, self.power = scale, power
+            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
+                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
+
+        def _get_fill_probabilities(self, depths):
+            return 1.0 / (1.0 + (self.scale * depths) ** self.power)
+
+        @property
+        def max_depth(self):
+            return 99.0 ** (1.0 / self.power) / self.scale
+
+        def update(self, arrivals, fills, actions, state=None):
+            pass
+
+    class UserExponentialInventoryCost(RewardFunction):
+        def __init__(self, phi, eta, alpha):
+            self.phi, self.eta, self.alpha = phi, eta, alpha
+
+        def calculate(self, current_state, action, next_state, is_terminal_step=False):
+            value = lambda s: s[:, CASH_INDEX] + s[:, INVENTORY_INDEX] * s[:, ASSET_PRICE_INDEX]  # noqa: E731
+            dt = next_state[:, TIME_INDEX] - current_state[:, TIME_INDEX]
+            q = next_state[:, INVENTORY_INDEX]
+            return value(next_state) - value(current_state) - dt * self.phi * (np.exp(self.eta * np.abs(q)) - 1.0) - self.alpha * int(is_terminal_step) * q**2
+
+        def reset(self, initial_state):
+            pass
+
+    common = dict(normalise_action_space=False, normalise_observation_space=False)
+    scale, power = 1.25, 1.5
+    prob = lambda d: 1.0 / (1.0 + (scale * d) ** power)  # noqa: E731
+
+    def dynamics(n, ns, cls=LimitOrderModelDynamics, mid=None, arr=None, **kw):
+        return cls(midprice_model=mid or BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                   arrival_model=arr or PoissonArrivalModel(intensity=np.array([60.0, 45.0]), step_size=1 / ns, num_trajectories=n),
+                   fill_probability_model=UserPowerLawFill(scale, power, step_size=1 / ns, num_trajectories=n), num_trajectories=n, **kw)
+
+    # U. user fill + user reward, limit orders, tight inventory limit
+    n, ns = 32, 80
+    run_case(
+        "user_fill_and_reward",
+        lambda: TradingEnvironment(terminal_time=1.0, n_steps=ns, seed=61, initial_inventory=(-2, 3), max_inventory=5, num_trajectories=n,
+                                   reward_function=UserExponentialInventoryCost(0.05, 0.3, 0.02), model_dynamics=dynamics(n, ns), **common),
+        ns, n, 2, 61,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson", intensity=[60.0, 45.0],
+             fill="user_power_law", fill_scale=scale, fill_power=power, dynamics="limit", reward="user_exp_inventory_cost", phi=0.05, eta=0.3,
+             alpha=0.02, initial_inventory=[-2, 3], max_inventory=5, seed=61, **common),
+        poisson_thr=45.0 / ns, fill_prob=prob)
+
+    # V. user fill with a built-in reward, Hawkes arrivals, OU midprice, limit + market orders, normalised spaces
+    n, ns = 24, 70
+    both = dict(normalise_action_space=True, normalise_observation_space=True)
+    run_case(
+        "user_fill_hawkes_market_normalised",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=62, initial_inventory=0, max_inventory=8, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.05),
+            model_dynamics=dynamics(
+                n, ns, cls=LimitAndMarketOrderModelDynamics, fixed_market_half_spread=0.4,
+                mid=OuMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.02, volatility=1.5, initial_price=100.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arr=HawkesArrivalModel(baseline_arrival_rate=np.array([[15.0, 10.0]]), step_size=1 / ns, jump_size=20.0, mean_reversion_speed=30.0, terminal_time=1.0, num_trajectories=n)),
+            **both),
+        ns, n, 4, 62,
+        dict(n_steps=ns, terminal_time=1.0, midprice="ou", ou_level=100.0, ou_speed=0.02, volatility=1.5, initial_price=100.0, arrival="hawkes",
+             intensity=[15.0, 10.0], hawkes_jump=20.0, hawkes_speed=30.0, fill="user_power_law", fill_scale=scale, fill_power=power,
+             dynamics="limit_and_market", market_half_spread=0.4, reward="running", phi=0.01, alpha=0.05, initial_inventory=0, max_inventory=8,
+             seed=62, **both),
+        normalised=True)
+
+    # W. user reward with the built-in exponential fill, at the touch
+    n, ns = 24, 60
+    run_case(
+        "user_reward_touch",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=63, initial_inventory=1, max_inventory=4, num_trajectories=n,
+            reward_function=UserExponentialInventoryCost(0.1, 0.5, 0.05),
+            model_dynamics=AtTheTouchModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(drift=0.1, volatility=1.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=PoissonArrivalModel(intensity=np.array([40.0, 40.0]), step_size=1 / ns, num_trajectories=n),
+                num_trajectories=n, fixed_market_half_spread=0.25),
+            **common),
+        ns, n, 2, 63,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.1, volatility=1.0, initial_price=100.0, arrival="poisson", intensity=[40.0, 40.0],
+             dynamics="touch", market_half_spread=0.25, reward="user_exp_inventory_cost", phi=0.1, eta=0.5, alpha=0.05, initial_inventory=1,
+             max_inventory=4, seed=63, **common),
+        poisson_thr=40.0 / ns, action_kind="touch")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
+        user_plugin_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
         exogenous_fill_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-round2":
         round2_cases()
     else:
         main()
         round2_cases()
+        user_plugin_cases()
