@@ -1,15 +1,20 @@
 """Parity of the HIP step kernel (through the C ABI and the public Python API) with the reference.
 
 Inputs: the committed golden fixtures (what the REAL reference produced for the same injected noise and actions)
-and, redundantly, the float64 oracle run live on the same inputs.  Stated tolerances:
+and, redundantly, the float64 oracle run live on the same inputs.  Stated tolerances - each at most 2x what
+tests/perf/parity_report.py measures (profiles/r02_parity_report.txt):
   arrivals, fills (post mask), market-order flags, inventory, dones ....... bit-exact
-  rewards ................................................................ |err| <= 1e-5 (float32 vs float64)
-      except on lane-steps where the cash/inventory clip of TE:283-289 changed a value (the reference prints its
-      whole state there): the reward then contains the midprice / cash level itself, so |err| <= 1e-3
+  rewards ................................................................ |err| <= 1e-5 + 1e-6 |r|   (float32 output:
+      the relative term matters only for |r| >> 1 - a terminal penalty on real-valued inventory, a GBM price move
+      times the inventory; measured: <= 6.3e-6 for |r| <= 13, relative <= 7.6e-7 beyond)
+      EXCEPT on lane-steps where the cash / inventory clip of TE:283-289 changed a value (the reference prints its
+      whole state there): the reward then contains the LEVEL of the float32 cash / midprice state, not just the step's
+      increments: |err| <= 1.2e-4 (measured 5.8e-5).  `precise_state=True` removes this exception
+      (tests/test_gpu_precise.py: <= 1e-5 on every lane-step, measured 3.7e-6).
   cash ................................................................... |err| <= 1e-6 * (largest |cash| the lane
                                                                            has held this episode) + 1e-4
-  midprice ............................................................... |err| <= 3e-4   (S ~ 100: ulp = 7.6e-6,
-                                                                           random-walk of the per-step rounding)
+  midprice ............................................................... |err| <= 2e-4   (S ~ 100: ulp = 7.6e-6,
+                                                                           random-walk of the per-step rounding; measured 8.4e-5)
   Hawkes intensities ..................................................... |err| <= 2e-5 + 3e-7 |lambda|
   time ................................................................... 1e-6 abs
   normalised observations ................................................ 5e-5 abs (midprice drift / half-width 8)
@@ -25,10 +30,8 @@ from tests.golden_io import CASES, load_case, step_size_changes
 
 pytestmark = pytest.mark.gpu
 
-REWARD_ATOL = 1e-5
-# Midprice models whose increment is proportional to the price itself (GBM: S (mu dt + sigma sqrt(dt) Z)) carry the
-# float32 state error of S into the reward, scaled by the inventory: |err| <= |q| |dS/S| |err_S| ~ 4 * 5e-2 * 1e-4
-STATE_DEPENDENT_DIFFUSION = {"gbm_nonlinear_touch": 5e-5}
+REWARD_ATOL, REWARD_RTOL = 1e-5, 1e-6   # north_star's 1e-5, plus the float32 output's own rounding of a reward >> 1
+REWARD_ATOL_CLIPPED = 1.2e-4             # lane-steps where TE:283-289 clipped: 2x the measured 5.8e-5
 
 
 def _is_speed(name):
@@ -52,7 +55,7 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
     np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=0, atol=1e-6, err_msg=f"{name} step {k}: time")
     cash_tol = 1e-4 + 1e-6 * (np.abs(want[:, 0]) if cash_scale is None else cash_scale)
     assert np.all(np.abs(got[:, 0] - want[:, 0]) <= cash_tol), f"{name} step {k}: cash {np.max(np.abs(got[:, 0] - want[:, 0]))}"
-    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=3e-4, err_msg=f"{name} step {k}: midprice")
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=2e-4, err_msg=f"{name} step {k}: midprice")
     if want.shape[1] > 5:
         # float32 state: 2e-5 absolute around the baselines (10..50), float32 relative accuracy where arrivals have driven an
         # intensity to ~150 (ulp 1.5e-5 there)
@@ -93,10 +96,8 @@ def test_step_matches_reference_fixture(name, record):
         if record:
             np.testing.assert_array_equal((env.last_events >> 6) != 0, clipped, err_msg=f"{name} step {k}: clip flags")
         err = np.abs(rew - g["rewards"][k])
-        assert np.all(err[clipped] <= 1e-3), f"{name} step {k}: reward on clipped lanes {err[clipped].max()}"
-        tol = np.full(err.shape, STATE_DEPENDENT_DIFFUSION.get(name, REWARD_ATOL))
-        if _is_speed(name):  # real-valued inventory: a terminal penalty alpha q^2 ~ 50 is only good to float32 RELATIVE accuracy
-            tol = tol + 2e-6 * np.abs(g["rewards"][k])
+        assert np.all(err[clipped] <= REWARD_ATOL_CLIPPED), f"{name} step {k}: reward on clipped lanes {err[clipped].max()}"
+        tol = REWARD_ATOL + REWARD_RTOL * np.abs(g["rewards"][k])
         assert np.all(err[~clipped] <= tol[~clipped]), f"{name} step {k}: rewards off by {err[~clipped].max()}"
         assert dones.shape == (cfg.num_trajectories,) and bool(dones[0]) == bool(g["done"][k])
         assert len(infos) == cfg.num_trajectories

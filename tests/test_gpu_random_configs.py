@@ -32,8 +32,10 @@ def _random_config(rng, n):
         initial_inventory=int(rng.integers(-2, 3)), max_inventory=int(rng.choice([2, 5, 50])), seed=int(rng.integers(1, 2**31)),
         normalise_action_space=normalised, normalise_observation_space=normalised,
     )
-    # the explicit Euler recursion of the Hawkes intensity (ARR:110-119) amplifies rounding when speed * dt > 1: keep
-    # the random draw inside the stable range, where float32 and float64 stay together
+    # the explicit Euler recursion of the Hawkes intensity (ARR:110-119) is a contraction only for speed * dt < 1; beyond
+    # that it oscillates (>= 2: diverges, in the float64 reference too) and float32 state stops tracking float64 state.
+    # That is the documented domain of the device (include/mbt_env.h: allow_stiff_hawkes) - mbt_env_create REFUSES a
+    # configuration outside it (tests/test_gpu_round2.py) - so the random draw stays inside
     cfg.hawkes_speed = min(cfg.hawkes_speed, 0.9 / cfg.step_size)
     if rng.integers(0, 4) == 0:
         cfg.start_time = cfg.terminal_time * 0.25
@@ -103,7 +105,7 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
                 inventory = o_obs[:, 1] if not cfg.normalise_observation_space else (o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory
                 tol = tol + cfg.ou_speed * np.abs(inventory) * 1e-4
             err = np.abs(rew - o_rew)
-            assert np.all(err[clipped] <= 2e-3), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
+            assert np.all(err[clipped] <= 5e-4), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
             assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]

@@ -68,7 +68,8 @@ def test_philox_mode_equals_injected_mode_on_the_same_draws(name):
         if not cfg.normalise_observation_space:
             np.testing.assert_array_equal(got_p[k][0][:, 1].astype(np.float64), o_obs[:, 1])
         err = np.abs(got_p[k][1] - o_rew)
-        tol = {"limit_and_market": 1e-3, "exo_fill_hawkes_market": 1e-3, "gbm_nonlinear_touch": 5e-5}.get(name, 1e-5)  # see test_gpu_parity.py
+        # as in test_gpu_parity.py: 1e-5 (+ float32 rounding of a large reward); 1.2e-4 where the clip of TE:283-289 fires
+        tol = {"limit_and_market": 1.2e-4, "exo_fill_hawkes_market": 1.2e-4}.get(name, 1e-5) + 1e-6 * np.abs(o_rew)
         assert np.all(err <= tol), err.max()
     env_p.close()
     env_i.close()

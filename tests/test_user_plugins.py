@@ -85,7 +85,7 @@ def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw)
         clipped = oracle.last_clipped
         err = np.abs(rew - o_rew)
         assert np.all(err[~clipped] <= 1e-5 + 1e-6 * np.abs(o_rew[~clipped])), f"step {k}: reward {err[~clipped].max()}"
-        assert np.all(err[clipped] <= 1e-3)
+        assert np.all(err[clipped] <= 2e-4)
     assert dones[0]
     fused.set_action_host(action)
     assert fused.step_repeat_device(steps) == (steps, True)
