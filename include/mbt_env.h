@@ -263,9 +263,18 @@ enum {
                                          memory, row = round(t / dt), col = clamp(q + table_q_offset, 0, table_cols - 1) */
   MBT_POLICY_TIME_TABLE = 3,          /* open-loop schedule: table[row * A + j], row = round(t / dt), table_cols = A; e.g. the
                                          Cartea-Jaimungal optimal-execution speed (agents/BaselineAgents.py:173-210) */
-  MBT_POLICY_ACTION_BUFFER = 4        /* every lane repeats ITS row of the (N, A) action buffer (mbt_env_action_ptr / set_action_host)
+  MBT_POLICY_ACTION_BUFFER = 4,       /* every lane repeats ITS row of the (N, A) action buffer (mbt_env_action_ptr / set_action_host)
                                          for max_steps steps: "action repeat" - k env.step(action) calls of a consumer that acts
                                          every k-th step, in one launch */
+  /* LEARNED policies, evaluated inside the kernel on the observation the environment would hand out (normalised when it
+   * normalises, TE:112-118) and clipped to the action space the agent acts in, as Stable-Baselines3 does before env.step -
+   * the consumer the reference trains (agents/SbAgent.py, experiments/helpers.py:63-96).  Limit and limit + market
+   * dynamics.  Weights are float32 in host memory in torch.nn.Linear layout (out x in, row-major), concatenated: */
+  MBT_POLICY_LINEAR = 5,              /* action = clip(W obs + b): table = [W (A x D) | b (A)], table_rows = 0, table_cols = A D + A */
+  MBT_POLICY_MLP = 6                  /* two hidden layers of width H <= 64 (SB3's MlpPolicy actor is [64, 64] tanh):
+                                         table = [W1 (H x D) | b1 (H) | W2 (H x H) | b2 (H) | W3 (A x H) | b3 (A)], table_rows = H,
+                                         table_cols = the number of floats; params[0] = activation (0 tanh, 1 relu).  Runs on the
+                                         matrix cores (v_mfma_f32_16x16x16_f16: operands rounded to fp16, fp32 accumulation). */
 };
 typedef struct mbt_policy {
   int32_t kind;
@@ -282,6 +291,10 @@ int mbt_env_rollout_device(mbt_env* env, const mbt_policy* policy, uint32_t max_
 /* Host variant: trajectory pointers are host memory with exactly N lanes per time slice; synchronous. */
 int mbt_env_rollout_host(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
                          float* rew_traj, uint32_t* steps_done, int32_t* done);
+/* Evaluates a LEARNED policy (MBT_POLICY_LINEAR / MBT_POLICY_MLP) on the current observation into the buffer of
+ * mbt_env_action_ptr(): the step-loop form of what the fused rollout does in-kernel - "mbt_env_policy_device, then
+ * mbt_env_step_device(NULL)" repeated is bit-identical to one mbt_env_rollout_device with the same policy.  Asynchronous. */
+int mbt_env_policy_device(mbt_env* env, const mbt_policy* policy);
 uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to whole 512-lane tiles (quads for speed dynamics):
                                                 lanes per time slice of device trajectories */
 

@@ -78,6 +78,8 @@ def user_code(fill=None, reward=None) -> MbtUserCode:
 
 
 POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE, POLICY_ACTION_BUFFER = 0, 1, 2, 3, 4
+POLICY_LINEAR, POLICY_MLP = 5, 6
+ACTIVATION_TANH, ACTIVATION_RELU = 0, 1
 
 
 class MbtPolicy(C.Structure):
@@ -95,6 +97,31 @@ def table_policy(table: np.ndarray, q_offset: int) -> MbtPolicy:
     pol = MbtPolicy(kind=POLICY_TIME_INVENTORY_TABLE, table=arr.ctypes.data_as(C.POINTER(C.c_float)),
                     table_rows=arr.shape[0], table_cols=arr.shape[1], table_q_offset=int(q_offset))
     pol._keepalive = arr
+    return pol
+
+
+def linear_policy(weight: np.ndarray, bias: np.ndarray) -> MbtPolicy:
+    """action = clip(weight @ obs + bias): weight (A, D), bias (A) in torch.nn.Linear layout (keeps the blob alive)."""
+    w, b = np.asarray(weight, dtype=np.float32), np.asarray(bias, dtype=np.float32)
+    assert w.ndim == 2 and b.shape == (w.shape[0],)
+    blob = np.ascontiguousarray(np.concatenate([w.reshape(-1), b]))
+    pol = MbtPolicy(kind=POLICY_LINEAR, table=blob.ctypes.data_as(C.POINTER(C.c_float)), table_rows=0, table_cols=blob.size)
+    pol._keepalive = blob
+    return pol
+
+
+def mlp_policy(layers, activation: str = "tanh") -> MbtPolicy:
+    """A two-hidden-layer MLP actor evaluated inside the kernels on the matrix cores: `layers` = [(W1, b1), (W2, b2), (W3, b3)]
+    in torch.nn.Linear layout (W: out x in) with W1 (H, D), W2 (H, H), W3 (A, H), H <= 64 - e.g. the `mlp_extractor.policy_net`
+    and `action_net` weights of a Stable-Baselines3 MlpPolicy with net_arch [64, 64] (keeps the blob alive)."""
+    assert len(layers) == 3, "two hidden layers + the output layer"
+    (w1, b1), (w2, b2), (w3, b3) = [(np.asarray(w, dtype=np.float32), np.asarray(b, dtype=np.float32)) for w, b in layers]
+    hidden = w1.shape[0]
+    assert w2.shape == (hidden, hidden) and w3.shape[1] == hidden and b1.shape == b2.shape == (hidden,) and b3.shape == (w3.shape[0],)
+    blob = np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in (w1, b1, w2, b2, w3, b3)]))
+    pol = MbtPolicy(kind=POLICY_MLP, table=blob.ctypes.data_as(C.POINTER(C.c_float)), table_rows=hidden, table_cols=blob.size)
+    pol.params[0] = {"tanh": ACTIVATION_TANH, "relu": ACTIVATION_RELU}[activation]
+    pol._keepalive = blob
     return pol
 
 
@@ -143,6 +170,7 @@ SIGNATURES = {
     "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "mbt_env_rollout_host": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, _F, _F, _F, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "mbt_env_policy_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy)]),
     "mbt_env_padded_lanes": (C.c_uint64, [_ENV]),
     "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),
     "mbt_env_action_ptr": (C.c_void_p, [_ENV]),

@@ -257,6 +257,8 @@ struct mbt_env {
   mbt::StepParams params;
   hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
   double user_fill_p[8] = {}, user_reward_p[8] = {};        // parameters of the user's device expressions
+  char* learned_dev = nullptr;                               // packed weights of a learned policy (policy_mlp.hpp), device
+  std::vector<char> learned_host;                            // what learned_dev holds (re-uploaded only when the policy changes)
   uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
   bool stream_loads = false;       // the non-temporal-load instantiation of the step kernel, see tune_for_size()
   bool q0_per_lane_reset = false;  // the last explicit reset passed per-lane initial inventories (kept in q_init for auto-reset)
@@ -461,6 +463,105 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   return MBT_OK;
 }
 
+// ---- learned policies (policy_mlp.hpp) --------------------------------------------------------------------------------
+using LearnedRolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams, const mbt::LearnedPolicyParams);
+
+// Two tiers x arrivals x {limit, limit + market} = 8 kernels: Brownian midprice with plain PnL (the reference's default
+// environment, BASELINE configs[1]: the environment part needs ~95 registers there) and the general tier (runtime midprice
+// coefficients, every reward); both with run-time normalisation flags.
+template <int ARR, int DYN>
+LearnedRolloutKernel pick_learned_tier(bool brownian_pnl) {
+  return brownian_pnl ? mbt::learned_rollout_kernel<mbt::Variant<ARR, DYN, true, mbt::kRewardPnl, true, false>>
+                      : mbt::learned_rollout_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false>>;
+}
+LearnedRolloutKernel pick_learned_rollout(const mbt_config& c) {
+  const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
+  const bool brownian_pnl = c.midprice_kind == MBT_MID_BROWNIAN && c.reward_kind == MBT_REW_PNL;
+  if (c.arrival_kind == MBT_ARR_HAWKES)
+    return market ? pick_learned_tier<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(brownian_pnl) : pick_learned_tier<mbt::kArrHawkes, mbt::kDynLimit>(brownian_pnl);
+  return market ? pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(brownian_pnl) : pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimit>(brownian_pnl);
+}
+
+// Device image of a learned policy: [w1: 4 x 64 half4 | w2: 16 x 64 half4 | w3: 4 x 64 half4 | b2: 64 f32 | b3: 16 f32 | lin_w: 32 f32 | lin_b: 4 f32]
+constexpr size_t kLearnedW1 = 0, kLearnedW2 = kLearnedW1 + 4 * 64 * 8, kLearnedW3 = kLearnedW2 + 16 * 64 * 8, kLearnedB2 = kLearnedW3 + 4 * 64 * 8,
+                 kLearnedB3 = kLearnedB2 + 64 * 4, kLearnedLinW = kLearnedB3 + 16 * 4, kLearnedLinB = kLearnedLinW + 32 * 4,
+                 kLearnedBytes = kLearnedLinB + 4 * 4;
+
+// Validates a MBT_POLICY_LINEAR / MBT_POLICY_MLP descriptor, lays its weights out in MFMA A-operand order (fp16, rounded
+// to nearest even here on the host) and uploads them when they differ from what the device holds.
+int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPolicyParams& LP) {
+  const mbt_config& c = e->cfg;
+  if (e->speed || c.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "learned policies quote depths: limit or limit + market dynamics");
+  if (exogenous_fill(c) || c.precise_state || e->jit_step != nullptr)
+    return fail(MBT_ERR_INVALID, "learned policies have no kernel for the exogenous-depth fill model, precise_state or user-defined plugins");
+  const int D = e->dim, A = e->act_dim;
+  if (policy->table == nullptr) return fail(MBT_ERR_INVALID, "a learned policy needs its weights (mbt_policy.table)");
+  std::vector<char> image(kLearnedBytes, 0);
+  std::memset(&LP, 0, sizeof LP);
+  LP.obs_dim = D;
+  LP.act_dim = A;
+  const bool norm = c.normalise_action != 0;
+  for (int j = 0; j < 4; ++j) {  // the action space the agent acts in (TE:243-255 when normalised)
+    LP.act_lo[j] = j < A ? (norm ? -1.0f : c.act_lo[j]) : 0.0f;
+    LP.act_hi[j] = j < A ? (norm ? 1.0f : c.act_hi[j]) : 0.0f;
+  }
+  const float* w = policy->table;
+  if (policy->kind == MBT_POLICY_LINEAR) {
+    if (policy->table_cols != static_cast<uint32_t>(A * D + A)) return fail(MBT_ERR_INVALID, "a linear policy holds A*D + A = %d floats (got %u)", A * D + A, policy->table_cols);
+    LP.is_linear = 1;
+    float* lw = reinterpret_cast<float*>(image.data() + kLearnedLinW);
+    float* lb = reinterpret_cast<float*>(image.data() + kLearnedLinB);
+    for (int a = 0; a < A; ++a) {
+      for (int d = 0; d < D; ++d) lw[a * 8 + d] = w[a * D + d];
+      lb[a] = w[A * D + a];
+    }
+  } else {
+    const int H = static_cast<int>(policy->table_rows);
+    if (H < 1 || H > mbt::kMlpHidden) return fail(MBT_ERR_INVALID, "MLP policies have a hidden width of 1..64 (got %d)", H);
+    if (D + 1 > mbt::kMlpInPad) return fail(MBT_ERR_INVALID, "MLP policies take observations of at most 15 columns");
+    const size_t floats = size_t(H) * D + H + size_t(H) * H + H + size_t(A) * H + A;
+    if (policy->table_cols != floats) return fail(MBT_ERR_INVALID, "an MLP policy of width %d holds %zu floats for D = %d, A = %d (got %u)", H, floats, D, A, policy->table_cols);
+    const int act = static_cast<int>(policy->params[0]);
+    if (act != mbt::kActTanh && act != mbt::kActRelu) return fail(MBT_ERR_INVALID, "activation %d: 0 = tanh, 1 = relu", act);
+    LP.activation = act;
+    const float *W1 = w, *b1 = W1 + size_t(H) * D, *W2 = b1 + H, *b2 = W2 + size_t(H) * H, *W3 = b2 + H, *b3 = W3 + size_t(A) * H;
+    auto w1p = [&](int m, int k) -> float { return m >= H ? 0.0f : (k < D ? W1[m * D + k] : (k == D ? b1[m] : 0.0f)); };  // [W1 | b1 | 0]
+    auto w2p = [&](int m, int k) -> float { return (m < H && k < H) ? W2[m * H + k] : 0.0f; };
+    auto w3p = [&](int m, int k) -> float { return (m < A && k < H) ? W3[m * H + k] : 0.0f; };
+    _Float16* f1 = reinterpret_cast<_Float16*>(image.data() + kLearnedW1);
+    _Float16* f2 = reinterpret_cast<_Float16*>(image.data() + kLearnedW2);
+    _Float16* f3 = reinterpret_cast<_Float16*>(image.data() + kLearnedW3);
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 4; ++j) {
+        const int row = lane % 16, k = 4 * (lane / 16) + j;
+        for (int mt = 0; mt < 4; ++mt) {
+          f1[(mt * 64 + lane) * 4 + j] = static_cast<_Float16>(w1p(16 * mt + row, k));
+          f3[(mt * 64 + lane) * 4 + j] = static_cast<_Float16>(w3p(row, 16 * mt + k));  // (mt plays the K-chunk here)
+          for (int kc = 0; kc < 4; ++kc) f2[((mt * 4 + kc) * 64 + lane) * 4 + j] = static_cast<_Float16>(w2p(16 * mt + row, 16 * kc + k));
+        }
+      }
+    float* pb2 = reinterpret_cast<float*>(image.data() + kLearnedB2);
+    float* pb3 = reinterpret_cast<float*>(image.data() + kLearnedB3);
+    for (int m = 0; m < H; ++m) pb2[m] = b2[m];
+    for (int a = 0; a < A; ++a) pb3[a] = b3[a];
+  }
+  if (e->learned_dev == nullptr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->learned_dev), kLearnedBytes));
+  if (e->learned_host != image) {
+    // the previous image may still be read by a rollout in flight: order the overwrite behind it
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->learned_dev, image.data(), kLearnedBytes, hipMemcpyHostToDevice));
+    e->learned_host.swap(image);
+  }
+  LP.w.w1 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW1);
+  LP.w.w2 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW2);
+  LP.w.w3 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW3);
+  LP.w.b2 = reinterpret_cast<const float*>(e->learned_dev + kLearnedB2);
+  LP.w.b3 = reinterpret_cast<const float*>(e->learned_dev + kLearnedB3);
+  LP.w.lin_w = reinterpret_cast<const float*>(e->learned_dev + kLearnedLinW);
+  LP.w.lin_b = reinterpret_cast<const float*>(e->learned_dev + kLearnedLinB);
+  return MBT_OK;
+}
+
 // Enqueue one fused rollout from the current state; trajectory pointers are device memory (or nullptr).
 int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj, float* rew_traj,
                    uint32_t* steps_done, int32_t* done) {
@@ -469,7 +570,12 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   if (policy == nullptr) return fail(MBT_ERR_INVALID, "null policy");
   mbt::RolloutParams R;
   std::memset(&R, 0, sizeof R);
-  if (policy->kind == MBT_POLICY_FIXED) {
+  const bool learned = policy->kind == MBT_POLICY_LINEAR || policy->kind == MBT_POLICY_MLP;
+  mbt::LearnedPolicyParams LP;
+  if (learned) {
+    int rc = prepare_learned_policy(e, policy, LP);
+    if (rc != MBT_OK) return rc;
+  } else if (policy->kind == MBT_POLICY_FIXED) {
     R.policy = mbt::kPolicyFixed;
     for (int j = 0; j < e->act_dim; ++j) R.action[j] = static_cast<float>(policy->params[j]);
   } else if (policy->kind == MBT_POLICY_ACTION_BUFFER) {
@@ -558,7 +664,10 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
   B.wave_sums = e->wave_sums;
   B.clip_count = e->clip_count;
-  if (e->jit_rollout != nullptr) {
+  if (learned) {
+    hipLaunchKernelGGL(pick_learned_rollout(e->cfg), dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R, LP);
+    HIP_TRY(hipGetLastError());
+  } else if (e->jit_rollout != nullptr) {
     void* args[] = {&B, &P, &R};
     HIP_TRY(hipModuleLaunchKernel(e->jit_rollout, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, 0, e->stream, args, nullptr));
   } else {
@@ -1134,7 +1243,7 @@ void mbt_env_destroy(mbt_env* e) {
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
   void* bufs[] = {e->resid, e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
                   e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
-                  e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2]};
+                  e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2], e->learned_dev};
   for (void* b : bufs)
     if (b != nullptr) (void)hipFree(b);
   if (e->log_host != nullptr) (void)hipHostFree(e->log_host);
@@ -1356,6 +1465,19 @@ int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
     action_device = nullptr;
   }
   return launch_step(e, action_device, done);
+}
+
+int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
+  if (e == nullptr || policy == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (policy->kind != MBT_POLICY_LINEAR && policy->kind != MBT_POLICY_MLP) return fail(MBT_ERR_INVALID, "mbt_env_policy_device evaluates learned policies (MBT_POLICY_LINEAR / MBT_POLICY_MLP)");
+  if (!e->was_reset) return fail(MBT_ERR_STATE, "policy evaluation before reset()");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  mbt::LearnedPolicyParams LP;
+  int rc = prepare_learned_policy(e, policy, LP);
+  if (rc != MBT_OK) return rc;
+  hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP);
+  HIP_TRY(hipGetLastError());
+  return MBT_OK;
 }
 
 uint64_t mbt_env_padded_lanes(mbt_env* e) { return e != nullptr ? e->n_pad : 0; }

@@ -1,0 +1,193 @@
+// Learned policies evaluated INSIDE the kernels: a linear map, or a two-hidden-layer MLP of
+// width <= 64 - the shape of Stable-Baselines3's MlpPolicy actor ([64, 64], tanh), the consumer the reference trains
+// (agents/SbAgent.py, experiments/helpers.py:63-96) - acting on the observation the environment would hand out.
+//
+// This is the one dense contraction on the path, hence the one use of the matrix cores: per environment step a wave
+// evaluates 128 rows (64 threads x the 2 lanes each owns) x [D -> 64 -> 64 -> A] = 8960 flop per row on
+// v_mfma_f32_16x16x16_f16 (first layer) and v_mfma_f32_16x16x32_f16 (the other two): fp16 operands, fp32 accumulate.  Formulated TRANSPOSED, H^T = W X^T: the weights are the
+// A operand (M = output features, held in registers for the whole rollout - 48 VGPRs), the batch rows are N, and the
+// accumulator layout of one layer (lane L: rows m = 4 (L / 16) + r, r = 0..3, column n = L % 16) IS the B-operand layout
+// of the next (lane L: k = 4 (L / 16) + j, n = L % 16), so hidden activations never leave registers: activation,
+// convert to fp16, feed the next MFMA.  Only the observations (in) and the actions (out) cross lanes, through 6 KB of
+// LDS per wave.  Biases are free: the first layer's rides on a constant-one input feature, the others initialise the
+// accumulators.
+//
+// Numerics: operands are rounded to fp16 (observations normalised to [-1, 1] or raw, weights, hidden activations);
+// products and sums are fp32.  tests/test_gpu_policy.py compares with a NumPy restatement that rounds where the kernel
+// rounds (<= 2e-3 on actions of magnitude ~1) and with the plain fp32 network (<= 2e-2).  The policy kernel
+// (policy_kernel, used by a step loop) and the fused rollout run THIS code on the same values, so a rollout remains
+// bit-identical to "evaluate policy, step" repeated.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
+
+namespace mbt {
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float acc4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kMlpHidden = 64;              // hidden width (narrower networks are zero-padded by the host)
+constexpr int kMlpTiles = kMlpHidden / 16;  // 16-feature tiles per hidden layer
+constexpr int kMlpInPad = 16;               // observation features + the constant one, padded to one K step
+constexpr int kMlpRowsPerWave = 128;        // 64 threads x 2 lanes
+enum : int { kActTanh = 0, kActRelu = 1 };
+
+// What the host uploads (mbt_env.hip: pack_mlp): fragments in MFMA A-operand order, one 8-byte entry per lane.
+//   w1[mt][lane]      W1p[16 mt + lane % 16][4 (lane / 16) + j]            W1p = [W1 | b1 | 0]  (64 x 16)
+//   w2[mt][kc][lane]  W2 [16 mt + lane % 16][16 kc + 4 (lane / 16) + j]                        (64 x 64)
+//   w3[kc][lane]      W3p[lane % 16][16 kc + 4 (lane / 16) + j]           W3p = rows >= A zero (16 x 64)
+//   b2[64], b3[16] float32; linear policies: lin_w[A][8], lin_b[4] float32
+struct MlpDeviceWeights {
+  const half4_t* w1;   // [4][64]
+  const half4_t* w2;   // [4][4][64]
+  const half4_t* w3;   // [4][64]
+  const float* b2;     // [64]
+  const float* b3;     // [16]
+  const float* lin_w;  // [4][8]  (linear policy)
+  const float* lin_b;  // [4]
+};
+
+struct LearnedPolicyParams {
+  MlpDeviceWeights w;
+  int32_t is_linear;    // 1: action = clip(lin_w obs + lin_b); 0: the MLP
+  int32_t activation;   // kActTanh / kActRelu
+  int32_t obs_dim, act_dim;
+  float act_lo[4], act_hi[4];  // the action space the agent acts in: outputs are clipped to it, as SB3 does before env.step
+};
+
+// the weights of one wave, in registers
+struct MlpRegisters {
+  half4_t w1[kMlpTiles];
+  half4_t w2[kMlpTiles][kMlpTiles];
+  half4_t w3[kMlpTiles];
+  acc4_t b2[kMlpTiles];
+  acc4_t b3;
+};
+
+__device__ __forceinline__ MlpRegisters load_mlp(const MlpDeviceWeights& w) {
+  const int lane = threadIdx.x & 63;
+  MlpRegisters r;
+#pragma unroll
+  for (int mt = 0; mt < kMlpTiles; ++mt) {
+    r.w1[mt] = w.w1[mt * 64 + lane];
+    r.w3[mt] = w.w3[mt * 64 + lane];
+#pragma unroll
+    for (int kc = 0; kc < kMlpTiles; ++kc) r.w2[mt][kc] = w.w2[(mt * kMlpTiles + kc) * 64 + lane];
+    const float* b = w.b2 + 16 * mt + 4 * (lane >> 4);  // accumulator rows of this lane: 4 (lane / 16) + r
+    r.b2[mt] = acc4_t{b[0], b[1], b[2], b[3]};
+  }
+  const float* b = w.b3 + 4 * (lane >> 4);
+  r.b3 = acc4_t{b[0], b[1], b[2], b[3]};
+  return r;
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float x) {
+  if (ACT == kActRelu) return __builtin_fmaxf(x, 0.0f);
+  // tanh(x) = 1 - 2 / (1 + e^{2x}) on the hardware exp2 / rcp (two quarter-rate instructions); saturates cleanly at +-1
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <int ACT>
+__device__ __forceinline__ half4_t activate_to_half(acc4_t v) {
+  return half4_t{static_cast<_Float16>(activate<ACT>(v.x)), static_cast<_Float16>(activate<ACT>(v.y)),
+                 static_cast<_Float16>(activate<ACT>(v.z)), static_cast<_Float16>(activate<ACT>(v.w))};
+}
+
+// Two 16-feature fragments side by side = the 8-element operand of the K = 32 instruction.  The hardware pairs element
+// (lane group g = lane / 16, j) of A with element (g, j) of B, whatever k those stand for - so as long as the weight
+// fragment is assembled the same way (elements 0..3 from K-chunk 2c, 4..7 from chunk 2c + 1, both at 4 g + j), the
+// accumulator layout of the previous layer still IS the operand layout of this one, and the hidden layers run on
+// v_mfma_f32_16x16x32_f16 at twice the rate of the K = 16 form.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8_t join(half4_t lo, half4_t hi) { return half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}; }
+
+// LDS scratch of one wave: 128 observation rows of 16 halfs (features, the constant one, zeros) + 128 action rows of 4 floats
+constexpr int kMlpLdsBytesPerWave = kMlpRowsPerWave * (kMlpInPad * 2 + 16);
+
+// obs[l][c]: the observation rows of this thread's two lanes (columns >= obs_dim ignored).  act[l][a]: the clipped actions.
+// Every lane of the wave must call this together (MFMA and the wave-level LDS exchange).
+template <int ACT>
+__device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
+                                                     char* lds_wave) {
+  const int lane = threadIdx.x & 63;
+  _Float16* x_rows = reinterpret_cast<_Float16*>(lds_wave);                                // [128][16]
+  float* a_rows = reinterpret_cast<float*>(lds_wave + kMlpRowsPerWave * kMlpInPad * 2);      // [128][4]
+  // 1. observations -> fp16 rows [features | 1 | 0...] in LDS (row = l * 64 + lane)
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    _Float16 row[kMlpInPad];
+#pragma unroll
+    for (int c = 0; c < kMlpInPad; ++c) {
+      const float feature = c < 8 ? obs[l][c] : 0.0f;
+      row[c] = static_cast<_Float16>(c < L.obs_dim ? feature : (c == L.obs_dim ? 1.0f : 0.0f));  // [features | 1 | 0 ...]
+    }
+    half4_t* dst = reinterpret_cast<half4_t*>(x_rows + (l * 64 + lane) * kMlpInPad);
+#pragma unroll
+    for (int c4 = 0; c4 < kMlpInPad / 4; ++c4) dst[c4] = half4_t{row[4 * c4], row[4 * c4 + 1], row[4 * c4 + 2], row[4 * c4 + 3]};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // 2. eight tiles of 16 rows through the three layers, activations in registers
+#pragma unroll 1
+  for (int t = 0; t < kMlpRowsPerWave / 16; ++t) {
+    // B operand of layer 1: k = 4 (lane / 16) + j of row n = lane % 16
+    const half4_t x = *reinterpret_cast<const half4_t*>(x_rows + (16 * t + (lane & 15)) * kMlpInPad + 4 * (lane >> 4));
+    half4_t h1[kMlpTiles], h2[kMlpTiles];
+#pragma unroll
+    for (int mt = 0; mt < kMlpTiles; ++mt) {
+      const acc4_t a = __builtin_amdgcn_mfma_f32_16x16x16f16(W.w1[mt], x, acc4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      h1[mt] = activate_to_half<ACT>(a);
+    }
+    const half8_t h1_lo = join(h1[0], h1[1]), h1_hi = join(h1[2], h1[3]);
+#pragma unroll
+    for (int mt = 0; mt < kMlpTiles; ++mt) {
+      acc4_t a = W.b2[mt];
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w2[mt][0], W.w2[mt][1]), h1_lo, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w2[mt][2], W.w2[mt][3]), h1_hi, a, 0, 0, 0);
+      h2[mt] = activate_to_half<ACT>(a);
+    }
+    acc4_t out = W.b3;
+    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w3[0], W.w3[1]), join(h2[0], h2[1]), out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w3[2], W.w3[3]), join(h2[2], h2[3]), out, 0, 0, 0);
+    // lanes 0..15 hold output rows 0..3 (= the action components) of batch row 16 t + lane
+    if (lane < 16) *reinterpret_cast<acc4_t*>(a_rows + (16 * t + lane) * 4) = out;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // 3. each thread takes its own two rows back and clips them to the action space
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const acc4_t a = *reinterpret_cast<const acc4_t*>(a_rows + (l * 64 + lane) * 4);
+    act[l][0] = __builtin_amdgcn_fmed3f(a.x, L.act_lo[0], L.act_hi[0]);
+    act[l][1] = __builtin_amdgcn_fmed3f(a.y, L.act_lo[1], L.act_hi[1]);
+    act[l][2] = __builtin_amdgcn_fmed3f(a.z, L.act_lo[2], L.act_hi[2]);
+    act[l][3] = __builtin_amdgcn_fmed3f(a.w, L.act_lo[3], L.act_hi[3]);
+  }
+  __builtin_amdgcn_wave_barrier();  // the rows are reused by the next call
+}
+
+// (the activation is a template parameter: chosen once per call, outside the tile loop, instead of per value)
+__device__ __forceinline__ void mlp_forward_wave(const MlpRegisters& W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
+                                                 char* lds_wave) {
+  if (L.activation == kActRelu) mlp_forward_wave_act<kActRelu>(W, L, obs, act, lds_wave);
+  else mlp_forward_wave_act<kActTanh>(W, L, obs, act, lds_wave);
+}
+
+// action = clip(W obs + b): D x A <= 32 FMAs per row in fp32 on the vector unit (no contraction worth a matrix core)
+__device__ __forceinline__ void linear_forward(const LearnedPolicyParams& L, const float (&obs)[8], float (&act)[4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float s = L.w.lin_b[a];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s = __builtin_fmaf(L.w.lin_w[a * 8 + c], c < L.obs_dim ? obs[c] : 0.0f, s);
+    act[a] = __builtin_amdgcn_fmed3f(s, L.act_lo[a], L.act_hi[a]);
+  }
+}
+
+}  // namespace mbt

@@ -34,6 +34,9 @@
 #endif
 
 #include "philox.hpp"
+#ifndef MBT_JIT_USER_CODE
+#include "policy_mlp.hpp"
+#endif
 
 namespace mbt {
 
@@ -802,8 +805,14 @@ struct RolloutParams {
   float* rew_traj;         // (n_steps, n_pad) or nullptr
 };
 
-template <class V>
-__device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepParams& P, const RolloutParams& R) {
+#ifdef MBT_JIT_USER_CODE
+struct LearnedPolicyParams {};  // (learned policies are not part of the run-time compiled translation unit)
+#endif
+
+// LEARNED: the policy is a linear map or an MLP evaluated on the matrix cores (policy_mlp.hpp) instead of a closed form;
+// separate instantiations, so that the closed-form rollouts keep their register budget.
+template <class V, bool LEARNED = false>
+__device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepParams& P, const RolloutParams& R, const LearnedPolicyParams* LP = nullptr) {
   static_assert(!V::INJECT, "rollouts draw their own noise");
   constexpr int A = (V::DYN == kDynLimitAndMarket) ? 4 : 2;
   const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
@@ -833,12 +842,42 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
   }
   uint32_t clips = 0;
   double t = R.t_start;
-  LaneResult last[2];
+  float last_reward[2] = {0.f, 0.f};  // what step() leaves behind for the final step: its rewards and event bytes
+  uint32_t last_events[2] = {0u, 0u};
+#ifndef MBT_JIT_USER_CODE
+  __shared__ __attribute__((aligned(16))) char policy_lds[LEARNED ? (kBlockThreads / 64) * kMlpLdsBytesPerWave : 16];
+#endif
   for (uint32_t k = 0; k < R.n_steps; ++k) {
     LaneNoise nz[2];
-    philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);
+    if (!LEARNED) philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);
     float4 act[2];
-    if (R.policy == kPolicyFixed) {
+    if (LEARNED) {
+#ifndef MBT_JIT_USER_CODE
+      // the observation the agent would be handed (normalised per TE:112-118 when the environment normalises)
+      float o[2][8], a[2][4];
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        float4 c = core[l];
+        float2 m = lam[l];
+        if (V::NORM) normalise_row(c, m, P);
+        o[l][0] = c.x; o[l][1] = c.y; o[l][2] = c.z; o[l][3] = c.w; o[l][4] = m.x; o[l][5] = m.y; o[l][6] = 0.f; o[l][7] = 0.f;
+      }
+      if (LP->is_linear) {
+        linear_forward(*LP, o[0], a[0]);
+        linear_forward(*LP, o[1], a[1]);
+      } else {
+        // The weight fragments (68 registers) are re-read every step - 12 KB that stay in the L1 / L2 - instead of being
+        // held across the environment step, whose own peak is ~130 registers in this tier: the kernel then fits 3 waves
+        // per SIMD instead of 2 (the barrier keeps the compiler from hoisting the loads out of the loop again).
+        asm volatile("" ::: "memory");
+        const MlpRegisters mlp_w = load_mlp(LP->w);
+        mlp_forward_wave(mlp_w, *LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
+      }
+#pragma unroll
+      for (int l = 0; l < 2; ++l) act[l] = make_float4(a[l][0], a[l][1], A == 4 ? a[l][2] : 0.f, A == 4 ? a[l][3] : 0.f);
+      philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);  // after the network: the draws are not live across it
+#endif
+    } else if (R.policy == kPolicyFixed) {
       act[0] = act[1] = make_float4(R.action[0], R.action[1], R.action[2], R.action[3]);
     } else if (R.policy == kPolicyBuffer) {
       act[0] = held[0];
@@ -873,7 +912,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       resid[l] = r.resid;
       ret[l] += r.reward;
       clips += (lanes[l] < P.n && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
-      last[l] = r;
+      last_reward[l] = r.reward;
+      if (B.events != nullptr) last_events[l] = event_byte(r);
       if (R.obs_traj != nullptr) store_row<V, false>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lanes[l], core[l], lam[l], V::NORM, P);
       if (R.act_traj != nullptr) {
         float* dst = R.act_traj + static_cast<size_t>(k) * n_pad * A;
@@ -890,8 +930,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     if (V::PRECISE) reinterpret_cast<float2*>(B.resid)[lanes[l]] = resid[l];
     if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
     if (R.n_steps > 0) {
-      B.reward[lanes[l]] = last[l].reward;
-      if (B.events != nullptr) B.events[lanes[l]] = static_cast<uint8_t>(event_byte(last[l]));
+      B.reward[lanes[l]] = last_reward[l];
+      if (B.events != nullptr) B.events[lanes[l]] = static_cast<uint8_t>(last_events[l]);
     }
     if (B.lane_returns != nullptr) B.lane_returns[lanes[l]] += ret[l];
     ret_sum += lanes[l] < P.n ? ret[l] : 0.0f;
@@ -908,6 +948,40 @@ template <class V>
 __global__ __launch_bounds__(kBlockThreads) void rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
   rollout_body<V>(B, P, R);
 }
+
+#ifndef MBT_JIT_USER_CODE
+template <class V>
+__global__ __launch_bounds__(kBlockThreads, 4) void learned_rollout_kernel(const StepBuffers B, const StepParams P, const RolloutParams R,
+                                                                         const LearnedPolicyParams LP) {
+  rollout_body<V, true>(B, P, R, &LP);
+}
+
+// The same policy as a kernel of its own, for a step loop: observation buffer (n_pad, D) -> action buffer (n_pad, A), in
+// the step kernel's lane <-> thread mapping (so the wave-level MLP sees the same rows in the same places as the rollout).
+__global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs, float* action, int dim, int act_dim, const LearnedPolicyParams LP) {
+  __shared__ __attribute__((aligned(16))) char policy_lds[(kBlockThreads / 64) * kMlpLdsBytesPerWave];
+  const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
+  float o[2][8], a[2][4];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const float* row = obs + static_cast<size_t>(lanes[l]) * dim;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[l][c] = c < dim ? row[c] : 0.0f;
+  }
+  if (LP.is_linear) {
+    linear_forward(LP, o[0], a[0]);
+    linear_forward(LP, o[1], a[1]);
+  } else {
+    const MlpRegisters w = load_mlp(LP.w);
+    mlp_forward_wave(w, LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
+  }
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    float* row = action + static_cast<size_t>(lanes[l]) * act_dim;
+    for (int c = 0; c < act_dim; ++c) row[c] = a[l][c];
+  }
+}
+#endif
 
 #ifndef MBT_JIT_USER_CODE  // the run-time compiled translation unit needs the step and rollout bodies only
 // ---- small helper kernels ----------------------------------------------------------------------------------

@@ -420,6 +420,14 @@ class TradingEnvironment(_EnvBase):
             self._handle, C.byref(pol), k, obs_ptr, act_ptr, rew_ptr, C.byref(steps), C.byref(done)))
         return int(steps.value), bool(done.value)
 
+    def policy_device(self, policy):
+        """Evaluate a learned policy (`_native.linear_policy` / `_native.mlp_policy`, or an agent exposing `device_policy()`)
+        on the current observation into `action_device`, on the device (the MLP on the matrix cores).  Followed by
+        `step_device()` this is one agent-environment interaction with nothing leaving HBM; `rollout_device(policy)` is the
+        same thing fused over a whole episode, bit-identical."""
+        pol = policy.device_policy() if hasattr(policy, "device_policy") else policy
+        _native.check(_native.load_library().mbt_env_policy_device(self._handle, C.byref(pol)))
+
     def step_repeat_device(self, repeats: int) -> Tuple[int, bool]:
         """Action repeat: `repeats` environment steps with the action buffer held fixed, in ONE launch of the fused rollout
         kernel (bit-identical to that many `step_device()` calls).  For consumers that act every k-th step - the

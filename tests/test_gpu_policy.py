@@ -1,0 +1,183 @@
+"""Learned policies evaluated inside the kernels (csrc/policy_mlp.hpp): a linear map on the vector unit, a [D -> H -> H -> A]
+MLP on the matrix cores (v_mfma_f32_16x16x16_f16).
+
+Numerics contract, stated here and in the header: operands (observation, weights, hidden activations) are rounded to fp16,
+products and sums are fp32, tanh is 1 - 2 / (1 + 2^(2 log2(e) x)) on the hardware exp2 / rcp.  The NumPy restatement below
+rounds where the kernel rounds; actions agree with it to 2e-3 (fp32 summation order, one-ulp fp16 rounding flips of
+hidden units) and with the plain fp32 network to 2e-2.  The fused rollout is BIT-identical to "policy kernel, step kernel"
+repeated, and the environment under a learned policy still matches the float64 oracle (decisions exact, rewards 1e-5) when the
+oracle is fed the device's own actions and draws."""
+import numpy as np
+import pytest
+
+from mbt_gym_amd import _native
+from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv
+from tests.env_factory import make_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(n, **kw):
+    base = dict(num_trajectories=n, n_steps=40, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=20, seed=5,
+                normalise_action_space=True, normalise_observation_space=True)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+def _random_mlp(rng, d, hidden, a, scale=1.0):
+    def layer(out, inp):
+        return (rng.normal(0, scale / np.sqrt(inp), size=(out, inp)).astype(np.float32), rng.normal(0, 0.1, size=out).astype(np.float32))
+    return [layer(hidden, d), layer(hidden, hidden), layer(a, hidden)]
+
+
+def _f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def mlp_reference(obs, layers, activation, lo, hi, emulate_fp16=True):
+    """NumPy restatement of policy_mlp.hpp: fp16 operands (when emulating), fp32 accumulation, clip to the action space."""
+    r = _f16 if emulate_fp16 else (lambda a: np.asarray(a, dtype=np.float32))
+    act = (lambda x: np.tanh(x)) if activation == "tanh" else (lambda x: np.maximum(x, 0.0))
+    (w1, b1), (w2, b2), (w3, b3) = layers
+    x = r(np.concatenate([obs, np.ones((len(obs), 1), np.float32)], axis=1))
+    w1p = r(np.concatenate([w1, b1[:, None]], axis=1))  # the first bias rides on the constant-one feature: it is fp16 too
+    h1 = r(act(x.astype(np.float64) @ w1p.T.astype(np.float64)).astype(np.float32))
+    h2 = r(act(h1.astype(np.float64) @ r(w2).T.astype(np.float64) + b2).astype(np.float32))
+    out = (h2.astype(np.float64) @ r(w3).T.astype(np.float64) + b3).astype(np.float32)
+    return np.clip(out, lo, hi)
+
+
+def _action_space(env):
+    return env.action_space.low.astype(np.float32), env.action_space.high.astype(np.float32)
+
+
+@pytest.mark.parametrize("activation", ["tanh", "relu"])
+@pytest.mark.parametrize("kw,hidden", [(dict(), 64), (dict(dynamics="limit_and_market", market_half_spread=0.4), 64),
+                                       (dict(arrival="hawkes", intensity=(10.0, 10.0), hawkes_speed=20.0, midprice="ou", ou_level=100.0, ou_speed=0.02), 32),
+                                       (dict(normalise_action_space=False, normalise_observation_space=False), 48)])
+def test_mlp_policy_kernel_matches_the_numpy_restatement(kw, hidden, activation):
+    n = 3000  # not a multiple of the 512-lane tile: pad rows are evaluated and never reported
+    cfg = _cfg(n, **kw)
+    env = make_env(cfg)
+    rng = np.random.default_rng(11)
+    raw = not cfg.normalise_observation_space
+    layers = _random_mlp(rng, env.observation_dim, hidden, env.action_dim, scale=0.05 if raw else 1.5)
+    policy = _native.mlp_policy(layers, activation)
+    env.reset()
+    warm = np.tile(np.array([[0.0] * env.action_dim], np.float32), (n, 1)) if not raw else np.tile(np.array([[0.5] * env.action_dim], np.float32), (n, 1))
+    for _ in range(7):  # move away from the reset state so that rows differ
+        obs, _, _, _ = env.step(warm)
+    env.policy_device(policy)
+    env.synchronize()
+    import torch
+
+    got = torch.as_tensor(env.action_device, device="cuda").cpu().numpy()
+    lo, hi = _action_space(env)
+    want = mlp_reference(obs, layers, activation, lo, hi)
+    plain = mlp_reference(obs, layers, activation, lo, hi, emulate_fp16=False)
+    assert got.shape == want.shape == (n, env.action_dim)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-3 * scale)
+    np.testing.assert_allclose(got, plain, rtol=0, atol=2e-2 * scale)
+    assert np.std(want) > 0.01 * (hi[0] - lo[0]), "the test network must not be saturated or constant"
+    env.close()
+
+
+def test_linear_policy_is_fp32_exact_up_to_summation_order():
+    n = 2048
+    cfg = _cfg(n)
+    env = make_env(cfg)
+    rng = np.random.default_rng(3)
+    w, b = rng.normal(0, 0.5, size=(2, 4)).astype(np.float32), rng.normal(0, 0.1, size=2).astype(np.float32)
+    policy = _native.linear_policy(w, b)
+    env.reset()
+    for _ in range(5):
+        obs, _, _, _ = env.step(np.zeros((n, 2), np.float32))
+    env.policy_device(policy)
+    env.synchronize()
+    import torch
+
+    got = torch.as_tensor(env.action_device, device="cuda").cpu().numpy()
+    want = np.clip(obs.astype(np.float64) @ w.T.astype(np.float64) + b, -1.0, 1.0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    env.close()
+
+
+@pytest.mark.parametrize("kind", ["mlp_tanh", "mlp_relu", "linear"])
+@pytest.mark.parametrize("kw", [dict(), dict(dynamics="limit_and_market", market_half_spread=0.4, reward="running", phi=0.01, alpha=0.05, max_inventory=4)])
+def test_fused_rollout_with_a_learned_policy_is_bit_identical_to_the_policy_and_step_kernels(kw, kind):
+    n = 4096 + 300
+    cfg = _cfg(n, **kw)
+    fused, loop = make_env(cfg), make_env(cfg)
+    rng = np.random.default_rng(23)
+    d, a = fused.observation_dim, fused.action_dim
+    if kind == "linear":
+        policy = _native.linear_policy(rng.normal(0, 0.8, size=(a, d)).astype(np.float32), rng.normal(0, 0.2, size=a).astype(np.float32))
+    else:
+        policy = _native.mlp_policy(_random_mlp(rng, d, 64, a, scale=1.5), kind.split("_")[1])
+    fused.reset(), loop.reset()
+    steps, done = fused.rollout_device(policy)
+    assert (steps, done) == (cfg.n_steps, True)
+    for k in range(cfg.n_steps):
+        loop.policy_device(policy)
+        finished = loop.step_device()
+    assert finished
+    np.testing.assert_array_equal(fused.state, loop.state)
+    np.testing.assert_array_equal(fused.observation_host(), loop.observation_host())
+    # (the sums are accumulated per step by the step kernel and per lane by the rollout: same values, different summation order)
+    assert fused.episode_return_sums()[0] == pytest.approx(loop.episode_return_sums()[0], rel=1e-6)
+    fused.close(), loop.close()
+
+
+def test_environment_under_an_in_kernel_mlp_policy_matches_the_oracle():
+    """The recorded rollout: actions are what the NumPy restatement computes from the recorded observations, and the
+    float64 oracle driven by the device's own actions and Philox draws reproduces inventory exactly and rewards to 1e-5."""
+    n, seed = 2000, 5
+    cfg = _cfg(n, reward="running", phi=0.01, alpha=0.02)
+    env = make_env(cfg)
+    rng = np.random.default_rng(7)
+    layers = _random_mlp(rng, 4, 64, 2, scale=1.5)
+    env.reset()
+    obs_t, act_t, rew_t, steps, done = env.rollout(_native.mlp_policy(layers, "tanh"))
+    assert steps == cfg.n_steps and done and obs_t.shape == (steps + 1, n, 4) and act_t.shape == (steps, n, 2)
+    lo, hi = _action_space(env)
+    for k in (0, 1, steps // 2, steps - 1):
+        np.testing.assert_allclose(act_t[k], mlp_reference(obs_t[k], layers, "tanh", lo, hi), rtol=0, atol=2e-3)
+    assert np.std(act_t) > 0.1  # a policy that actually reacts to the state
+    draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    o_obs = oracle.reset()
+    np.testing.assert_allclose(obs_t[0], o_obs, rtol=0, atol=1e-6)
+    for k in range(steps):
+        o_obs, o_rew, _ = oracle.step(act_t[k].astype(np.float64))
+        q_got = np.rint((obs_t[k + 1][:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
+        q_want = np.rint((o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory)
+        np.testing.assert_array_equal(q_got, q_want, err_msg=f"step {k}: inventory")
+        clipped = oracle.last_clipped
+        err = np.abs(rew_t[k] - o_rew)
+        assert np.all(err[~clipped] <= 1e-5 + 1e-6 * np.abs(o_rew[~clipped])), f"step {k}: {err[~clipped].max()}"
+    env.close()
+
+
+def test_learned_policy_refusals():
+    from mbt_gym_amd._native import NativeError
+
+    env = make_env(_cfg(512))
+    env.reset()
+    rng = np.random.default_rng(1)
+    with pytest.raises(NativeError, match="floats"):
+        env.policy_device(_native.mlp_policy(_random_mlp(rng, 5, 64, 2)))  # wrong observation width
+    with pytest.raises(AssertionError):
+        _native.mlp_policy(_random_mlp(rng, 4, 64, 2)[:2])
+    wide = _random_mlp(rng, 4, 80, 2)
+    with pytest.raises(NativeError, match="hidden width"):
+        env.policy_device(_native.mlp_policy(wide))
+    with pytest.raises(NativeError, match="learned"):
+        env.policy_device(_native.MbtPolicy(kind=_native.POLICY_FIXED))
+    env.close()
+    touch = make_env(_cfg(512, dynamics="touch", market_half_spread=0.25, normalise_action_space=False, normalise_observation_space=False))
+    touch.reset()
+    with pytest.raises(NativeError, match="quote depths"):
+        touch.policy_device(_native.mlp_policy(_random_mlp(rng, 4, 64, 2)))
+    touch.close()
