@@ -1,39 +1,45 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ in ONE GPU-box call:
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'   then   cp gpurun_out/profiles_r01/* profiles/
+#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r02'   then   cp gpurun_out/profiles_r02/* profiles/
 # rocprofv3 passes: kernel trace + stats alone; FETCH_SIZE and WRITE_SIZE each in its own --pmc pass (the MI355X guide's
 # HBM recipe); never combined with hip/hsa/sys tracing.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$(pwd)
+t0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a "$OUT/timeline.txt"; }
 
-python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"
+# the bench lines: default arguments, and the driver's (--steps 20 --warmup 5)
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"; stamp "bench default rc=$?"
+python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>> "$OUT/bench.stderr"; stamp "bench driver args rc=$?"
 
-# the same command under rocprofv3 (kernel trace + stats)
-rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/${TAG}_bench_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_stats.stderr")
-find /tmp/prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_bench_kernel_stats.csv"
+profile() {  # profile <name> <bench args...>: kernel trace + stats, then the two PMC passes
+  local name=$1; shift
+  rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident "$@" > "$ROOT/$OUT/${TAG}_${name}_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_${name}.stderr")
+  find /tmp/prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_${name}_kernel_stats.csv"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --prewarm-steps 0 "${@:1:2}" --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_${name}_$C.stderr")
+  done
+  F=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+  W=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+  python tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_${name}_pmc_summary.json" > /dev/null
+  stamp "profile $name"
+}
+# the headline workload (2^20 lanes, Infinity-Cache resident) and the same kernel where every byte crosses HBM (2^24 lanes)
+profile bench --lanes 1048576
+profile hbm_resident --lanes 16777216 --steps 600 --warmup 100
+cp "$OUT/${TAG}_bench_pmc_summary.json" "$OUT/${TAG}_pmc_summary.json"   # the name bench.py's roofline.traffic reads
 
-# PMC: one counter per pass, short run (every launch is serialised by the profiler)
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_$C.stderr")
-done
-F=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' | head -1)
-W=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python tools/pmc_summary.py "$F" "$W" "$OUT/${TAG}_pmc_summary.json" > /dev/null
-
-python tests/perf/parity_report.py > "$OUT/${TAG}_parity_report.txt" 2> /dev/null
-MBT_BENCH_STEPS=1000 python tests/perf/bench_configs.py > "$OUT/${TAG}_step_kernel_all_configs.json" 2> /dev/null
-python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null
-python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null
+python tests/perf/parity_report.py > "$OUT/${TAG}_parity_report.txt" 2> /dev/null; stamp "parity report"
+MBT_BENCH_STEPS=1000 python tests/perf/bench_configs.py > "$OUT/${TAG}_step_kernel_all_configs.json" 2> /dev/null; stamp "all configs"
+python tests/perf/bench_regimes.py > "$OUT/${TAG}_regimes.json" 2> /dev/null; stamp "regimes"
+python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null; stamp "rollout"
+python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; stamp "policy rollout"
+python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
 
 make -C tools/microbench > /dev/null 2>&1
-{
-  for n in 20 22 24; do echo "== mb_copy $n (buffers of zeros)"; tools/microbench/mb_copy $n; done
-  for n in 20 22 24; do echo "== mb_copy $n, random data"; MB_RANDOM_DATA=1 tools/microbench/mb_copy $n; done
-  for n in 18 20 22 24; do echo "== mb_step $n"; tools/microbench/mb_step $n; done
-  for n in 20 22 24; do echo "== mb_rows6 $n"; tools/microbench/mb_rows6 $n; done
-} > "$OUT/${TAG}_microbench_raw.txt" 2>&1
+tools/microbench/mb_floor > "$OUT/${TAG}_floors.txt" 2>&1; stamp "floors"
 ls -la "$OUT"
