@@ -9,12 +9,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "examples", "as_episode.c")
 EXE = os.path.join(ROOT, "examples", "as_episode")
+SHARDED_SRC = os.path.join(ROOT, "examples", "sharded_returns.c")
+SHARDED_EXE = os.path.join(ROOT, "examples", "sharded_returns")
 LIB_DIR = os.path.join(ROOT, "mbt_gym_amd")
 
 
-def _compile():
-    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-L" + LIB_DIR, "-lmbtenv", "-lm",
-           "-Wl,-rpath," + LIB_DIR, "-o", EXE]
+def _compile(src=SRC, exe=EXE):
+    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-L" + LIB_DIR, "-lmbtenv", "-lm",
+           "-Wl,-rpath," + LIB_DIR, "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
@@ -23,7 +25,8 @@ def test_c_example_compiles_and_links_against_the_library():
 
     build_native()  # no-op when libmbtenv.so is newer than its sources
     _compile()
-    assert os.path.exists(EXE)
+    _compile(SHARDED_SRC, SHARDED_EXE)
+    assert os.path.exists(EXE) and os.path.exists(SHARDED_EXE)
 
 
 @pytest.mark.gpu
@@ -35,3 +38,18 @@ def test_c_example_runs_an_episode():
     assert lines[0].startswith("step loop : 200 steps") and lines[1].startswith("rollout   : 200 steps")
     mean = float(lines[0].split("mean episode return")[1].split()[0])
     assert 60.0 < mean < 70.0  # the reference's published table for this configuration: 64.9 +- 6.5 / sqrt(1000)
+
+
+@pytest.mark.gpu
+def test_c_example_of_the_sharded_return_allreduce_runs_with_one_rank():
+    """examples/sharded_returns.c: communicator through mbt_comm_*, episode log all-reduced on the environment's stream,
+    mbt_env_allreduce_returns - from plain C, against the system's RCCL (no PyTorch in the process).  One rank here (one
+    GPU box); the N-rank invocation is the same binary with `rank world id-file` arguments."""
+    _compile(SHARDED_SRC, SHARDED_EXE)
+    out = subprocess.run([SHARDED_EXE], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("rank 0/1")]
+    assert len(lines) == 4 and "65536 lanes in total" in lines[0]
+    means = [float(ln.split("mean return")[1].split(",")[0]) for ln in lines[:3]]
+    # three different episodes of the same market: 100 steps x 2 sides x P(arrival) 0.14 x P(fill) e^{-1.05} x depth 0.7 = 6.86
+    assert all(6.6 < m < 7.1 for m in means) and len(set(means)) == 3
