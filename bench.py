@@ -404,12 +404,13 @@ def main():
                 out["roofline"]["hbm_resident"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:  # the very last thing written to stdout (RCCL prints its version banner there when communicators are made)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@ last observation under infos[i]["terminal_observation"] and returns the observat
 the terminal step's rewards and dones (SBE:28-37).  stable_baselines3 is optional: without it the class derives
 from a minimal stand-in with the same attributes, so the adapter's semantics can be tested anywhere.
 """
+import collections.abc
 from typing import Any, List, Optional, Sequence
 
 import numpy as np
@@ -26,6 +27,29 @@ except Exception:  # noqa: BLE001
         def step(self, actions):
             self.step_async(actions)
             return self.step_wait()
+
+
+LAZY_INFOS_ABOVE = 1 << 16  # lanes: beyond this the terminal infos are a lazy sequence instead of a list of dicts
+
+
+class TerminalObservationInfos(collections.abc.Sequence):
+    """infos of a terminal step for a large batch: behaves like the list of dicts SB3 expects - `len`, iteration, `infos[i]`,
+    `infos[i].get("terminal_observation")`, slicing - but builds a lane's dict only when it is asked for.  The reference
+    writes one dict entry per lane in a Python loop at every episode end (SBE:31-35): 0.4 s per episode at 2^20 lanes before
+    any consumer has looked at them.  (A consumer that touches every lane - SB3's VecMonitor and collect_rollouts do, in
+    Python, every step - is O(num_envs) on its own side; at that scale the device-resident interface is the intended one:
+    `step_device`, `rollout_device`, `episode_log_pop`.)"""
+
+    def __init__(self, terminal_observation: np.ndarray):
+        self._obs = terminal_observation
+
+    def __len__(self):
+        return len(self._obs)
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [{"terminal_observation": row} for row in self._obs[index]]
+        return {"terminal_observation": self._obs[index, :]}
 
 
 class StableBaselinesTradingEnvironment(_VecEnvBase):
@@ -50,9 +74,12 @@ class StableBaselinesTradingEnvironment(_VecEnvBase):
             return obs, rewards, dones, infos
         # episode over in every lane (the clock is shared): hand out the terminal observation, then auto-reset (SBE:28-37)
         if self.store_terminal_observation_info:
-            infos = list(infos) if isinstance(infos, list) else [infos]
-            for lane in range(len(infos)):
-                infos[lane]["terminal_observation"] = obs[lane, :]
+            if len(obs) > LAZY_INFOS_ABOVE:
+                infos = TerminalObservationInfos(obs)
+            else:
+                infos = list(infos) if isinstance(infos, list) else [infos]
+                for lane in range(len(infos)):
+                    infos[lane]["terminal_observation"] = obs[lane, :]
         return self.env.reset(), rewards, dones, infos
 
     def seed(self, seed: Optional[int] = None):

@@ -168,6 +168,22 @@ def test_sb3_adapter_auto_reset_and_terminal_observation():
     assert inner.seeded == 7
 
 
+def test_sb3_adapter_terminal_infos_are_lazy_for_large_batches(monkeypatch):
+    """Above LAZY_INFOS_ABOVE lanes the terminal infos are a sequence that builds a lane's dict on demand (same reads as the
+    list of dicts of SBE:31-35, no O(N) Python loop at the episode boundary)."""
+    import mbt_gym_amd.gym.StableBaselinesTradingEnvironment as sbe
+
+    monkeypatch.setattr(sbe, "LAZY_INFOS_ABOVE", 2)
+    venv = StableBaselinesTradingEnvironment(_ScriptedEnv())
+    venv.reset()
+    act = np.zeros((3, 2), np.float32)
+    for _ in range(3):
+        obs, rew, dones, infos = venv.step(act)
+    assert dones.all() and isinstance(infos, sbe.TerminalObservationInfos) and len(infos) == 3
+    assert infos[1]["terminal_observation"][0] == 103.0 and infos[2].get("terminal_observation") is not None
+    assert [i["terminal_observation"][0] for i in infos] == [103.0] * 3 and len(infos[:2]) == 2 and isinstance(infos[:], list)
+
+
 @pytest.mark.parametrize("name", ["as_limit_pnl", "hawkes_ou", "exo_fill_hawkes_market", "speed_temp_transient_pnl", "cjp_cjmm"])
 def test_initial_state_and_small_api_surface(name, no_device):
     """initial_state (TE:131-140) equals the reference's first observation; fill_multiplier, RandomAgent and the
