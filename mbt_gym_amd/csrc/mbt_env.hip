@@ -111,11 +111,13 @@ StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, bool stre
     default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, stream);
   }
 }
-// `staged` = the instantiation that loads 20-byte rows through LDS (see speed_step_kernel; only with an impact state)
+// `staged` = the instantiation that loads 20-byte rows through LDS (cache-resident sizes, only with an impact state);
+// `stream` = non-temporal direct loads (sizes beyond the Infinity Cache); see speed_step_kernel
 template <bool STATE>
-StepKernel pick_speed(bool norm, bool inject, bool staged) {
+StepKernel pick_speed(bool norm, bool inject, bool stream) {
   if (inject) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true>>;
-  if (STATE && staged) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, true>;
+  if (stream) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, false, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, false, true>;
+  if (STATE) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, true>;
   return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>>;
 }
 bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
@@ -150,7 +152,7 @@ StepKernel pick_precise_dyn(int dyn, bool inject) {
 StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
-  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject, !stream) : pick_speed<false>(norm, inject, false);
+  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject, stream) : pick_speed<false>(norm, inject, stream);
   if (c.precise_state)
     return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, inject) : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, inject);
   if (exogenous_fill(c)) {

@@ -95,13 +95,14 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
 constexpr uint32_t kSpeedTileLanes = 4 * kBlockThreads;
 
 // one state row of a lane: [cash, inventory, time, midprice (, y)]
-template <class V>
+template <class V, bool NT = false>
 __device__ __forceinline__ SpeedLane load_speed_row(const float* state, uint32_t lane) {
   if (V::DIM == 4) {
-    const float4 r = reinterpret_cast<const float4*>(state)[lane];
+    const float4 r = load4<NT>(state + static_cast<size_t>(lane) * 4);
     return SpeedLane{r.x, r.y, r.w, 0.0f};
   }
   const float* r = state + static_cast<size_t>(lane) * 5;
+  if (NT) return SpeedLane{__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 3), __builtin_nontemporal_load(r + 4)};
   return SpeedLane{r[0], r[1], r[3], r[4]};
 }
 
@@ -126,10 +127,12 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
 // instead of five dword loads per lane that walk the same cache lines.  Measured with the traffic-only kernels of
 // tools/microbench/mb_floor.hip (48 B/lane, 2^20 lanes): 7.94 us for the dword loads, 7.50 us staged - but at 2^24 lanes,
 // where every byte crosses HBM, 134.9 vs 144.3 us the other way round.  The host picks the instantiation by size
-// (mbt_env.hip: tune_for_size).
-template <class V, bool STAGED = false>
+// (mbt_env.hip: tune_for_size).  STREAM: beyond the Infinity Cache the direct loads carry the non-temporal bit, as in
+// step_kernel.
+template <class V, bool STAGED = false, bool STREAM = false>
 __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuffers B, const StepParams P) {
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
+  static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
   const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
   const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
   // 20-byte rows (D = 5) would leave the thread as five 4-byte stores per lane, each covering part of a cache line: such
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
 #pragma unroll
   for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
     const uint32_t lane = lane0 + l * kBlockThreads;
-    if (!kStaged) s[l] = load_speed_row<V>(B.state_in, lane);
-    act[l] = B.action[lane];
+    if (!kStaged) s[l] = load_speed_row<V, STREAM>(B.state_in, lane);
+    act[l] = STREAM ? __builtin_nontemporal_load(B.action + lane) : B.action[lane];
     if (V::INJECT) z[l] = B.z[lane];
     qi[l] = P.q_init_scalar;
   }

@@ -24,6 +24,8 @@ MODELS = {
     "Hawkes+OU (60 B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), [0.7, 0.7], (22, 24)),
     "speed+impact state (48 B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015,
                                        reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10), [0.5], (20, 24)),
+    "speed (40 B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.0, reward="pnl",
+                          initial_inventory=10), [0.5], (20, 24)),
 }
 KNOBS = [("default policy", None, None), ("loads default, 8 WG/CU", "0", "0"), ("loads default, 5 WG/CU", "0", "32768"),
          ("loads nt, 8 WG/CU", "1", "0"), ("loads nt, 5 WG/CU", "1", "32768"), ("loads nt, 4 WG/CU", "1", "40960")]
@@ -53,8 +55,8 @@ def main():
         for log2n in sizes:
             row = {}
             for label, stream, lds in KNOBS:
-                if name.startswith("speed") and (stream == "1" or lds not in (None, "0")) and label != "default policy":
-                    continue  # the speed kernels have no streaming instantiation / occupancy knob
+                if name.startswith("speed") and lds not in (None, "0") and label != "default policy":
+                    continue  # (the occupancy knob is an order-book experiment)
                 for key, val in (("MBT_STREAM_LOADS", stream), ("MBT_STEP_DYNAMIC_LDS", lds)):
                     os.environ.pop(key, None)
                     if val is not None:
