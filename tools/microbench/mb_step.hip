@@ -70,6 +70,55 @@ __global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_tiles(const mb
   if ((threadIdx.x & 63u) == 0u) unsafeAtomicAdd(&B.wave_sums[blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)], static_cast<double>(total));
 }
 
+// Experiment (the north star's "LDS-staged RNG draws"): the workgroup's noise goes THROUGH LDS between the generator and
+// the arithmetic that consumes it.  MODE 0: each thread stages the ten draws of its own pair (the cost of staging alone).
+// MODE 1: producer / consumer waves - waves 0-1 generate the draws of all 512 lanes of the tile (two pairs per thread)
+// while waves 2-3 have nothing to compute and only keep their loads in flight; after the barrier every thread finishes
+// its own pair from LDS.  Philox is counter-based: no state is shared between lanes, so staging cannot remove a single
+// generator instruction; it adds 2 x 10 LDS accesses per pair and a workgroup barrier.  D = 4 variants only.
+template <class V, int MODE>
+__global__ __launch_bounds__(mbt::kBlockThreads) void step_kernel_lds_rng(const mbt::StepBuffers B, const mbt::StepParams P) {
+  using namespace mbt;
+  __shared__ float staged[2 * kTileLanes * 5];  // [lane in tile][ua_bid, ua_ask, uf_bid, uf_ask, z]
+  const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
+  LaneLoads L0 = load_lane<V>(B, P, lane0), L1 = load_lane<V>(B, P, lane1);
+  auto put = [&](uint32_t slot, const LaneNoise& n) {
+    float* p = staged + slot * 5;
+    p[0] = n.ua_bid; p[1] = n.ua_ask; p[2] = n.uf_bid; p[3] = n.uf_ask; p[4] = n.z;
+  };
+  auto get = [&](uint32_t slot) {
+    const float* p = staged + slot * 5;
+    return LaneNoise{p[0], p[1], p[2], p[3], p[4]};
+  };
+  if (MODE == 0) {
+    LaneNoise a, b;
+    philox_pair_noise(P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x, P.philox_step, P.key0, P.key1, a, b);
+    put(threadIdx.x, a);
+    put(threadIdx.x + kBlockThreads, b);
+  } else if (threadIdx.x < kBlockThreads / 2) {  // producer waves: two pairs each
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t j = threadIdx.x + h * (kBlockThreads / 2);
+      LaneNoise a, b;
+      philox_pair_noise(P.pair_offset + blockIdx.x * kBlockThreads + j, P.philox_step, P.key0, P.key1, a, b);
+      put(j, a);
+      put(j + kBlockThreads, b);
+    }
+  }
+  __syncthreads();
+  const LaneNoise nz0 = get(threadIdx.x), nz1 = get(threadIdx.x + kBlockThreads);
+  LaneDraw d0 = make_draw<V>(nz0, P), d1 = make_draw<V>(nz1, P);
+  bool c0, c1;
+  float r = finish_lane<V>(B, P, lane0, L0, d0, c0, nullptr, nz0.z);
+  r += finish_lane<V>(B, P, lane1, L1, d1, c1, nullptr, nz1.z);
+  const uint32_t clips = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c1));
+  const float total = wave_sum(r);
+  if ((threadIdx.x & 63u) == 0u) {
+    unsafeAtomicAdd(&B.wave_sums[blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6)], static_cast<double>(total));
+    if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
+  }
+}
+
 template <typename F>
 float time_it(F launch, int iters) {
   hipEvent_t e0, e1;
@@ -136,6 +185,12 @@ int main(int argc, char** argv) {
   RUNL(AS, 40 * 1024, "  AS, 4 workgroups/CU")
   RUNL(AS, 53 * 1024, "  AS, 3 workgroups/CU")
   RUNL(CJ, 32 * 1024, "  CjMm, 5 workgroups/CU")
+#define RUNR(VARIANT, MODE, LABEL)                                                                                       \
+  t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
+                           hipLaunchKernelGGL((step_kernel_lds_rng<VARIANT, MODE>), dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
+  printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, 44.0 * n / t * 1e-3);
+  RUNR(AS, 0, "  AS, draws staged in LDS")
+  RUNR(AS, 1, "  AS, producer/consumer waves")
   RUNT(AS, 1, "  tiles/block 1")
   RUNT(AS, 2, "  tiles/block 2")
   RUNT(AS, 4, "  tiles/block 4")
