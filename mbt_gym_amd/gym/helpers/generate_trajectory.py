@@ -47,7 +47,7 @@ def generate_trajectory(env, agent, seed: int = None, include_log_probs: bool = 
         env.seed(seed)
     n, horizon = env.num_trajectories, env.n_steps
     if fused is None:
-        fused = hasattr(agent, "device_policy") and getattr(env, "noise", "philox") == "philox"
+        fused = hasattr(agent, "device_policy") and getattr(agent, "has_device_policy", True) and getattr(env, "noise", "philox") == "philox"
     if fused:
         env.reset()
         obs_t, act_t, rew_t, steps, _ = env.rollout(agent, max_steps=horizon, record=True)

@@ -181,3 +181,28 @@ def test_learned_policy_refusals():
     with pytest.raises(NativeError, match="quote depths"):
         touch.policy_device(_native.mlp_policy(_random_mlp(rng, 4, 64, 2)))
     touch.close()
+
+
+def test_generate_trajectory_with_an_sb3_shaped_agent_runs_fused_and_agrees_with_the_host_loop():
+    """The reference's caller, unchanged: generate_trajectory(env, SbAgent(model)) (GT:8-38, agents/SbAgent.py).  With an
+    SB3-shaped MlpPolicy actor the episode runs in one launch with the policy in-kernel; the actions it records are what
+    model.predict returns for the recorded observations (fp16-operand tolerance), and the episode statistics agree with the
+    reference-style loop (model.predict on the host + env.step per time step) statistically."""
+    from mbt_gym_amd.agents.SbAgent import SbAgent
+    from mbt_gym_amd.gym.helpers.generate_trajectory import generate_trajectory
+    from tests.test_host_logic import _fake_sb3_model
+
+    n = 4096
+    cfg = _cfg(n, n_steps=30)
+    env, twin = make_env(cfg), make_env(cfg)
+    agent = SbAgent(_fake_sb3_model(4, 64, 2, "Tanh", seed=3, env=env))
+    assert agent.has_device_policy
+    obs_f, act_f, rew_f = generate_trajectory(env, agent)                 # fused: one launch
+    obs_h, act_h, rew_h = generate_trajectory(twin, SbAgent(_fake_sb3_model(4, 64, 2, "Tanh", seed=3, env=twin)), fused=False)
+    assert obs_f.shape == obs_h.shape == (n, 4, 31) and act_f.shape == act_h.shape == (n, 2, 30) and rew_f.shape == rew_h.shape == (n, 1, 30)
+    for k in (0, 10, 29):
+        np.testing.assert_allclose(act_f[:, :, k], agent.get_action(np.ascontiguousarray(obs_f[:, :, k])), rtol=0, atol=2e-2)
+    np.testing.assert_allclose(act_f[:, :, 0], act_h[:, :, 0], rtol=0, atol=2e-2)  # same first observation
+    total_f, total_h = rew_f.sum(axis=(1, 2)), rew_h.sum(axis=(1, 2))
+    assert total_f.mean() == pytest.approx(total_h.mean(), abs=5 * total_h.std() / np.sqrt(n) + 1e-3)
+    env.close(), twin.close()

@@ -231,3 +231,61 @@ def test_sb_agent_wraps_any_predictor():
     agent = SbAgent(model, num_trajectories=5)
     agent.train(123)
     assert model.learned == 123 and agent.num_actions == 2
+
+
+def _fake_sb3_model(d, hidden, a, activation="Tanh", seed=0, env=None):
+    """The attribute shape of a Stable-Baselines3 ActorCriticPolicy (policy.mlp_extractor.policy_net, policy.action_net)
+    built from torch modules; `predict(deterministic=True)` = the actor's mean clipped to the action space."""
+    import types
+
+    import torch
+
+    from mbt_gym_amd.spaces import Box
+
+    torch.manual_seed(seed)
+    act = getattr(torch.nn, activation)
+    net = torch.nn.Sequential(torch.nn.Linear(d, hidden), act(), torch.nn.Linear(hidden, hidden), act())
+    head = torch.nn.Linear(hidden, a)
+    model = types.SimpleNamespace()
+    model.policy = types.SimpleNamespace(mlp_extractor=types.SimpleNamespace(policy_net=net), action_net=head)
+    model.action_space = Box(low=-np.ones(a, np.float32), high=np.ones(a, np.float32))
+    model.env = env if env is not None else types.SimpleNamespace(num_trajectories=7, observation_dim=d)
+
+    def predict(obs, deterministic=False):
+        with torch.no_grad():
+            out = head(net(torch.as_tensor(np.asarray(obs, np.float32))))
+        return np.clip(out.numpy(), -1, 1), None
+
+    model.predict = predict
+    return model
+
+
+def test_sb_agent_hands_an_mlp_actor_to_the_device_policy():
+    """SbAgent.actor_layers / device_policy: the weights of an SB3-shaped [Linear, Tanh, Linear, Tanh] + Linear actor in
+    torch.nn.Linear layout, reduced observation columns widened with zeros; a NumPy forward pass of what is handed over
+    equals model.predict.  Unsupported architectures say so (and generate_trajectory then takes the host loop)."""
+    from mbt_gym_amd import _native
+    from mbt_gym_amd.agents.SbAgent import SbAgent
+
+    def forward(layers, activation, obs):
+        f = np.tanh if activation == "tanh" else (lambda x: np.maximum(x, 0))
+        (w1, b1), (w2, b2), (w3, b3) = layers
+        return np.clip(f(f(obs @ w1.T + b1) @ w2.T + b2) @ w3.T + b3, -1, 1)
+
+    obs = np.random.default_rng(0).uniform(-1, 1, size=(7, 4)).astype(np.float32)
+    for activation in ("Tanh", "ReLU"):
+        model = _fake_sb3_model(4, 64, 2, activation)
+        agent = SbAgent(model)
+        layers, name = agent.actor_layers()
+        assert name == activation.lower() and [w.shape for w, _ in layers] == [(64, 4), (64, 64), (2, 64)] and agent.has_device_policy
+        np.testing.assert_allclose(forward(layers, name, obs), agent.get_action(obs), rtol=0, atol=1e-6)
+        pol = agent.device_policy()
+        assert pol.kind == _native.POLICY_MLP and pol.table_rows == 64 and pol.table_cols == 64 * 4 + 64 + 64 * 64 + 64 + 2 * 64 + 2
+    reduced = SbAgent(_fake_sb3_model(2, 32, 2), reduced_training_indices=[1, 3])
+    layers, _ = reduced.actor_layers(observation_dim=4)
+    assert layers[0][0].shape == (32, 4) and not layers[0][0][:, [0, 2]].any()
+    np.testing.assert_allclose(forward(layers, "tanh", obs), reduced.get_action(obs), rtol=0, atol=1e-6)
+    for bad in (_fake_sb3_model(4, 128, 2), _fake_sb3_model(4, 64, 2, "Sigmoid")):
+        assert not SbAgent(bad).has_device_policy
+        with pytest.raises(ValueError):
+            SbAgent(bad).device_policy()
