@@ -43,16 +43,26 @@ def test_config_struct_layout_matches_a_c_compiler(lib, tmp_path):
     fields = ["abi_version", "num_trajectories", "n_steps", "terminal_time", "midprice_kind", "noise_mode", "drift",
               "intensity", "fill_exponent", "inventory_exponent", "initial_inventory", "reward_scale", "seed",
               "normalise_observation", "obs_lo", "act_hi", "midprice_step_size", "impact_kind", "temporary_impact",
-              "impact_step_size"]
-    body = "\n".join(f'  printf("{f} %zu\\n", offsetof(mbt_config, {f}));' for f in fields)
+              "impact_step_size", "exogenous_depth", "reward_terminal_time", "mid_coef_mul", "precise_state", "allow_stiff_hawkes"]
+    others = {"mbt_policy": (_native.MbtPolicy, ["kind", "params", "table", "table_rows", "table_cols", "table_q_offset"]),
+              "mbt_user_code": (_native.MbtUserCode, ["fill_probability", "fill_param_names", "fill_params", "reward", "reward_param_names", "reward_params"])}
+    body = "\n".join(f'  printf("mbt_config.{f} %zu\\n", offsetof(mbt_config, {f}));' for f in fields)
+    for struct, (_, names) in others.items():
+        body += f'\n  printf("{struct}.sizeof %zu\\n", sizeof({struct}));'
+        body += "".join(f'\n  printf("{struct}.{f} %zu\\n", offsetof({struct}, {f}));' for f in names)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(void) {{\n'
-                   f'  printf("sizeof %zu\\n", sizeof(mbt_config));\n{body}\n  return 0; }}\n')
+                   f'  printf("mbt_config.sizeof %zu\\n", sizeof(mbt_config));\n{body}\n  return 0; }}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    assert int(out.pop("sizeof")) == C.sizeof(_native.MbtConfig) == lib.mbt_config_sizeof()
-    for name, offset in out.items():
-        assert getattr(_native.MbtConfig, name).offset == int(offset), name
+    assert int(out.pop("mbt_config.sizeof")) == C.sizeof(_native.MbtConfig) == lib.mbt_config_sizeof()
+    binding = {"mbt_config": _native.MbtConfig, **{k: v[0] for k, v in others.items()}}
+    for key, offset in out.items():
+        struct, name = key.split(".")
+        if name == "sizeof":
+            assert C.sizeof(binding[struct]) == int(offset), key
+        else:
+            assert getattr(binding[struct], name).offset == int(offset), key
 
 
 def test_header_is_plain_c(tmp_path):
