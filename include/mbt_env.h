@@ -58,7 +58,8 @@ enum {
 };
 enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
-  MBT_ARR_NONE = 3 /* speed dynamics: no order flow (MD:47-48) */
+  MBT_ARR_NONE = 3 /* speed dynamics: no order flow (MD:47-48) */,
+  MBT_ARR_USER = 4 /* a user-defined, stateless ArrivalModel subclass (ARR:9-29): mbt_env_create_jit only */
 };
 enum {
   MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */,
@@ -182,6 +183,12 @@ void mbt_env_destroy(mbt_env* env);
  *                      MBT_FILL_USER: an expression of type double in `depth` (double: the de-normalised quote depth),
  *                      `side` (int: 0 bid, 1 ask) and the named parameters.  A fill happens when u < expression, with
  *                      u the lane's uniform, compared in double.
+ *   arrival_probability replaces ArrivalModel.get_arrivals (ARR:27-29) when cfg.arrival_kind == MBT_ARR_USER: an expression
+ *                      of type double in `t` (double: the time at the BEGINNING of the step, i.e. the time stamp of the
+ *                      observation the agent acted on), `side` (0 = a sell order arriving at the bid, 1 = a buy order at
+ *                      the ask, ARR:9-13), `dt` (the arrival model's step size) and the named parameters - e.g. a
+ *                      time-of-day intensity profile.  An arrival happens when u < expression.  The model is stateless
+ *                      (no state columns; what it needs of the past it must get from `t`).
  *   reward             replaces RewardFunction.calculate (RW:10-13) when cfg.reward_kind == MBT_REW_USER: an expression of
  *                      type double in  cash, q, t, mid  (current state)  cash_next, q_next, t_next, mid_next  (next state)
  *                      a0, a1, a2, a3 (the action as given)  pnl (the mark-to-market change, from the step's increments)
@@ -198,6 +205,9 @@ typedef struct mbt_user_code {
   const char* reward;             /* NULL unless cfg.reward_kind == MBT_REW_USER */
   const char* reward_param_names;
   double reward_params[8];
+  const char* arrival_probability; /* NULL unless cfg.arrival_kind == MBT_ARR_USER */
+  const char* arrival_param_names;
+  double arrival_params[8];
 } mbt_user_code;
 int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out);
 const char* mbt_jit_log(void);    /* thread local; "" when the last compilation had nothing to say */

@@ -258,7 +258,7 @@ struct mbt_env {
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
   hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
-  double user_fill_p[8] = {}, user_reward_p[8] = {};        // parameters of the user's device expressions
+  double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {};  // parameters of the user's device expressions
   char* learned_dev = nullptr;                               // packed weights of a learned policy (policy_mlp.hpp), device
   std::vector<char> learned_host;                            // what learned_dev holds (re-uploaded only when the policy changes)
   uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
@@ -288,6 +288,7 @@ void fill_static_params(mbt_env* e) {
   for (int j = 0; j < 8; ++j) {
     P.user_fill_p[j] = e->user_fill_p[j];
     P.user_reward_p[j] = e->user_reward_p[j];
+    P.user_arrival_p[j] = e->user_arrival_p[j];
   }
   P.dt = static_cast<float>(e->dt);
   // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
@@ -433,6 +434,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   P.philox_step = e->philox_step;
   P.is_terminal = terminal ? 1 : 0;
   P.t_next = static_cast<float>(t_next);
+  P.t_now = e->time;
 
   mbt::StepBuffers B;
   B.state_in = e->state[e->cur];
@@ -882,11 +884,13 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
 
 // The translation unit: the library's own kernel source with the user's functions and ONE instantiation.
 int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
-  const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER;
-  std::string fill_decl, reward_decl;
+  const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER, user_arrival = c.arrival_kind == MBT_ARR_USER;
+  std::string fill_decl, reward_decl, arrival_decl;
   int rc = param_declarations(u.fill_param_names, fill_decl);
   if (rc != MBT_OK) return rc;
   rc = param_declarations(u.reward_param_names, reward_decl);
+  if (rc != MBT_OK) return rc;
+  rc = param_declarations(u.arrival_param_names, arrival_decl);
   if (rc != MBT_OK) return rc;
   const int arr = c.arrival_kind == MBT_ARR_HAWKES ? mbt::kArrHawkes : mbt::kArrPoisson;
   const int dyn = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? mbt::kDynLimitAndMarket : c.dynamics_kind == MBT_DYN_AT_THE_TOUCH ? mbt::kDynTouch : mbt::kDynLimit;
@@ -900,9 +904,11 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "               is_terminal = s_.is_terminal, q0 = s_.q0, episode_length = s_.episode_length;\n"
          "  (void)cash; (void)q; (void)t; (void)mid; (void)cash_next; (void)q_next; (void)t_next; (void)mid_next; (void)a0; (void)a1; (void)a2;\n"
          "  (void)a3; (void)pnl; (void)dt; (void)is_terminal; (void)q0; (void)episode_length; (void)p;\n" +
-         reward_decl + "  return static_cast<double>(" + std::string(user_reward ? u.reward : "0.0") + ");\n}\n}  // namespace mbt\n";
+         reward_decl + "  return static_cast<double>(" + std::string(user_reward ? u.reward : "0.0") + ");\n}\n";
+  src += "__device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p) {\n  (void)t; (void)side; (void)dt; (void)p;\n" + arrival_decl +
+         "  return static_cast<double>(" + std::string(user_arrival ? u.arrival_probability : "0.0") + ");\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ">;\n";
+         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
@@ -1028,13 +1034,16 @@ int mbt_device_name(int device, char* buf, size_t buf_len) {
 static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
   if (cfg == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   *out = nullptr;
+  const bool user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
-  if ((user_fill || user_reward) && code == nullptr)
-    return fail(MBT_ERR_INVALID, "user-defined plugin kinds (MBT_FILL_USER / MBT_REW_USER) need their device expressions: use mbt_env_create_jit");
+  const bool needs_jit = user_fill || user_reward || user_arrival;
+  if (needs_jit && code == nullptr)
+    return fail(MBT_ERR_INVALID, "user-defined plugin kinds (MBT_ARR_USER / MBT_FILL_USER / MBT_REW_USER) need their device expressions: use mbt_env_create_jit");
+  if (user_arrival && (code->arrival_probability == nullptr || code->arrival_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_ARR_USER without an arrival_probability expression");
   if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
-  if (code != nullptr && !user_fill && !user_reward) return fail(MBT_ERR_INVALID, "mbt_env_create_jit: neither fill_kind nor reward_kind names a user-defined plugin");
-  if (user_fill || user_reward) {
+  if (code != nullptr && !needs_jit) return fail(MBT_ERR_INVALID, "mbt_env_create_jit: no plugin kind of the configuration names a user-defined plugin");
+  if (needs_jit) {
     if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill))
       return fail(MBT_ERR_INVALID, "user-defined plugins run on the order-book kernels (a fill model needs limit or limit + market dynamics)");
     if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state has no kernel for user-defined plugins");
@@ -1064,7 +1073,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
       return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
   } else {
-    if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR)
+    if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR && !user_arrival)
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
     if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
       if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
@@ -1116,10 +1125,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
   tune_for_size(e);
-  if (user_fill || user_reward) {
+  if (needs_jit) {
     for (int j = 0; j < 8; ++j) {
       e->user_fill_p[j] = code->fill_params[j];
       e->user_reward_p[j] = code->reward_params[j];
+      e->user_arrival_p[j] = code->arrival_params[j];
     }
     std::string source;
     JitKernels kernels;
@@ -1228,10 +1238,11 @@ const char* mbt_jit_log(void) { return g_jit_log.c_str(); }
 
 int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   if (cfg == nullptr || code == nullptr) return fail(MBT_ERR_INVALID, "null argument");
-  const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
-  if (!user_fill && !user_reward) return fail(MBT_ERR_INVALID, "neither fill_kind nor reward_kind names a user-defined plugin");
+  const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER, user_arrival = cfg->arrival_kind == MBT_ARR_USER;
+  if (!user_fill && !user_reward && !user_arrival) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
   if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
+  if (user_arrival && (code->arrival_probability == nullptr || code->arrival_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_ARR_USER without an arrival_probability expression");
   std::string source;
   std::vector<char> object;
   int rc = jit_source(*cfg, *code, source);

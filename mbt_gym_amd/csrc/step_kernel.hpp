@@ -57,7 +57,7 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
-          bool USER_FILL_ = false, bool USER_REWARD_ = false>
+          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -80,6 +80,8 @@ struct Variant {
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
   static constexpr bool USER_FILL = USER_FILL_, USER_REWARD = USER_REWARD_;
+  static constexpr bool USER_ARRIVAL = USER_ARRIVAL_;  // a stateless ArrivalModel.get_arrivals (ARR:27-29) as an expression of time
+  static_assert(!(USER_ARRIVAL_ && ARR_ == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (no state columns)");
   static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
   static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
 };
@@ -145,7 +147,8 @@ struct StepParams {
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
   PreciseParams X;
-  double user_fill_p[8], user_reward_p[8];  // parameters of the user's device expressions (mbt_user_code)
+  double user_fill_p[8], user_reward_p[8], user_arrival_p[8];  // parameters of the user's device expressions (mbt_user_code)
+  double t_now;  // the clock BEFORE this step (TE:216 accumulates it in double on the host): what a user arrival model sees
 };
 
 #ifdef MBT_JIT_USER_CODE
@@ -159,6 +162,7 @@ struct UserRewardArgs {
   double dt, is_terminal, q0, episode_length;  // step size, 1.0 on the terminal step, initial inventory, T - t_start
 };
 __device__ double mbt_user_reward(const UserRewardArgs& s, const double* p);
+__device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p);
 #endif
 
 struct StepBuffers {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void fill_thresholds(float u, const StepParams& P, fl
 template <class V>
 __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepParams& P) {
   LaneDraw d;
-  if (V::ARR == kArrPoisson) {  // strict '<' against thresholds rounded UP to float32: exact vs the float64 compare
+  if (V::ARR == kArrPoisson && !V::USER_ARRIVAL) {  // strict '<' against thresholds rounded UP to float32: exact vs the float64 compare
     d.arr_bid = nz.ua_bid < P.arr_thr_bid ? 1.0f : 0.0f;
     d.arr_ask = nz.ua_ask < P.arr_thr_ask ? 1.0f : 0.0f;
   } else {
@@ -367,7 +371,8 @@ __device__ __forceinline__ uint32_t event_byte(const LaneResult& r) {
 template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
-                                                const StepParams& P, const float2 resid = make_float2(0.f, 0.f), const float z = 0.f) {
+                                                const StepParams& P, const float2 resid = make_float2(0.f, 0.f), const float z = 0.f,
+                                                const double t_now = 0.0) {
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
   r.resid = resid;
@@ -378,6 +383,13 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   if (V::ARR == kArrHawkes) {
     arr_bid = static_cast<double>(dr.arr_bid) < static_cast<double>(lam.x) * P.arr_dt_f64 ? 1.0f : 0.0f;
     arr_ask = static_cast<double>(dr.arr_ask) < static_cast<double>(lam.y) * P.arr_dt_f64 ? 1.0f : 0.0f;
+  }
+  if (V::USER_ARRIVAL) {
+#ifdef MBT_JIT_USER_CODE
+    // the user's get_arrivals (ARR:27-29): u < p(t, side), in double, at the time stamp of the observation acted on
+    arr_bid = static_cast<double>(dr.arr_bid) < mbt_user_arrival_probability(t_now, 0, P.arr_dt_f64, P.user_arrival_p) ? 1.0f : 0.0f;
+    arr_ask = static_cast<double>(dr.arr_ask) < mbt_user_arrival_probability(t_now, 1, P.arr_dt_f64, P.user_arrival_p) ? 1.0f : 0.0f;
+#endif
   }
   r.arr_bid = arr_bid != 0.0f;
   r.arr_ask = arr_ask != 0.0f;
@@ -691,7 +703,7 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f) {
-  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, L.resid, z);
+  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, L.resid, z, P.t_now);
   if (V::PRECISE) store_through(reinterpret_cast<float2*>(B.resid) + lane, r.resid);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
@@ -902,11 +914,12 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
         act[l] = make_float4(shift + half, -shift + half, 0.f, 0.f);
       }
     }
+    const double t_now = t;
     t += R.dt_f64;
     const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, resid[l], nz[l].z);
+      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, resid[l], nz[l].z, t_now);
       core[l] = r.core;
       lam[l] = r.lam;
       resid[l] = r.resid;

@@ -234,12 +234,13 @@ class TradingEnvironment(_EnvBase):
 
     def _user_code(self):
         """struct mbt_user_code for the user-defined plugins of this environment (None when every plugin is built in)."""
-        fill, reward = self.model_dynamics.fill_probability_model, self.reward_function
+        fill, reward, arrival = self.model_dynamics.fill_probability_model, self.reward_function, self.model_dynamics.arrival_model
         fill_code = fill.device_code() if getattr(fill, "device_kind", None) == _native.FILL_USER else None
         reward_code = reward.device_code() if getattr(reward, "device_kind", None) == _native.REW_USER else None
-        if fill_code is None and reward_code is None:
+        arrival_code = arrival.device_code() if getattr(arrival, "device_kind", None) == _native.ARR_USER else None
+        if fill_code is None and reward_code is None and arrival_code is None:
             return None
-        return _native.user_code(fill_code, reward_code)
+        return _native.user_code(fill_code, reward_code, arrival_code)
 
     def check_device_expressions(self):
         """Compile the user-defined plugins' device expressions without creating anything (needs no GPU); raises

@@ -28,6 +28,41 @@ class ArrivalModel(StochasticProcessModel):
 _EMPTY = np.array([[]])
 
 
+class DeviceExpressionArrivalModel(ArrivalModel):
+    """The device route for USER-DEFINED, stateless arrival models (the reference's plugin contract, ARR:9-29).
+
+    The reference asks a subclass for `get_arrivals()` in NumPy; there is no CPU path here to run NumPy code in the step,
+    so a subclass states the probability of an arrival within one step as a C++ device expression in `t` (the time stamp of
+    the observation the agent acted on), `side` (0: a sell order arriving at the bid, 1: a buy order at the ask), `dt` (this
+    model's step size) and its own named parameters:
+
+        class SeasonalArrivals(DeviceExpressionArrivalModel):        # a U-shaped intensity profile over the trading day
+            device_expression = "(side == 0 ? base_bid : base_ask) * (1.0 + amplitude * cos(6.283185307179586 * t / period)) * dt"
+            def device_expression_params(self):
+                return {"base_bid": ..., "base_ask": ..., "amplitude": ..., "period": ...}
+
+    An arrival happens when the lane's uniform u < expression, compared in double.  The model adds no state columns (what it
+    needs of the past it must get from `t`); self-exciting models are `HawkesArrivalModel`.  Compiled into the step and rollout
+    kernels at run time (include/mbt_env.h, mbt_env_create_jit)."""
+
+    device_kind = _native.ARR_USER
+    device_expression: str = None
+
+    def __init__(self, step_size: float = 0.001, num_trajectories: int = 1, seed: Optional[int] = None):
+        if not self.device_expression:
+            raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of get_arrivals)")
+        super().__init__(_EMPTY, _EMPTY, step_size, 0.0, _EMPTY, num_trajectories, seed)
+
+    def device_expression_params(self) -> dict:
+        return {}
+
+    def device_params(self):
+        return dict(arrival_kind=self.device_kind, arrival_step_size=self.step_size)
+
+    def device_code(self):
+        return self.device_expression, dict(self.device_expression_params())
+
+
 class PoissonArrivalModel(ArrivalModel):
     device_kind = _native.ARR_POISSON
 

@@ -64,7 +64,11 @@ class OracleConfig:
     ou_speed: float = 1.0  # mean_reversion_speed MID:118
     jump_size: float = 1.0  # MID:199 / MID:240: the midprice moves by +-jump_size on the agent's own fills
     # arrivals: "poisson" (ARR:32-56), "poisson_nonlinear" (ARR:59-83), "hawkes" (ARR:86-126), "none" (speed dynamics)
+    # "user_seasonal": a USER-DEFINED stateless ArrivalModel subclass (plugin contract ARR:9-29) with a time-of-day profile:
+    #   p_side(t) = intensity_side (1 + seasonal_amplitude cos(2 pi t / seasonal_period)) dt, t = the time before the step
     arrival: str = "poisson"
+    seasonal_amplitude: float = 0.0
+    seasonal_period: float = 1.0
     intensity: Sequence[float] = (140.0, 140.0)  # Poisson rate / Hawkes baseline (bid, ask)
     hawkes_jump: float = 40.0
     hawkes_speed: float = 60.0
@@ -391,6 +395,9 @@ class OracleEnv:
                 arrivals = u_arr < np.array(cfg.intensity) * adt
             elif cfg.arrival == "poisson_nonlinear":
                 arrivals = u_arr < 1.0 - np.exp(-np.array(cfg.intensity) * adt)
+            elif cfg.arrival == "user_seasonal":  # the user's get_arrivals: the profile at the CURRENT time (the state's, before TE:216)
+                t_now = prev[0, TIME]
+                arrivals = u_arr < np.array(cfg.intensity) * (1.0 + cfg.seasonal_amplitude * np.cos(2 * np.pi * t_now / cfg.seasonal_period)) * adt
             else:
                 arrivals = u_arr < st[:, 4:6] * adt
             depths = action[:, 0:2]  # MD:50-51

@@ -45,6 +45,8 @@ def make_env(cfg, noise="philox", **overrides):
         "hawkes": lambda: arr_m.HawkesArrivalModel(baseline_arrival_rate=np.array([list(cfg.intensity)]), step_size=arr_dt, jump_size=cfg.hawkes_jump,
                                                    mean_reversion_speed=cfg.hawkes_speed, terminal_time=T, num_trajectories=n),
         "none": lambda: None,
+        "user_seasonal": lambda: __import__("tests.user_plugins", fromlist=["x"]).SeasonalArrivals(
+            base=cfg.intensity, amplitude=cfg.seasonal_amplitude, period=cfg.seasonal_period, step_size=arr_dt, num_trajectories=n),
     }[cfg.arrival]()
     if cfg.fill == "exogenous":  # any two one-dimensional processes with these initial states and bounds (FILL:146-154)
         best = [_FixedBoundsProcess(cfg.exo_depth[s], cfg.exo_depth_lo[s], cfg.exo_depth_hi[s], dt, n) for s in range(2)]

@@ -36,6 +36,8 @@ def test_device_expressions_compile_without_a_gpu(no_device):
         ExponentialInventoryCost.device_expression = good
     built_in = make_env(_cfg(64, fill="exponential", reward="pnl"))
     built_in.check_device_expressions()  # nothing to compile: a no-op
+    all_three = make_env(_cfg(64, arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5))
+    all_three.check_device_expressions()  # a user arrival model, fill model and reward in one kernel
 
 
 def test_a_plugin_class_without_a_device_form_is_refused(no_device):
@@ -65,7 +67,10 @@ def test_a_plugin_class_without_a_device_form_is_refused(no_device):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(), dict(dynamics="limit_and_market", market_half_spread=0.4, arrival="hawkes", intensity=(15.0, 10.0), hawkes_speed=20.0),
-                                dict(fill="exponential"), dict(reward="running")])
+                                dict(fill="exponential"), dict(reward="running"),
+                                dict(arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5),
+                                dict(arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5, fill="exponential", reward="pnl",
+                                     dynamics="touch", market_half_spread=0.25)])
 def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw):
     from mbt_gym_amd import _native
 
@@ -74,6 +79,8 @@ def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw)
     steps = cfg.n_steps
     a_dim = 4 if cfg.dynamics == "limit_and_market" else 2
     action = np.tile(np.array([[0.3, 0.5, 0.0, 1.0][:a_dim]], np.float32), (n, 1))
+    if cfg.dynamics == "touch":
+        action = np.tile(np.array([[1.0, 1.0]], np.float32), (n, 1))  # post on both sides
     env, fused = make_env(cfg), make_env(cfg)
     draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
     oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))

@@ -668,6 +668,43 @@ def user_plugin_cases():
              seed=62, **both),
         normalised=True)
 
+    # X. a user-defined, stateless ArrivalModel: a time-of-day intensity profile.  The reference hands the state matrix to
+    #    update() (TE:206-211), which is where a plugin written against its API learns the time
+    from mbt_gym.stochastic_processes.arrival_models import ArrivalModel
+
+    class UserSeasonalArrivals(ArrivalModel):
+        def __init__(self, base, amplitude, period, step_size, num_trajectories, seed=None):
+            self.base, self.amplitude, self.period, self.time = np.array(base, dtype=float), amplitude, period, 0.0
+            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
+                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
+
+        def reset(self):
+            super().reset()
+            self.time = 0.0
+
+        def update(self, arrivals, fills, actions, state=None):
+            self.time = state[0, TIME_INDEX]
+
+        def get_arrivals(self):
+            unif = self.rng.uniform(size=(self.num_trajectories, 2))
+            return unif < self.base * (1.0 + self.amplitude * np.cos(2 * np.pi * self.time / self.period)) * self.step_size
+
+    n, ns = 32, 100
+    run_case(
+        "user_seasonal_arrivals",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=64, initial_inventory=0, max_inventory=6, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.02, 0.05),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(volatility=1.5, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                UserSeasonalArrivals([40.0, 30.0], 0.8, 0.5, step_size=1 / ns, num_trajectories=n)),
+            **common),
+        ns, n, 2, 64,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", volatility=1.5, initial_price=100.0, arrival="user_seasonal", intensity=[40.0, 30.0],
+             seasonal_amplitude=0.8, seasonal_period=0.5, fill_exponent=1.5, dynamics="limit", reward="running", phi=0.02, alpha=0.05,
+             initial_inventory=0, max_inventory=6, seed=64, **common))
+
     # W. user reward with the built-in exponential fill, at the touch
     n, ns = 24, 60
     run_case(
