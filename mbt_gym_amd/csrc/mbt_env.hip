@@ -486,7 +486,7 @@ LearnedRolloutKernel pick_learned_rollout(const mbt_config& c) {
   return market ? pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(brownian_pnl) : pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimit>(brownian_pnl);
 }
 
-// Device image of a learned policy: [w1: 4 x 64 half4 | w2: 16 x 64 half4 | w3: 4 x 64 half4 | b2: 64 f32 | b3: 16 f32 | lin_w: 32 f32 | lin_b: 4 f32]
+// Device image of a learned policy: [w1: 4 x 64 half4 | w2: 8 x 64 half8 | w3: 2 x 64 half8 | b2: 64 f32 | b3: 16 f32 | lin_w: 32 f32 | lin_b: 4 f32]
 constexpr size_t kLearnedW1 = 0, kLearnedW2 = kLearnedW1 + 4 * 64 * 8, kLearnedW3 = kLearnedW2 + 16 * 64 * 8, kLearnedB2 = kLearnedW3 + 4 * 64 * 8,
                  kLearnedB3 = kLearnedB2 + 64 * 4, kLearnedLinW = kLearnedB3 + 16 * 4, kLearnedLinB = kLearnedLinW + 32 * 4,
                  kLearnedBytes = kLearnedLinB + 4 * 4;
@@ -535,15 +535,17 @@ int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPol
     _Float16* f1 = reinterpret_cast<_Float16*>(image.data() + kLearnedW1);
     _Float16* f2 = reinterpret_cast<_Float16*>(image.data() + kLearnedW2);
     _Float16* f3 = reinterpret_cast<_Float16*>(image.data() + kLearnedW3);
-    for (int lane = 0; lane < 64; ++lane)
-      for (int j = 0; j < 4; ++j) {
-        const int row = lane % 16, k = 4 * (lane / 16) + j;
-        for (int mt = 0; mt < 4; ++mt) {
-          f1[(mt * 64 + lane) * 4 + j] = static_cast<_Float16>(w1p(16 * mt + row, k));
-          f3[(mt * 64 + lane) * 4 + j] = static_cast<_Float16>(w3p(row, 16 * mt + k));  // (mt plays the K-chunk here)
-          for (int kc = 0; kc < 4; ++kc) f2[((mt * 4 + kc) * 64 + lane) * 4 + j] = static_cast<_Float16>(w2p(16 * mt + row, 16 * kc + k));
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = lane % 16, group = lane / 16;
+      for (int mt = 0; mt < 4; ++mt)
+        for (int j = 0; j < 4; ++j) f1[(mt * 64 + lane) * 4 + j] = static_cast<_Float16>(w1p(16 * mt + row, 4 * group + j));
+      for (int c = 0; c < 2; ++c)      // K = 32 operands: elements 0..3 from 16-feature chunk 2c, 4..7 from chunk 2c + 1
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * (2 * c + j / 4) + 4 * group + j % 4;
+          f3[(c * 64 + lane) * 8 + j] = static_cast<_Float16>(w3p(row, k));
+          for (int mt = 0; mt < 4; ++mt) f2[((mt * 2 + c) * 64 + lane) * 8 + j] = static_cast<_Float16>(w2p(16 * mt + row, k));
         }
-      }
+    }
     float* pb2 = reinterpret_cast<float*>(image.data() + kLearnedB2);
     float* pb3 = reinterpret_cast<float*>(image.data() + kLearnedB3);
     for (int m = 0; m < H; ++m) pb2[m] = b2[m];
@@ -557,8 +559,8 @@ int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPol
     e->learned_host.swap(image);
   }
   LP.w.w1 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW1);
-  LP.w.w2 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW2);
-  LP.w.w3 = reinterpret_cast<const mbt::half4_t*>(e->learned_dev + kLearnedW3);
+  LP.w.w2 = reinterpret_cast<const mbt::half8_t*>(e->learned_dev + kLearnedW2);
+  LP.w.w3 = reinterpret_cast<const mbt::half8_t*>(e->learned_dev + kLearnedW3);
   LP.w.b2 = reinterpret_cast<const float*>(e->learned_dev + kLearnedB2);
   LP.w.b3 = reinterpret_cast<const float*>(e->learned_dev + kLearnedB3);
   LP.w.lin_w = reinterpret_cast<const float*>(e->learned_dev + kLearnedLinW);

@@ -35,14 +35,16 @@ constexpr int kMlpRowsPerWave = 128;        // 64 threads x 2 lanes
 enum : int { kActTanh = 0, kActRelu = 1 };
 
 // What the host uploads (mbt_env.hip: pack_mlp): fragments in MFMA A-operand order, one 8-byte entry per lane.
-//   w1[mt][lane]      W1p[16 mt + lane % 16][4 (lane / 16) + j]            W1p = [W1 | b1 | 0]  (64 x 16)
-//   w2[mt][kc][lane]  W2 [16 mt + lane % 16][16 kc + 4 (lane / 16) + j]                        (64 x 64)
-//   w3[kc][lane]      W3p[lane % 16][16 kc + 4 (lane / 16) + j]           W3p = rows >= A zero (16 x 64)
+//   w1[mt][lane]      4 halfs: W1p[16 mt + lane % 16][4 (lane / 16) + j]          W1p = [W1 | b1 | 0]  (64 x 16), K = 16 form
+//   w2[mt][c][lane]   8 halfs: W2 [16 mt + lane % 16][16 (2c + j / 4) + 4 (lane / 16) + j % 4]      (64 x 64), K = 32 form
+//   w3[c][lane]       8 halfs: W3p[lane % 16][16 (2c + j / 4) + 4 (lane / 16) + j % 4]    W3p = rows >= A zero (16 x 64)
 //   b2[64], b3[16] float32; linear policies: lin_w[A][8], lin_b[4] float32
+// (8-half entries are the operands of the K = 32 instruction as they are: two 16-feature chunks side by side, see `pair`)
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 struct MlpDeviceWeights {
   const half4_t* w1;   // [4][64]
-  const half4_t* w2;   // [4][4][64]
-  const half4_t* w3;   // [4][64]
+  const half8_t* w2;   // [4][2][64]
+  const half8_t* w3;   // [2][64]
   const float* b2;     // [64]
   const float* b3;     // [16]
   const float* lin_w;  // [4][8]  (linear policy)
@@ -60,8 +62,8 @@ struct LearnedPolicyParams {
 // the weights of one wave, in registers
 struct MlpRegisters {
   half4_t w1[kMlpTiles];
-  half4_t w2[kMlpTiles][kMlpTiles];
-  half4_t w3[kMlpTiles];
+  half8_t w2[kMlpTiles][kMlpTiles / 2];
+  half8_t w3[kMlpTiles / 2];
   acc4_t b2[kMlpTiles];
   acc4_t b3;
 };
@@ -72,9 +74,9 @@ __device__ __forceinline__ MlpRegisters load_mlp(const MlpDeviceWeights& w) {
 #pragma unroll
   for (int mt = 0; mt < kMlpTiles; ++mt) {
     r.w1[mt] = w.w1[mt * 64 + lane];
-    r.w3[mt] = w.w3[mt * 64 + lane];
+    if (mt < kMlpTiles / 2) r.w3[mt] = w.w3[mt * 64 + lane];
 #pragma unroll
-    for (int kc = 0; kc < kMlpTiles; ++kc) r.w2[mt][kc] = w.w2[(mt * kMlpTiles + kc) * 64 + lane];
+    for (int c = 0; c < kMlpTiles / 2; ++c) r.w2[mt][c] = w.w2[(mt * (kMlpTiles / 2) + c) * 64 + lane];
     const float* b = w.b2 + 16 * mt + 4 * (lane >> 4);  // accumulator rows of this lane: 4 (lane / 16) + r
     r.b2[mt] = acc4_t{b[0], b[1], b[2], b[3]};
   }
@@ -91,19 +93,19 @@ __device__ __forceinline__ float activate(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// Two accumulator tiles (features 16 (2c) .. and 16 (2c + 1) ..) -> activation -> ONE 8-half operand of the K = 32 instruction.
 template <int ACT>
-__device__ __forceinline__ half4_t activate_to_half(acc4_t v) {
-  return half4_t{static_cast<_Float16>(activate<ACT>(v.x)), static_cast<_Float16>(activate<ACT>(v.y)),
-                 static_cast<_Float16>(activate<ACT>(v.z)), static_cast<_Float16>(activate<ACT>(v.w))};
+__device__ __forceinline__ half8_t activate_pair(acc4_t lo, acc4_t hi) {
+  return half8_t{static_cast<_Float16>(activate<ACT>(lo.x)), static_cast<_Float16>(activate<ACT>(lo.y)), static_cast<_Float16>(activate<ACT>(lo.z)),
+                 static_cast<_Float16>(activate<ACT>(lo.w)), static_cast<_Float16>(activate<ACT>(hi.x)), static_cast<_Float16>(activate<ACT>(hi.y)),
+                 static_cast<_Float16>(activate<ACT>(hi.z)), static_cast<_Float16>(activate<ACT>(hi.w))};
 }
 
 // Two 16-feature fragments side by side = the 8-element operand of the K = 32 instruction.  The hardware pairs element
 // (lane group g = lane / 16, j) of A with element (g, j) of B, whatever k those stand for - so as long as the weight
-// fragment is assembled the same way (elements 0..3 from K-chunk 2c, 4..7 from chunk 2c + 1, both at 4 g + j), the
-// accumulator layout of the previous layer still IS the operand layout of this one, and the hidden layers run on
-// v_mfma_f32_16x16x32_f16 at twice the rate of the K = 16 form.
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ half8_t join(half4_t lo, half4_t hi) { return half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}; }
+// fragment is assembled the same way (elements 0..3 from K-chunk 2c, 4..7 from chunk 2c + 1, both at 4 g + j; the host
+// packs them so), the accumulator layout of the previous layer still IS the operand layout of this one, and the hidden
+// layers run on v_mfma_f32_16x16x32_f16 at twice the rate of the K = 16 form.
 
 // LDS scratch of one wave: 128 observation rows of 16 halfs (features, the constant one, zeros) + 128 action rows of 4 floats
 constexpr int kMlpLdsBytesPerWave = kMlpRowsPerWave * (kMlpInPad * 2 + 16);
@@ -137,23 +139,18 @@ __device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, cons
   for (int t = 0; t < kMlpRowsPerWave / 16; ++t) {
     // B operand of layer 1: k = 4 (lane / 16) + j of row n = lane % 16
     const half4_t x = *reinterpret_cast<const half4_t*>(x_rows + (16 * t + (lane & 15)) * kMlpInPad + 4 * (lane >> 4));
-    half4_t h1[kMlpTiles], h2[kMlpTiles];
+    acc4_t a1[kMlpTiles], a2[kMlpTiles];
+#pragma unroll
+    for (int mt = 0; mt < kMlpTiles; ++mt) a1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(W.w1[mt], x, acc4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const half8_t h1_lo = activate_pair<ACT>(a1[0], a1[1]), h1_hi = activate_pair<ACT>(a1[2], a1[3]);
 #pragma unroll
     for (int mt = 0; mt < kMlpTiles; ++mt) {
-      const acc4_t a = __builtin_amdgcn_mfma_f32_16x16x16f16(W.w1[mt], x, acc4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      h1[mt] = activate_to_half<ACT>(a);
+      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w2[mt][0], h1_lo, W.b2[mt], 0, 0, 0);
+      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w2[mt][1], h1_hi, a2[mt], 0, 0, 0);
     }
-    const half8_t h1_lo = join(h1[0], h1[1]), h1_hi = join(h1[2], h1[3]);
-#pragma unroll
-    for (int mt = 0; mt < kMlpTiles; ++mt) {
-      acc4_t a = W.b2[mt];
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w2[mt][0], W.w2[mt][1]), h1_lo, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w2[mt][2], W.w2[mt][3]), h1_hi, a, 0, 0, 0);
-      h2[mt] = activate_to_half<ACT>(a);
-    }
-    acc4_t out = W.b3;
-    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w3[0], W.w3[1]), join(h2[0], h2[1]), out, 0, 0, 0);
-    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(join(W.w3[2], W.w3[3]), join(h2[2], h2[3]), out, 0, 0, 0);
+    const half8_t h2_lo = activate_pair<ACT>(a2[0], a2[1]), h2_hi = activate_pair<ACT>(a2[2], a2[3]);
+    acc4_t out = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w3[0], h2_lo, W.b3, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w3[1], h2_hi, out, 0, 0, 0);
     // lanes 0..15 hold output rows 0..3 (= the action components) of batch row 16 t + lane
     if (lane < 16) *reinterpret_cast<acc4_t*>(a_rows + (16 * t + lane) * 4) = out;
   }
