@@ -93,3 +93,41 @@ def test_precise_state_refusals():
     cfg, _ = load_case("exo_fill_bm_poisson")
     with pytest.raises(NativeError, match="precise_state"):
         make_env(cfg, precise_state=True)
+
+
+@pytest.mark.timeout(600)
+def test_config4_at_2_to_21_lanes_every_reward_within_1e5_with_precise_state():
+    """BASELINE configs[4]'s dynamics at its per-GPU size (2^21 lanes), inventory limit tight enough that the clip of TE:283-289
+    fires on ~10 % of lane-steps: with precise_state EVERY lane-step's reward is within north_star's 1e-5 of the float64
+    oracle (fed the kernel's own Philox draws), inventory is exact, and observations are the nearest float32 of the oracle's
+    state - where the float32 tier is allowed 1.2e-4 on the clipped lane-steps."""
+    from mbt_gym_amd import _native
+    from oracle.mbt_oracle import OracleConfig
+
+    n, steps, seed = 1 << 21, 12, 77
+    cfg = OracleConfig(num_trajectories=n, n_steps=1000, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                       intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit_and_market", market_half_spread=0.5, reward="running", phi=0.01,
+                       alpha=0.1, initial_inventory=9, max_inventory=10, seed=seed, normalise_action_space=False, normalise_observation_space=False)
+    rng = np.random.default_rng(5)
+    env = make_env(cfg, precise_state=True)
+    draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    env.reset(), oracle.reset()
+    clipped_total, worst = 0, 0.0
+    for k in range(steps):
+        action = np.empty((n, 4), np.float32)
+        action[:, :2] = rng.uniform(0.2, 1.2, size=(n, 2))
+        action[:, 2] = rng.uniform(size=n) < 0.15  # market buys push the inventory over the limit
+        action[:, 3] = rng.uniform(size=n) < 0.05
+        obs, rew, _, _ = env.step(action)
+        o_obs, o_rew, _ = oracle.step(action.astype(np.float64))
+        clipped_total += int(oracle.last_clipped.sum())
+        err = np.abs(rew - o_rew)
+        worst = max(worst, float(err.max()))
+        assert np.all(err <= 1e-5 + HALF_ULP * np.abs(o_rew)), f"step {k}: reward off by {err.max()}"
+        np.testing.assert_array_equal(obs[:, 1], o_obs[:, 1], err_msg=f"step {k}: inventory")
+        for col in (0, 3):
+            assert np.all(np.abs(obs[:, col] - o_obs[:, col]) <= 1.001 * HALF_ULP * np.abs(o_obs[:, col]) + 1e-9), f"step {k}: column {col}"
+    assert clipped_total > n * steps // 50, "the configuration must actually clip"
+    assert env.clip_count == clipped_total
+    env.close()
