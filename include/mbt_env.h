@@ -352,8 +352,8 @@ int mbt_env_return_sums_begin(mbt_env* env);
 int mbt_env_return_sums_end(mbt_env* env, double sums[3]);
 /* Episode log of mbt_env_step_many_device(auto_reset): pops the OLDEST finished episode's [sum R, sum R^2, lanes] (global
  * over all ranks when a communicator is set).  Returns 1 and fills sums if one was popped, 0 if the log is empty - or,
- * with wait == 0, if the oldest entry's reduction has not completed yet.  At most 16 episodes are kept in flight; a
- * 17th waits for the oldest. */
+ * with wait == 0, if the oldest entry's reduction has not completed yet.  The log holds the 16 most recent episodes: when
+ * a 17th ends before the oldest has been popped, the library waits for the oldest entry's reduction and DROPS it. */
 int mbt_env_episode_log_pop(mbt_env* env, double sums[3], int32_t wait);
 
 /* ---- multi-GPU: the trajectory axis is sharded, one handle per GPU; this is the ONLY collective on the path -------
