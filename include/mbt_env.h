@@ -54,7 +54,8 @@ enum {
    *        + jump_size * (ask fills - bid fills)
    * e.g. CEV-free local-volatility mixtures, drifting OU, GBM with trade impact.  The built-in kinds are the rows
    * (1,0,theta=0) BM, (1,0,theta) OU [drift forced to 0], (0,1) GBM, +jump_size for the jump variants, (0,0) constant. */
-  MBT_MID_LINEAR_SDE = 6
+  MBT_MID_LINEAR_SDE = 6,
+  MBT_MID_USER = 7 /* a user-defined one-column MidpriceModel subclass (SP:8-53) with an arbitrary increment: mbt_env_create_jit only */
 };
 enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
@@ -183,6 +184,12 @@ void mbt_env_destroy(mbt_env* env);
  *                      MBT_FILL_USER: an expression of type double in `depth` (double: the de-normalised quote depth),
  *                      `side` (int: 0 bid, 1 ask) and the named parameters.  A fill happens when u < expression, with
  *                      u the lane's uniform, compared in double.
+ *   midprice_increment replaces MidpriceModel.update (MID:60-65 and its siblings) when cfg.midprice_kind == MBT_MID_USER: an
+ *                      expression of type double for S' - S in `S` (the midprice before the step), `t` (the time at the
+ *                      beginning of the step), `z` (this lane's standard normal draw), `dt` (the midprice model's step
+ *                      size), `fills_bid`, `fills_ask` (1.0 where the agent's bid / ask quote was filled this step,
+ *                      MID:220-221) and the named parameters - e.g. CEV: "mu * S * dt + sigma * pow(S, gamma) * sqrt(dt) * z".
+ *                      One state column, one normal per step; evaluated in double, the state itself is float32.
  *   arrival_probability replaces ArrivalModel.get_arrivals (ARR:27-29) when cfg.arrival_kind == MBT_ARR_USER: an expression
  *                      of type double in `t` (double: the time at the BEGINNING of the step, i.e. the time stamp of the
  *                      observation the agent acted on), `side` (0 = a sell order arriving at the bid, 1 = a buy order at
@@ -208,6 +215,9 @@ typedef struct mbt_user_code {
   const char* arrival_probability; /* NULL unless cfg.arrival_kind == MBT_ARR_USER */
   const char* arrival_param_names;
   double arrival_params[8];
+  const char* midprice_increment;  /* NULL unless cfg.midprice_kind == MBT_MID_USER */
+  const char* midprice_param_names;
+  double midprice_params[8];
 } mbt_user_code;
 int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out);
 const char* mbt_jit_log(void);    /* thread local; "" when the last compilation had nothing to say */

@@ -11,7 +11,7 @@ import numpy as np
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
 ABI_VERSION = 4
 
-MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE = 0, 1, 2, 3, 4, 5, 6
+MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER = 0, 1, 2, 3, 4, 5, 6, 7
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER = 0, 1, 2, 3, 4
 FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER = 0, 1, 2, 3
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
@@ -59,19 +59,20 @@ class MbtUserCode(C.Structure):
 
     _fields_ = [("fill_probability", C.c_char_p), ("fill_param_names", C.c_char_p), ("fill_params", C.c_double * 8),
                 ("reward", C.c_char_p), ("reward_param_names", C.c_char_p), ("reward_params", C.c_double * 8),
-                ("arrival_probability", C.c_char_p), ("arrival_param_names", C.c_char_p), ("arrival_params", C.c_double * 8)]
+                ("arrival_probability", C.c_char_p), ("arrival_param_names", C.c_char_p), ("arrival_params", C.c_double * 8),
+                ("midprice_increment", C.c_char_p), ("midprice_param_names", C.c_char_p), ("midprice_params", C.c_double * 8)]
 
 
-def user_code(fill=None, reward=None, arrival=None) -> MbtUserCode:
+def user_code(fill=None, reward=None, arrival=None, midprice=None) -> MbtUserCode:
     """(expression, {name: value}) pairs -> struct mbt_user_code."""
     code = MbtUserCode()
-    for prefix, part in (("fill", fill), ("reward", reward), ("arrival", arrival)):
+    for prefix, part in (("fill", fill), ("reward", reward), ("arrival", arrival), ("midprice", midprice)):
         if part is None:
             continue
         expression, params = part
         if len(params) > 8:
             raise ValueError("a device expression takes at most 8 parameters")
-        setattr(code, {"fill": "fill_probability", "reward": "reward", "arrival": "arrival_probability"}[prefix], expression.encode())
+        setattr(code, {"fill": "fill_probability", "reward": "reward", "arrival": "arrival_probability", "midprice": "midprice_increment"}[prefix], expression.encode())
         setattr(code, prefix + "_param_names", ",".join(params).encode())
         for j, value in enumerate(params.values()):
             getattr(code, prefix + "_params")[j] = float(value)

@@ -258,7 +258,7 @@ struct mbt_env {
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
   hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
-  double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {};  // parameters of the user's device expressions
+  double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {}, user_mid_p[8] = {};  // parameters of the user's device expressions
   char* learned_dev = nullptr;                               // packed weights of a learned policy (policy_mlp.hpp), device
   std::vector<char> learned_host;                            // what learned_dev holds (re-uploaded only when the policy changes)
   uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
@@ -285,15 +285,18 @@ void fill_static_params(mbt_env* e) {
   P.n = e->n;
   P.n_pairs = e->n_pairs;
   P.pair_offset = c.trajectory_offset >> 1;
+  P.mid_dt_f64 = e->mid_dt;
   for (int j = 0; j < 8; ++j) {
     P.user_fill_p[j] = e->user_fill_p[j];
     P.user_reward_p[j] = e->user_reward_p[j];
     P.user_arrival_p[j] = e->user_arrival_p[j];
+    P.user_mid_p[j] = e->user_mid_p[j];
   }
   P.dt = static_cast<float>(e->dt);
   // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
   const int mk = c.midprice_kind;
   const bool sde = mk == MBT_MID_LINEAR_SDE;  // the family itself: every coefficient comes from the caller
+  // (MBT_MID_USER: the run-time compiled kernel replaces the increment; the coefficients below are then unused)
   const bool ou = mk == MBT_MID_OU || mk == MBT_MID_OU_JUMP, jump = mk == MBT_MID_BROWNIAN_JUMP || mk == MBT_MID_OU_JUMP;
   P.mid_add = sde ? static_cast<float>(c.mid_coef_add) : (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0f : 1.0f;
   P.mid_mul = sde ? static_cast<float>(c.mid_coef_mul) : mk == MBT_MID_GBM ? 1.0f : 0.0f;
@@ -887,7 +890,9 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
 // The translation unit: the library's own kernel source with the user's functions and ONE instantiation.
 int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER, user_arrival = c.arrival_kind == MBT_ARR_USER;
-  std::string fill_decl, reward_decl, arrival_decl;
+  const bool user_mid = c.midprice_kind == MBT_MID_USER;
+  std::string fill_decl, reward_decl, arrival_decl, mid_decl;
+  if (int rc_mid = param_declarations(u.midprice_param_names, mid_decl); rc_mid != MBT_OK) return rc_mid;
   int rc = param_declarations(u.fill_param_names, fill_decl);
   if (rc != MBT_OK) return rc;
   rc = param_declarations(u.reward_param_names, reward_decl);
@@ -908,9 +913,12 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "  (void)a3; (void)pnl; (void)dt; (void)is_terminal; (void)q0; (void)episode_length; (void)p;\n" +
          reward_decl + "  return static_cast<double>(" + std::string(user_reward ? u.reward : "0.0") + ");\n}\n";
   src += "__device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p) {\n  (void)t; (void)side; (void)dt; (void)p;\n" + arrival_decl +
-         "  return static_cast<double>(" + std::string(user_arrival ? u.arrival_probability : "0.0") + ");\n}\n}  // namespace mbt\n";
+         "  return static_cast<double>(" + std::string(user_arrival ? u.arrival_probability : "0.0") + ");\n}\n";
+  src += "__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const double* p) {\n"
+         "  (void)S; (void)t; (void)z; (void)dt; (void)fills_bid; (void)fills_ask; (void)p;\n" + mid_decl +
+         "  return static_cast<double>(" + std::string(user_mid ? u.midprice_increment : "0.0") + ");\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ">;\n";
+         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
@@ -1038,7 +1046,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   *out = nullptr;
   const bool user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
-  const bool needs_jit = user_fill || user_reward || user_arrival;
+  const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
+  const bool needs_jit = user_fill || user_reward || user_arrival || user_mid;
+  if (user_mid && (code == nullptr || code->midprice_increment == nullptr || code->midprice_increment[0] == 0))
+    return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression (mbt_env_create_jit)");
   if (needs_jit && code == nullptr)
     return fail(MBT_ERR_INVALID, "user-defined plugin kinds (MBT_ARR_USER / MBT_FILL_USER / MBT_REW_USER) need their device expressions: use mbt_env_create_jit");
   if (user_arrival && (code->arrival_probability == nullptr || code->arrival_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_ARR_USER without an arrival_probability expression");
@@ -1056,7 +1067,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
   if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
   const bool speed = cfg->dynamics_kind == MBT_DYN_SPEED;
-  if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_LINEAR_SDE)
+  if (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_USER)
     return fail(MBT_ERR_INVALID, "midprice kind %d has no device implementation", cfg->midprice_kind);
   if (cfg->reward_terminal_time != 0.0 && !(cfg->reward_terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "reward_terminal_time must be positive (or 0 = terminal_time)");
   if (cfg->dynamics_kind < MBT_DYN_LIMIT || cfg->dynamics_kind > MBT_DYN_SPEED)
@@ -1072,6 +1083,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
         (cfg->midprice_kind == MBT_MID_LINEAR_SDE && cfg->jump_size != 0.0))
       return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
     if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state applies to order-book dynamics");
+    if (cfg->midprice_kind == MBT_MID_USER) return fail(MBT_ERR_INVALID, "user-defined midprice expressions run on the order-book kernels");
     if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
       return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
   } else {
@@ -1132,6 +1144,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
       e->user_fill_p[j] = code->fill_params[j];
       e->user_reward_p[j] = code->reward_params[j];
       e->user_arrival_p[j] = code->arrival_params[j];
+      e->user_mid_p[j] = code->midprice_params[j];
     }
     std::string source;
     JitKernels kernels;
@@ -1241,7 +1254,9 @@ const char* mbt_jit_log(void) { return g_jit_log.c_str(); }
 int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   if (cfg == nullptr || code == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER, user_arrival = cfg->arrival_kind == MBT_ARR_USER;
-  if (!user_fill && !user_reward && !user_arrival) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
+  const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
+  if (!user_fill && !user_reward && !user_arrival && !user_mid) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
+  if (user_mid && (code->midprice_increment == nullptr || code->midprice_increment[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression");
   if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
   if (user_arrival && (code->arrival_probability == nullptr || code->arrival_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_ARR_USER without an arrival_probability expression");

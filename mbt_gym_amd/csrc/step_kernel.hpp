@@ -57,7 +57,7 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
-          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false>
+          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -80,6 +80,7 @@ struct Variant {
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
   static constexpr bool USER_FILL = USER_FILL_, USER_REWARD = USER_REWARD_;
+  static constexpr bool USER_MID = USER_MID_;  // MidpriceModel.update as an expression for S' - S (one column, one normal per step)
   static constexpr bool USER_ARRIVAL = USER_ARRIVAL_;  // a stateless ArrivalModel.get_arrivals (ARR:27-29) as an expression of time
   static_assert(!(USER_ARRIVAL_ && ARR_ == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (no state columns)");
   static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
@@ -147,7 +148,8 @@ struct StepParams {
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
   PreciseParams X;
-  double user_fill_p[8], user_reward_p[8], user_arrival_p[8];  // parameters of the user's device expressions (mbt_user_code)
+  double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8];  // parameters of the user's device expressions (mbt_user_code)
+  double mid_dt_f64;  // the midprice model's own step size (SP:21), for a user midprice expression
   double t_now;  // the clock BEFORE this step (TE:216 accumulates it in double on the host): what a user arrival model sees
 };
 
@@ -163,6 +165,7 @@ struct UserRewardArgs {
 };
 __device__ double mbt_user_reward(const UserRewardArgs& s, const double* p);
 __device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p);
+__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const double* p);
 #endif
 
 struct StepBuffers {
@@ -503,7 +506,12 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   r.clipped_c = dc_clip != 0.0f;
 
   // -- midprice, then the Hawkes intensities, which jump on arrivals, not on fills (ARR:110-119)
-  const float d_mid = V::BROWNIAN ? dr.dz : midprice_increment(mid, dr.dz, n_bid, n_ask, P);
+  float d_mid = V::BROWNIAN ? dr.dz : midprice_increment(mid, dr.dz, n_bid, n_ask, P);
+  if (V::USER_MID) {
+#ifdef MBT_JIT_USER_CODE
+    d_mid = static_cast<float>(mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, P.user_mid_p));
+#endif
+  }
   const float mid_new = mid + d_mid;
   r.lam = lam;
   if (V::ARR == kArrHawkes) {

@@ -238,9 +238,11 @@ class TradingEnvironment(_EnvBase):
         fill_code = fill.device_code() if getattr(fill, "device_kind", None) == _native.FILL_USER else None
         reward_code = reward.device_code() if getattr(reward, "device_kind", None) == _native.REW_USER else None
         arrival_code = arrival.device_code() if getattr(arrival, "device_kind", None) == _native.ARR_USER else None
-        if fill_code is None and reward_code is None and arrival_code is None:
+        mid = self.model_dynamics.midprice_model
+        mid_code = mid.device_code() if getattr(mid, "device_kind", None) == _native.MID_USER else None
+        if fill_code is None and reward_code is None and arrival_code is None and mid_code is None:
             return None
-        return _native.user_code(fill_code, reward_code, arrival_code)
+        return _native.user_code(fill_code, reward_code, arrival_code, mid_code)
 
     def check_device_expressions(self):
         """Compile the user-defined plugins' device expressions without creating anything (needs no GPU); raises

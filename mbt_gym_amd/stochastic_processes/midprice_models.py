@@ -242,3 +242,41 @@ class LinearSdeMidpriceModel(MidpriceModel):
         return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, mid_coef_add=self.scale_constant,
                     mid_coef_mul=self.scale_proportional, ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed,
                     jump_size=self.jump_size, initial_price=self.initial_price, midprice_step_size=self.step_size)
+
+
+class DeviceExpressionMidpriceModel(MidpriceModel):
+    """The device route for USER-DEFINED one-column midprice models whose increment is NOT of the linear-SDE form above: the
+    subclass states `update` (the reference's contract, SP:33-35) as a C++ device expression for S' - S in
+        S            the midprice before the step          t    the time at the beginning of the step
+        z            this lane's N(0, 1) draw of the step   dt   this model's step size
+        fills_bid, fills_ask   1.0 where the agent's bid / ask quote was filled this step (MID:220-221)
+    and its own named parameters (`device_expression_params()`, at most 8), e.g. a constant-elasticity-of-variance price
+
+        class CevMidprice(DeviceExpressionMidpriceModel):
+            device_expression = "mu * S * dt + sigma * pow(S, gamma) * sqrt(dt) * z"
+
+    (the reference's own CEV class adds shape-(N,) noise to an (N, 1) state and is unusable for N > 1, MID:402-409).
+    Evaluated in double inside the fused step / rollout kernels, compiled at run time (include/mbt_env.h,
+    mbt_env_create_jit); the state column itself is float32.  min_value / max_value are the observation bounds."""
+
+    device_kind = _native.MID_USER
+    device_expression: str = None
+
+    def __init__(self, initial_price: float = 100.0, min_value: float = 0.0, max_value: float = 200.0, terminal_time: float = 1.0,
+                 step_size: float = 0.01, num_trajectories: int = 1, seed: Optional[int] = None):
+        if not self.device_expression:
+            raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of update: S' - S)")
+        super().__init__(np.array([[min_value]]), np.array([[max_value]]), step_size, terminal_time, np.array([[initial_price]]), num_trajectories, seed)
+
+    @property
+    def initial_price(self) -> float:
+        return float(self.initial_state[0, 0])
+
+    def device_expression_params(self) -> dict:
+        return {}
+
+    def device_params(self):
+        return dict(midprice_kind=self.device_kind, initial_price=self.initial_price, midprice_step_size=self.step_size)
+
+    def device_code(self):
+        return self.device_expression, dict(self.device_expression_params())

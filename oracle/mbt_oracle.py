@@ -52,7 +52,10 @@ class OracleConfig:
     # "linear_sde": a USER-DEFINED MidpriceModel subclass (the plugin contract SP:8-53) of the form
     #   S <- S + (mid_coef_add + mid_coef_mul S) (drift dt + volatility sqrt(dt) Z) - ou_speed (S - ou_level) + jump terms
     # with its own observation bounds (midprice_lo, midprice_hi); the family every built-in midprice is a member of
+    # "user_cev": a USER-DEFINED MidpriceModel with a non-linear increment (constant elasticity of variance):
+    #   S <- S + drift S dt + volatility S^cev_gamma sqrt(dt) Z, bounds (midprice_lo, midprice_hi)
     midprice: str = "bm"
+    cev_gamma: float = 1.0
     mid_coef_add: float = 1.0
     mid_coef_mul: float = 0.0
     midprice_lo: Optional[float] = None
@@ -177,7 +180,7 @@ def midprice_bounds(cfg: OracleConfig) -> Tuple[float, float]:
         hi = cfg.initial_price * np.exp(cfg.drift * cfg.terminal_time) + 4 * stdev
     elif cfg.midprice == "constant":  # MID:21-23
         return float(cfg.initial_price), float(cfg.initial_price)
-    elif cfg.midprice == "linear_sde":  # the user's class states its own min_value / max_value (SP:11-12)
+    elif cfg.midprice in ("linear_sde", "user_cev"):  # the user's class states its own min_value / max_value (SP:11-12)
         return float(cfg.midprice_lo), float(cfg.midprice_hi)
     else:
         raise ValueError(cfg.midprice)
@@ -459,6 +462,8 @@ class OracleEnv:
         elif cfg.midprice == "linear_sde":  # user plugin: same structure as MID:222-227 / MID:264-270 with a state-dependent scale
             scale = cfg.mid_coef_add + cfg.mid_coef_mul * s_old
             s_new = s_old + scale * (cfg.drift * mdt * np.ones((n, 1)) + noise_term) - cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + jump
+        elif cfg.midprice == "user_cev":  # the user's update(): per-trajectory CEV (what MID:401-409 meant)
+            s_new = s_old + cfg.drift * s_old * mdt + cfg.volatility * s_old**cfg.cev_gamma * math.sqrt(mdt) * z
         else:  # constant, MID:32-33
             s_new = s_old
         st[:, PRICE] = s_new[:, 0]

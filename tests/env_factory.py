@@ -38,6 +38,9 @@ def make_env(cfg, noise="philox", **overrides):
             drift=cfg.drift, volatility=cfg.volatility, scale_constant=cfg.mid_coef_add, scale_proportional=cfg.mid_coef_mul,
             mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, jump_size=cfg.jump_size, initial_price=cfg.initial_price,
             min_value=cfg.midprice_lo, max_value=cfg.midprice_hi, **common),
+        "user_cev": lambda: __import__("tests.user_plugins", fromlist=["x"]).CevMidprice(
+            drift=cfg.drift, volatility=cfg.volatility, gamma=cfg.cev_gamma, initial_price=cfg.initial_price, min_value=cfg.midprice_lo,
+            max_value=cfg.midprice_hi, **common),
     }[cfg.midprice]()
     arr = {
         "poisson": lambda: arr_m.PoissonArrivalModel(intensity=np.array(cfg.intensity), step_size=arr_dt, num_trajectories=n),

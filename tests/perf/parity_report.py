@@ -63,6 +63,6 @@ for name in CASES:
 print("\n== precise_state=True (cash / midprice as float32 pairs, double arithmetic) ==")
 print(HEADER)
 for name in CASES:
-    if name.startswith(("speed_", "exo_fill", "user_fill", "user_reward", "user_seasonal")) or name.endswith("_speed"):
+    if name.startswith(("speed_", "exo_fill", "user_fill", "user_reward", "user_seasonal", "user_cev")) or name.endswith("_speed"):
         continue
     run(name, precise_state=True)

@@ -15,7 +15,7 @@ from tests.golden_io import CASES, load_case, step_size_changes
 
 pytestmark = pytest.mark.gpu
 
-ORDER_BOOK = [c for c in CASES if not (c.startswith("speed_") or c.endswith("_speed") or c.startswith("exo_fill") or c.startswith("user_fill") or c.startswith("user_reward") or c.startswith("user_seasonal"))]
+ORDER_BOOK = [c for c in CASES if not (c.startswith("speed_") or c.endswith("_speed") or c.startswith("exo_fill") or c.startswith("user_fill") or c.startswith("user_reward") or c.startswith("user_seasonal") or c.startswith("user_cev"))]
 HALF_ULP = 2.0 ** -24  # relative half-spacing of float32
 
 

@@ -24,7 +24,7 @@ def test_fixture_set_is_complete():
         "gbm_nonlinear_touch", "bmjump_exputility", "oujump_hawkes_running", "constant_midprice",
         "speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transient_pnl", "speed_transient_pnl",
         "step_size_change_hawkes", "step_size_change_speed", "user_linear_sde_midprice",
-        "user_fill_and_reward", "user_fill_hawkes_market_normalised", "user_reward_touch", "user_seasonal_arrivals",
+        "user_fill_and_reward", "user_fill_hawkes_market_normalised", "user_reward_touch", "user_seasonal_arrivals", "user_cev_midprice",
     }
 
 

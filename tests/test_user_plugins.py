@@ -70,7 +70,10 @@ def test_a_plugin_class_without_a_device_form_is_refused(no_device):
                                 dict(fill="exponential"), dict(reward="running"),
                                 dict(arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5),
                                 dict(arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5, fill="exponential", reward="pnl",
-                                     dynamics="touch", market_half_spread=0.25)])
+                                     dynamics="touch", market_half_spread=0.25),
+                                dict(midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0, midprice_hi=80.0),
+                                dict(midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0, midprice_hi=80.0,
+                                     fill="exponential", reward="pnl")])
 def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw):
     from mbt_gym_amd import _native
 

@@ -8,6 +8,7 @@ import numpy as np
 from mbt_gym_amd.rewards.RewardFunctions import DeviceExpressionReward
 from mbt_gym_amd.stochastic_processes.arrival_models import DeviceExpressionArrivalModel
 from mbt_gym_amd.stochastic_processes.fill_probability_models import DeviceExpressionFillModel
+from mbt_gym_amd.stochastic_processes.midprice_models import DeviceExpressionMidpriceModel
 
 
 class PowerLawFill(DeviceExpressionFillModel):
@@ -54,3 +55,16 @@ class SeasonalArrivals(DeviceExpressionArrivalModel):
 
     def device_expression_params(self):
         return {"base_bid": self.base[0], "base_ask": self.base[1], "amplitude": self.amplitude, "period": self.period}
+
+
+class CevMidprice(DeviceExpressionMidpriceModel):
+    """Constant elasticity of variance: S <- S + mu S dt + sigma S^gamma sqrt(dt) Z, per trajectory."""
+
+    device_expression = "mu * S * dt + sigma * pow(S, gamma) * sqrt(dt) * z"
+
+    def __init__(self, drift: float = 0.0, volatility: float = 0.5, gamma: float = 1.0, **kw):
+        self.drift, self.volatility, self.gamma = drift, volatility, gamma
+        super().__init__(**kw)
+
+    def device_expression_params(self):
+        return {"mu": self.drift, "sigma": self.volatility, "gamma": self.gamma}

@@ -705,6 +705,38 @@ def user_plugin_cases():
              seasonal_amplitude=0.8, seasonal_period=0.5, fill_exponent=1.5, dynamics="limit", reward="running", phi=0.02, alpha=0.05,
              initial_inventory=0, max_inventory=6, seed=64, **common))
 
+    # Y. a user-defined midprice with a NON-linear increment: constant elasticity of variance, per trajectory (the reference's
+    #    own CEV class broadcasts (N,) noise against an (N, 1) state and cannot be used for N > 1, MID:401-409)
+    from mbt_gym.stochastic_processes.midprice_models import MidpriceModel
+
+    class UserCevMidprice(MidpriceModel):
+        def __init__(self, drift, volatility, gamma, initial_price, lo, hi, terminal_time, step_size, num_trajectories, seed=None):
+            self.drift, self.volatility, self.gamma = drift, volatility, gamma
+            super().__init__(min_value=np.array([[lo]]), max_value=np.array([[hi]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[initial_price]]), num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            s = self.current_state
+            z = self.rng.normal(size=(self.num_trajectories, 1))
+            self.current_state = s + self.drift * s * self.step_size + self.volatility * s**self.gamma * np.sqrt(self.step_size) * z
+
+    n, ns = 32, 80
+    run_case(
+        "user_cev_midprice",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=65, initial_inventory=2, max_inventory=8, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.02),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                UserCevMidprice(0.05, 0.6, 0.75, 50.0, 20.0, 80.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                PoissonArrivalModel(intensity=np.array([50.0, 50.0]), step_size=1 / ns, num_trajectories=n)),
+            **common),
+        ns, n, 2, 65,
+        dict(n_steps=ns, terminal_time=1.0, midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0,
+             midprice_hi=80.0, arrival="poisson", intensity=[50.0, 50.0], fill_exponent=1.5, dynamics="limit", reward="running", phi=0.01, alpha=0.02,
+             initial_inventory=2, max_inventory=8, seed=65, **common),
+        poisson_thr=50.0 / ns)
+
     # W. user reward with the built-in exponential fill, at the touch
     n, ns = 24, 60
     run_case(
