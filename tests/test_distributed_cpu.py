@@ -85,3 +85,23 @@ def test_allreduce_without_a_process_group_is_identity():
     sums = np.array([3.0, np.nan, 2.0])
     out = allreduce_return_sums(sums)
     assert out[0] == 3.0 and np.isnan(out[1]) and out[2] == 2.0
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_spawn_reports_failure_instead_of_hanging():
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks (bench.py: spawn_ranks).  Without GPUs every rank
+    refuses with a clear message; the parent must come back with a non-zero status - not wait for ranks that will never
+    reach their collective - and print no JSON line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    from mbt_gym_amd import _native
+
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible: the success path is tests/test_gpu_round2.py")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0
+    assert "needs 2 visible GPUs" in out.stderr and not any(line.startswith("{") for line in out.stdout.splitlines())
