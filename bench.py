@@ -29,6 +29,7 @@ import argparse
 import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -97,7 +98,7 @@ def pmc_traffic(n):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, the
     newest profiles/r*_pmc_summary.json, produced by tools/pmc_summary.py for this workload at 2^20 lanes); None for
     other sizes.  Counters cannot be read from inside the benchmark process, so this is the profiled value."""
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")) if re.fullmatch(r"r\d+_pmc_summary\.json", os.path.basename(p)))
     if n != LANES_PER_GPU or not paths:
         return None
     for name, row in json.load(open(paths[-1])).items():
