@@ -290,7 +290,12 @@ enum {
    * normalises, TE:112-118) and clipped to the action space the agent acts in, as Stable-Baselines3 does before env.step -
    * the consumer the reference trains (agents/SbAgent.py, experiments/helpers.py:63-96).  Limit and limit + market
    * dynamics.  Weights are float32 in host memory in torch.nn.Linear layout (out x in, row-major), concatenated: */
-  MBT_POLICY_LINEAR = 5,              /* action = clip(W obs + b): table = [W (A x D) | b (A)], table_rows = 0, table_cols = A D + A */
+  /* Both: params[1] = 1 clips the action to the action space (SB3 before env.step), 0 passes it on as computed (the
+   * reference's PolicyGradientAgent, agents/PolicyGradientAgent.py:34-47); params[2..2+A) = exploration std per action
+   * component (0 = deterministic): action = mean + std * eps with eps ~ N(0, 1) from Philox blocks of their own
+   * (independent of the environment's noise, reproducible from the seed) - for consumers that COLLECT training data with
+   * a stochastic policy; the recorded action trajectory holds the action as applied. */
+  MBT_POLICY_LINEAR = 5,              /* mean = W obs + b: table = [W (A x D) | b (A)], table_rows = 0, table_cols = A D + A */
   MBT_POLICY_MLP = 6                  /* two hidden layers of width H <= 64 (SB3's MlpPolicy actor is [64, 64] tanh):
                                          table = [W1 (H x D) | b1 (H) | W2 (H x H) | b2 (H) | W3 (A x H) | b3 (A)], table_rows = H,
                                          table_cols = the number of floats; params[0] = activation (0 tanh, 1 relu).  Runs on the

@@ -102,17 +102,28 @@ def table_policy(table: np.ndarray, q_offset: int) -> MbtPolicy:
     return pol
 
 
-def linear_policy(weight: np.ndarray, bias: np.ndarray) -> MbtPolicy:
-    """action = clip(weight @ obs + bias): weight (A, D), bias (A) in torch.nn.Linear layout (keeps the blob alive)."""
+def _exploration(pol: MbtPolicy, n_actions: int, action_std, clip: bool):
+    """params[1] = clip to the action space; params[2..2+A) = exploration std per action component (scalar or vector)."""
+    pol.params[1] = 1.0 if clip else 0.0
+    if action_std is not None:
+        std = np.broadcast_to(np.asarray(action_std, dtype=np.float64), (n_actions,))
+        for j in range(n_actions):
+            pol.params[2 + j] = float(std[j])
+
+
+def linear_policy(weight: np.ndarray, bias: np.ndarray, action_std=None, clip: bool = True) -> MbtPolicy:
+    """action = clip(weight @ obs + bias [+ action_std * N(0, 1)]): weight (A, D), bias (A) in torch.nn.Linear layout (keeps
+    the blob alive)."""
     w, b = np.asarray(weight, dtype=np.float32), np.asarray(bias, dtype=np.float32)
     assert w.ndim == 2 and b.shape == (w.shape[0],)
     blob = np.ascontiguousarray(np.concatenate([w.reshape(-1), b]))
     pol = MbtPolicy(kind=POLICY_LINEAR, table=blob.ctypes.data_as(C.POINTER(C.c_float)), table_rows=0, table_cols=blob.size)
+    _exploration(pol, w.shape[0], action_std, clip)
     pol._keepalive = blob
     return pol
 
 
-def mlp_policy(layers, activation: str = "tanh") -> MbtPolicy:
+def mlp_policy(layers, activation: str = "tanh", action_std=None, clip: bool = True) -> MbtPolicy:
     """A two-hidden-layer MLP actor evaluated inside the kernels on the matrix cores: `layers` = [(W1, b1), (W2, b2), (W3, b3)]
     in torch.nn.Linear layout (W: out x in) with W1 (H, D), W2 (H, H), W3 (A, H), H <= 64 - e.g. the `mlp_extractor.policy_net`
     and `action_net` weights of a Stable-Baselines3 MlpPolicy with net_arch [64, 64] (keeps the blob alive)."""
@@ -123,6 +134,7 @@ def mlp_policy(layers, activation: str = "tanh") -> MbtPolicy:
     blob = np.ascontiguousarray(np.concatenate([a.reshape(-1) for a in (w1, b1, w2, b2, w3, b3)]))
     pol = MbtPolicy(kind=POLICY_MLP, table=blob.ctypes.data_as(C.POINTER(C.c_float)), table_rows=hidden, table_cols=blob.size)
     pol.params[0] = {"tanh": ACTIVATION_TANH, "relu": ACTIVATION_RELU}[activation]
+    _exploration(pol, w3.shape[0], action_std, clip)  # action_std: exploration noise for data collection (None = deterministic)
     pol._keepalive = blob
     return pol
 

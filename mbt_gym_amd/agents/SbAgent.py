@@ -76,10 +76,18 @@ class SbAgent(Agent):
         except ValueError:
             return False
 
-    def device_policy(self):
+    def device_policy(self, deterministic: bool = True):
+        """deterministic=False adds the policy's exploration noise (SB3: std = exp(policy.log_std), state independent) in the
+        kernel - what `model.predict(deterministic=False)` / rollout collection samples - for data collection at device speed."""
         from mbt_gym_amd import _native
 
         env = getattr(self.model, "env", None)
         dim = getattr(getattr(env, "env", env), "observation_dim", None) or (getattr(env, "observation_space", None).shape[0] if env is not None else None)
         layers, activation = self.actor_layers(observation_dim=dim)
-        return _native.mlp_policy(layers, activation)
+        std = None
+        if not deterministic:
+            log_std = getattr(getattr(self.model, "policy", None), "log_std", None)
+            if log_std is None:
+                raise ValueError("the model's policy has no log_std: a stochastic device policy needs the exploration std")
+            std = np.exp(_to_numpy(log_std)).reshape(-1)
+        return _native.mlp_policy(layers, activation, action_std=std, clip=True)

@@ -512,6 +512,12 @@ int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPol
     LP.act_lo[j] = j < A ? (norm ? -1.0f : c.act_lo[j]) : 0.0f;
     LP.act_hi[j] = j < A ? (norm ? 1.0f : c.act_hi[j]) : 0.0f;
   }
+  LP.clip = policy->params[1] != 0.0 ? 1 : 0;
+  for (int j = 0; j < 4; ++j) {
+    LP.act_std[j] = j < A ? static_cast<float>(policy->params[2 + j]) : 0.0f;
+    if (!(LP.act_std[j] >= 0.0f)) return fail(MBT_ERR_INVALID, "the exploration std of action %d is %g: must be >= 0", j, policy->params[2 + j]);
+    if (LP.act_std[j] != 0.0f) LP.stochastic = 1;
+  }
   const float* w = policy->table;
   if (policy->kind == MBT_POLICY_LINEAR) {
     if (policy->table_cols != static_cast<uint32_t>(A * D + A)) return fail(MBT_ERR_INVALID, "a linear policy holds A*D + A = %d floats (got %u)", A * D + A, policy->table_cols);
@@ -1505,7 +1511,8 @@ int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   mbt::LearnedPolicyParams LP;
   int rc = prepare_learned_policy(e, policy, LP);
   if (rc != MBT_OK) return rc;
-  hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP);
+  hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
+                     e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
   HIP_TRY(hipGetLastError());
   return MBT_OK;
 }

@@ -23,6 +23,8 @@
 #include <stdint.h>
 #endif
 
+#include "philox.hpp"
+
 namespace mbt {
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -57,7 +59,40 @@ struct LearnedPolicyParams {
   int32_t activation;   // kActTanh / kActRelu
   int32_t obs_dim, act_dim;
   float act_lo[4], act_hi[4];  // the action space the agent acts in: outputs are clipped to it, as SB3 does before env.step
+  // Exploration, for consumers that COLLECT training data (SB3's PPO: a state-independent std per action dimension;
+  // the reference's PolicyGradientAgent, agents/PolicyGradientAgent.py:34-47: one scalar): action = mean + std * eps,
+  // eps ~ N(0, 1) from Philox blocks of their own (counter word 3 = 8, 9: independent of the environment's draws).
+  float act_std[4];     // all zero = deterministic
+  int32_t stochastic;   // any act_std != 0
+  int32_t clip;         // 1: clip to [act_lo, act_hi] after the noise (SB3 before env.step); 0: pass the sample on (PolicyGradientAgent)
 };
+
+// eps of the two lanes of a pair: block (pair, step, 8) -> two Box-Muller transforms -> lane a: (e0, e1), lane b: (e2, e3);
+// a second block (word 3 = 9) for the third and fourth action components of limit + market dynamics.
+__device__ __forceinline__ void explore_and_clip(const LearnedPolicyParams& L, uint64_t pair, uint32_t step, uint32_t k0, uint32_t k1, float (&act)[2][4]) {
+  if (L.stochastic) {
+    const uint32_t plo = static_cast<uint32_t>(pair), phi = static_cast<uint32_t>(pair >> 32);
+    const PhiloxWords w = philox4x32_10(plo, phi, step, 8u, k0, k1);
+    float e[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    box_muller(w.w0, w.w1, e[0][0], e[0][1]);
+    box_muller(w.w2, w.w3, e[1][0], e[1][1]);
+    if (L.act_dim > 2) {
+      const PhiloxWords v = philox4x32_10(plo, phi, step, 9u, k0, k1);
+      box_muller(v.w0, v.w1, e[0][2], e[0][3]);
+      box_muller(v.w2, v.w3, e[1][2], e[1][3]);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) act[l][a] = __builtin_fmaf(L.act_std[a], e[l][a], act[l][a]);
+  }
+  if (L.clip) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) act[l][a] = __builtin_amdgcn_fmed3f(act[l][a], L.act_lo[a], L.act_hi[a]);
+  }
+}
 
 // the weights of one wave, in registers
 struct MlpRegisters {
@@ -110,7 +145,7 @@ __device__ __forceinline__ half8_t activate_pair(acc4_t lo, acc4_t hi) {
 // LDS scratch of one wave: 128 observation rows of 16 halfs (features, the constant one, zeros) + 128 action rows of 4 floats
 constexpr int kMlpLdsBytesPerWave = kMlpRowsPerWave * (kMlpInPad * 2 + 16);
 
-// obs[l][c]: the observation rows of this thread's two lanes (columns >= obs_dim ignored).  act[l][a]: the clipped actions.
+// obs[l][c]: the observation rows of this thread's two lanes (columns >= obs_dim ignored).  act[l][a]: the actor's mean (unclipped).
 // Every lane of the wave must call this together (MFMA and the wave-level LDS exchange).
 template <int ACT>
 __device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
@@ -161,10 +196,10 @@ __device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, cons
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     const acc4_t a = *reinterpret_cast<const acc4_t*>(a_rows + (l * 64 + lane) * 4);
-    act[l][0] = __builtin_amdgcn_fmed3f(a.x, L.act_lo[0], L.act_hi[0]);
-    act[l][1] = __builtin_amdgcn_fmed3f(a.y, L.act_lo[1], L.act_hi[1]);
-    act[l][2] = __builtin_amdgcn_fmed3f(a.z, L.act_lo[2], L.act_hi[2]);
-    act[l][3] = __builtin_amdgcn_fmed3f(a.w, L.act_lo[3], L.act_hi[3]);
+    act[l][0] = a.x;  // the actor's mean: exploration noise and the clip to the action space follow (explore_and_clip)
+    act[l][1] = a.y;
+    act[l][2] = a.z;
+    act[l][3] = a.w;
   }
   __builtin_amdgcn_wave_barrier();  // the rows are reused by the next call
 }
@@ -176,14 +211,14 @@ __device__ __forceinline__ void mlp_forward_wave(const MlpRegisters& W, const Le
   else mlp_forward_wave_act<kActTanh>(W, L, obs, act, lds_wave);
 }
 
-// action = clip(W obs + b): D x A <= 32 FMAs per row in fp32 on the vector unit (no contraction worth a matrix core)
+// mean action = W obs + b: D x A <= 32 FMAs per row in fp32 on the vector unit (no contraction worth a matrix core)
 __device__ __forceinline__ void linear_forward(const LearnedPolicyParams& L, const float (&obs)[8], float (&act)[4]) {
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     float s = L.w.lin_b[a];
 #pragma unroll
     for (int c = 0; c < 8; ++c) s = __builtin_fmaf(L.w.lin_w[a * 8 + c], c < L.obs_dim ? obs[c] : 0.0f, s);
-    act[a] = __builtin_amdgcn_fmed3f(s, L.act_lo[a], L.act_hi[a]);
+    act[a] = a < L.act_dim ? s : 0.0f;
   }
 }
 

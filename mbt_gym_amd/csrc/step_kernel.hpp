@@ -893,6 +893,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
         const MlpRegisters mlp_w = load_mlp(LP->w);
         mlp_forward_wave(mlp_w, *LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
       }
+      explore_and_clip(*LP, pair, P.philox_step + k, P.key0, P.key1, a);
 #pragma unroll
       for (int l = 0; l < 2; ++l) act[l] = make_float4(a[l][0], a[l][1], A == 4 ? a[l][2] : 0.f, A == 4 ? a[l][3] : 0.f);
       philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);  // after the network: the draws are not live across it
@@ -979,7 +980,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void learned_rollout_kernel(const
 
 // The same policy as a kernel of its own, for a step loop: observation buffer (n_pad, D) -> action buffer (n_pad, A), in
 // the step kernel's lane <-> thread mapping (so the wave-level MLP sees the same rows in the same places as the rollout).
-__global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs, float* action, int dim, int act_dim, const LearnedPolicyParams LP) {
+__global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs, float* action, int dim, int act_dim, const LearnedPolicyParams LP,
+                                                              uint64_t pair_offset, uint32_t philox_step, uint32_t key0, uint32_t key1) {
   __shared__ __attribute__((aligned(16))) char policy_lds[(kBlockThreads / 64) * kMlpLdsBytesPerWave];
   const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
   float o[2][8], a[2][4];
@@ -996,6 +998,8 @@ __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs,
     const MlpRegisters w = load_mlp(LP.w);
     mlp_forward_wave(w, LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
   }
+  // exploration noise of the step that is about to be taken: the same (pair, philox step) the fused rollout would use
+  explore_and_clip(LP, pair_offset + blockIdx.x * kBlockThreads + threadIdx.x, philox_step, key0, key1, a);
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     float* row = action + static_cast<size_t>(lanes[l]) * act_dim;

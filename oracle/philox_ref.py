@@ -86,3 +86,33 @@ class PhiloxNoise:
         u_arr, u_fill, z = pair_stream_noise(self.seed, self.offset, self.step, n)
         self.step += 1
         return u_arr.astype(np.float64), u_fill.astype(np.float64), z.reshape(n, 1)
+
+
+def policy_exploration_noise(seed, trajectory_offset, step, n, n_actions=2):
+    """eps (n, n_actions) of a learned policy's exploration at philox step `step` (csrc/policy_mlp.hpp: explore_and_clip):
+    block (pair, step, 8) -> Box-Muller(w0, w1) -> the lower lane's (e0, e1), Box-Muller(w2, w3) -> the upper lane's; block
+    word 3 = 9 the same for action components 2 and 3.  float64 here; the device uses the hardware transcendentals."""
+    assert trajectory_offset % TILE == 0
+    tiles = (n + TILE - 1) // TILE
+    half = TILE // 2
+    pairs = np.arange(tiles * half, dtype=np.uint64) + np.uint64(trajectory_offset // 2)
+    plo, phi = (pairs & MASK).astype(np.uint32), (pairs >> np.uint64(32)).astype(np.uint32)
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    st = np.full_like(plo, np.uint32(step))
+    local = np.arange(tiles * half)
+    lower = (local // half) * TILE + local % half
+    eps = np.zeros((tiles * TILE, 4))
+
+    def box_muller(wr, wt):
+        u1 = ((wr >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0**-24
+        r = np.sqrt(-2.0 * np.log(u1))
+        theta = 2.0 * np.pi * (wt >> np.uint32(8)).astype(np.float64) * 2.0**-24
+        return r * np.cos(theta), r * np.sin(theta)
+
+    for block, first in ((8, 0), (9, 2)):
+        if first >= n_actions:
+            break
+        w = philox4x32_10((plo, phi, st, np.full_like(plo, np.uint32(block))), key)
+        eps[lower, first], eps[lower, first + 1] = box_muller(w[0], w[1])
+        eps[lower + half, first], eps[lower + half, first + 1] = box_muller(w[2], w[3])
+    return eps[:n, :n_actions]

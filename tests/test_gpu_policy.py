@@ -206,3 +206,69 @@ def test_generate_trajectory_with_an_sb3_shaped_agent_runs_fused_and_agrees_with
     total_f, total_h = rew_f.sum(axis=(1, 2)), rew_h.sum(axis=(1, 2))
     assert total_f.mean() == pytest.approx(total_h.mean(), abs=5 * total_h.std() / np.sqrt(n) + 1e-3)
     env.close(), twin.close()
+
+
+@pytest.mark.parametrize("kw,clip", [(dict(), False), (dict(dynamics="limit_and_market", market_half_spread=0.4), True)])
+def test_stochastic_policy_draws_its_exploration_noise_from_its_own_philox_blocks(kw, clip):
+    """action = mean + std * eps (SB3's PPO, the reference's PolicyGradientAgent, AG-PG:34-47): eps comes from Philox blocks
+    with counter word 3 = 8, 9 - restated in oracle/philox_ref.py - so a stochastic rollout is reproducible from the seed,
+    independent of the environment's draws, identical between the policy kernel and the fused rollout, and the recorded
+    actions are what the consumer needs for its policy gradient."""
+    from oracle.philox_ref import policy_exploration_noise
+
+    n, seed = 3000, 5
+    cfg = _cfg(n, n_steps=12, **kw)
+    env, loop = make_env(cfg), make_env(cfg)
+    a_dim = env.action_dim
+    rng = np.random.default_rng(2)
+    layers = _random_mlp(rng, env.observation_dim, 64, a_dim, scale=0.5)
+    std = np.array([0.05, 0.1, 0.2, 0.3][:a_dim])
+    policy = _native.mlp_policy(layers, "tanh", action_std=std, clip=clip)
+    env.reset()
+    obs_t, act_t, rew_t, steps, done = env.rollout(policy)
+    assert steps == cfg.n_steps and done
+    lo, hi = _action_space(env)
+    for k in (0, 5, 11):
+        mean = mlp_reference(obs_t[k], layers, "tanh", -np.inf, np.inf)
+        want = mean + std * policy_exploration_noise(seed, 0, k, n, a_dim)
+        if clip:
+            want = np.clip(want, lo, hi)
+        np.testing.assert_allclose(act_t[k], want, rtol=0, atol=3e-3)  # fp16 operands of the mean + hardware Box-Muller (3e-5 x std)
+    if not clip:
+        eps = (act_t - np.stack([mlp_reference(o, layers, "tanh", -np.inf, np.inf) for o in obs_t[:-1]])) / std
+        assert abs(eps.mean()) < 0.02 and eps.std() == pytest.approx(1.0, abs=0.03)
+    # the step loop with the policy kernel draws the same noise: bit-identical to the fused rollout
+    loop.reset()
+    for _ in range(cfg.n_steps):
+        loop.policy_device(policy)
+        loop.step_device()
+    np.testing.assert_array_equal(loop.state, env.state)
+    # std = 0 is the deterministic policy
+    quiet = make_env(cfg)
+    quiet.reset()
+    _, act_q, _, _, _ = quiet.rollout(_native.mlp_policy(layers, "tanh", action_std=0.0, clip=True))
+    np.testing.assert_allclose(act_q[0], np.clip(mlp_reference(obs_t[0], layers, "tanh", -np.inf, np.inf), lo, hi), rtol=0, atol=2e-3)
+    env.close(), loop.close(), quiet.close()
+
+
+@pytest.mark.timeout(300)
+def test_policy_gradient_example_improves_the_return():
+    """examples/policy_gradient_on_device.py: the reference's PolicyGradientAgent.train loop (PG:49-73) with the sampling in
+    the kernel.  A smoke test of the whole consumer path (stochastic in-kernel MLP -> recorded tensors -> torch log-probs of
+    the kernel's samples -> update): the mean episode return under the inventory-penalised reward improves."""
+    import importlib.util
+    import os
+    import sys
+
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("policy_gradient_on_device", os.path.join(root, "examples", "policy_gradient_on_device.py"))
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    argv = sys.argv
+    try:
+        sys.argv = ["policy_gradient_on_device.py", "13", "40"]
+        history = module.main()
+    finally:
+        sys.argv = argv
+    assert len(history) == 40 and np.mean(history[-5:]) > np.mean(history[:5])
