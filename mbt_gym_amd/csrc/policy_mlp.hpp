@@ -131,6 +131,12 @@ __device__ __forceinline__ float activate(float x) {
 // Two accumulator tiles (features 16 (2c) .. and 16 (2c + 1) ..) -> activation -> ONE 8-half operand of the K = 32 instruction.
 template <int ACT>
 __device__ __forceinline__ half8_t activate_pair(acc4_t lo, acc4_t hi) {
+  if (ACT == kActRelu) {  // round first, then max(x, 0) on packed halves (v_pk_max_f16: two values per instruction); same result
+    const half8_t h = {static_cast<_Float16>(lo.x), static_cast<_Float16>(lo.y), static_cast<_Float16>(lo.z), static_cast<_Float16>(lo.w),
+                       static_cast<_Float16>(hi.x), static_cast<_Float16>(hi.y), static_cast<_Float16>(hi.z), static_cast<_Float16>(hi.w)};
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_elementwise_max(h, zero);
+  }
   return half8_t{static_cast<_Float16>(activate<ACT>(lo.x)), static_cast<_Float16>(activate<ACT>(lo.y)), static_cast<_Float16>(activate<ACT>(lo.z)),
                  static_cast<_Float16>(activate<ACT>(lo.w)), static_cast<_Float16>(activate<ACT>(hi.x)), static_cast<_Float16>(activate<ACT>(hi.y)),
                  static_cast<_Float16>(activate<ACT>(hi.z)), static_cast<_Float16>(activate<ACT>(hi.w))};
