@@ -408,7 +408,12 @@ int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key
 
 /* ---- timing on the environment's stream (HIP events) ------------------------------------------- */
 int mbt_env_timer_begin(mbt_env* env);
-int mbt_env_timer_end(mbt_env* env, float* elapsed_ms); /* synchronises */
+int mbt_env_timer_end(mbt_env* env, float* elapsed_ms); /* = stop + elapsed: synchronises */
+/* The same in two halves, for a caller whose own clock brackets the work: `stop` only records the closing event (no
+ * wait: nothing but the launches sits between the caller's two synchronisation points), `elapsed` waits for it and
+ * reads the device time between the two events - to be called once the caller's clock has stopped. */
+int mbt_env_timer_stop(mbt_env* env);
+int mbt_env_timer_elapsed(mbt_env* env, float* elapsed_ms);
 
 #ifdef __cplusplus
 }

@@ -218,6 +218,8 @@ SIGNATURES = {
     "mbt_philox4x32_10_host": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_timer_begin": (C.c_int, [_ENV]),
     "mbt_env_timer_end": (C.c_int, [_ENV, C.POINTER(C.c_float)]),
+    "mbt_env_timer_stop": (C.c_int, [_ENV]),
+    "mbt_env_timer_elapsed": (C.c_int, [_ENV, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -1827,16 +1827,28 @@ int mbt_env_timer_begin(mbt_env* e) {
   return MBT_OK;
 }
 
-int mbt_env_timer_end(mbt_env* e, float* elapsed_ms) {
-  if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+int mbt_env_timer_stop(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipEventRecord(e->ev_end, e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_timer_elapsed(mbt_env* e, float* elapsed_ms) {
+  if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
   const auto t0 = std::chrono::steady_clock::now();  // poll before blocking, like mbt_env_synchronize
   while (hipEventQuery(e->ev_end) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {
   }
   HIP_TRY(hipEventSynchronize(e->ev_end));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev_begin, e->ev_end));
   return MBT_OK;
+}
+
+int mbt_env_timer_end(mbt_env* e, float* elapsed_ms) {
+  if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  const int rc = mbt_env_timer_stop(e);
+  return rc != MBT_OK ? rc : mbt_env_timer_elapsed(e, elapsed_ms);
 }
 
 }  // extern "C"
