@@ -48,7 +48,14 @@ BYTES_PER_ENV_STEP = 4 * (4 + 2 + 4 + 1)  # state read + action read + next-stat
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED = 50
 QUOTE = (0.7, 0.7)
-PREWARM_SECONDS = 0.05  # untimed: brings the clocks up before the warm-up the caller asked for
+PREWARM_STEPS_AT_2_20 = 8192  # untimed, ~55 ms of launches: brings the clocks up before the warm-up the caller asked for
+
+
+def default_prewarm_steps(lanes):
+    """The same ~55 ms at any size - and a function of the arguments alone: every rank takes EXACTLY the same number of
+    steps, so every rank finishes the same number of episodes and enqueues the same number of return all-reduces (a
+    time-based warm-up would let the ranks drift apart by an episode, and the odd collective out would never complete)."""
+    return int(min(PREWARM_STEPS_AT_2_20, max(64, PREWARM_STEPS_AT_2_20 * LANES_PER_GPU // max(1, lanes))))
 
 
 def build_env(n, offset, device):
@@ -259,7 +266,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--lanes", type=int, default=LANES_PER_GPU, help="trajectories per GPU (default 2^20)")
-    ap.add_argument("--prewarm-steps", type=int, default=-1, help="untimed clock warm-up before --warmup; -1 = ~50 ms worth (default), 0 = none (reproducible episode count)")
+    ap.add_argument("--prewarm-steps", type=int, default=-1, help="untimed clock warm-up before --warmup; -1 = ~55 ms worth, a fixed count for the size (default), 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
@@ -343,9 +350,9 @@ def main():
             out.append(sums if (comm is not None or world == 1) else allreduce_return_sums(sums, device=tdev))
 
     # clocks up (untimed, not part of --warmup), then the warm-up the caller asked for
-    prewarm, t0 = 0, time.perf_counter()
-    while (time.perf_counter() - t0 < PREWARM_SECONDS) if args.prewarm_steps < 0 else (prewarm < args.prewarm_steps):
-        prewarm += env.step_many_device(256 if args.prewarm_steps < 0 else min(256, args.prewarm_steps - prewarm), auto_reset=True)[0]
+    prewarm, prewarm_target = 0, args.prewarm_steps if args.prewarm_steps >= 0 else default_prewarm_steps(n)
+    while prewarm < prewarm_target:
+        prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
         env.synchronize()
     if args.warmup > 0:
         env.step_many_device(args.warmup, auto_reset=True)

@@ -249,7 +249,9 @@ def preload_torch_rccl():
     if path is None:
         return None
     os.environ.setdefault("MBT_RCCL_LIBRARY", path)
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # local scope (the default mode): with RTLD_GLOBAL the librocm_smi64 that librccl depends on lends its amd::smi globals
+    # to /opt/rocm/lib/libamd_smi.so, which RCCL opens later, and the process aborts at exit in a double free
+    return C.CDLL(path)
 
 
 def _preload_torch_hip_runtime():

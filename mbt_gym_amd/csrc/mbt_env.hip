@@ -773,13 +773,13 @@ const HiprtcApi& hiprtc() {
     HiprtcApi a;
     void* h = nullptr;
     const char* override_path = std::getenv("MBT_HIPRTC_LIBRARY");
-    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"libhiprtc.so.7", "libhiprtc.so"};
     for (const char* name : names)
       if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     for (const char* name : names)
-      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (h == nullptr) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h == nullptr) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
     if (h == nullptr) {
       const char* err = dlerror();
       a.why = std::string("libhiprtc.so could not be loaded: ") + (err != nullptr ? err : "unknown error");
@@ -946,18 +946,21 @@ struct RcclApi {
   std::string why;
 };
 
+// RTLD_LOCAL on purpose: librccl brings librocm_smi64 along, and /opt/rocm/lib/libamd_smi.so (which RCCL opens at
+// initialisation) carries its own copy of the same amd::smi globals - with the first copy in the global scope the second
+// binds to it and both destructors free it at exit ("double free or corruption", measured: tools/dbg/exit_abort.sh).
 const RcclApi& rccl() {
   static const RcclApi api = [] {
     RcclApi a;
     void* h = nullptr;
     const char* override_path = std::getenv("MBT_RCCL_LIBRARY");
-    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    if (override_path != nullptr && override_path[0] != 0) h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* name : names)  // already in the process?
       if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     for (const char* name : names)
-      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (h == nullptr) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (h == nullptr) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h == nullptr) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (h == nullptr) {
       const char* err = dlerror();
       a.why = std::string("librccl.so.1 could not be loaded: ") + (err != nullptr ? err : "unknown error");

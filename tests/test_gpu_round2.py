@@ -129,6 +129,20 @@ def test_rccl_allreduce_through_the_c_abi_world_size_one():
     comm.close()
 
 
+def test_a_process_that_made_a_communicator_without_torch_exits_cleanly():
+    """Regression: librccl used to be opened RTLD_GLOBAL; its librocm_smi64 then lent its amd::smi globals to the
+    libamd_smi.so RCCL opens at initialisation, and the interpreter died in a double free AT EXIT (return code 134 after
+    every test had passed) - unless torch had been imported first.  A fresh interpreter, no torch, must return 0."""
+    code = ("from mbt_gym_amd.distributed import RcclCommunicator\n"
+            "import sys\n"
+            "c = RcclCommunicator(0, 1, 0)\n"
+            "c.close()\n"
+            "assert 'torch' not in sys.modules\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+
+
 def _bench(*args):
     env = dict(os.environ)
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
@@ -166,6 +180,23 @@ def test_bench_at_the_drivers_arguments_is_not_dominated_by_fixed_costs():
     assert line["steps"] == 20 and line["warmup"] == 5
     assert line["ms_per_step"] * 1e3 <= 2.0 * line["roofline"]["avg_launch_us"], line
     assert line["roofline"]["avg_launch_us"] < 12.0
+    assert line["config"]["prewarm_steps"] == 8192  # a count, not a time budget: the same on every rank
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_at_the_drivers_arguments_finish_the_same_number_of_episodes():
+    """The driver's N > 1 line with everything at its default: both ranks take the same 8192 + 5 + 20 steps, so both end
+    8 episodes and the 8 per-episode all-reduces pair up (with a time-based warm-up the ranks could drift apart by an
+    episode, and the odd collective out would wait for ever)."""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "20", "--warmup", "5")
+    assert line["n_gpus"] == 2 and line["config"]["prewarm_steps"] == 8192
+    assert line["config"]["num_trajectories_total"] == 1 << 21
+    assert line["config"]["episodes_finished_in_timed_region"] == 0
+    # no episode ends inside the 20 timed steps: the line reports the running episode (217 steps old), over both shards -
+    # the same number one rank stepping all 2^21 lanes for as long reports
+    one = _bench("--gpus", "1", "--lanes", str(1 << 21), "--steps", "20", "--warmup", "5", "--prewarm-steps", "8192")
+    assert line["mean_episode_return"] == pytest.approx(one["mean_episode_return"], rel=1e-12)
+    assert 10.0 < line["mean_episode_return"] < 20.0  # about 67 * 0.217
 
 
 def test_reward_scaling_matches_the_reference_calibration(repo_root):
