@@ -44,7 +44,7 @@ class RcclCommunicator:
         ident = C.create_string_buffer(_native.COMM_ID_BYTES)
         if rank == 0:
             _native.check(lib.mbt_comm_unique_id(ident))
-        raw = (exchange or _broadcast_bytes)(ident.raw)
+        raw = ident.raw if world_size == 1 else (exchange or _broadcast_bytes)(ident.raw)  # (a world of one needs no launcher, and no torch)
         assert len(raw) == _native.COMM_ID_BYTES
         handle = C.c_void_p()
         _native.check(lib.mbt_comm_init_rank(int(device), int(world_size), C.create_string_buffer(raw, _native.COMM_ID_BYTES), int(rank), C.byref(handle)))
