@@ -10,7 +10,14 @@ from mbt_gym_amd import _native
 from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv, action_bounds
 from tests.env_factory import make_env
 
+import os
+
 pytestmark = pytest.mark.gpu
+
+# Soak knobs (the defaults are what the suite runs): MBT_FUZZ_SCALE multiplies the number of random configurations per test,
+# MBT_FUZZ_SEED shifts every case's seed - `MBT_FUZZ_SCALE=10 MBT_FUZZ_SEED=100000 pytest tests/test_gpu_random_configs.py`.
+FUZZ_SCALE = int(os.environ.get("MBT_FUZZ_SCALE", "1"))
+FUZZ_SEED = int(os.environ.get("MBT_FUZZ_SEED", "0"))
 
 
 def _random_config(rng, n):
@@ -58,9 +65,9 @@ def _random_actions(rng, cfg, steps):
     return act.astype(np.float32)
 
 
-@pytest.mark.parametrize("case", range(150))
+@pytest.mark.parametrize("case", range(150 * FUZZ_SCALE))
 def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
-    rng = np.random.default_rng(7000 + case)
+    rng = np.random.default_rng(FUZZ_SEED + 7000 + case)
     n = int(rng.choice([7, 192, 600]))
     cfg = _random_config(rng, n)
     env = make_env(cfg, noise="philox")
@@ -133,9 +140,9 @@ def _random_speed_config(rng, n):
     return cfg
 
 
-@pytest.mark.parametrize("case", range(60))
+@pytest.mark.parametrize("case", range(60 * FUZZ_SCALE))
 def test_random_speed_configuration_matches_the_oracle(case):
-    rng = np.random.default_rng(9000 + case)
+    rng = np.random.default_rng(FUZZ_SEED + 9000 + case)
     n = int(rng.choice([5, 300, 1100]))
     cfg = _random_speed_config(rng, n)
     steps = cfg.n_steps
@@ -150,19 +157,31 @@ def test_random_speed_configuration_matches_the_oracle(case):
     oracle = OracleEnv(cfg, InjectedNoise(np.zeros((steps, n, 2)), np.zeros((steps, n, 2)), z))
     obs, o_obs = env.reset(), oracle.reset()
     tag = f"speed case {case}: {cfg.midprice}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    grad = (oracle.obs_hi.astype(np.float64) - oracle.obs_lo) / 2
+
+    def raw(x):  # compare in raw units: a narrow Box (small volatility) magnifies float32 rounding
+        return (np.asarray(x, dtype=np.float64) + 1) * grad + oracle.obs_lo if cfg.normalise_observation_space else np.asarray(x, dtype=np.float64)
+
+    prev, o_prev = raw(obs), raw(o_obs)
+    cash_scale = 0.0
     for k in range(steps):
         obs, rew, dones, _ = env.step(actions[k])
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
         clipped = oracle.last_clipped
-        if cfg.normalise_observation_space:  # compare in raw units: a narrow Box (small volatility) magnifies float32 rounding
-            grad = (oracle.obs_hi.astype(np.float64) - oracle.obs_lo) / 2
-            obs, o_obs = (obs.astype(np.float64) + 1) * grad + oracle.obs_lo, (o_obs + 1) * grad + oracle.obs_lo
-            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=0, atol=2e-6 * cfg.max_inventory + 1e-6, err_msg=f"{tag} step {k}: inventory")
-            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=0, atol=1e-3 + 2e-7 * oracle.max_cash, err_msg=f"{tag} step {k}: cash")
+        obs, o_obs = raw(obs), raw(o_obs)
+        # cash is float32 state of whatever magnitude the episode reaches (to 1e4 here: an ulp of 1e-3): one rounding per
+        # step, independent - 3 sqrt(k) half-ulps is a 5-sigma bound on their sum (measured: up to 3.6 ulp after 35 steps)
+        cash_scale = max(cash_scale, float(np.abs(o_obs[:, 0]).max()))
+        cash_drift = 3 * np.sqrt(k + 1) * 2.0 ** -24 * cash_scale
+        # The inventory here is REAL-valued float32 state: q' = q + v dt rounds once per step and the roundings add up
+        # (|q| <= 32 here: half an ulp is 1e-6; measured over 900 configurations x <= 60 steps: <= 2.5e-6 at any |q|)
+        if cfg.normalise_observation_space:
+            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=0, atol=2e-6 * cfg.max_inventory + 1e-5, err_msg=f"{tag} step {k}: inventory")
+            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=0, atol=1e-3 + 2e-7 * oracle.max_cash + cash_drift, err_msg=f"{tag} step {k}: cash")
             np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
         else:
-            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=2e-6, atol=2e-6, err_msg=f"{tag} step {k}: inventory")
-            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=4e-6, atol=1e-3, err_msg=f"{tag} step {k}: cash")
+            np.testing.assert_allclose(obs[:, 1], o_obs[:, 1], rtol=2e-6, atol=1e-5, err_msg=f"{tag} step {k}: inventory")
+            np.testing.assert_allclose(obs[:, 0], o_obs[:, 0], rtol=0, atol=1e-3 + cash_drift, err_msg=f"{tag} step {k}: cash")
             np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
             if obs.shape[1] > 4:
                 np.testing.assert_allclose(obs[:, 4], o_obs[:, 4], rtol=1e-5, atol=1e-6, err_msg=f"{tag} step {k}: impact state")
@@ -170,20 +189,31 @@ def test_random_speed_configuration_matches_the_oracle(case):
         tol = 1e-5 + 4e-6 * np.abs(o_rew)
         if cfg.midprice == "ou":
             tol = tol + cfg.ou_speed * np.abs(o_obs[:, 1] if not cfg.normalise_observation_space else cfg.max_inventory) * 1e-4
+        if cfg.midprice == "gbm":
+            # dS = S (mu dt + sigma sqrt(dt) z) multiplies the float32 drift of S itself (bounded above: 3e-4 + 2e-6 S), and
+            # the reward holds q dS: the part of the reward error that the ALREADY-CHECKED state error explains is
+            # |q| |dS / S| |S_hip - S_ref| (up to 1.7e-4 over 900 configurations); nothing beyond it is allowed
+            growth = np.abs(o_obs[:, 3] - o_prev[:, 3]) / np.abs(o_prev[:, 3])
+            tol = tol + 1.5 * np.maximum(np.abs(o_obs[:, 1]), np.abs(o_prev[:, 1])) * growth * (np.abs(prev[:, 3] - o_prev[:, 3]) + 4e-6 * np.abs(o_prev[:, 3]))
+        # the same for the inventory: the reward holds q' dS, so the (checked) drift of the real-valued float32 inventory
+        # shows in it times the price move - which is several units per step in the wilder draws (17 % per step)
+        move = np.nan_to_num(np.abs(o_obs[:, 3] - o_prev[:, 3]), nan=0.0)  # (constant midprice, normalised: a zero-width Box column is NaN on both sides)
+        tol = tol + 1.5 * move * (np.abs(obs[:, 1] - o_obs[:, 1]) + 1e-6)
         assert np.all(err[clipped] <= 5e-3 + 1e-5 * np.abs(o_rew[clipped])), f"{tag} step {k}: reward on clipped lanes"
-        assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
+        assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()} (allowed {tol[~clipped][np.argmax((err - tol)[~clipped])]})"
+        prev, o_prev = obs, o_obs
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]
     env.close()
 
 
-@pytest.mark.parametrize("case", range(60))
+@pytest.mark.parametrize("case", range(60 * FUZZ_SCALE))
 def test_random_configuration_rollout_equals_the_step_loop(case):
     """The fused rollout kernel inlines the step kernel's arithmetic and draws the same Philox counters: for any
     configuration a fixed-action rollout must equal the loop of step() calls bit for bit (states, rewards, return sums)."""
     from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
 
-    rng = np.random.default_rng(11000 + case)
+    rng = np.random.default_rng(FUZZ_SEED + 11000 + case)
     n = int(rng.choice([3, 513, 1500]))
     cfg = _random_speed_config(rng, n) if case % 3 == 2 else _random_config(rng, n)
     lo, hi = action_bounds(cfg)
@@ -215,7 +245,12 @@ def test_random_configuration_rollout_equals_the_step_loop(case):
     np.testing.assert_array_equal(env_a.state, env_b.state)
     sums_a, sums_b = env_a.episode_return_sums(), env_b.episode_return_sums()
     assert sums_a[2] == sums_b[2] == n
-    np.testing.assert_allclose(sums_a[:2], sums_b[:2], rtol=1e-5, atol=1e-5, equal_nan=True)
+    # The two paths add the same float32 rewards in different orders (per lane over the steps, then over lanes / per step over
+    # lanes in double): equal up to float32 rounding of the TERMS - a sum of returns of either sign can cancel to ~1 while
+    # sum |R| <= sqrt(n sum R^2) is 1e4 (seen: 3e-4 on a sum of 1.3 with sum R^2 = 1.2e6)
+    magnitude = float(np.sqrt(n * sums_b[1]))
+    np.testing.assert_allclose(sums_a[0], sums_b[0], rtol=1e-5, atol=1e-5 + 2e-7 * magnitude)
+    np.testing.assert_allclose(sums_a[1], sums_b[1], rtol=1e-5, atol=1e-5)
     assert env_a.clip_count == env_b.clip_count
     env_a.close()
     env_b.close()
