@@ -119,6 +119,41 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
     env.close()
 
 
+@pytest.mark.parametrize("case", range(60 * FUZZ_SCALE))
+def test_random_configuration_with_precise_state_is_within_1e5_on_every_lane(case):
+    """precise_state=True over the same plugin space: cash and midprice follow the float64 oracle (they come back as the
+    float32 NEAREST its value), so every reward - clipped lanes, GBM, OU pull, terminal penalties, exponential utility -
+    is within 1e-5 plus the rounding of the float32 output itself; decisions stay exact."""
+    rng = np.random.default_rng(FUZZ_SEED + 13000 + case)
+    n = int(rng.choice([7, 192, 600]))
+    cfg = _random_config(rng, n)
+    env = make_env(cfg, noise="philox", precise_state=True)
+    steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+    actions = _random_actions(rng, cfg, steps)
+    draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    env.reset(), oracle.reset()
+    half_ulp = 2.0 ** -24
+    tag = f"precise case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    for k in range(steps):
+        obs, rew, dones, _ = env.step(actions[k])
+        o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
+        o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
+        err = np.abs(rew.astype(np.float64) - o_rew)
+        assert np.all(err <= 1e-5 + 1.001 * half_ulp * np.abs(o_rew)), f"{tag} step {k}: reward off by {err.max()}"
+        if cfg.normalise_observation_space:
+            q = np.rint((obs[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
+            np.testing.assert_array_equal(q, np.rint((o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory), err_msg=f"{tag} step {k}: inventory")
+        else:
+            np.testing.assert_array_equal(obs[:, 1].astype(np.float64), o_obs[:, 1], err_msg=f"{tag} step {k}: inventory")
+            for col, label in ((0, "cash"), (3, "midprice")):
+                bound = 1.001 * half_ulp * np.maximum(np.abs(o_obs[:, col]), 1e-30) + 1e-9
+                assert np.all(np.abs(obs[:, col] - o_obs[:, col]) <= bound), f"{tag} step {k}: {label} off by {np.abs(obs[:, col] - o_obs[:, col]).max()}"
+        assert bool(dones[0]) == bool(o_dones[0])
+    assert dones[0]
+    env.close()
+
+
 def _random_speed_config(rng, n):
     impact = rng.choice(["temp_power", "temp_perm", "temp_transient", "transient"])
     n_steps = int(rng.integers(20, 60))
