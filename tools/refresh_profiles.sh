@@ -39,7 +39,9 @@ python tests/perf/bench_regimes.py > "$OUT/${TAG}_regimes.json" 2> /dev/null; st
 python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null; stamp "rollout"
 python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; stamp "policy rollout"
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
+python tests/perf/bench_timed_region.py > "$OUT/${TAG}_timed_region.json" 2> /dev/null; stamp "timed region"
 
 make -C tools/microbench > /dev/null 2>&1
 tools/microbench/mb_floor > "$OUT/${TAG}_floors.txt" 2>&1; stamp "floors"
+tools/microbench/mb_sync > "$OUT/${TAG}_mb_sync.txt" 2>&1; stamp "sync latency"
 ls -la "$OUT"
