@@ -1,23 +1,39 @@
 """OracleConfig -> mbt_gym_amd.TradingEnvironment, through the public plugin classes (the way a user of the
-reference builds an environment, notebooks/Test_1...ipynb:68-99)."""
+reference builds an environment, notebooks/Test_1...ipynb:68-99).
+
+`package` names the root the classes are imported from.  The module layout, class names and constructor arguments mirror
+the reference's, so the SAME construction code builds the reference's own environment when given "mbt_gym" (used only
+where the reference is importable: tests/test_oracle_vs_reference_live.py, in the build container)."""
+import importlib
+
 import numpy as np
 
 
-def _FixedBoundsProcess(initial, lo, hi, dt, n):
+def _FixedBoundsProcess(initial, lo, hi, dt, n, package="mbt_gym_amd"):
     """A one-dimensional process descriptor with the given initial state and value range."""
-    from mbt_gym_amd.stochastic_processes.StochasticProcessModel import StochasticProcessModel
+    base = importlib.import_module(package + ".stochastic_processes.StochasticProcessModel").StochasticProcessModel
+    if package != "mbt_gym_amd":  # the reference's base class is abstract (SP:8): any concrete one-dimensional process will do
 
-    return StochasticProcessModel(np.array([[lo]]), np.array([[hi]]), dt, 1.0, np.array([[initial]]), n)
+        class Fixed(base):
+            def reset(self):
+                self.current_state = np.repeat(self.initial_state, self.num_trajectories, axis=0)
+
+            def update(self, arrivals, fills, actions, state=None):
+                pass
+
+        base = Fixed
+    return base(np.array([[lo]]), np.array([[hi]]), dt, 1.0, np.array([[initial]]), n)
 
 
-def make_env(cfg, noise="philox", **overrides):
-    from mbt_gym_amd.gym import ModelDynamics as dyn
-    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
-    from mbt_gym_amd.rewards import RewardFunctions as rw
-    from mbt_gym_amd.stochastic_processes import arrival_models as arr_m
-    from mbt_gym_amd.stochastic_processes import midprice_models as mid_m
-    from mbt_gym_amd.stochastic_processes import price_impact_models as imp_m
-    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExogenousMmFillProbabilityModel, ExponentialFillFunction
+def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
+    dyn = importlib.import_module(package + ".gym.ModelDynamics")
+    TradingEnvironment = importlib.import_module(package + ".gym.TradingEnvironment").TradingEnvironment
+    rw = importlib.import_module(package + ".rewards.RewardFunctions")
+    arr_m = importlib.import_module(package + ".stochastic_processes.arrival_models")
+    mid_m = importlib.import_module(package + ".stochastic_processes.midprice_models")
+    imp_m = importlib.import_module(package + ".stochastic_processes.price_impact_models")
+    fill_m = importlib.import_module(package + ".stochastic_processes.fill_probability_models")
+    ExogenousMmFillProbabilityModel, ExponentialFillFunction = fill_m.ExogenousMmFillProbabilityModel, fill_m.ExponentialFillFunction
 
     n, dt, T = cfg.num_trajectories, cfg.step_size, cfg.terminal_time
     mid_dt = cfg.midprice_step_size or dt
@@ -52,7 +68,7 @@ def make_env(cfg, noise="philox", **overrides):
             base=cfg.intensity, amplitude=cfg.seasonal_amplitude, period=cfg.seasonal_period, step_size=arr_dt, num_trajectories=n),
     }[cfg.arrival]()
     if cfg.fill == "exogenous":  # any two one-dimensional processes with these initial states and bounds (FILL:146-154)
-        best = [_FixedBoundsProcess(cfg.exo_depth[s], cfg.exo_depth_lo[s], cfg.exo_depth_hi[s], dt, n) for s in range(2)]
+        best = [_FixedBoundsProcess(cfg.exo_depth[s], cfg.exo_depth_lo[s], cfg.exo_depth_hi[s], dt, n, package) for s in range(2)]
         fill = ExogenousMmFillProbabilityModel(tuple(best), fill_exponent=cfg.fill_exponent, base_fill_probability=cfg.base_fill_probability,
                                                step_size=dt, num_trajectories=n)
     elif cfg.fill == "user_power_law":  # a user-defined plugin: compiled into the kernel at run time
@@ -92,7 +108,8 @@ def make_env(cfg, noise="philox", **overrides):
         initial_inventory=cfg.initial_inventory, max_inventory=cfg.max_inventory, max_cash=cfg.max_cash,
         max_stock_price=cfg.max_stock_price, start_time=cfg.start_time, seed=cfg.seed, num_trajectories=n,
         normalise_action_space=cfg.normalise_action_space, normalise_observation_space=cfg.normalise_observation_space,
-        noise=noise,
     )
+    if package == "mbt_gym_amd":
+        kwargs["noise"] = noise  # (production Philox noise, or draws injected per step: an extension of ours)
     kwargs.update(overrides)
     return TradingEnvironment(**kwargs)

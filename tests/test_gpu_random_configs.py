@@ -3,14 +3,17 @@ parameters (seeded), the HIP environment in production (Philox) mode against the
 kernel made.  The fixtures pin the oracle to the reference on 18 hand-picked configurations; this spreads the same
 comparison over combinations nobody picked by hand (at-the-touch + Hawkes + CjMm, normalised limit-and-market, late start
 times, tight inventory limits ...).  Tolerances are those of test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
 from mbt_gym_amd import _native
 from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv, action_bounds
 from tests.env_factory import make_env
-
-import os
+from tests.random_configs import random_actions as _random_actions
+from tests.random_configs import random_config as _random_config
+from tests.random_configs import random_speed_actions, random_speed_config as _random_speed_config
 
 pytestmark = pytest.mark.gpu
 
@@ -18,51 +21,6 @@ pytestmark = pytest.mark.gpu
 # MBT_FUZZ_SEED shifts every case's seed - `MBT_FUZZ_SCALE=10 MBT_FUZZ_SEED=100000 pytest tests/test_gpu_random_configs.py`.
 FUZZ_SCALE = int(os.environ.get("MBT_FUZZ_SCALE", "1"))
 FUZZ_SEED = int(os.environ.get("MBT_FUZZ_SEED", "0"))
-
-
-def _random_config(rng, n):
-    dynamics = rng.choice(["limit", "limit", "limit_and_market", "touch"])
-    arrival = rng.choice(["poisson", "poisson_nonlinear", "hawkes"])
-    midprice = rng.choice(["bm", "ou", "gbm", "bm_jump", "ou_jump", "constant"])
-    reward = rng.choice(["pnl", "running", "cjmm", "exp_utility"])
-    n_steps = int(rng.integers(20, 60))
-    normalised = bool(rng.integers(0, 2)) and dynamics != "touch"
-    s0 = float(rng.choice([10.0, 50.0, 100.0]))
-    cfg = OracleConfig(
-        num_trajectories=n, n_steps=n_steps, terminal_time=float(rng.choice([0.5, 1.0, 2.0])), midprice=midprice,
-        drift=float(rng.uniform(-0.2, 0.2)), volatility=float(rng.uniform(0.05, 0.3) if midprice == "gbm" else rng.uniform(0.5, 3.0)),
-        initial_price=s0, ou_level=s0 + float(rng.uniform(-1, 1)), ou_speed=float(rng.uniform(0.0, 0.1)), jump_size=float(rng.uniform(0.0, 0.3)),
-        arrival=arrival, intensity=(float(rng.uniform(5, 60)), float(rng.uniform(5, 60))), hawkes_jump=float(rng.uniform(5, 40)),
-        hawkes_speed=float(rng.uniform(20, 80)), fill_exponent=float(rng.uniform(0.5, 3.0)), dynamics=dynamics,
-        market_half_spread=float(rng.uniform(0.1, 0.6)), reward=reward, risk_aversion=float(rng.uniform(0.001, 0.05)),
-        phi=float(rng.uniform(0.0, 0.05)), alpha=float(rng.uniform(0.0, 0.1)), inventory_exponent=2.0,
-        initial_inventory=int(rng.integers(-2, 3)), max_inventory=int(rng.choice([2, 5, 50])), seed=int(rng.integers(1, 2**31)),
-        normalise_action_space=normalised, normalise_observation_space=normalised,
-    )
-    # the explicit Euler recursion of the Hawkes intensity (ARR:110-119) is a contraction only for speed * dt < 1; beyond
-    # that it oscillates (>= 2: diverges, in the float64 reference too) and float32 state stops tracking float64 state.
-    # That is the documented domain of the device (include/mbt_env.h: allow_stiff_hawkes) - mbt_env_create REFUSES a
-    # configuration outside it (tests/test_gpu_round2.py) - so the random draw stays inside
-    cfg.hawkes_speed = min(cfg.hawkes_speed, 0.9 / cfg.step_size)
-    if rng.integers(0, 4) == 0:
-        cfg.start_time = cfg.terminal_time * 0.25
-    return cfg
-
-
-def _random_actions(rng, cfg, steps):
-    lo, hi = action_bounds(cfg)
-    n, a = cfg.num_trajectories, cfg.action_dim
-    if cfg.dynamics == "touch":
-        return rng.integers(0, 2, size=(steps, n, 2)).astype(np.float32)
-    if cfg.normalise_action_space:
-        act = rng.uniform(-1, 1, size=(steps, n, a))
-        if a == 4:  # market orders: mostly clearly off / clearly on
-            act[:, :, 2:] = rng.choice([-1.0, 1.0, 0.3], p=[0.85, 0.1, 0.05], size=(steps, n, 2))
-        return act.astype(np.float32)
-    act = rng.uniform(0, 0.8, size=(steps, n, a)) * hi
-    if a == 4:
-        act[:, :, 2:] = rng.choice([0.0, 1.0, 0.4], p=[0.85, 0.1, 0.05], size=(steps, n, 2))
-    return act.astype(np.float32)
 
 
 @pytest.mark.parametrize("case", range(150 * FUZZ_SCALE))
@@ -154,39 +112,13 @@ def test_random_configuration_with_precise_state_is_within_1e5_on_every_lane(cas
     env.close()
 
 
-def _random_speed_config(rng, n):
-    impact = rng.choice(["temp_power", "temp_perm", "temp_transient", "transient"])
-    n_steps = int(rng.integers(20, 60))
-    T = float(rng.choice([0.5, 1.0, 2.0]))
-    normalised = bool(rng.integers(0, 2))
-    cfg = OracleConfig(
-        num_trajectories=n, n_steps=n_steps, terminal_time=T, midprice=rng.choice(["bm", "ou", "gbm", "constant"]),
-        drift=float(rng.uniform(-0.1, 0.1)), volatility=float(rng.uniform(0.05, 0.3)), initial_price=float(rng.choice([20.0, 100.0])),
-        ou_level=100.0, ou_speed=float(rng.uniform(0.0, 0.05)), arrival="none", dynamics="speed", impact=impact,
-        temporary_impact=float(rng.uniform(0.005, 0.05)), impact_exponent=float(rng.choice([1.0, 1.0, 1.5, 0.6])),
-        permanent_impact=float(rng.uniform(0.0, 0.03)), transient_impact=float(rng.uniform(0.1, 0.6)), resilience=float(rng.uniform(0.5, 3.0)),
-        initial_transient_impact=float(rng.uniform(0.0, 0.2)), kernel_coefficient=float(rng.uniform(0.0, 0.4)), impact_step_size=T / n_steps,
-        reward=rng.choice(["pnl", "running", "cjoe"]), phi=float(rng.uniform(0.0, 0.05)), alpha=float(rng.uniform(0.0, 0.2)),
-        initial_inventory=int(rng.integers(1, 20)), max_inventory=int(rng.choice([15, 1000])), seed=int(rng.integers(1, 2**31)),
-        normalise_action_space=normalised, normalise_observation_space=normalised,
-    )
-    if rng.integers(0, 3) == 0:  # MD:265 trades the MIDPRICE model's step size, which need not be the environment's
-        cfg.midprice_step_size = float(rng.choice([0.5, 2.0])) * cfg.step_size
-    return cfg
-
-
 @pytest.mark.parametrize("case", range(60 * FUZZ_SCALE))
 def test_random_speed_configuration_matches_the_oracle(case):
     rng = np.random.default_rng(FUZZ_SEED + 9000 + case)
     n = int(rng.choice([5, 300, 1100]))
     cfg = _random_speed_config(rng, n)
     steps = cfg.n_steps
-    lo, hi = action_bounds(cfg)
-    positive = cfg.impact == "temp_power" and cfg.impact_exponent != 1.0  # v ** e with a fractional exponent needs v >= 0
-    if cfg.normalise_action_space:
-        actions = rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)).astype(np.float32)
-    else:
-        actions = (rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)) * hi).astype(np.float32)
+    actions = random_speed_actions(rng, cfg, steps)
     z = np.stack([_native.rng_fill_quad(cfg.seed, 0, k, n) for k in range(steps)])
     env = make_env(cfg, noise="philox")
     oracle = OracleEnv(cfg, InjectedNoise(np.zeros((steps, n, 2)), np.zeros((steps, n, 2)), z))

@@ -1,0 +1,118 @@
+"""The oracle against the reference ITSELF, over random draws from the plugin space - where the reference is importable.
+
+tests/golden/*.npz pin oracle/mbt_oracle.py to the reference on 26 hand-picked configurations (the fixtures travel to the GPU
+box, the reference cannot).  In the build container /root/reference is present, so here the pin is spread over the whole
+space the GPU fuzz tests draw from (tests/random_configs.py: every built-in midprice / arrival / dynamics / reward /
+price-impact kind, normalised or not, late start times, foreign step sizes): the REAL reference environment - built by the
+same construction code as ours (tests/env_factory.py, package="mbt_gym") - and the oracle are fed identical
+float32-representable draws and actions, and every observation, reward and done flag must agree.  Together with the GPU
+fuzz (HIP vs oracle on the same space) this closes the chain reference -> oracle -> HIP for every combination drawn.
+
+Skipped where /root/reference does not exist (the GPU box; nothing here is marked gpu).  Never reads the reference's sources:
+it imports the package, read-only, with bytecode writing off, and gym satisfied by the numerics-free stand-in of
+tools/refgen/gym_standin (gym is not installed here and there is no network)."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.mbt_oracle import InjectedNoise, OracleEnv
+from tests.env_factory import make_env
+from tests.random_configs import random_actions, random_config, random_speed_actions, random_speed_config
+
+REFERENCE = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "mbt_gym")), reason="the reference is only present in the build container")
+
+CASES = int(os.environ.get("MBT_LIVE_CASES", "40"))
+SEED = int(os.environ.get("MBT_FUZZ_SEED", "0"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def reference_on_path():
+    sys.dont_write_bytecode = True
+    added = [os.path.join(ROOT, "tools", "refgen", "gym_standin"), REFERENCE]
+    for p in added:
+        sys.path.insert(0, p)
+    yield
+    for p in added:
+        sys.path.remove(p)
+
+
+class Replay:
+    """Stands in for the numpy Generator of one reference process (they only call uniform(size=) / normal(size=):
+    ARR:55, ARR:122, FILL:33, MID:64, MID:143)."""
+
+    def __init__(self, draws):
+        self.draws, self.k = draws, 0
+
+    def _next(self, size):
+        out = np.asarray(self.draws[self.k], dtype=np.float64).reshape(size)
+        self.k += 1
+        return out
+
+    def uniform(self, size=None):
+        return self._next(size)
+
+    def normal(self, size=None):
+        return self._next(size)
+
+
+def _noise(rng, steps, n):
+    u_arr = (rng.integers(0, 1 << 24, size=(steps, n, 2)) / float(1 << 24)).astype(np.float32)
+    u_fill = (rng.integers(0, 1 << 24, size=(steps, n, 2)) / float(1 << 24)).astype(np.float32)
+    z = rng.normal(size=(steps, n)).astype(np.float32)
+    return u_arr, u_fill, z
+
+
+def _compare(cfg, actions, u_arr, u_fill, z, tag):
+    with contextlib.redirect_stdout(io.StringIO()):  # TE:291-297 prints whole arrays whenever a clip fires
+        ref = make_env(cfg, package="mbt_gym")
+    md = ref.model_dynamics
+    md.midprice_model.rng = Replay(z)
+    if md.arrival_model is not None:
+        md.arrival_model.rng = Replay(u_arr)
+    if md.fill_probability_model is not None:
+        md.fill_probability_model.rng = Replay(u_fill)
+    oracle = OracleEnv(cfg, InjectedNoise(u_arr, u_fill, z))
+    n = cfg.num_trajectories
+    with contextlib.redirect_stdout(io.StringIO()):
+        r_obs = ref.reset()
+    o_obs = oracle.reset()
+    np.testing.assert_array_equal(np.asarray(r_obs, dtype=np.float64), o_obs, err_msg=f"{tag}: reset")
+    for k in range(actions.shape[0]):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r_obs, r_rew, r_done, _ = ref.step(actions[k].astype(np.float64))
+        o_obs, o_rew, o_done = oracle.step(actions[k].astype(np.float64))
+        r_rew = np.broadcast_to(np.asarray(r_rew, dtype=np.float64), (n,))  # ExponentialUtility returns the scalar 0 (RW:156-163)
+        o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
+        np.testing.assert_array_equal(np.asarray(r_obs, dtype=np.float64), o_obs, err_msg=f"{tag} step {k}: observation")
+        np.testing.assert_array_equal(r_rew, o_rew, err_msg=f"{tag} step {k}: reward")
+        assert bool(r_done[0]) == bool(o_done[0]), f"{tag} step {k}: done"
+    assert bool(r_done[0])
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_oracle_equals_the_reference_on_a_random_order_book_configuration(case):
+    rng = np.random.default_rng(SEED + 21000 + case)
+    n = int(rng.choice([1, 5, 64]))
+    cfg = random_config(rng, n)
+    steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+    actions = random_actions(rng, cfg, steps)
+    u_arr, u_fill, z = _noise(rng, steps, n)
+    tag = f"live case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    _compare(cfg, actions, u_arr, u_fill, z, tag)
+
+
+@pytest.mark.parametrize("case", range(CASES // 2))
+def test_oracle_equals_the_reference_on_a_random_optimal_execution_configuration(case):
+    rng = np.random.default_rng(SEED + 23000 + case)
+    n = int(rng.choice([1, 5, 64]))
+    cfg = random_speed_config(rng, n)
+    actions = random_speed_actions(rng, cfg, cfg.n_steps)
+    u_arr, u_fill, z = _noise(rng, cfg.n_steps, n)
+    tag = f"live speed case {case}: {cfg.midprice}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    _compare(cfg, actions, u_arr, u_fill, z, tag)
