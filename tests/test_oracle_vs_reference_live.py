@@ -116,3 +116,59 @@ def test_oracle_equals_the_reference_on_a_random_optimal_execution_configuration
     u_arr, u_fill, z = _noise(rng, cfg.n_steps, n)
     tag = f"live speed case {case}: {cfg.midprice}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
     _compare(cfg, actions, u_arr, u_fill, z, tag)
+
+
+# ---- the closed-form agents (callers of the path; host code on both sides) -------------------------------------------
+
+def _agents(package):
+    import importlib
+
+    return importlib.import_module(package + ".agents.BaselineAgents")
+
+
+@pytest.mark.parametrize("case", range(max(4, CASES // 4)))
+def test_closed_form_agents_equal_the_references_on_random_parameters(case, no_device):
+    """AvellanedaStoikov (AG:52-83), CarteaJaimungalMm (AG:86-170; asymmetric intensities, the matrix exponential) and
+    CarteaJaimungalOe (AG:173-210) of this package against the reference's own classes, each constructed on its own
+    package's environment of the same random market, on a batch of random states with a common time stamp."""
+    from oracle.mbt_oracle import OracleConfig
+
+    rng = np.random.default_rng(SEED + 25000 + case)
+    n, ns, T = 16, int(rng.integers(20, 200)), float(rng.choice([0.5, 1.0, 2.0]))
+    q_max = int(rng.integers(3, 25))
+    market = dict(num_trajectories=n, n_steps=ns, terminal_time=T, midprice="bm", volatility=float(rng.uniform(0.5, 3.0)), initial_price=100.0,
+                  arrival="poisson", intensity=(float(rng.uniform(20, 160)), float(rng.uniform(20, 160))), fill_exponent=float(rng.uniform(0.5, 3.0)),
+                  initial_inventory=0, max_inventory=q_max, seed=11, normalise_action_space=False, normalise_observation_space=False)
+    state = np.zeros((n, 4))
+    state[:, 1] = rng.integers(-q_max - 2, q_max + 3, size=n)  # including inventories beyond the agent's table (AG:133-135 clamps)
+    state[:, 2] = T * int(rng.integers(0, ns)) / ns
+    state[:, 3] = 100.0 + rng.normal(size=n)
+
+    def both(cfg):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return make_env(cfg), make_env(cfg, package="mbt_gym")
+
+    # Avellaneda-Stoikov on plain PnL
+    ours, ref = both(OracleConfig(dynamics="limit", reward="pnl", **market))
+    gamma = float(rng.choice([0.0, 0.01, 0.1, 1.0]))
+    a, b = _agents("mbt_gym_amd").AvellanedaStoikovAgent(gamma, ours), _agents("mbt_gym").AvellanedaStoikovAgent(gamma, ref)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "quoting a negative spread" for large inventories, on both sides
+        np.testing.assert_allclose(a.get_action(state), b.get_action(state), rtol=1e-6, atol=1e-6, err_msg=f"AS case {case}")  # float32 actions
+    # Cartea-Jaimungal market making on its criterion
+    ours, ref = both(OracleConfig(dynamics="limit", reward="cjmm", phi=float(rng.uniform(0.0, 0.05)), alpha=float(rng.uniform(0.0, 0.01)), **market))
+    a, b = _agents("mbt_gym_amd").CarteaJaimungalMmAgent(ours), _agents("mbt_gym").CarteaJaimungalMmAgent(ref)
+    np.testing.assert_allclose(a.get_action(state), b.get_action(state), rtol=2e-6, atol=2e-6, err_msg=f"CJ-MM case {case}")
+    # (the reference's calculate_true_value_function adds (n,1) to (n,): an (n,n) broadcast - compared through h instead)
+    np.testing.assert_allclose(a.h_table()[int(round(state[0, 2] / T * ns))], b._calculate_ht(state[0, 2]).reshape(-1), rtol=1e-8, atol=1e-10, err_msg=f"CJ-MM h case {case}")
+    # Cartea-Jaimungal optimal execution on temporary + permanent impact
+    cfg = OracleConfig(num_trajectories=n, n_steps=ns, terminal_time=T, midprice="bm", volatility=market["volatility"], initial_price=100.0, arrival="none",
+                       dynamics="speed", impact="temp_perm", temporary_impact=float(rng.uniform(0.005, 0.05)), permanent_impact=float(rng.uniform(0.0, 0.01)),
+                       impact_step_size=T / ns, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=int(rng.integers(1, 30)), max_inventory=1000, seed=11,
+                       normalise_action_space=False, normalise_observation_space=False)
+    ours, ref = both(cfg)
+    phi, alpha = float(rng.uniform(1e-4, 1e-2)), float(rng.uniform(1e-3, 1e-1))
+    a, b = _agents("mbt_gym_amd").CarteaJaimungalOeAgent(phi, alpha, ours), _agents("mbt_gym").CarteaJaimungalOeAgent(phi, alpha, ref)
+    np.testing.assert_allclose(a.get_action(state), b.get_action(state), rtol=2e-6, atol=1e-6, err_msg=f"CJ-OE case {case}")
