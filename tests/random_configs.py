@@ -32,6 +32,14 @@ def random_config(rng, n):
     cfg.hawkes_speed = min(cfg.hawkes_speed, 0.9 / cfg.step_size)
     if rng.integers(0, 4) == 0:
         cfg.start_time = cfg.terminal_time * 0.25
+    if dynamics != "touch" and rng.integers(0, 5) == 0:
+        # ExogenousMmFillProbabilityModel (FILL:126-170): fills are certain inside an exogenous best depth, exponential
+        # beyond it; two more state columns (which the reference never advances).  float32-representable best depths, so
+        # that a quote can sit exactly on one
+        best = np.float32(rng.uniform(0.05, 0.6, size=2)).astype(np.float64)
+        cfg.fill, cfg.exo_depth, cfg.base_fill_probability = "exogenous", (float(best[0]), float(best[1])), float(rng.uniform(0.3, 1.0))
+        cfg.exo_depth_lo = (float(best[0] - rng.uniform(0.1, 0.5)), float(best[1] - rng.uniform(0.1, 0.5)))
+        cfg.exo_depth_hi = (float(best[0] + rng.uniform(0.1, 0.5)), float(best[1] + rng.uniform(0.1, 0.5)))
     return cfg
 
 

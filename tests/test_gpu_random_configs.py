@@ -23,6 +23,18 @@ FUZZ_SCALE = int(os.environ.get("MBT_FUZZ_SCALE", "1"))
 FUZZ_SEED = int(os.environ.get("MBT_FUZZ_SEED", "0"))
 
 
+def _undecidable_hawkes_lanes(cfg, oracle, u_arr):
+    """Lanes whose Hawkes arrival draw sits closer to the threshold lambda dt (ARR:121-123) than the float32 intensity
+    state can resolve (its error bound, asserted below, is 2e-5 + 3e-7 lambda): there the float32 and the float64
+    comparison may legitimately differ, and from then on the lane is a different trajectory.  About one lane-step in
+    10^7 (one of 33 000 soak configurations showed it: u - lambda dt = +6.5e-8 in float64, -4e-9 with the float32 state)."""
+    if cfg.arrival != "hawkes":
+        return np.zeros(cfg.num_trajectories, dtype=bool)
+    adt = cfg.arrival_step_size or cfg.step_size
+    lam = oracle.state[:, 4:6]
+    return np.any(np.abs(u_arr.astype(np.float64) - lam * adt) <= (2e-5 + 3e-7 * lam) * adt, axis=1)
+
+
 @pytest.mark.parametrize("case", range(150 * FUZZ_SCALE))
 def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
     rng = np.random.default_rng(FUZZ_SEED + 7000 + case)
@@ -38,19 +50,23 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
     tag = f"case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
     np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-5, err_msg=tag)
     scale = np.maximum(1.0, np.abs(o_obs[:, 0])) if not cfg.normalise_observation_space else None
+    alive = np.ones(n, dtype=bool)
     for k in range(steps):
+        alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0])
         obs, rew, dones, _ = env.step(actions[k])
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
         o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
         clipped = oracle.last_clipped
+        if scale is not None:
+            scale = np.maximum(scale, np.abs(o_obs[:, 0]))
+        obs, rew, o_obs, o_rew, clipped, scale_k = obs[alive], rew[alive], o_obs[alive], o_rew[alive], clipped[alive], (scale[alive] if scale is not None else None)
         if cfg.normalise_observation_space:
             np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-4, err_msg=f"{tag} step {k}")
             q = np.rint((obs[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
             np.testing.assert_array_equal(q, np.rint((o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory), err_msg=f"{tag} step {k}: inventory")
         else:
             np.testing.assert_array_equal(obs[:, 1].astype(np.float64), o_obs[:, 1], err_msg=f"{tag} step {k}: inventory")
-            scale = np.maximum(scale, np.abs(o_obs[:, 0]))
-            assert np.all(np.abs(obs[:, 0] - o_obs[:, 0]) <= 1e-4 + 2e-6 * scale), f"{tag} step {k}: cash"
+            assert np.all(np.abs(obs[:, 0] - o_obs[:, 0]) <= 1e-4 + 2e-6 * scale_k), f"{tag} step {k}: cash"
             np.testing.assert_allclose(obs[:, 3], o_obs[:, 3], rtol=2e-6, atol=3e-4, err_msg=f"{tag} step {k}: midprice")
             if obs.shape[1] > 4:
                 np.testing.assert_allclose(obs[:, 4:], o_obs[:, 4:], rtol=5e-6, atol=5e-5, err_msg=f"{tag} step {k}: intensities")
@@ -61,7 +77,7 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
                 assert np.all(rew == 0.0) and np.all(o_rew == 0.0)
             else:
                 w_got, w_want = -np.log(-rew.astype(np.float64)) / cfg.risk_aversion, -np.log(-o_rew) / cfg.risk_aversion
-                wealth_tol = 1e-3 + 4e-6 * (np.abs(w_want) + (scale if scale is not None else 0.0)) + 1e-2 * clipped
+                wealth_tol = 1e-3 + 4e-6 * (np.abs(w_want) + (scale_k if scale_k is not None else 0.0)) + 1e-2 * clipped
                 assert np.all(np.abs(w_got - w_want) <= wealth_tol), f"{tag} step {k}: terminal wealth off by {np.max(np.abs(w_got - w_want))}"
         else:
             # rewards: 1e-5, except where the reward itself carries float32 state (a clip; state-proportional diffusion)
@@ -85,6 +101,8 @@ def test_random_configuration_with_precise_state_is_within_1e5_on_every_lane(cas
     rng = np.random.default_rng(FUZZ_SEED + 13000 + case)
     n = int(rng.choice([7, 192, 600]))
     cfg = _random_config(rng, n)
+    if cfg.fill == "exogenous":  # the precise tier is not instantiated for the exogenous-depth model (mbt_env_create refuses it)
+        cfg.fill = "exponential"
     env = make_env(cfg, noise="philox", precise_state=True)
     steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
     actions = _random_actions(rng, cfg, steps)
@@ -93,10 +111,13 @@ def test_random_configuration_with_precise_state_is_within_1e5_on_every_lane(cas
     env.reset(), oracle.reset()
     half_ulp = 2.0 ** -24
     tag = f"precise case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    alive = np.ones(n, dtype=bool)
     for k in range(steps):
+        alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0])  # (the Hawkes intensities stay float32 state in this tier too)
         obs, rew, dones, _ = env.step(actions[k])
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
         o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
+        obs, rew, o_obs, o_rew = obs[alive], rew[alive], o_obs[alive], o_rew[alive]
         err = np.abs(rew.astype(np.float64) - o_rew)
         assert np.all(err <= 1e-5 + 1.001 * half_ulp * np.abs(o_rew)), f"{tag} step {k}: reward off by {err.max()}"
         if cfg.normalise_observation_space:
@@ -154,6 +175,9 @@ def test_random_speed_configuration_matches_the_oracle(case):
                 np.testing.assert_allclose(obs[:, 4], o_obs[:, 4], rtol=1e-5, atol=1e-6, err_msg=f"{tag} step {k}: impact state")
         err = np.abs(rew - o_rew)
         tol = 1e-5 + 4e-6 * np.abs(o_rew)
+        # a lane whose inventory ends within its float32 drift of the limit may be clipped on one side only: it then marks
+        # that drift to market (1e-6 x S = 2e-5 seen), exactly like a lane the clip changed on both sides
+        clipped = clipped | (np.abs(o_obs[:, 1]) >= cfg.max_inventory - 1e-4)
         if cfg.midprice == "ou":
             tol = tol + cfg.ou_speed * np.abs(o_obs[:, 1] if not cfg.normalise_observation_space else cfg.max_inventory) * 1e-4
         if cfg.midprice == "gbm":

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One random order-book configuration of tests/test_gpu_random_configs.py: the first lane whose inventory leaves the oracle's."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from mbt_gym_amd import _native
+from oracle.mbt_oracle import InjectedNoise, OracleEnv
+from tests.env_factory import make_env
+from tests.random_configs import random_actions, random_config
+
+seed, case = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed + 7000 + case)
+n = int(rng.choice([7, 192, 600]))
+cfg = random_config(rng, n)
+print(cfg)
+env = make_env(cfg, noise="philox")
+steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+actions = random_actions(rng, cfg, steps)
+draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(steps)]
+u_arr = np.stack([d[0] for d in draws])
+oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+obs, o_obs = env.reset(), oracle.reset()
+for k in range(steps):
+    lam_hip, lam_or = obs[:, 4:6].astype(np.float64), o_obs[:, 4:6]
+    obs, rew, dones, _ = env.step(actions[k])
+    o_obs, o_rew, _ = oracle.step(actions[k].astype(np.float64))
+    bad = np.nonzero(obs[:, 1] != o_obs[:, 1])[0]
+    if len(bad):
+        i = bad[0]
+        dt = cfg.arrival_step_size or cfg.step_size
+        print(f"step {k} lane {i}: q hip {obs[i,1]} oracle {o_obs[i,1]}")
+        print("  u_arr", u_arr[k][i].astype(np.float64), "lambda hip", lam_hip[i], "lambda oracle", lam_or[i])
+        print("  thr hip", lam_hip[i] * dt, "thr oracle", lam_or[i] * dt, "u - thr_oracle", u_arr[k][i] - lam_or[i] * dt, "u - thr_hip", u_arr[k][i] - lam_hip[i] * dt)
+        break
+env.close()
