@@ -86,3 +86,42 @@ def test_a_closed_environment_refuses_work():
     with pytest.raises(_native.NativeError):
         env.reset()
     env.close()
+
+
+def test_two_host_threads_each_with_its_own_environment():
+    """The ABI's threading contract is one host thread per handle: two threads stepping two environments at the same time
+    (own streams, thread-local error strings, shared module / library state) get exactly what each gets alone."""
+    import threading
+
+    from oracle.mbt_oracle import OracleConfig
+
+    def cfg(seed):
+        return OracleConfig(num_trajectories=5000, n_steps=120, terminal_time=1.0, midprice="ou", ou_level=100.0, ou_speed=0.02, volatility=2.0,
+                            initial_price=100.0, arrival="hawkes", intensity=(20.0, 15.0), hawkes_jump=20.0, hawkes_speed=40.0, fill_exponent=1.5,
+                            dynamics="limit_and_market", market_half_spread=0.4, reward="running", phi=0.01, alpha=0.05, initial_inventory=1,
+                            max_inventory=4, seed=seed, normalise_action_space=False, normalise_observation_space=False)
+
+    action = np.tile(np.array([[0.4, 0.6, 0.0, 1.0]], np.float32), (5000, 1))
+
+    def run(seed, out):
+        env = make_env(cfg(seed))
+        env.reset()
+        total = np.zeros(5000)
+        for _ in range(120):
+            obs, rew, dones, _ = env.step(action)
+            total += rew
+        out[seed] = (obs.copy(), total)
+        env.close()
+
+    alone, together = {}, {}
+    for seed in (11, 12):
+        run(seed, alone)
+    threads = [threading.Thread(target=run, args=(seed, together)) for seed in (11, 12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for seed in (11, 12):
+        np.testing.assert_array_equal(together[seed][0], alone[seed][0])
+        np.testing.assert_array_equal(together[seed][1], alone[seed][1])
+    assert not np.array_equal(alone[11][0], alone[12][0])
