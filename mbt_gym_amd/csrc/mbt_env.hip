@@ -496,11 +496,15 @@ constexpr size_t kLearnedW1 = 0, kLearnedW2 = kLearnedW1 + 4 * 64 * 8, kLearnedW
 
 // Validates a MBT_POLICY_LINEAR / MBT_POLICY_MLP descriptor, lays its weights out in MFMA A-operand order (fp16, rounded
 // to nearest even here on the host) and uploads them when they differ from what the device holds.
+// The fused learned rollout is instantiated for the float32 tiers of the built-in order-book models; the exogenous-depth
+// fill model, precise_state and run-time compiled plugins take the policy as a kernel of its own in front of each step
+// (policy_kernel: same rows, same exploration counters - launch_rollout falls back to that loop, results identical).
+float* current_obs(mbt_env* e);
+bool learned_rollout_is_fused(const mbt_env* e) { return !exogenous_fill(e->cfg) && !e->cfg.precise_state && e->jit_step == nullptr; }
+
 int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPolicyParams& LP) {
   const mbt_config& c = e->cfg;
   if (e->speed || c.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "learned policies quote depths: limit or limit + market dynamics");
-  if (exogenous_fill(c) || c.precise_state || e->jit_step != nullptr)
-    return fail(MBT_ERR_INVALID, "learned policies have no kernel for the exogenous-depth fill model, precise_state or user-defined plugins");
   const int D = e->dim, A = e->act_dim;
   if (policy->table == nullptr) return fail(MBT_ERR_INVALID, "a learned policy needs its weights (mbt_policy.table)");
   std::vector<char> image(kLearnedBytes, 0);
@@ -655,6 +659,25 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
     terminal = t >= e->cfg.terminal_time - e->dt / 2;
   }
   if (steps == 0) return fail(MBT_ERR_INVALID, "max_steps must be positive");
+  if (learned && !learned_rollout_is_fused(e)) {
+    // policy kernel + step kernel per step, recording by device-to-device copies in the rollout's own layout
+    const size_t row_obs = size_t(e->n_pad) * e->dim, row_act = size_t(e->n_pad) * e->act_dim, row_rew = e->n_pad;
+    int32_t ended = 0;
+    for (uint32_t k = 0; k < steps; ++k) {
+      if (obs_traj != nullptr) HIP_TRY(hipMemcpyAsync(obs_traj + k * row_obs, current_obs(e), row_obs * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+      hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
+                         e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
+      HIP_TRY(hipGetLastError());
+      if (act_traj != nullptr) HIP_TRY(hipMemcpyAsync(act_traj + k * row_act, e->action, row_act * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+      const int rc = launch_step(e, nullptr, &ended);
+      if (rc != MBT_OK) return rc;
+      if (rew_traj != nullptr) HIP_TRY(hipMemcpyAsync(rew_traj + k * row_rew, e->reward, row_rew * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    }
+    if (obs_traj != nullptr) HIP_TRY(hipMemcpyAsync(obs_traj + size_t(steps) * row_obs, current_obs(e), row_obs * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    if (steps_done != nullptr) *steps_done = steps;
+    if (done != nullptr) *done = ended;
+    return MBT_OK;
+  }
   R.n_steps = steps;
   R.last_is_terminal = terminal ? 1 : 0;
   R.t_start = e->time;

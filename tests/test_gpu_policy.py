@@ -272,3 +272,47 @@ def test_policy_gradient_example_improves_the_return():
     finally:
         sys.argv = argv
     assert len(history) == 40 and np.mean(history[-5:]) > np.mean(history[:5])
+
+
+@pytest.mark.parametrize("kind", ["exogenous_fill", "precise_state", "user_plugins"])
+def test_learned_policy_rollout_on_environments_without_a_fused_kernel(kind):
+    """The fused learned rollout exists for the float32 tiers of the built-in models.  The exogenous-depth fill model (two
+    more observation columns), precise_state and run-time compiled user plugins take the policy as a kernel of its own in
+    front of every step instead - behind the same rollout call, with the same recording layout and the same exploration
+    counters: the recording equals what the caller's own "policy_device, step_device" loop produces, bit for bit."""
+    from tests.golden_io import load_case
+
+    n = 1500
+    if kind == "exogenous_fill":
+        cfg = _cfg(n, fill="exogenous", exo_depth=(0.25, 0.375), exo_depth_lo=(0.0, 0.1), exo_depth_hi=(0.6, 0.7), base_fill_probability=0.8,
+                   arrival="hawkes", intensity=(15.0, 10.0), hawkes_speed=20.0, hawkes_jump=10.0)
+        kw = {}
+    elif kind == "precise_state":
+        cfg, kw = _cfg(n, dynamics="limit_and_market", market_half_spread=0.4, reward="running", phi=0.01, alpha=0.05, max_inventory=4), dict(precise_state=True)
+    else:
+        cfg, _ = load_case("user_fill_and_reward")
+        cfg.num_trajectories, kw = n, {}
+    recorded, loop = make_env(cfg, **kw), make_env(cfg, **kw)
+    rng = np.random.default_rng(31)
+    d, a = recorded.observation_dim, recorded.action_dim
+    raw = not cfg.normalise_observation_space
+    policy = _native.mlp_policy(_random_mlp(rng, d, 64, a, scale=0.05 if raw else 1.5), "tanh", action_std=[0.05] * a)
+    recorded.reset(), loop.reset()
+    obs_t, act_t, rew_t, steps, done = recorded.rollout(policy)
+    assert done and steps == cfg.n_steps and obs_t.shape == (steps + 1, n, d) and act_t.shape == (steps, n, a) and rew_t.shape == (steps, n)
+    np.testing.assert_array_equal(obs_t[0], loop.observation_host())
+    import torch
+
+    for k in range(steps):
+        loop.policy_device(policy)
+        loop.synchronize()
+        np.testing.assert_array_equal(torch.as_tensor(loop.action_device, device="cuda").cpu().numpy(), act_t[k], err_msg=f"{kind} step {k}: action")
+        finished = loop.step_device()
+        np.testing.assert_array_equal(loop.observation_host(), obs_t[k + 1], err_msg=f"{kind} step {k}: observation")
+        loop.synchronize()
+        np.testing.assert_array_equal(torch.as_tensor(loop.reward_device, device="cuda").cpu().numpy(), rew_t[k], err_msg=f"{kind} step {k}: reward")
+    assert finished
+    assert np.std(act_t) > 1e-3
+    np.testing.assert_array_equal(recorded.state, loop.state)
+    assert recorded.episode_return_sums()[0] == loop.episode_return_sums()[0]
+    recorded.close(), loop.close()
