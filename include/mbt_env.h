@@ -288,10 +288,10 @@ enum {
                                          every k-th step, in one launch */
   /* LEARNED policies, evaluated inside the kernel on the observation the environment would hand out (normalised when it
    * normalises, TE:112-118) and clipped to the action space the agent acts in, as Stable-Baselines3 does before env.step -
-   * the consumer the reference trains (agents/SbAgent.py, experiments/helpers.py:63-96).  Limit and limit + market
-   * dynamics.  One fused kernel for the float32 tiers of the built-in models; with the exogenous-depth fill model,
-   * precise_state or user-defined plugins (mbt_env_create_jit) the same call runs the policy as a kernel of its own in
-   * front of each step (same recording, same exploration draws: bit-identical to the caller doing so itself).
+   * the consumer the reference trains (agents/SbAgent.py, experiments/helpers.py:63-96).  Every dynamics with
+   * real-valued actions (limit, limit + market, trading speed).  One fused kernel for the float32 tiers of the built-in
+   * order-book models; with the exogenous-depth fill model, precise_state, user-defined plugins (mbt_env_create_jit) or
+   * speed dynamics the same call runs the policy as a kernel of its own in front of each step (same recording, same exploration draws: bit-identical to the caller doing so itself).
    * Weights are float32 in host memory in torch.nn.Linear layout (out x in, row-major), concatenated: */
   /* Both: params[1] = 1 clips the action to the action space (SB3 before env.step), 0 passes it on as computed (the
    * reference's PolicyGradientAgent, agents/PolicyGradientAgent.py:34-47); params[2..2+A) = exploration std per action

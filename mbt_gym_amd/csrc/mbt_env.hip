@@ -500,11 +500,13 @@ constexpr size_t kLearnedW1 = 0, kLearnedW2 = kLearnedW1 + 4 * 64 * 8, kLearnedW
 // fill model, precise_state and run-time compiled plugins take the policy as a kernel of its own in front of each step
 // (policy_kernel: same rows, same exploration counters - launch_rollout falls back to that loop, results identical).
 float* current_obs(mbt_env* e);
-bool learned_rollout_is_fused(const mbt_env* e) { return !exogenous_fill(e->cfg) && !e->cfg.precise_state && e->jit_step == nullptr; }
+bool learned_rollout_is_fused(const mbt_env* e) { return !e->speed && !exogenous_fill(e->cfg) && !e->cfg.precise_state && e->jit_step == nullptr; }
+// (the policy kernel walks 512-lane tiles whatever the environment's own tile is: speed dynamics pad to 1024)
+uint32_t policy_blocks(const mbt_env* e) { return e->n_pad / mbt::kTileLanes; }
 
 int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPolicyParams& LP) {
   const mbt_config& c = e->cfg;
-  if (e->speed || c.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "learned policies quote depths: limit or limit + market dynamics");
+  if (c.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "learned policies output real-valued actions (depths, market-order scores, a trading speed): not the binary actions of at-the-touch dynamics");
   const int D = e->dim, A = e->act_dim;
   if (policy->table == nullptr) return fail(MBT_ERR_INVALID, "a learned policy needs its weights (mbt_policy.table)");
   std::vector<char> image(kLearnedBytes, 0);
@@ -665,7 +667,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
     int32_t ended = 0;
     for (uint32_t k = 0; k < steps; ++k) {
       if (obs_traj != nullptr) HIP_TRY(hipMemcpyAsync(obs_traj + k * row_obs, current_obs(e), row_obs * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
-      hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
+      hipLaunchKernelGGL(mbt::policy_kernel, dim3(policy_blocks(e)), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
                          e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
       HIP_TRY(hipGetLastError());
       if (act_traj != nullptr) HIP_TRY(hipMemcpyAsync(act_traj + k * row_act, e->action, row_act * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -1537,7 +1539,7 @@ int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   mbt::LearnedPolicyParams LP;
   int rc = prepare_learned_policy(e, policy, LP);
   if (rc != MBT_OK) return rc;
-  hipLaunchKernelGGL(mbt::policy_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
+  hipLaunchKernelGGL(mbt::policy_kernel, dim3(policy_blocks(e)), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
                      e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
   HIP_TRY(hipGetLastError());
   return MBT_OK;

@@ -178,7 +178,7 @@ def test_learned_policy_refusals():
     env.close()
     touch = make_env(_cfg(512, dynamics="touch", market_half_spread=0.25, normalise_action_space=False, normalise_observation_space=False))
     touch.reset()
-    with pytest.raises(NativeError, match="quote depths"):
+    with pytest.raises(NativeError, match="binary actions"):
         touch.policy_device(_native.mlp_policy(_random_mlp(rng, 4, 64, 2)))
     touch.close()
 
@@ -274,7 +274,7 @@ def test_policy_gradient_example_improves_the_return():
     assert len(history) == 40 and np.mean(history[-5:]) > np.mean(history[:5])
 
 
-@pytest.mark.parametrize("kind", ["exogenous_fill", "precise_state", "user_plugins"])
+@pytest.mark.parametrize("kind", ["exogenous_fill", "precise_state", "user_plugins", "speed", "speed_with_impact_state"])
 def test_learned_policy_rollout_on_environments_without_a_fused_kernel(kind):
     """The fused learned rollout exists for the float32 tiers of the built-in models.  The exogenous-depth fill model (two
     more observation columns), precise_state and run-time compiled user plugins take the policy as a kernel of its own in
@@ -289,6 +289,12 @@ def test_learned_policy_rollout_on_environments_without_a_fused_kernel(kind):
         kw = {}
     elif kind == "precise_state":
         cfg, kw = _cfg(n, dynamics="limit_and_market", market_half_spread=0.4, reward="running", phi=0.01, alpha=0.05, max_inventory=4), dict(precise_state=True)
+    elif kind.startswith("speed"):  # optimal execution: one real-valued action (the trading speed), 1024-lane tiles, D = 4 or 5
+        cfg = OracleConfig(num_trajectories=n, n_steps=40, terminal_time=1.0, midprice="bm", volatility=0.2, initial_price=100.0, arrival="none",
+                           dynamics="speed", impact="temp_power" if kind == "speed" else "temp_transient", temporary_impact=0.02, transient_impact=0.3,
+                           resilience=1.5, kernel_coefficient=0.2, impact_step_size=1.0 / 40, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=12,
+                           max_inventory=1000, seed=5, normalise_action_space=True, normalise_observation_space=True)
+        kw = {}
     else:
         cfg, _ = load_case("user_fill_and_reward")
         cfg.num_trajectories, kw = n, {}
