@@ -634,8 +634,11 @@ class TradingEnvironment(_EnvBase):
         q0 = self.initial_inventory
         if isinstance(q0, tuple) and len(q0) == 2:
             return self.rng.integers(*q0, size=self.num_trajectories).astype(np.float32)
-        if isinstance(q0, int):
+        if isinstance(q0, (int, np.integer)):
             return None
+        if isinstance(q0, np.ndarray):  # an extension: one value per lane (MultiDeviceTradingEnvironment hands each shard its slice)
+            assert q0.shape == (self.num_trajectories,), f"per-lane initial inventories must have shape ({self.num_trajectories},)"
+            return np.ascontiguousarray(q0, dtype=np.float32)
         if isinstance(q0, Callable):
             value = q0()
             if self.model_dynamics.round_initial_inventory:
