@@ -143,3 +143,50 @@ def test_two_to_the_28_lanes_addressing():
     assert env_a.episode_return_sums()[0] == pytest.approx(env_b.episode_return_sums()[0], rel=1e-9)
     env_a.close()
     env_b.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("log2_lanes,kw", [
+    (28, dict()),  # 16-byte rows: the state buffers are 4 GiB each - every byte offset past 2^32 is exercised
+    (27, dict(arrival="hawkes", intensity=(10.0, 14.0), hawkes_jump=40.0, hawkes_speed=60.0, midprice="ou", ou_level=100.0, ou_speed=0.01)),  # 24-byte rows via LDS
+])
+def test_top_end_sizes_address_every_lane(log2_lanes, kw):
+    """Maximum sizes: 2^28 lanes (Avellaneda-Stoikov; ~14 GB of device buffers) and 2^27 lanes with 24-byte rows.  The last
+    tile of the big environment must be EXACTLY what a 1024-lane environment placed at that global offset computes (noise is a
+    function of the global lane id; any 32-bit overflow in an index or byte offset would land somewhere else), the first
+    tile what one at offset 0 computes, and the episode-return sums must count every lane."""
+    torch = pytest.importorskip("torch")
+    n, steps, tail = 1 << log2_lanes, 12, 1024
+    base = dict(n_steps=1000, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson", intensity=(140.0, 140.0),
+                fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=1000, seed=91, normalise_action_space=False,
+                normalise_observation_space=False)
+    base.update(kw)
+    big = make_env(OracleConfig(num_trajectories=n, **base))
+    big.reset_device()
+    torch.as_tensor(big.action_device, device="cuda").fill_(0.7)  # no 2 GB host array: the quote is written where it lives
+    for _ in range(steps):
+        big.step_device()
+    big.synchronize()
+    obs = torch.as_tensor(big.obs_device, device="cuda")
+    rew = torch.as_tensor(big.reward_device, device="cuda")
+    assert obs.shape == (n, big.observation_dim) and rew.shape == (n,)
+    for offset in (0, n - tail, n // 2 + 3 * tail):
+        small = make_env(OracleConfig(num_trajectories=tail, **base), trajectory_offset=offset)
+        small.reset_device()
+        small.set_action_host(np.full((tail, 2), 0.7, np.float32))
+        for _ in range(steps):
+            small.step_device()
+        small.synchronize()
+        np.testing.assert_array_equal(obs[offset:offset + tail].cpu().numpy(), small.observation_host(), err_msg=f"lanes from {offset}")
+        np.testing.assert_array_equal(rew[offset:offset + tail].cpu().numpy(), torch.as_tensor(small.reward_device, device="cuda").cpu().numpy())
+        small.close()
+    total, _, count = big.episode_return_sums()
+    assert count == n
+    # lanes traded everywhere, not just below the first 2^32 bytes: the same share of non-zero inventories in both halves
+    lower, upper = (float(torch.count_nonzero(half[:, 1]).item()) / (n // 2) for half in (obs[: n // 2], obs[n // 2:]))
+    assert lower > 0.05 and upper == pytest.approx(lower, rel=5e-3)
+    per_lane = total / n
+    expected = steps * (140.0 + 140.0) * 1e-3 * np.exp(-1.5 * np.float64(np.float32(0.7))) * 0.7 if not kw else None
+    if expected is not None:
+        assert per_lane == pytest.approx(expected, rel=2e-3)  # E sum R of a fixed quote (test above); s.e. ~ 1e-5 at this size
+    big.close()
