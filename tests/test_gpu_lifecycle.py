@@ -125,3 +125,21 @@ def test_two_host_threads_each_with_its_own_environment():
         np.testing.assert_array_equal(together[seed][0], alone[seed][0])
         np.testing.assert_array_equal(together[seed][1], alone[seed][1])
     assert not np.array_equal(alone[11][0], alone[12][0])
+
+
+def test_empty_and_single_lane_batches():
+    """num_trajectories = 0 is refused at construction (the reference builds empty arrays and fails later, in its first
+    reduction); one lane - the reference's default - runs: the partner lane of the pair and the rest of the tile are padding."""
+    rng = np.random.default_rng(8)
+    cfg = random_config(rng, 1)
+    cfg.normalise_action_space = cfg.normalise_observation_space = False
+    cfg.dynamics, cfg.fill = "limit", "exponential"
+    env = make_env(cfg)
+    obs = env.reset()
+    assert obs.shape == (1, env.observation_dim)
+    obs, rew, dones, infos = env.step(np.full((1, 2), 0.3, np.float32))
+    assert obs.shape == (1, env.observation_dim) and rew.shape == (1,) and dones.shape == (1,) and infos == {}  # TE:320-321: a dict for N = 1
+    env.close()
+    cfg.num_trajectories = 0
+    with pytest.raises((_native.NativeError, AssertionError, ValueError)):
+        make_env(cfg)
