@@ -53,6 +53,8 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
     alive = np.ones(n, dtype=bool)
     for k in range(steps):
         alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0])
+        if cfg.midprice == "gbm":  # raw (un-normalised) states before the step, for the reward bound below
+            hip_prev, or_prev = env.state.astype(np.float64), oracle.state.copy()
         obs, rew, dones, _ = env.step(actions[k])
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
         o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
@@ -82,6 +84,13 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
         else:
             # rewards: 1e-5, except where the reward itself carries float32 state (a clip; state-proportional diffusion)
             tol = 1e-5 + (2e-6 * np.abs(o_rew) if cfg.midprice == "gbm" else 0.0)
+            if cfg.midprice == "gbm":
+                # dS = S (mu dt + sigma sqrt(dt) z + ...) multiplies the float32 drift of S itself (bounded above), and the reward
+                # holds q' dS: |q| |dS / S| |S_hip - S_ref| of the reward error is explained by that already-checked state error
+                # (5.3e-5 seen at q = 40, a 9 % move, S off by 1.5e-5); nothing beyond it is allowed
+                growth = np.abs(oracle.state[:, 3] - or_prev[:, 3]) / np.abs(or_prev[:, 3])
+                q_abs = np.maximum(np.abs(oracle.state[:, 1]), np.abs(or_prev[:, 1]))
+                tol = tol + (1.5 * q_abs * growth * (np.abs(hip_prev[:, 3] - or_prev[:, 3]) + 4e-6 * np.abs(or_prev[:, 3])))[alive]
             if cfg.midprice in ("ou", "ou_jump"):  # the pull -theta (S - level) carries the float32 error of S (<= 3e-4) times q
                 inventory = o_obs[:, 1] if not cfg.normalise_observation_space else (o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory
                 tol = tol + cfg.ou_speed * np.abs(inventory) * 1e-4
@@ -239,7 +248,7 @@ def test_random_configuration_rollout_equals_the_step_loop(case):
     # The two paths add the same float32 rewards in different orders (per lane over the steps, then over lanes / per step over
     # lanes in double): equal up to float32 rounding of the TERMS - a sum of returns of either sign can cancel to ~1 while
     # sum |R| <= sqrt(n sum R^2) is 1e4 (seen: 3e-4 on a sum of 1.3 with sum R^2 = 1.2e6)
-    magnitude = float(np.sqrt(n * sums_b[1]))
+    magnitude = float(np.abs(rew_r).sum())  # (per-step rewards of +-300 can cancel to an episode return of 0.1: the roundings do not)
     np.testing.assert_allclose(sums_a[0], sums_b[0], rtol=1e-5, atol=1e-5 + 2e-7 * magnitude)
     np.testing.assert_allclose(sums_a[1], sums_b[1], rtol=1e-5, atol=1e-5)
     assert env_a.clip_count == env_b.clip_count
