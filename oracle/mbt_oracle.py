@@ -28,7 +28,7 @@ Side 0 = bid, side 1 = ask (index_names.py:6-7).
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from mbt_gym_amd import _native
-from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv, action_bounds
+from oracle.mbt_oracle import InjectedNoise, OracleEnv, action_bounds
 from tests.env_factory import make_env
 from tests.random_configs import random_actions as _random_actions
 from tests.random_configs import random_config as _random_config

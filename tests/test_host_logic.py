@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 
 from mbt_gym_amd import _native
-from mbt_gym_amd.gym import TradingEnvironment as te_module
 from mbt_gym_amd.gym.StableBaselinesTradingEnvironment import StableBaselinesTradingEnvironment
 from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment, UnsupportedOnDevice
 from mbt_gym_amd.stochastic_processes.StochasticProcessModel import DeviceResidentError, StochasticProcessModel
