@@ -41,6 +41,18 @@ python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; s
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
 python tests/perf/bench_timed_region.py > "$OUT/${TAG}_timed_region.json" 2> /dev/null; stamp "timed region"
 
+# per-kernel statistics of the other kernel families (every BASELINE config's step kernel, the fused rollouts, the learned
+# policies) and the HBM-side traffic of every config's step kernel
+stats() {  # stats <name> <script>
+  rm -rf /tmp/prof_$1 && (cd /tmp && MBT_BENCH_STEPS=200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python "$ROOT/$2" > /dev/null 2> "$ROOT/$OUT/rocprof_$1.stderr")
+  find /tmp/prof_$1 -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_$1_kernel_stats.csv"
+  stamp "kernel stats $1"
+}
+stats all_configs tests/perf/bench_configs.py
+stats rollout tools/bench_rollout.py
+stats policy tools/bench_policy.py
+bash tools/pmc_all_configs.sh "$TAG" > /dev/null 2>&1; stamp "pmc all configs"
+
 make -C tools/microbench > /dev/null 2>&1
 tools/microbench/mb_floor > "$OUT/${TAG}_floors.txt" 2>&1; stamp "floors"
 tools/microbench/mb_sync > "$OUT/${TAG}_mb_sync.txt" 2>&1; stamp "sync latency"
