@@ -5,10 +5,15 @@ describing themselves to the fused rollout kernel (closed forms and tables only)
 and the tests compare the two."""
 from abc import ABC, abstractmethod
 
-from numpy import ndarray
+from numpy import array, ndarray
 
 
 class Agent(ABC):
     @abstractmethod
     def get_action(self, state: ndarray) -> ndarray:
         """(N, D) observations -> (N, A) actions."""
+
+    def get_expected_action(self, state: ndarray, n_samples: int = 1000) -> ndarray:
+        """Monte-Carlo mean of `get_action` over `n_samples` calls (Agent.py:11-12): the action itself for a deterministic
+        agent, the mean action of a sampling one."""
+        return array([self.get_action(state) for _ in range(n_samples)]).mean(axis=0)

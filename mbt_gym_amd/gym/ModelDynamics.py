@@ -84,6 +84,9 @@ class ModelDynamics(metaclass=abc.ABCMeta):
     def update_state(self, arrivals, fills, action):
         raise DeviceResidentError("cash/inventory updates run inside the fused HIP step kernel; call env.step().")
 
+    def get_fills(self, action):
+        return None  # a stub upstream too (MD:44-45)
+
     def get_arrivals_and_fills(self, action):
         raise DeviceResidentError("arrivals and fills are drawn inside the fused HIP step kernel; call env.step().")
 

@@ -38,6 +38,10 @@ except Exception:  # noqa: BLE001
         def unwrapped(self):
             return getattr(self.env, "unwrapped", self.env)
 
+        @property
+        def metadata(self):
+            return getattr(self.env, "metadata", {})
+
         def seed(self, seed=None):
             return self.env.seed(seed)
 
@@ -113,6 +117,9 @@ class RemoveTerminalRewards(Wrapper):
 
     def __init__(self, env, num_final_steps: int = 5):
         super().__init__(env)
+
+    def reset(self):
+        return self.env.reset()
 
     def step(self, action):
         state, reward, done, _ = self.env.step(action)

@@ -172,3 +172,67 @@ def test_closed_form_agents_equal_the_references_on_random_parameters(case, no_d
     phi, alpha = float(rng.uniform(1e-4, 1e-2)), float(rng.uniform(1e-3, 1e-1))
     a, b = _agents("mbt_gym_amd").CarteaJaimungalOeAgent(phi, alpha, ours), _agents("mbt_gym").CarteaJaimungalOeAgent(phi, alpha, ref)
     np.testing.assert_allclose(a.get_action(state), b.get_action(state), rtol=2e-6, atol=1e-6, err_msg=f"CJ-OE case {case}")
+
+
+# ---- the API surface: every mirrored class takes the reference's constructor arguments and offers its public methods ----
+
+MIRRORED = {
+    "gym.TradingEnvironment": ["TradingEnvironment"],
+    "gym.ModelDynamics": ["ModelDynamics", "LimitOrderModelDynamics", "LimitAndMarketOrderModelDynamics", "AtTheTouchModelDynamics", "TradinghWithSpeedModelDynamics"],
+    "stochastic_processes.StochasticProcessModel": ["StochasticProcessModel"],
+    "stochastic_processes.midprice_models": ["ConstantMidpriceModel", "BrownianMotionMidpriceModel", "GeometricBrownianMotionMidpriceModel", "OuMidpriceModel",
+                                             "BrownianMotionJumpMidpriceModel", "OuJumpMidpriceModel"],
+    "stochastic_processes.arrival_models": ["ArrivalModel", "PoissonArrivalModel", "PoissonArrivalNonLinearModel", "HawkesArrivalModel"],
+    "stochastic_processes.fill_probability_models": ["FillProbabilityModel", "ExponentialFillFunction", "ExogenousMmFillProbabilityModel"],
+    "stochastic_processes.price_impact_models": ["PriceImpactModel", "TemporaryPowerPriceImpact", "TemporaryAndPermanentPriceImpact",
+                                                 "TemporaryAndTransientPriceImpact", "TransientPriceImpact"],
+    "rewards.RewardFunctions": ["RewardFunction", "PnL", "CjOeCriterion", "CjMmCriterion", "RunningInventoryPenalty", "ExponentialUtility"],
+    "agents.BaselineAgents": ["RandomAgent", "FixedActionAgent", "FixedSpreadAgent", "AvellanedaStoikovAgent", "CarteaJaimungalMmAgent", "CarteaJaimungalOeAgent"],
+    "gym.wrappers": ["ReduceStateSizeWrapper", "NormaliseASObservation", "RemoveTerminalRewards"],
+}
+
+
+@pytest.mark.parametrize("module", sorted(MIRRORED))
+def test_mirrored_classes_take_the_references_arguments_and_offer_its_methods(module):
+    """Drop-in at the source level: for every class on the path, the reference's constructor parameters exist here under the
+    same names, in the same order, with the same defaults (ours may ADD keyword-only ones: device, trajectory_offset, ...), and
+    every public method / property of the reference's class exists here."""
+    import importlib
+    import inspect
+
+    ref_mod, our_mod = importlib.import_module("mbt_gym." + module), importlib.import_module("mbt_gym_amd." + module)
+    gaps = []
+    for name in MIRRORED[module]:
+        ref_cls, our_cls = getattr(ref_mod, name), getattr(our_mod, name)
+        ref_params = [p for p in inspect.signature(ref_cls.__init__).parameters.values() if p.name != "self"]
+        our_params = {p.name: p for p in inspect.signature(our_cls.__init__).parameters.values()}
+        our_positional = [p.name for p in our_params.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.name != "self"]
+        ref_positional = [p.name for p in ref_params if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        assert our_positional[: len(ref_positional)] == ref_positional, f"{module}.{name}: constructor parameters {our_positional} vs the reference's {ref_positional}"
+        for p in ref_params:
+            if p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD):
+                continue
+            assert p.name in our_params, f"{module}.{name}: constructor parameter {p.name} is missing"
+            ours = our_params[p.name].default
+            same = (ours is p.default) or (isinstance(p.default, np.ndarray) and np.array_equal(ours, p.default)) or \
+                   (not isinstance(p.default, np.ndarray) and not isinstance(ours, np.ndarray) and ours == p.default)
+            assert same, f"{module}.{name}: default of {p.name} is {ours!r}, the reference's is {p.default!r}"
+        public = {m for m, _ in inspect.getmembers(ref_cls) if not m.startswith("_")}
+        missing = sorted(m for m in public if not hasattr(our_cls, m))
+        if missing:
+            gaps.append(f"{name}: {missing}")
+    assert not gaps, f"{module}: public members of the reference's classes missing here: {gaps}"
+
+
+def test_generate_trajectory_and_index_names_match_the_references():
+    import importlib
+    import inspect
+
+    ref = importlib.import_module("mbt_gym.gym.helpers.generate_trajectory").generate_trajectory
+    ours = importlib.import_module("mbt_gym_amd.gym.helpers.generate_trajectory").generate_trajectory
+    ref_params, our_params = list(inspect.signature(ref).parameters.values()), list(inspect.signature(ours).parameters.values())
+    assert [p.name for p in our_params][: len(ref_params)] == [p.name for p in ref_params]
+    assert [p.default for p in our_params][: len(ref_params)] == [p.default for p in ref_params]
+    ref_idx, our_idx = importlib.import_module("mbt_gym.gym.index_names"), importlib.import_module("mbt_gym_amd.gym.index_names")
+    names = [n for n in dir(ref_idx) if n.isupper()]
+    assert names and all(getattr(our_idx, n) == getattr(ref_idx, n) for n in names)
