@@ -41,11 +41,11 @@ def generate_trajectory_on_device(env, agent, seed: int = None):
 
 
 def generate_trajectory(env, agent, seed: int = None, include_log_probs: bool = False, fused: bool = None):
-    if include_log_probs:
-        raise NotImplementedError("log-probabilities belong to the learning agent, not to the environment path")
     if seed is not None:
         env.seed(seed)
     n, horizon = env.num_trajectories, env.n_steps
+    if include_log_probs:
+        fused = False  # the agent's own sampling carries the autograd graph (GT:16-17, GT:22-23): the reference's loop
     if fused is None:
         fused = hasattr(agent, "device_policy") and getattr(agent, "has_device_policy", True) and getattr(env, "noise", "philox") == "philox"
     if fused:
@@ -59,14 +59,25 @@ def generate_trajectory(env, agent, seed: int = None, include_log_probs: bool = 
     observations = np.zeros((n, env.observation_space.shape[0], horizon + 1), dtype=np.float32)
     actions = np.zeros((n, env.action_space.shape[0], horizon), dtype=np.float32)
     rewards = np.zeros((n, 1, horizon), dtype=np.float32)
+    log_probs = None
+    if include_log_probs:
+        import torch
+
+        log_probs = torch.zeros((n, env.action_space.shape[0], horizon))
     obs = env.reset()
     observations[:, :, 0] = obs
     for k in range(horizon):
-        action = agent.get_action(obs)
+        if include_log_probs:
+            action, log_prob = agent.get_action(obs, include_log_probs=True)
+            log_probs[:, :, k] = log_prob.to(log_probs.device)
+        else:
+            action = agent.get_action(obs)
         obs, reward, done, _ = env.step(action)
         actions[:, :, k] = action
         observations[:, :, k + 1] = obs
         rewards[:, 0, k] = np.asarray(reward).reshape(-1)
         if (n > 1 and done[0]) or (n == 1 and done):  # GT:32
             break
+    if include_log_probs:
+        return observations, actions, rewards, log_probs
     return observations, actions, rewards
