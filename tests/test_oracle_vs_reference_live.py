@@ -189,6 +189,7 @@ MIRRORED = {
     "rewards.RewardFunctions": ["RewardFunction", "PnL", "CjOeCriterion", "CjMmCriterion", "RunningInventoryPenalty", "ExponentialUtility"],
     "agents.BaselineAgents": ["RandomAgent", "FixedActionAgent", "FixedSpreadAgent", "AvellanedaStoikovAgent", "CarteaJaimungalMmAgent", "CarteaJaimungalOeAgent"],
     "gym.wrappers": ["ReduceStateSizeWrapper", "NormaliseASObservation", "RemoveTerminalRewards"],
+    "agents.PolicyGradientAgent": ["PolicyGradientAgent"],
 }
 
 
