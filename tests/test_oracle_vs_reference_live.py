@@ -284,3 +284,38 @@ def test_instance_attributes_of_environment_processes_and_rewards(case, no_devic
             assert a.shape == b.shape and a.dtype == b.dtype
     assert not gaps, f"attributes of the reference's objects missing here: {gaps}"
     assert not differs, f"attributes that differ: {differs}"
+
+
+def test_backtesting_statistics_equal_the_references_on_the_same_trajectory(monkeypatch):
+    """gym/backtesting.py: both packages' functions are fed the SAME recorded trajectory (their generate_trajectory is
+    replaced by a stub returning it), so what is compared is the three formulas - per lane here, one lane there."""
+    import importlib
+    import warnings
+
+    ours, ref = importlib.import_module("mbt_gym_amd.gym.backtesting"), importlib.import_module("mbt_gym.gym.backtesting")
+    rng = np.random.default_rng(SEED + 29000)
+    steps, lanes = 60, 7
+    obs = np.zeros((lanes, 4, steps + 1))
+    obs[:, 3, :] = 100.0 + np.cumsum(rng.normal(0, 0.5, size=(lanes, steps + 1)), axis=-1)
+    obs[:, 1, :] = np.cumsum(rng.integers(-1, 2, size=(lanes, steps + 1)), axis=-1)
+    obs[:, 0, :] = 1000.0 + np.cumsum(rng.normal(0, 20.0, size=(lanes, steps + 1)), axis=-1)
+
+    class Env:
+        n_steps = steps
+
+        def __init__(self, n):
+            self.num_trajectories = n
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name in ("get_sharpe_ratio", "get_sortino_ratio", "get_maximum_drawdown"):
+            monkeypatch.setattr(ours, "generate_trajectory", lambda env, agent: (obs, None, None))
+            batch = getattr(ours, name)(Env(lanes), None)
+            assert batch.shape == (lanes,)
+            for lane in range(lanes):
+                one = obs[lane:lane + 1]
+                monkeypatch.setattr(ref, "generate_trajectory", lambda env, agent, one=one: (one, None, None))
+                monkeypatch.setattr(ours, "generate_trajectory", lambda env, agent, one=one: (one, None, None))
+                want = getattr(ref, name)(Env(1), None)
+                assert getattr(ours, name)(Env(1), None) == pytest.approx(want, rel=1e-12), (name, lane)
+                assert batch[lane] == pytest.approx(want, rel=1e-12), (name, lane)
