@@ -33,6 +33,7 @@ import re
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -260,7 +261,56 @@ def spawn_ranks(args):
     return rc
 
 
+def rccl_probe_child(rank, world, gpu, id_path):
+    """`bench.py --probe-rccl rank world gpu path`: one rank of a throw-away job that makes a C-ABI RCCL communicator (the
+    128-byte id travels by file, like examples/sharded_returns.c) and all-reduces three doubles on an environment's stream.
+    Exit code 0 = the sum is right."""
+    from mbt_gym_amd.distributed import RcclCommunicator
+
+    def exchange(payload):
+        if rank == 0:
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(payload)
+            os.replace(id_path + ".tmp", id_path)
+            return payload
+        deadline = time.time() + 60
+        while not os.path.exists(id_path):
+            if time.time() > deadline:
+                raise TimeoutError("rank 0's RCCL id never appeared")
+            time.sleep(0.02)
+        with open(id_path, "rb") as f:
+            return f.read()
+
+    env = build_env(1024, rank * 1024, gpu)
+    comm = RcclCommunicator(rank, world, gpu, exchange=exchange)
+    sums = env.allreduce_return_sums(comm, [float(rank + 1), 0.0, 1.0])
+    ok = sums[0] == world * (world + 1) / 2 and sums[2] == world
+    env.close()
+    comm.close()
+    return 0 if ok else 4
+
+
+def probe_c_abi_rccl(rank, world, gpu, id_path, timeout_s=120.0):
+    """Before the measured job binds its one collective to the C ABI's own RCCL communicator, the same thing is tried in a
+    child process with a deadline: a collective that never completes cannot be cancelled from inside the process it hangs,
+    but a child can be killed - and the job then takes the torch.distributed transport instead of hanging the run."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-rccl", str(rank), str(world), str(gpu), id_path]
+    try:
+        child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    except OSError as exc:
+        return False, f"probe could not start: {exc}"
+    try:
+        _, err = child.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        child.kill()  # exactly the process started here
+        child.communicate()
+        return False, f"probe did not finish within {timeout_s:.0f} s"
+    return child.returncode == 0, (err.decode("utf-8", "replace")[-400:] if child.returncode != 0 else "")
+
+
 def main():
+    if len(sys.argv) == 6 and sys.argv[1] == "--probe-rccl":
+        sys.exit(rccl_probe_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
@@ -319,14 +369,29 @@ def main():
     if world > 1:
         transport = f"torch.distributed/{args.backend}"
         if args.backend == "nccl":
-            ok = 1.0
+            # (i) the same communicator + collective in throw-away child processes, with a deadline (probe_c_abi_rccl)
+            box = [os.path.join(tempfile.gettempdir(), f"mbt_rccl_probe_{os.getpid()}_{time.time_ns()}")]
+            dist.broadcast_object_list(box, src=0)
             try:
-                comm = RcclCommunicator(rank, world, gpu)
-                env.set_communicator(comm)
-            except Exception as exc:  # noqa: BLE001 - fall back to torch.distributed on EVERY rank, or on none
-                print(f"[rank {rank}] C-ABI RCCL communicator unavailable ({exc}); using torch.distributed", file=sys.stderr)
-                ok = 0.0
-            flag = torch.tensor([ok], dtype=torch.float64, device=tdev)
+                ok, why = probe_c_abi_rccl(rank, world, gpu, box[0])
+            except Exception as exc:  # noqa: BLE001
+                ok, why = False, str(exc)
+            if not ok:
+                print(f"[rank {rank}] C-ABI RCCL probe failed ({why}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if rank == 0 and os.path.exists(box[0]):
+                os.remove(box[0])
+            # (ii) every rank's probe came back: the measured job makes its own
+            ok = flag.item() >= 1.0
+            if ok:
+                try:
+                    comm = RcclCommunicator(rank, world, gpu)
+                    env.set_communicator(comm)
+                except Exception as exc:  # noqa: BLE001 - fall back to torch.distributed on EVERY rank, or on none
+                    print(f"[rank {rank}] C-ABI RCCL communicator unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                    ok = False
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() < 1.0:
                 if comm is not None:

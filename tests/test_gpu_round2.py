@@ -143,6 +143,33 @@ def test_a_process_that_made_a_communicator_without_torch_exits_cleanly():
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
 
 
+def test_the_bounded_time_rccl_probe(tmp_path):
+    """bench.py tries the C ABI's communicator + collective in a child process with a deadline before the measured job
+    relies on it (a hung collective cannot be cancelled in-process; a child can be killed).  World of one: succeeds.  A
+    deadline that cannot be met: reported as failed, child gone.  Two ranks on ONE GPU - which RCCL refuses - fail on both
+    sides within the deadline instead of hanging: the path the job then takes is torch.distributed."""
+    import threading
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    ok, why = bench.probe_c_abi_rccl(0, 1, 0, str(tmp_path / "id1"))
+    assert ok, why
+    ok, why = bench.probe_c_abi_rccl(0, 1, 0, str(tmp_path / "id2"), timeout_s=0.05)
+    assert not ok and "did not finish" in why
+    results = {}
+
+    def one(rank):
+        results[rank] = bench.probe_c_abi_rccl(rank, 2, 0, str(tmp_path / "id3"), timeout_s=90.0)
+
+    threads = [threading.Thread(target=one, args=(r,)) for r in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not results[0][0] and not results[1][0], results
+
+
 def _bench(*args):
     env = dict(os.environ)
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
