@@ -312,6 +312,14 @@ void fill_static_params(mbt_env* e) {
     P.arr_thr_bid = round_up_f32(c.intensity[0] * e->arr_dt);
     P.arr_thr_ask = round_up_f32(c.intensity[1] * e->arr_dt);
   }
+  {  // the Philox uniforms are k * 2^-24, k integer: u < thr <=> k < ceil(thr * 2^24) (the product is exact in double)
+    const auto as_count = [](float thr) -> uint32_t {
+      const double x = std::ceil(static_cast<double>(thr) * 16777216.0);
+      return x <= 0.0 ? 0u : (x >= 16777216.0 ? 16777216u : static_cast<uint32_t>(x));
+    };
+    P.arr_thr_k_bid = as_count(P.arr_thr_bid);
+    P.arr_thr_k_ask = as_count(P.arr_thr_ask);
+  }
   P.arr_dt_f64 = e->arr_dt;
   P.arr_dt = static_cast<float>(e->arr_dt);
   P.hawkes_base_bid = static_cast<float>(c.intensity[0]);

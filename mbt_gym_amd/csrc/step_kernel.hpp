@@ -113,6 +113,7 @@ struct StepParams {
   float jump_size;       // MID:226, MID:269
   // arrivals
   float arr_thr_bid, arr_thr_ask;  // Poisson: smallest float32 >= lambda*dt_arr (ARR:56) or 1-exp(-lambda*dt_arr) (ARR:83)
+  uint32_t arr_thr_k_bid, arr_thr_k_ask;  // the same thresholds for u = k * 2^-24 as integers: u < thr <=> k < ceil(thr * 2^24)
   double arr_dt_f64;               // Hawkes: threshold lambda_lane * dt_arr in double (ARR:123)
   float arr_dt;
   float hawkes_base_bid, hawkes_base_ask, hawkes_speed, hawkes_jump;
@@ -208,7 +209,12 @@ __device__ __forceinline__ void fill_thresholds(float u, const StepParams& P, fl
 template <class V>
 __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepParams& P) {
   LaneDraw d;
-  if (V::ARR == kArrPoisson && !V::USER_ARRIVAL) {  // strict '<' against thresholds rounded UP to float32: exact vs the float64 compare
+  if (V::ARR == kArrPoisson && !V::USER_ARRIVAL && !V::INJECT) {
+    // Philox draws are 24-bit integers k (u = k * 2^-24): the decision u < thr is the integer compare k < ceil(thr * 2^24) -
+    // no conversion, no multiply (the float uniforms of the arrival side are then dead code in this instantiation)
+    d.arr_bid = nz.ka_bid < P.arr_thr_k_bid ? 1.0f : 0.0f;
+    d.arr_ask = nz.ka_ask < P.arr_thr_k_ask ? 1.0f : 0.0f;
+  } else if (V::ARR == kArrPoisson && !V::USER_ARRIVAL) {  // strict '<' against thresholds rounded UP to float32: exact vs the float64 compare
     d.arr_bid = nz.ua_bid < P.arr_thr_bid ? 1.0f : 0.0f;
     d.arr_ask = nz.ua_ask < P.arr_thr_ask ? 1.0f : 0.0f;
   } else {
