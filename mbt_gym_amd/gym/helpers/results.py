@@ -2,8 +2,8 @@
 `generate_results_table_and_hist`): mean quoted spread, mean / std of the total reward, mean / std of the terminal
 inventory.  The reference builds it from a host-side trajectory; here the episode is one fused rollout launch and, when
 PyTorch sees the GPU, the five statistics are reduced on the device from the recording, so nothing but five numbers (and
-the per-trajectory totals the reference also returns) crosses PCIe.  The histogram figure needs matplotlib + seaborn, which
-are optional: without them the second return value is None."""
+the per-trajectory totals the reference also returns) crosses PCIe.  The histogram figure needs matplotlib (helpers/plotting.py), which
+is optional: without it the second return value is None."""
 import numpy as np
 
 from mbt_gym_amd.gym.helpers.generate_trajectory import generate_trajectory, generate_trajectory_on_device
@@ -57,13 +57,6 @@ def _torch_sees_the_gpu() -> bool:
 
 
 def _plot_pnl(rewards):
-    try:
-        import matplotlib.pyplot as plt
-        import seaborn as sns
-    except Exception:  # noqa: BLE001
-        return None
-    fig, ax = plt.subplots(1, 1, figsize=(20, 10))
-    sns.histplot(rewards, label="Rewards", color="red", stat="density", bins=50, ax=ax)
-    ax.legend()
-    plt.close()
-    return fig
+    from mbt_gym_amd.gym.helpers.plotting import plot_pnl  # (matplotlib only; None without it)
+
+    return plot_pnl(rewards)
