@@ -319,3 +319,51 @@ def test_backtesting_statistics_equal_the_references_on_the_same_trajectory(monk
                 want = getattr(ref, name)(Env(1), None)
                 assert getattr(ours, name)(Env(1), None) == pytest.approx(want, rel=1e-12), (name, lane)
                 assert batch[lane] == pytest.approx(want, rel=1e-12), (name, lane)
+
+
+def test_wrappers_equal_the_references_on_a_scripted_environment():
+    """gym/wrappers.py: each package's three wrappers around the same scripted environment (its Box built from that package's
+    own Box class) return the same observations, rewards, dones and bounds, step by step - including the reference's
+    reset / step asymmetry in NormaliseASObservation and its terminal-reward rescaling."""
+    import importlib
+
+    ref_w, our_w = importlib.import_module("mbt_gym.gym.wrappers"), importlib.import_module("mbt_gym_amd.gym.wrappers")
+    ref_box = importlib.import_module("gym").spaces.box.Box
+    our_box = importlib.import_module("mbt_gym_amd.spaces").Box
+
+    class Reward:
+        per_step_inventory_aversion, terminal_inventory_aversion = 0.01, 0.5
+
+    def scripted(box):
+        class Env:
+            metadata, spec = {}, None
+
+            def __init__(self):
+                self.observation_space = box(low=np.float32([-10, -4, 0, 90]), high=np.float32([10, 4, 1, 110]))
+                self.action_space = box(low=np.float32([0, 0]), high=np.float32([3, 3]))
+                self.reward_function, self.num_trajectories, self.k = Reward(), 1, 0
+
+            def _obs(self):
+                return np.array([[1.5 + self.k, -2.0, 0.25 * self.k, 101.0 - self.k]])
+
+            def reset(self):
+                self.k = 0
+                return self._obs()
+
+            def step(self, action):
+                self.k += 1
+                return self._obs(), np.array([2.0 + self.k]), np.array([self.k == 3]), [{}]
+
+        return Env()
+
+    for name, kwargs in (("ReduceStateSizeWrapper", {}), ("ReduceStateSizeWrapper", {"list_of_state_indices": [3, 0]}), ("NormaliseASObservation", {}),
+                         ("RemoveTerminalRewards", {})):
+        a, b = getattr(our_w, name)(scripted(our_box), **kwargs), getattr(ref_w, name)(scripted(ref_box), **kwargs)
+        np.testing.assert_array_equal(a.observation_space.low, b.observation_space.low, err_msg=name)
+        np.testing.assert_array_equal(a.observation_space.high, b.observation_space.high, err_msg=name)
+        assert a.observation_space.dtype == b.observation_space.dtype, name
+        np.testing.assert_array_equal(a.reset(), b.reset(), err_msg=name)
+        for _ in range(3):
+            out_a, out_b = a.step(None), b.step(None)
+            for x, y in zip(out_a[:3], out_b[:3]):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=name)
