@@ -405,3 +405,21 @@ def test_host_side_draws_at_reset_equal_the_references(seed, no_device):
         ref.reset()
     np.testing.assert_array_equal(no_device[-1][1].astype(np.float64), ref.model_dynamics.state[:, 1])
     assert [p.seed_ for p in ours.stochastic_processes.values()] == [p.seed_ for p in ref.stochastic_processes.values()]
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_host_side_normalisation_maps_equal_the_references(case, no_device):
+    """normalise_action / normalise_observation and their inverses (TE:112-126) on random arrays, both packages' environments
+    of the same random market: same float32 Box bounds, same arithmetic, equal results."""
+    rng = np.random.default_rng(SEED + 31000 + case)
+    cfg = random_speed_config(rng, 16) if case % 3 == 2 else random_config(rng, 16)
+    cfg.normalise_action_space = cfg.normalise_observation_space = cfg.dynamics != "touch"
+    with contextlib.redirect_stdout(io.StringIO()):
+        ours, ref = make_env(cfg), make_env(cfg, package="mbt_gym")
+    act = rng.uniform(-1, 1, size=(16, cfg.action_dim))
+    obs = rng.uniform(-1, 1, size=(16, ours.observation_space.shape[0]))
+    for inverse in (False, True):
+        np.testing.assert_array_equal(ours.normalise_action(act, inverse=inverse), ref.normalise_action(act, inverse=inverse))
+        with np.errstate(divide="ignore", invalid="ignore"):  # a constant midprice has a zero-width Box column on both sides
+            np.testing.assert_array_equal(ours.normalise_observation(obs, inverse=inverse), ref.normalise_observation(obs, inverse=inverse))
+    np.testing.assert_array_equal(ours.normalise_rewards(act[:, 0]), ref.normalise_rewards(act[:, 0]))
