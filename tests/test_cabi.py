@@ -90,3 +90,17 @@ def test_abi_version_mismatch_is_rejected(lib):
     cfg.abi_version = 999
     handle = C.c_void_p()
     assert lib.mbt_env_create(C.byref(cfg), C.byref(handle)) == -5  # MBT_ERR_ABI
+
+
+def test_the_stub_shown_in_integration_md_matches_the_binding():
+    """INTEGRATION.md section 2 shows a maintainer the ctypes struct to add: it must be the struct (names, order, types) the
+    package's own binding uses - documentation that compiles."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = text.index("class MbtConfig(C.Structure):")
+    end = text.index("lib = C.CDLL", start)
+    namespace = {"C": C}
+    exec(text[start:end], namespace)  # noqa: S102 - the repository's own documentation
+    shown, bound = namespace["MbtConfig"], _native.MbtConfig
+    assert [(n, t) for n, t in shown._fields_] == [(n, t) for n, t in bound._fields_]
+    assert C.sizeof(shown) == C.sizeof(bound)
+    assert f"abi_version={_native.ABI_VERSION}" in text
