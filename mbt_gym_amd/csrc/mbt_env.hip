@@ -403,15 +403,15 @@ void tune_for_size(mbt_env* e) {
   e->stream_loads = hbm_resident;
   e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;  // AS 2^24: 115.7 -> 114.2 us; Hawkes (D = 6) loses with it
   // Inside the cache the same cap pays for ONE kernel: the lightest one (Brownian midprice, Poisson arrivals, limit orders,
-  // plain PnL, nothing normalised - BASELINE configs[1], the benchmark workload), from 2^20 lanes up: 6.76 / 6.85 / 6.84 ->
-  // 6.70 / 6.62 / 6.62 us at 2^20 (three alternating runs of bench.py), 14.53 -> 14.25 at 2^21, 26.74 -> 26.59 at 2^22; at 2^18
+  // plain PnL - BASELINE configs[1], the benchmark workload, and with normalised spaces the reference's default
+  // environment), from 2^20 lanes up: 6.76 / 6.85 / 6.84 -> 6.70 / 6.62 / 6.62 us at 2^20 (three alternating runs of bench.py),
+  // 14.53 -> 14.25 at 2^21, 26.74 -> 26.59 at 2^22; normalised: 9.37 / 9.37 / 9.34 -> 8.97 / 9.01 / 8.90 us at 2^20; at 2^18
   // it costs (3.52 -> 3.69 us), and the kernels with more arithmetic per lane need their waves (CJP 6.7 -> 7.6 us, speed + impact
   // state 8.0 -> 10.0: profiles/r02_occupancy_cap_all_configs.txt).
   const mbt_config& c = e->cfg;
   const bool lightest = !e->speed && e->dim == 4 && !c.precise_state && c.midprice_kind == MBT_MID_BROWNIAN &&
                         (c.arrival_kind == MBT_ARR_POISSON || c.arrival_kind == MBT_ARR_POISSON_NONLINEAR) && c.fill_kind == MBT_FILL_EXPONENTIAL &&
-                        c.dynamics_kind == MBT_DYN_LIMIT && c.reward_kind == MBT_REW_PNL && !c.normalise_action && !c.normalise_observation &&
-                        c.noise_mode == MBT_NOISE_PHILOX;
+                        c.dynamics_kind == MBT_DYN_LIMIT && c.reward_kind == MBT_REW_PNL && c.noise_mode == MBT_NOISE_PHILOX;
   if (!hbm_resident && lightest && bytes_per_launch >= (size_t(40) << 20)) e->step_dynamic_lds = 32u * 1024u;
   if (const char* v = std::getenv("MBT_STREAM_LOADS")) e->stream_loads = std::atoi(v) != 0;
   if (const char* v = std::getenv("MBT_STEP_DYNAMIC_LDS")) e->step_dynamic_lds = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
