@@ -104,3 +104,27 @@ def test_the_stub_shown_in_integration_md_matches_the_binding():
     assert [(n, t) for n, t in shown._fields_] == [(n, t) for n, t in bound._fields_]
     assert C.sizeof(shown) == C.sizeof(bound)
     assert f"abi_version={_native.ABI_VERSION}" in text
+
+
+def test_a_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    """No HIP extension, no product: the binding refuses to load, and so does everything above it - there is nothing to fall
+    back to (the oracle is test infrastructure and is never imported by the package)."""
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libmbtenv.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.load_library()
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TradingEnvironment(num_trajectories=4)
+    import subprocess as sp
+    import sys
+
+    # and the package never reaches for the oracle: importing every module of it leaves `oracle` unimported
+    code = ("import importlib, pkgutil, sys, mbt_gym_amd\n"
+            "for m in pkgutil.walk_packages(mbt_gym_amd.__path__, 'mbt_gym_amd.'):\n"
+            "    if not m.name.endswith('libmbtenv'):  # (the shared library itself sits in the package directory)\n"
+            "        importlib.import_module(m.name)\n"
+            "assert not any(n == 'oracle' or n.startswith('oracle.') for n in sys.modules), 'the package imports the oracle'\n")
+    out = sp.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 0, out.stderr[-1500:]
