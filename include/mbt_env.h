@@ -341,6 +341,17 @@ int mbt_env_action_dim(mbt_env* env);
 /* ---- state access / checkpoint (TE:142-144 `state`) -------------------------------------------- */
 /* Un-normalised state (N, D) row-major float32. */
 int mbt_env_get_state_host(mbt_env* env, float* state_host);
+/* The same as float64, the dtype of the reference's `state` (TE:142-144).  With precise_state these ARE the reference's
+ * float64 values (float32 rounding + int32 remainder, joined on the host; the TIME column is the host's float64 clock);
+ * without it, the float32 state widened. */
+int mbt_env_get_state_f64_host(mbt_env* env, double* state_host);
+/* The representation precise_state keeps a float64 value x in (8 bytes, the same as a float32 pair, but EXACT):
+ * hi = float32(x), rounded to nearest - what the observation shows - and lo = (x - hi) * 2^(53 - e) as an int32, e the
+ * exponent of hi.  x - hi is at most half a float32 ulp and a multiple of 2^(e-53), so lo is an integer of magnitude
+ * <= 2^29 and join(split(x)) == x for every double whose float32 rounding is a normal number (zero, denormal and
+ * non-finite hi carry lo = 0).  Host-side restatements of the device functions, for bindings and tests. */
+void mbt_exact_split(double x, float* hi, int32_t* lo);
+double mbt_exact_join(float hi, int32_t lo);
 /* Observation of the last reset/step as the API returns it ((N, D), normalised when configured, TE:112-118). */
 int mbt_env_get_obs_host(mbt_env* env, float* obs_host);
 /* Upload (N, A) actions into the buffer of mbt_env_action_ptr() (e.g. a fixed quote for step_device loops). */

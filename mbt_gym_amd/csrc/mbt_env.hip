@@ -66,6 +66,21 @@ float round_up_f32(double x) {
   return f;
 }
 
+// precise_state keeps a float64 value x as hi = float32(x) in the state row and lo = (x - hi) * 2^(53 - exponent(hi)) as an
+// int32 beside it (step_kernel.hpp: exact_join / exact_split); the same two functions for the host side (reset values,
+// mbt_env_get_state_f64_host).
+int f32_biased_exponent_host(float hi) {
+  uint32_t bits;
+  std::memcpy(&bits, &hi, sizeof bits);
+  return static_cast<int>((bits >> 23) & 0xffu);
+}
+void exact_split_host(double x, float& hi, int32_t& lo) {
+  hi = static_cast<float>(x);
+  const int e = f32_biased_exponent_host(hi);
+  lo = (e != 0 && e != 255) ? static_cast<int32_t>(std::ldexp(x - static_cast<double>(hi), (127 + 53) - e)) : 0;
+}
+double exact_join_host(float hi, int32_t lo) { return static_cast<double>(hi) + std::ldexp(static_cast<double>(lo), f32_biased_exponent_host(hi) - (127 + 53)); }
+
 // up to this many lanes the host API stages through device-mapped pinned memory (mbt_env_step_host); measured per step,
 // DMA path vs mapped staging: 52 vs 33 us at 8192 lanes, 85 vs 70 at 32768, 138 vs 131 at 65536, 149 vs 228 at 131072.
 // MBT_HOST_FAST_PATH_LANES overrides it (measurement knob).
@@ -133,28 +148,37 @@ StepKernel pick_exogenous(bool inject) {
                 : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>>;
 }
 
-// precise_state: the general tier again (runtime midprice coefficients, every reward, runtime normalisation flags) with
-// cash and midprice as float32 pairs: 12 step + 6 rollout kernels.
-template <int ARR, int DYN>
+// precise_state: the general tier again (every midprice model, every reward, runtime normalisation flags) on the
+// reference's float64 state: {Poisson-type, Hawkes} x {limit, limit + market, touch} + the exogenous-depth fill model on
+// {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 4 + 2 for speed dynamics.
+template <int ARR, int DYN, bool EXO>
 StepKernel pick_precise(bool inject) {
-  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, false, true>>
-                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, false, true>>;
+  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>
+                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>;
 }
 template <int ARR>
-StepKernel pick_precise_dyn(int dyn, bool inject) {
+StepKernel pick_precise_dyn(int dyn, bool exo, bool inject) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return pick_precise<ARR, mbt::kDynLimit>(inject);
-    case MBT_DYN_LIMIT_AND_MARKET: return pick_precise<ARR, mbt::kDynLimitAndMarket>(inject);
-    default: return pick_precise<ARR, mbt::kDynTouch>(inject);
+    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject) : pick_precise<ARR, mbt::kDynLimit, false>(inject);
+    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject) : pick_precise<ARR, mbt::kDynLimitAndMarket, false>(inject);
+    default: return pick_precise<ARR, mbt::kDynTouch, false>(inject);
   }
+}
+template <bool STATE>
+StepKernel pick_speed_precise(bool inject) {
+  return inject ? mbt::speed_step_exact_kernel<mbt::SpeedVariant<STATE, true, true, true>> : mbt::speed_step_exact_kernel<mbt::SpeedVariant<STATE, true, false, true>>;
 }
 
 StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
-  if (c.dynamics_kind == MBT_DYN_SPEED) return impact_has_state(c) ? pick_speed<true>(norm, inject, stream) : pick_speed<false>(norm, inject, stream);
+  if (c.dynamics_kind == MBT_DYN_SPEED) {
+    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(inject) : pick_speed_precise<false>(inject);
+    return impact_has_state(c) ? pick_speed<true>(norm, inject, stream) : pick_speed<false>(norm, inject, stream);
+  }
   if (c.precise_state)
-    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, inject) : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, inject);
+    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), inject)
+                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), inject);
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
     if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject);
@@ -185,20 +209,27 @@ RolloutKernel rpick_dyn(int dyn, bool bm, int rew, bool norm) {
   }
 }
 template <int ARR>
-RolloutKernel rpick_precise(int dyn) {
+RolloutKernel rpick_precise(int dyn, bool exo) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
-    case MBT_DYN_LIMIT_AND_MARKET: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
+    case MBT_DYN_LIMIT:
+      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true, true>>
+                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
+    case MBT_DYN_LIMIT_AND_MARKET:
+      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true, true>>
+                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
     default: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynTouch, false, mbt::kRewardGeneral, true, false, false, true>>;
   }
 }
 RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
+    if (c.precise_state)
+      return impact_has_state(c) ? mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<true, true, false, true>> : mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<false, true, false, true>>;
     if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
     return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
   }
-  if (c.precise_state) return c.arrival_kind == MBT_ARR_HAWKES ? rpick_precise<mbt::kArrHawkes>(c.dynamics_kind) : rpick_precise<mbt::kArrPoisson>(c.dynamics_kind);
+  if (c.precise_state)
+    return c.arrival_kind == MBT_ARR_HAWKES ? rpick_precise<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c)) : rpick_precise<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c));
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
     if (c.arrival_kind == MBT_ARR_HAWKES)
@@ -240,7 +271,8 @@ struct mbt_env {
   float* u_fill = nullptr;
   float* z = nullptr;
   float* q_init = nullptr;
-  float* resid = nullptr;      // precise_state: (n_pad, 2) residuals of (cash, midprice)
+  int32_t* resid = nullptr;    // precise_state: (n_pad, res) int32 remainders of the float64 state (step_kernel.hpp: exact_join)
+  int res = 0;                 // remainder columns per lane: [cash, midprice] (+ [bid, ask intensity]), speed: [cash, inventory, midprice, y]
   uint8_t* events = nullptr;
   float* lane_returns = nullptr;
   double* wave_sums = nullptr;
@@ -360,22 +392,40 @@ void fill_static_params(mbt_env* e) {
   P.trans_coef = static_cast<float>(c.transient_impact);
   P.resilience = static_cast<float>(c.resilience);
   P.kernel_coef = static_cast<float>(c.kernel_coefficient);
-  mbt::PreciseParams& X = P.X;  // the same quantities in double, for the precise_state tier
-  X.drift_dt = (ou || mk == MBT_MID_CONSTANT) ? 0.0 : c.drift * e->mid_dt;
-  X.vol_sqrt_dt = mk == MBT_MID_CONSTANT ? 0.0 : c.volatility * std::sqrt(e->mid_dt);
-  X.mid_add = sde ? c.mid_coef_add : (mk == MBT_MID_GBM || mk == MBT_MID_CONSTANT) ? 0.0 : 1.0;
-  X.mid_mul = sde ? c.mid_coef_mul : mk == MBT_MID_GBM ? 1.0 : 0.0;
-  X.ou_speed = (ou || sde) ? c.ou_speed : 0.0;
-  X.ou_level = (ou || sde) ? c.ou_level : 0.0;
-  X.jump_size = (jump || sde) ? c.jump_size : 0.0;
+  mbt::PreciseParams& X = P.X;  // what the precise_state tier computes with: the constructor arguments as the reference holds them
+  X.mid_kind = mk;
+  X.mu = c.drift;
+  X.sigma = c.volatility;
+  X.mid_dt = e->mid_dt;
+  X.sqrt_mid_dt = std::sqrt(e->mid_dt);
+  X.mu_dt = c.drift * e->mid_dt;                         // MID:63: self.drift * self.step_size
+  X.sigma_sqrt_dt = c.volatility * std::sqrt(e->mid_dt);  // MID:64, MID:143: self.volatility * sqrt(self.step_size)
+  X.mid_add = c.mid_coef_add;
+  X.mid_mul = c.mid_coef_mul;
+  X.ou_speed = c.ou_speed;
+  X.ou_level = c.ou_level;
+  X.jump_size = c.jump_size;
+  X.hawkes_speed = c.hawkes_speed;
+  X.hawkes_base_bid = c.intensity[0];
+  X.hawkes_base_ask = c.intensity[1];
+  X.hawkes_jump = c.hawkes_jump;
+  X.arr_dt = e->arr_dt;
   X.half_spread = c.market_half_spread;
+  X.q_max = c.max_inventory;
   X.c_max = c.max_cash;
-  X.dt = e->dt;
   X.phi = c.phi;
   X.alpha = c.alpha;
   X.exponent = c.inventory_exponent;
   X.risk_aversion = c.risk_aversion;
   X.reward_scale = c.reward_scale;
+  X.temp_coef = c.temporary_impact;
+  X.impact_exponent = c.impact_exponent;
+  X.perm_coef = c.permanent_impact;
+  X.trans_coef = c.transient_impact;
+  X.resilience = c.resilience;
+  X.kernel_coef = c.kernel_coefficient;
+  X.impact_dt = e->imp_dt;
+  X.speed_dt = e->mid_dt;
   P.norm_act = c.normalise_action;
   P.norm_obs = c.normalise_observation;
   for (int j = 0; j < 4; ++j) {
@@ -398,7 +448,7 @@ void fill_static_params(mbt_env* e) {
 // profiles/r01_microbench.txt; the non-temporal loads: 128.3 -> 118.7 us on the copy kernel).  MBT_STREAM_LOADS = 0 / 1 and
 // MBT_STEP_DYNAMIC_LDS = bytes override the choice (measurement knobs).
 void tune_for_size(mbt_env* e) {
-  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + (e->cfg.precise_state ? 4u : 0u));
+  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + 2u * e->res);
   const bool hbm_resident = bytes_per_launch > (size_t(320) << 20);
   e->stream_loads = hbm_resident;
   e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;  // AS 2^24: 115.7 -> 114.2 us; Hawkes (D = 6) loses with it
@@ -428,7 +478,7 @@ void fill_episode_params(mbt_env* e) {
   P.dt_over_episode = static_cast<float>(e->dt / length);  // RW:106, RW:113
   P.quad_init = c.reward_kind == MBT_REW_CJ_MM ? static_cast<float>(c.alpha * e->dt / length) : 0.0f;
   P.episode_length = static_cast<float>(length);  // RW:67, RW:74
-  P.X.dt_over_episode = e->dt / length;
+  P.X.episode_length = length;
 }
 
 void key_from_seed(mbt_env* e) {
@@ -457,6 +507,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   P.is_terminal = terminal ? 1 : 0;
   P.t_next = static_cast<float>(t_next);
   P.t_now = e->time;
+  P.t_next_f64 = t_next;
 
   mbt::StepBuffers B;
   B.state_in = e->state[e->cur];
@@ -763,26 +814,44 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
   mbt::StepParams& P = e->params;
   fill_episode_params(e);
   const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
-  mbt::ResetRow row0{static_cast<float>(c.initial_cash), static_cast<float>(start_time), static_cast<float>(c.initial_price),
-                     static_cast<float>(c.initial_inventory), {0.f, 0.f, 0.f, 0.f}};
-  int col = 0;  // process columns in registry order: arrival model, fill model, price impact model (TE:303-318)
+  mbt::ResetRow row0;
+  std::memset(&row0, 0, sizeof row0);
+  double* x = row0.exact;  // the row as the reference's float64 values (TE:131-140, SP:48-53), then its float32 rounding
+  x[0] = c.initial_cash;
+  x[1] = c.initial_inventory;
+  x[2] = start_time;
+  x[3] = c.initial_price;
+  int col = 4;  // process columns in registry order: arrival model, fill model, price impact model (TE:303-318)
   if (e->speed) {
-    row0.extra[col++] = static_cast<float>(c.impact_kind == MBT_IMPACT_TEMPORARY_AND_PERMANENT ? 0.0 : c.initial_transient_impact);  // IMP:81, IMP:121
+    if (impact_has_state(c)) x[col++] = c.impact_kind == MBT_IMPACT_TEMPORARY_AND_PERMANENT ? 0.0 : c.initial_transient_impact;  // IMP:81, IMP:121
   } else {
     if (c.arrival_kind == MBT_ARR_HAWKES) {  // ARR:103
-      row0.extra[col++] = static_cast<float>(c.intensity[0]);
-      row0.extra[col++] = static_cast<float>(c.intensity[1]);
+      x[col++] = c.intensity[0];
+      x[col++] = c.intensity[1];
     }
     if (exogenous_fill(c)) {  // FILL:148-154
-      row0.extra[col++] = static_cast<float>(c.exogenous_depth[0]);
-      row0.extra[col++] = static_cast<float>(c.exogenous_depth[1]);
+      x[col++] = c.exogenous_depth[0];
+      x[col++] = c.exogenous_depth[1];
+    }
+  }
+  row0.cash0 = static_cast<float>(x[0]);
+  row0.q0_scalar = static_cast<float>(x[1]);
+  row0.t0 = static_cast<float>(x[2]);
+  row0.s0 = static_cast<float>(x[3]);
+  for (int j = 4; j < 8; ++j) row0.extra[j - 4] = static_cast<float>(x[j]);
+  row0.res = e->res;
+  if (e->res != 0) {  // precise_state: what float32 left of each value (per-lane initial inventories are float32: no remainder)
+    float hi;
+    const int order_book[4] = {0, 3, 4, 5}, speed[4] = {0, 1, 3, 4};  // state columns behind the remainder columns
+    for (int j = 0; j < e->res; ++j) {
+      const int column = e->speed ? speed[j] : order_book[j];
+      exact_split_host(x[column], hi, row0.lo[j]);
+      if (column >= e->dim || (column == 1 && per_lane_q0)) row0.lo[j] = 0;
     }
   }
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
-                     per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P, e->resid,
-                     make_float2(static_cast<float>(c.initial_cash - static_cast<double>(row0.cash0)),
-                                 static_cast<float>(c.initial_price - static_cast<double>(row0.s0))));
+                     per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P, e->resid);
   HIP_TRY(hipGetLastError());
   if (q0_host != nullptr) HIP_TRY(hipStreamSynchronize(e->stream));  // q0_host may be freed by the caller
   e->was_reset = true;
@@ -968,7 +1037,7 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "  (void)S; (void)t; (void)z; (void)dt; (void)fills_bid; (void)fills_ask; (void)p;\n" + mid_decl +
          "  return static_cast<double>(" + std::string(user_mid ? u.midprice_increment : "0.0") + ");\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", false, false, " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ">;\n";
+         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
@@ -1112,7 +1181,6 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (needs_jit) {
     if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill))
       return fail(MBT_ERR_INVALID, "user-defined plugins run on the order-book kernels (a fill model needs limit or limit + market dynamics)");
-    if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state has no kernel for user-defined plugins");
   }
   if (cfg->abi_version != MBT_ABI_VERSION)
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
@@ -1135,7 +1203,6 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP ||
         (cfg->midprice_kind == MBT_MID_LINEAR_SDE && cfg->jump_size != 0.0))
       return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
-    if (cfg->precise_state) return fail(MBT_ERR_INVALID, "precise_state applies to order-book dynamics");
     if (cfg->midprice_kind == MBT_MID_USER) return fail(MBT_ERR_INVALID, "user-defined midprice expressions run on the order-book kernels");
     if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
       return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
@@ -1162,7 +1229,6 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     }
     if (cfg->reward_kind == MBT_REW_CJ_OE) return fail(MBT_ERR_INVALID, "CjOeCriterion needs the one-dimensional action of speed dynamics (RW:65)");
     if (cfg->impact_kind != MBT_IMPACT_NONE) return fail(MBT_ERR_INVALID, "price impact models belong to speed dynamics");
-    if (cfg->precise_state && exogenous_fill(*cfg)) return fail(MBT_ERR_INVALID, "precise_state has no kernel for the exogenous-depth fill model");
     if (cfg->trajectory_offset % mbt::kTileLanes != 0)
       return fail(MBT_ERR_INVALID, "order-book dynamics draw noise per 512-lane tile: trajectory_offset must be a multiple of 512");
   }
@@ -1191,6 +1257,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
+  e->res = !cfg->precise_state ? 0 : speed ? 4 : (cfg->arrival_kind == MBT_ARR_HAWKES ? 4 : 2);
   tune_for_size(e);
   if (needs_jit) {
     for (int j = 0; j < 8; ++j) {
@@ -1251,7 +1318,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     ENV_TRY(dev_alloc(&e->z, np, e->stream));
   }
   ENV_TRY(dev_alloc(&e->q_init, np, e->stream));
-  if (cfg->precise_state) ENV_TRY(dev_alloc(&e->resid, np * 2, e->stream));
+  if (e->res != 0) ENV_TRY(dev_alloc(&e->resid, np * e->res, e->stream));
   ENV_TRY(dev_alloc(&e->wave_sums, e->n_waves, e->stream));
   ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
   ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
@@ -1650,6 +1717,38 @@ int mbt_env_get_state_host(mbt_env* e, float* state_host) {
   return MBT_OK;
 }
 
+void mbt_exact_split(double x, float* hi, int32_t* lo) {
+  float h = 0.0f;
+  int32_t l = 0;
+  exact_split_host(x, h, l);
+  if (hi != nullptr) *hi = h;
+  if (lo != nullptr) *lo = l;
+}
+
+double mbt_exact_join(float hi, int32_t lo) { return exact_join_host(hi, lo); }
+
+int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
+  if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const size_t n = e->n, d = static_cast<size_t>(e->dim), r = static_cast<size_t>(e->res);
+  std::vector<float> rows(n * d);
+  std::vector<int32_t> lo(n * r);
+  HIP_TRY(hipMemcpyAsync(rows.data(), e->state[e->cur], rows.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (r != 0) HIP_TRY(hipMemcpyAsync(lo.data(), e->resid, lo.size() * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < n * d; ++i) state_host[i] = rows[i];
+  if (r != 0) {
+    const int order_book[4] = {0, 3, 4, 5}, speed[4] = {0, 1, 3, 4};  // state columns behind the remainder columns
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < r; ++j) {
+        const size_t column = static_cast<size_t>(e->speed ? speed[j] : order_book[j]);
+        if (column < d) state_host[i * d + column] = exact_join_host(rows[i * d + column], lo[i * r + j]);
+      }
+    for (size_t i = 0; i < n; ++i) state_host[i * d + 2] = e->time;  // the clock is kept in double on the host (TE:216); every lane shares it
+  }
+  return MBT_OK;
+}
+
 int mbt_env_get_obs_host(mbt_env* e, float* obs_host) {
   if (e == nullptr || obs_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1670,11 +1769,11 @@ int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uin
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->state[e->cur], state_host, size_t(e->n) * e->dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  if (e->resid != nullptr) HIP_TRY(hipMemsetAsync(e->resid, 0, size_t(e->n_pad) * 2 * sizeof(float), e->stream));  // a float32 state has no residual
+  if (e->resid != nullptr) HIP_TRY(hipMemsetAsync(e->resid, 0, size_t(e->n_pad) * e->res * sizeof(int32_t), e->stream));  // a float32 state has no remainder
   if (e->cfg.normalise_observation) {
     const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
     hipLaunchKernelGGL(mbt::normalise_rows_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->state[e->cur], e->obs,
-                       e->n_pad, e->dim, e->params);
+                       e->n_pad, e->dim, e->params, e->res != 0 ? 1 : 0);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(e->stream));

@@ -23,9 +23,13 @@
 
 namespace mbt {
 
-template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_>
+template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false>
 struct SpeedVariant {
   static constexpr bool HAS_IMPACT_STATE = HAS_IMPACT_STATE_, NORM = NORM_, INJECT = INJECT_;
+  // precise_state: [cash, inventory, midprice, impact state] held exactly as the reference's float64 values (the row's
+  // float32 + an int32 remainder each, step_kernel.hpp: exact_join) and stepped in double in the reference's operation order
+  static constexpr bool PRECISE = PRECISE_;
+  static constexpr int RES = PRECISE_ ? 4 : 0;
   static constexpr bool PENALISED = true;  // optimal-execution rewards are almost never plain PnL: one (general) variant
   static constexpr int REWARD = kRewardGeneral;
   static constexpr int DIM = HAS_IMPACT_STATE_ ? 5 : 4;
@@ -89,6 +93,50 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
   r.next = SpeedLane{c_clip, q_clip, mid_new, y_new};
   r.reward = finish_reward(pnl, s.q, q_clip, c_clip, mid_new, q_init, v, is_terminal, P);
   r.events = (dq_clip != 0.0f ? 64u : 0u) | (dc_clip != 0.0f ? 128u : 0u);
+  return r;
+}
+
+// precise_state: the same lane-step on the reference's float64 state (MD:262-267, IMP:55, :87-91, :130-135, :170-175), every
+// expression in the operation order of the NumPy statement it restates; rewards per reward_exact (RW:57-70 for CjOe).
+struct SpeedExact {
+  double cash, q, mid, y;
+};
+struct SpeedResultExact {
+  SpeedExact next;
+  float reward;
+  uint32_t events;
+};
+
+template <class V>
+__device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s, float a_raw, float z, float q_init, bool is_terminal,
+                                                             double t_now, double t_next, const StepParams& P) {
+  const PreciseParams& X = P.X;
+  double v = a_raw;
+  if (V::NORM && P.norm_act) v = (static_cast<double>(a_raw) + 1.0) * P.act_grad[0] + P.act_lo[0];  // TE:124
+  double impact, y_new = s.y;
+  switch (P.impact_kind) {
+    case kImpactTempPower: impact = X.temp_coef * numpy_power(v, X.impact_exponent); break;  // IMP:55-56
+    case kImpactTempPerm:
+      impact = X.temp_coef * v + s.y;                         // IMP:90-91
+      y_new = s.y + X.perm_coef * v * X.impact_dt;            // IMP:87-88
+      break;
+    case kImpactTempTransient:
+      impact = X.temp_coef * v + X.trans_coef * s.y;          // IMP:134-135
+      y_new = (s.y - X.resilience * s.y * X.impact_dt) + X.kernel_coef * v * X.impact_dt;  // IMP:130-132
+      break;
+    default:
+      impact = X.trans_coef * s.y;                            // IMP:174-175
+      y_new = (s.y - X.resilience * s.y * X.impact_dt) + X.kernel_coef * v * X.impact_dt;  // IMP:170-172
+  }
+  const double volume = v * X.speed_dt;                       // MD:265: the MIDPRICE model's step size
+  const double cash_new = s.cash - volume * (s.mid + impact); // MD:263-266
+  const double q_new = s.q + volume;
+  const double q_clip = fmin(fmax(q_new, -X.q_max), X.q_max), c_clip = fmin(fmax(cash_new, -X.c_max), X.c_max);  // TE:283-289
+  const double mid_new = midprice_step_exact(s.mid, z, 0.0, 0.0, X);
+  SpeedResultExact r;
+  r.next = SpeedExact{c_clip, q_clip, mid_new, y_new};
+  r.reward = static_cast<float>(reward_exact(s.cash, s.q, s.mid, c_clip, q_clip, mid_new, q_init, v, is_terminal, t_now, t_next, P));
+  r.events = (q_clip != q_new ? 64u : 0u) | (c_clip != cash_new ? 128u : 0u);
   return r;
 }
 
@@ -267,6 +315,148 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
     const uint32_t lane = lane0 + l * kBlockThreads;
     store_speed_row<V>(B.state_out, lane, s[l], static_cast<float>(t), false, P);
     if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, s[l], static_cast<float>(t), P.norm_obs != 0, P);
+    if (R.n_steps > 0) {
+      B.reward[lane] = rew[l];
+      if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(ev[l]);
+    }
+    if (B.lane_returns != nullptr) B.lane_returns[lane] += ret[l];
+    ret_sum += lane < P.n ? ret[l] : 0.0f;
+  }
+  if (__builtin_expect(clipped != 0u, 0)) atomicAdd(&B.clip_count[blockIdx.x & (kClipSlots - 1u)], static_cast<unsigned long long>(clipped));
+  const float total = wave_sum(ret_sum);
+  if ((threadIdx.x & 63u) == 0u) {
+    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
+  }
+}
+
+// ---- precise_state (SpeedVariant<..., PRECISE = true>) -----------------------------------------------------------------
+// Same lane <-> thread mapping and the same Philox quad stream as the float32 kernels; the state row holds the float32
+// rounding of the reference's float64 state and B.resid (n_pad, 4) int32 the remainders of [cash, inventory, midprice, y].
+template <class V>
+__device__ __forceinline__ SpeedExact load_speed_exact(const StepBuffers& B, uint32_t lane) {
+  const SpeedLane f = load_speed_row<V>(B.state_in, lane);
+  const ldi4_t lo = *reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
+  return SpeedExact{exact_join(f.cash, lo.x), exact_join(f.q, lo.y), exact_join(f.mid, lo.z), V::DIM == 5 ? exact_join(f.y, lo.w) : 0.0};
+}
+
+// row (float32 roundings) [+ remainders] of one lane; `obs`: the normalised observation row from the float64 values (TE:112-118)
+template <class V, bool THROUGH>
+__device__ __forceinline__ void store_speed_exact(float* state, int32_t* resid, float* obs, uint32_t lane, const SpeedExact& s, double t, const StepParams& P) {
+  const double x[5] = {s.cash, s.q, t, s.mid, s.y};
+  float hi[5];
+  int32_t lo[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) exact_split(x[c], hi[c], lo[c]);
+  hi[2] = static_cast<float>(t);
+  if (state != nullptr) store_speed_row<V, THROUGH>(state, lane, SpeedLane{hi[0], hi[1], hi[3], hi[4]}, hi[2], false, P);
+  if (resid != nullptr) store_through(reinterpret_cast<float4*>(resid) + lane, make_float4(__builtin_bit_cast(float, lo[0]), __builtin_bit_cast(float, lo[1]), __builtin_bit_cast(float, lo[3]), __builtin_bit_cast(float, V::DIM == 5 ? lo[4] : 0)));
+  if (obs != nullptr) {
+    float row[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) row[c] = P.norm_obs ? normalise_column_exact(x[c], c, P) : hi[c];
+    if (V::DIM == 4) {
+      reinterpret_cast<float4*>(obs)[lane] = make_float4(row[0], row[1], row[2], row[3]);
+    } else {
+      float* r = obs + static_cast<size_t>(lane) * 5;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) r[c] = row[c];
+    }
+  }
+}
+
+template <class V>
+__global__ __launch_bounds__(kBlockThreads) void speed_step_exact_kernel(const StepBuffers B, const StepParams P) {
+  static_assert(V::PRECISE, "the float32 tiers use speed_step_kernel");
+  const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;
+  const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
+  SpeedExact s[4];
+  float act[4], qi[4], z[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    s[l] = load_speed_exact<V>(B, lane);
+    act[l] = B.action[lane];
+    if (V::INJECT) z[l] = B.z[lane];
+    qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
+  }
+  if (!V::INJECT) {
+    const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
+  }
+  float r_sum = 0.0f;
+  uint32_t n_clipped = 0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    const SpeedResultExact r = speed_lane_exact<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P.t_now, P.t_next_f64, P);
+    store_speed_exact<V, false>(B.state_out, B.resid, B.obs, lane, r.next, P.t_next_f64, P);
+    B.reward[lane] = r.reward;
+    if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
+    if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
+    const bool real = lane < P.n;
+    r_sum += real ? r.reward : 0.0f;
+    n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && r.events != 0u));
+  }
+  const float total = wave_sum(r_sum);
+  if ((threadIdx.x & 63u) == 0u) {
+    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
+    if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
+  }
+}
+
+template <class V>
+__global__ __launch_bounds__(kBlockThreads) void speed_rollout_exact_kernel(const StepBuffers B, const StepParams P, const RolloutParams R) {
+  static_assert(V::PRECISE && !V::INJECT, "rollouts draw their own noise");
+  const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;
+  const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
+  const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
+  SpeedExact s[4];
+  float qi[4], ret[4] = {0.f, 0.f, 0.f, 0.f}, rew[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t ev[4] = {0u, 0u, 0u, 0u};
+  double t = R.t_start;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    s[l] = load_speed_exact<V>(B, lane);
+    qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
+    if (R.obs_traj != nullptr) store_speed_exact<V, false>(nullptr, nullptr, R.obs_traj, lane, s[l], t, P);
+  }
+  float held[4] = {0.f, 0.f, 0.f, 0.f};
+  if (R.policy == kPolicyBuffer) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) held[l] = B.action[lane0 + l * kBlockThreads];
+  }
+  uint32_t clipped = 0;
+  for (uint32_t k = 0; k < R.n_steps; ++k) {
+    const QuadNoise nz = philox_quad_noise(quad, P.philox_step + k, P.key0, P.key1);
+    float speed = R.action[0];
+    if (R.policy == kPolicyTimeTable) speed = reinterpret_cast<const float*>(R.table)[min(R.table_row0 + k, R.table_rows - 1u)];
+    const double t_now = t;
+    t += R.dt_f64;
+    const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const uint32_t lane = lane0 + l * kBlockThreads;
+      const float v = R.policy == kPolicyBuffer ? held[l] : speed;
+      const SpeedResultExact r = speed_lane_exact<V>(s[l], v, nz.z[l], qi[l], terminal, t_now, t, P);
+      s[l] = r.next;
+      rew[l] = r.reward;
+      ev[l] = r.events;
+      ret[l] += r.reward;
+      clipped += (lane < P.n && r.events != 0u) ? 1u : 0u;
+      if (R.obs_traj != nullptr) store_speed_exact<V, false>(nullptr, nullptr, R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lane, s[l], t, P);
+      if (R.act_traj != nullptr) R.act_traj[static_cast<size_t>(k) * n_pad + lane] = v;
+      if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lane] = r.reward;
+    }
+  }
+  float ret_sum = 0.0f;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const uint32_t lane = lane0 + l * kBlockThreads;
+    store_speed_exact<V, false>(B.state_out, B.resid, B.obs, lane, s[l], t, P);
     if (R.n_steps > 0) {
       B.reward[lane] = rew[l];
       if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(ev[l]);

@@ -46,7 +46,7 @@ namespace mbt {
 constexpr int kBlockThreads = MBT_BLOCK_THREADS;
 constexpr uint32_t kClipSlots = 1024;  // power of two  // wave64 x 4 per workgroup by default
 
-enum : int { kMidBrownian = 0, kMidOu = 1, kMidGbm = 2, kMidBrownianJump = 3, kMidOuJump = 4, kMidConstant = 5 };
+enum : int { kMidBrownian = 0, kMidOu = 1, kMidGbm = 2, kMidBrownianJump = 3, kMidOuJump = 4, kMidConstant = 5, kMidLinearSde = 6, kMidUser = 7 };
 enum : int { kArrPoisson = 0, kArrHawkes = 1 };
 enum : int { kDynLimit = 0, kDynLimitAndMarket = 1, kDynTouch = 2, kDynSpeed = 3 };
 enum : int { kRewPnl = 0, kRewRunning = 1, kRewCjMm = 2, kRewExpUtility = 3, kRewCjOe = 4 };
@@ -71,11 +71,12 @@ struct Variant {
   // reference never advances (FILL:168-170) - the kernel does not load them, it writes the constants.  Instantiated
   // only on the general tier (BROWNIAN false, kRewardGeneral, NORM true: each a superset of the specialised code).
   static constexpr bool EXO = EXO_;
-  // precise_state (mbt_config): cash and midprice are float32 PAIRS - the row holds the rounded value the observation
-  // shows, a side buffer its residual - advanced and rewarded in double, in the reference's own formulation (RW:27-33).
-  // Instantiated on the general tier only, like EXO.
+  // precise_state (mbt_config): every real-valued state column is held EXACTLY as the reference's float64 value - the row
+  // holds its float32 rounding (what the observation shows), a side buffer of int32 the rest (exact_join / exact_split) -
+  // and the step is evaluated in double in the reference's own order of operations (lane_step_exact): state and rewards
+  // are the reference's float64 results, bit for bit, rounded once to float32 on the way out.  General tier only, like EXO.
   static constexpr bool PRECISE = PRECISE_;
-  static_assert(!(EXO_ && PRECISE_), "precise_state is not instantiated for the exogenous-depth fill model");
+  static constexpr int RES = PRECISE_ ? (ARR_ == kArrHawkes ? 4 : 2) : 0;  // residual columns: [cash, midprice (, bid intensity, ask intensity)]
   // User-defined plugins (mbt_env_create_jit): this header is compiled at RUN TIME (hiprtc) together with the user's
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
@@ -88,11 +89,19 @@ struct Variant {
 };
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
-// float64 copies of what the precise_state tier computes with (everything else it shares with the float32 tiers)
+// What the precise_state tier computes with: the constructor arguments of the reference's classes as float64, kept
+// SEPARATE (mu and dt, not mu*dt) wherever the reference multiplies them inside the step - the order of the roundings is
+// part of the contract there.
 struct PreciseParams {
-  double drift_dt, vol_sqrt_dt, mid_add, mid_mul, ou_speed, ou_level, jump_size;  // midprice_increment() in double
-  double half_spread, c_max;
-  double dt, phi, alpha, exponent, risk_aversion, dt_over_episode, reward_scale;  // finish_reward() in double
+  int32_t mid_kind, reserved;  // MBT_MID_* (the exact tier follows each model's own expression, not the coefficient form)
+  double mu, sigma, mid_dt, sqrt_mid_dt;  // MID:63-64, MID:98-102: drift, volatility, the model's step size and its square root
+  double mu_dt, sigma_sqrt_dt;            // mu * dt and sigma * sqrt(dt): the products the reference forms before touching the state
+  double mid_add, mid_mul, ou_speed, ou_level, jump_size;
+  double hawkes_speed, hawkes_base_bid, hawkes_base_ask, hawkes_jump, arr_dt;  // ARR:110-119
+  double half_spread, q_max, c_max;
+  double phi, alpha, exponent, risk_aversion, episode_length, reward_scale;
+  // trading-with-speed dynamics (MD:262-267, IMP:34-179)
+  double temp_coef, impact_exponent, perm_coef, trans_coef, resilience, kernel_coef, impact_dt, speed_dt;
 };
 
 struct StepParams {
@@ -152,6 +161,7 @@ struct StepParams {
   double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8];  // parameters of the user's device expressions (mbt_user_code)
   double mid_dt_f64;  // the midprice model's own step size (SP:21), for a user midprice expression
   double t_now;  // the clock BEFORE this step (TE:216 accumulates it in double on the host): what a user arrival model sees
+  double t_next_f64;  // ... and after it: the precise_state tier's TIME column and the `dt` of its rewards (RW:99, RW:131)
 };
 
 #ifdef MBT_JIT_USER_CODE
@@ -179,7 +189,7 @@ struct StepBuffers {
   const float* u_fill;
   const float* z;
   const float* q_init;     // CjMm per-lane initial inventory or nullptr
-  float* resid;            // precise_state: (n_pad, 2) [cash residual, midprice residual], updated in place; else nullptr
+  int32_t* resid;          // precise_state: (n_pad, RES) int32 remainders of the float64 state (exact_join), updated in place; else nullptr
   uint8_t* events;         // nullptr unless recording
   float* lane_returns;     // nullptr unless tracking
   double* wave_sums;       // one slot per wave: running sum of rewards since reset
@@ -341,31 +351,73 @@ __device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_n
   return reward * P.reward_scale;
 }
 
-// The same in double and in the reference's order of operations, for the precise_state tier (order-book rewards only).
-__device__ __forceinline__ double finish_reward_f64(double pnl, double q_old, double q_new, double wealth_new, double q_init, bool is_terminal,
-                                                    const StepParams& P) {
+// ---- precise_state: the reference's float64 state, exactly, in 8 bytes per value ---------------------------------------
+// A double x is kept as  hi = float32(x)  (round to nearest: what the observation shows, np.float32(x)) in the state row
+// and  lo = (x - hi) * 2^(53 - e)  as an int32 in a side buffer, e = the exponent of hi.  x - hi is exact in double, at most
+// half a float32 ulp (2^(e-24)) in magnitude and a multiple of 2^(e-53) (the last bit of a double in hi's binade or the one
+// below it - the latter when hi rounded up to a power of two), so lo is an INTEGER of at most 2^29: the pair holds every
+// double whose float32 rounding is a normal number, exactly (zero, denormal or non-finite hi: lo = 0, |x| < 2^-126 is lost).
+// A float32 pair (hi, float32(x - hi)) would keep 48 of the 53 bits; this keeps all of them for the same bytes, which is
+// what makes "the same draws give the same arrivals" a theorem for Hawkes intensities instead of a 1 - 1e-14 event.
+__device__ __forceinline__ int f32_biased_exponent(float hi) { return static_cast<int>((__builtin_bit_cast(uint32_t, hi) >> 23) & 0xffu); }
+__device__ __forceinline__ double exact_join(float hi, int32_t lo) {
+  return static_cast<double>(hi) + __builtin_ldexp(static_cast<double>(lo), f32_biased_exponent(hi) - (127 + 53));
+}
+__device__ __forceinline__ void exact_split(double x, float& hi, int32_t& lo) {
+  hi = static_cast<float>(x);
+  const int e = f32_biased_exponent(hi);
+  const double scaled = __builtin_ldexp(x - static_cast<double>(hi), (127 + 53) - e);
+  lo = (e != 0 && e != 255) ? static_cast<int32_t>(scaled) : 0;
+}
+
+// numpy's `q ** p` for the exponents it special-cases (2: a multiplication, 1: the value itself) and pow() otherwise
+__device__ __forceinline__ double numpy_power(double q, double p) { return p == 2.0 ? q * q : (p == 1.0 ? q : pow(q, p)); }
+
+// One Euler step of the midprice in double, each model in the operation order of ITS update() (MID:60-65, :95-103,
+// :140-143, :222-227, :264-270; MBT_MID_LINEAR_SDE: the order LinearSdeMidpriceModel documents).  n_bid / n_ask: 1.0 where
+// the agent's quote was filled (MID:220-221).  The kind is wave-uniform.
+__device__ __forceinline__ double midprice_step_exact(double s, double z, double n_bid, double n_ask, const PreciseParams& X) {
+  const double noise = X.sigma_sqrt_dt * z;                           // (sigma * sqrt(dt)) * Z
+  const double jump = X.jump_size * n_ask - X.jump_size * n_bid;      // MID:226, MID:269
+  switch (X.mid_kind) {
+    case kMidBrownian: return (s + X.mu_dt) + noise;
+    case kMidOu: return s + (-X.ou_speed * (s - X.ou_level) + noise);  // the pull is NOT scaled by dt (MID:140-143)
+    case kMidGbm: return (s + X.mu * s * X.mid_dt) + X.sigma * s * X.sqrt_mid_dt * z;
+    case kMidBrownianJump: return ((s + X.mu_dt) + noise) + jump;
+    case kMidOuJump: return ((s - X.ou_speed * (s - X.ou_level)) + noise) + jump;
+    case kMidLinearSde: return ((s + (X.mid_add + X.mid_mul * s) * (X.mu_dt + noise)) - X.ou_speed * (s - X.ou_level)) + jump;
+    default: return s;  // constant (MID:32-33)
+  }
+}
+
+// RewardFunction.calculate in double, in the reference's order (RW:23-33, RW:96-109, RW:128-138, RW:57-70, RW:156-163).
+// dt is the difference of the two TIME columns (RW:99, RW:131), i.e. of the accumulated float64 clock, not step_size.
+__device__ __forceinline__ double reward_exact(double cash, double q, double mid, double cash_new, double q_new, double mid_new, double q_init,
+                                               double speed, bool is_terminal, double t_now, double t_next, const StepParams& P) {
   const PreciseParams& X = P.X;
+  const double wealth_new = cash_new + q_new * mid_new;
+  const double pnl = wealth_new - (cash + q * mid);
   double reward = pnl;
   if (P.reward_kind == kRewExpUtility) {
     reward = is_terminal ? -exp(-X.risk_aversion * wealth_new) : 0.0;
   } else if (P.reward_kind != kRewPnl) {
-    const bool two = P.exponent_is_two != 0;
-    const double qp = two ? q_new * q_new : pow(q_new, X.exponent);
-    reward -= X.dt * X.phi * qp;
+    const double dt = t_next - t_now;
+    const double qp = numpy_power(q_new, X.exponent);
     if (P.reward_kind == kRewRunning) {
-      reward -= is_terminal ? X.alpha * qp : 0.0;
-    } else {
-      const double qp_old = two ? q_old * q_old : pow(q_old, X.exponent), qp_init = two ? q_init * q_init : pow(q_init, X.exponent);
-      reward -= X.alpha * ((qp - qp_old) + X.dt_over_episode * qp_init);
+      reward = (pnl - dt * X.phi * qp) - X.alpha * (is_terminal ? 1.0 : 0.0) * qp;
+    } else if (P.reward_kind == kRewCjMm) {
+      reward = (pnl - dt * X.phi * qp) - X.alpha * ((qp - numpy_power(q, X.exponent)) + dt / X.episode_length * numpy_power(q_init, X.exponent));
+    } else {  // CjOe: the terminal term MULTIPLIES by the episode length (RW:67)
+      reward = (pnl - dt * X.phi * qp) - dt * X.alpha * (X.exponent * speed * numpy_power(q, X.exponent - 1.0) + numpy_power(q_init, X.exponent) * X.episode_length);
     }
   }
-  return reward * X.reward_scale;
+  return X.reward_scale * reward;  // TE:128-129 (1.0 when rewards are not normalised: exact)
 }
 
 struct LaneResult {
   float4 core;
   float2 lam;
-  float2 resid;  // precise_state: residuals of (cash, midprice) after the step
+  int4 lo;  // precise_state: what float32 left of [cash, midprice, bid intensity, ask intensity] (exact_split)
   float reward;
   // what happened, kept as predicates (scalar masks); turned into the event byte only when someone asks for it
   bool arr_bid, arr_ask, fill_bid, fill_ask, mo_buy, mo_sell, clipped_q, clipped_c;
@@ -376,22 +428,26 @@ __device__ __forceinline__ uint32_t event_byte(const LaneResult& r) {
          (r.mo_sell ? 32u : 0u) | (r.clipped_q ? 64u : 0u) | (r.clipped_c ? 128u : 0u);
 }
 
-// One env-step of one lane: everything that needs the loaded state and action.
-template <class V>
-__device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
-                                                const float q_init, const float t_next, const bool is_terminal,
-                                                const StepParams& P, const float2 resid = make_float2(0.f, 0.f), const float z = 0.f,
-                                                const double t_now = 0.0) {
-  const float cash = core.x, q = core.y, mid = core.w;
-  LaneResult r;
-  r.resid = resid;
-  const bool norm_act = V::NORM && P.norm_act;
+// The Bernoulli decisions of one lane-step - arrivals, fills after the max-inventory mask, market-order flags - which are
+// the same (bit-exact against the float64 reference) in every tier; the tiers differ in how they carry the state.
+struct Decisions {
+  float arr_bid, arr_ask;  // 1.0f / 0.0f (ARR:56, ARR:83, ARR:123)
+  float n_bid, n_ask;      // executed size on each side: arrival x fill (x posted size at the touch)
+  float off_bid, off_ask;  // distance of the execution price from the midprice: the (de-normalised) depth, or the half spread
+  bool fill_bid, fill_ask, mo_buy, mo_sell;
+};
 
+// lam_bid / lam_ask: the Hawkes intensities the comparison of ARR:123 is made with, as doubles (the float32 tiers pass their
+// float32 state, the exact tier the reference's float64 value).
+template <class V>
+__device__ __forceinline__ Decisions decide(const float q, const float4 act, const LaneDraw& dr, const double lam_bid, const double lam_ask,
+                                            const double t_now, const bool norm_act, const StepParams& P) {
+  Decisions D;
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
   float arr_bid = dr.arr_bid, arr_ask = dr.arr_ask;
   if (V::ARR == kArrHawkes) {
-    arr_bid = static_cast<double>(dr.arr_bid) < static_cast<double>(lam.x) * P.arr_dt_f64 ? 1.0f : 0.0f;
-    arr_ask = static_cast<double>(dr.arr_ask) < static_cast<double>(lam.y) * P.arr_dt_f64 ? 1.0f : 0.0f;
+    arr_bid = static_cast<double>(dr.arr_bid) < lam_bid * P.arr_dt_f64 ? 1.0f : 0.0f;
+    arr_ask = static_cast<double>(dr.arr_ask) < lam_ask * P.arr_dt_f64 ? 1.0f : 0.0f;
   }
   if (V::USER_ARRIVAL) {
 #ifdef MBT_JIT_USER_CODE
@@ -400,23 +456,22 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
     arr_ask = static_cast<double>(dr.arr_ask) < mbt_user_arrival_probability(t_now, 1, P.arr_dt_f64, P.user_arrival_p) ? 1.0f : 0.0f;
 #endif
   }
-  r.arr_bid = arr_bid != 0.0f;
-  r.arr_ask = arr_ask != 0.0f;
+  D.arr_bid = arr_bid;
+  D.arr_ask = arr_ask;
 
   // -- fills masked by the PRE-update inventory (TE:323-327).  Limit orders: the exponential fill test
   //    (FILL:28-34, FILL:57-58, after the de-normalisation of TE:104); at the touch: the action itself (MD:156-157)
   const bool open_bid = !(q >= P.q_max), open_ask = !(q <= -P.q_max);
-  float n_bid, n_ask, off_bid, off_ask;
   if (V::DYN == kDynTouch) {
     const float f_bid = open_bid ? act.x : 0.0f, f_ask = open_ask ? act.y : 0.0f;  // `fills` is the posted size (0/1)
-    r.fill_bid = f_bid != 0.0f;
-    r.fill_ask = f_ask != 0.0f;
-    n_bid = arr_bid * f_bid;
-    n_ask = arr_ask * f_ask;
-    off_bid = off_ask = P.half_spread;
+    D.fill_bid = f_bid != 0.0f;
+    D.fill_ask = f_ask != 0.0f;
+    D.n_bid = arr_bid * f_bid;
+    D.n_ask = arr_ask * f_ask;
+    D.off_bid = D.off_ask = P.half_spread;
   } else {
-    off_bid = depth_of(act.x, 0, norm_act, P);
-    off_ask = depth_of(act.y, 1, norm_act, P);
+    D.off_bid = depth_of(act.x, 0, norm_act, P);
+    D.off_ask = depth_of(act.y, 1, norm_act, P);
     bool fb = false, fa = false;
     if (V::USER_FILL) {
 #ifdef MBT_JIT_USER_CODE
@@ -427,8 +482,8 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
       fa = static_cast<double>(dr.uf_ask) < mbt_user_fill_probability(depth_a, 1, P.user_fill_p);
 #endif
     } else {
-      const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, off_bid, 0, P) : fill_test(off_bid, dr.lo_bid, dr.hi_bid);
-      const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, off_ask, 1, P) : fill_test(off_ask, dr.lo_ask, dr.hi_ask);
+      const FillTest tb = V::EXO ? fill_test_exogenous(dr.uf_bid, D.off_bid, 0, P) : fill_test(D.off_bid, dr.lo_bid, dr.hi_bid);
+      const FillTest ta = V::EXO ? fill_test_exogenous(dr.uf_ask, D.off_ask, 1, P) : fill_test(D.off_ask, dr.lo_ask, dr.hi_ask);
       fb = tb.fill;
       fa = ta.fill;
       if (__builtin_expect(tb.near | ta.near, 0)) {
@@ -441,66 +496,53 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
         }
       }
     }
-    r.fill_bid = fb && open_bid;
-    r.fill_ask = fa && open_ask;
-    n_bid = r.fill_bid ? arr_bid : 0.0f;
-    n_ask = r.fill_ask ? arr_ask : 0.0f;
+    D.fill_bid = fb && open_bid;
+    D.fill_ask = fa && open_ask;
+    D.n_bid = D.fill_bid ? arr_bid : 0.0f;
+    D.n_ask = D.fill_ask ? arr_ask : 0.0f;
   }
+  D.mo_buy = D.mo_sell = false;
+  if (V::DYN == kDynLimitAndMarket) {  // MD:209-210: scores above 0.5 are market orders
+    if (norm_act) {
+      D.mo_buy = (static_cast<double>(act.z) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
+      D.mo_sell = (static_cast<double>(act.w) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
+    } else {
+      D.mo_buy = act.z > 0.5f;
+      D.mo_sell = act.w > 0.5f;
+    }
+  }
+  return D;
+}
+
+// One env-step of one lane: everything that needs the loaded state and action.
+template <class V>
+__device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
+                                                const float q_init, const float t_next, const bool is_terminal,
+                                                const StepParams& P, const float z = 0.f, const double t_now = 0.0) {
+  const float cash = core.x, q = core.y, mid = core.w;
+  LaneResult r;
+  r.lo = make_int4(0, 0, 0, 0);
+  const bool norm_act = V::NORM && P.norm_act;
+  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P);
+  const float arr_bid = D.arr_bid, arr_ask = D.arr_ask, n_bid = D.n_bid, n_ask = D.n_ask;
+  r.arr_bid = arr_bid != 0.0f;
+  r.arr_ask = arr_ask != 0.0f;
+  r.fill_bid = D.fill_bid;
+  r.fill_ask = D.fill_ask;
+  r.mo_buy = D.mo_buy;
+  r.mo_sell = D.mo_sell;
 
   // -- cash / inventory with the OLD midprice (MD:82-84); market orders (MD:208-214) and limit fills (MD:108-116 /
   //    MD:215-222) or fills at the touch (MD:146-154) together: buying dq units in total costs dq * mid, and every
   //    trade earns its distance from the midprice (`gain`: + depth for a limit fill, - half spread for a market order)
   float dq = n_bid - n_ask;
-  float gain = __builtin_fmaf(n_ask, off_ask, n_bid * off_bid);
-  r.mo_buy = r.mo_sell = false;
+  float gain = __builtin_fmaf(n_ask, D.off_ask, n_bid * D.off_bid);
   if (V::DYN == kDynLimitAndMarket) {
-    if (norm_act) {
-      r.mo_buy = (static_cast<double>(act.z) + 1.0) * P.act_grad[2] + P.act_lo[2] > 0.5;
-      r.mo_sell = (static_cast<double>(act.w) + 1.0) * P.act_grad[3] + P.act_lo[3] > 0.5;
-    } else {
-      r.mo_buy = act.z > 0.5f;
-      r.mo_sell = act.w > 0.5f;
-    }
     const float mb = r.mo_buy ? 1.0f : 0.0f, ms = r.mo_sell ? 1.0f : 0.0f;
     dq += mb - ms;
     gain = __builtin_fmaf(-P.half_spread, mb + ms, gain);
   }
   const float q_new = q + dq;
-  if (V::PRECISE) {
-    // ---- precise_state: the decisions above stand (they never depended on the state's low bits); cash, midprice and the
-    //      reward are re-done in double on (value + residual), in the reference's formulation ----------------------
-    const PreciseParams& X = P.X;
-    const double cash64 = static_cast<double>(cash) + static_cast<double>(resid.x), mid64 = static_cast<double>(mid) + static_cast<double>(resid.y);
-    double depth_b = act.x, depth_a = act.y;  // the float32 action IS the reference's float64 action (TE:104 de-normalises in double)
-    if (V::DYN == kDynTouch) {
-      depth_b = depth_a = X.half_spread;
-    } else if (norm_act) {
-      depth_b = (static_cast<double>(act.x) + 1.0) * P.act_grad[0] + P.act_lo[0];
-      depth_a = (static_cast<double>(act.y) + 1.0) * P.act_grad[1] + P.act_lo[1];
-    }
-    double gain64 = static_cast<double>(n_ask) * depth_a + static_cast<double>(n_bid) * depth_b;
-    if (V::DYN == kDynLimitAndMarket) gain64 -= X.half_spread * ((r.mo_buy ? 1.0 : 0.0) + (r.mo_sell ? 1.0 : 0.0));
-    const double cash_new64 = cash64 + gain64 - static_cast<double>(dq) * mid64;  // MD:108-116, MD:208-222 with the OLD midprice
-    const float q_clip = __builtin_amdgcn_fmed3f(q_new, -P.q_max, P.q_max);       // TE:283-289
-    const double c_clip64 = fmin(fmax(cash_new64, -X.c_max), X.c_max);
-    r.clipped_q = q_clip != q_new;
-    r.clipped_c = c_clip64 != cash_new64;
-    const double dz64 = X.drift_dt + X.vol_sqrt_dt * static_cast<double>(z);
-    const double mid_new64 = mid64 + ((X.mid_add + X.mid_mul * mid64) * dz64 - X.ou_speed * (mid64 - X.ou_level) +
-                                      X.jump_size * static_cast<double>(n_ask - n_bid));
-    r.lam = lam;
-    if (V::ARR == kArrHawkes) {
-      r.lam.x = __builtin_fmaf(P.hawkes_jump, arr_bid, lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.arr_dt);
-      r.lam.y = __builtin_fmaf(P.hawkes_jump, arr_ask, lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.arr_dt);
-    }
-    const double wealth_new = c_clip64 + static_cast<double>(q_clip) * mid_new64;
-    const double pnl64 = wealth_new - (cash64 + static_cast<double>(q) * mid64);  // RW:27-33, literally
-    r.reward = static_cast<float>(finish_reward_f64(pnl64, q, q_clip, wealth_new, q_init, is_terminal, P));
-    const float c_hi = static_cast<float>(c_clip64), m_hi = static_cast<float>(mid_new64);
-    r.core = make_float4(c_hi, q_clip, t_next, m_hi);
-    r.resid = make_float2(static_cast<float>(c_clip64 - static_cast<double>(c_hi)), static_cast<float>(mid_new64 - static_cast<double>(m_hi)));
-    return r;
-  }
   const float cash_new = __builtin_fmaf(-dq, mid, cash + gain);
 
   // -- clip (TE:283-289): v_med3_f32
@@ -556,6 +598,95 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   return r;
 }
 
+// precise_state: the same lane-step on the reference's float64 state, in the reference's float64 arithmetic.  Every
+// expression below is written in the operation order of the NumPy statement it cites (the library is compiled with
+// -ffp-contract=off, IEEE double add / multiply / divide round like NumPy's), so cash, inventory, midprice, intensities and
+// rewards ARE the reference's values; the row gets their float32 rounding, `lo` what the rounding left (exact_split).
+// `lo` in: x cash, y midprice, z / w bid / ask intensity.  t_now / t_next: the float64 clock before / after the step.
+template <class V>
+__device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const float2 lam, const int4 lo, const float4 act, const LaneDraw& dr,
+                                                      const float q_init, const bool is_terminal, const StepParams& P, const float z,
+                                                      const double t_now, const double t_next) {
+  const PreciseParams& X = P.X;
+  const double cash = exact_join(core.x, lo.x), mid = exact_join(core.w, lo.y), q = core.y;  // (order-book inventories are integers)
+  const double lam_bid = V::ARR == kArrHawkes ? exact_join(lam.x, lo.z) : 0.0, lam_ask = V::ARR == kArrHawkes ? exact_join(lam.y, lo.w) : 0.0;
+  LaneResult r;
+  const bool norm_act = V::NORM && P.norm_act;
+  const Decisions D = decide<V>(core.y, act, dr, lam_bid, lam_ask, t_now, norm_act, P);
+  r.arr_bid = D.arr_bid != 0.0f;
+  r.arr_ask = D.arr_ask != 0.0f;
+  r.fill_bid = D.fill_bid;
+  r.fill_ask = D.fill_ask;
+  r.mo_buy = D.mo_buy;
+  r.mo_sell = D.mo_sell;
+  const double n_bid = D.n_bid, n_ask = D.n_ask;
+  // the prices limit orders execute at: midprice -/+ depth, the depth de-normalised in double (TE:124) - the float32
+  // action IS the reference's float64 action
+  double depth_b = act.x, depth_a = act.y;
+  if (V::DYN == kDynTouch) {
+    depth_b = depth_a = X.half_spread;  // MD:146-154
+  } else if (norm_act) {
+    depth_b = (static_cast<double>(act.x) + 1.0) * P.act_grad[0] + P.act_lo[0];
+    depth_a = (static_cast<double>(act.y) + 1.0) * P.act_grad[1] + P.act_lo[1];
+  }
+  double cash_new = cash, q_new = q;
+  if (V::DYN == kDynLimitAndMarket) {  // MD:208-214: market orders first, at the touch of the OLD midprice
+    const double mb = r.mo_buy ? 1.0 : 0.0, ms = r.mo_sell ? 1.0 : 0.0;
+    cash_new = cash_new + (ms * (mid - X.half_spread) - mb * (mid + X.half_spread));
+    q_new = q_new + (mb - ms);
+  }
+  // MD:108-116 / MD:146-154 / MD:215-222:  q += sum(arrivals fills -sign),  cash += sum(sign arrivals fills (mid + depth sign)),  sign = (-1, +1)
+  q_new = q_new + (n_bid + -n_ask);
+  cash_new = cash_new + (-n_bid * (mid + -depth_b) + n_ask * (mid + depth_a));
+  // clip (TE:283-289)
+  const double q_clip = fmin(fmax(q_new, -X.q_max), X.q_max), c_clip = fmin(fmax(cash_new, -X.c_max), X.c_max);
+  r.clipped_q = q_clip != q_new;
+  r.clipped_c = c_clip != cash_new;
+  // processes in registry order (TE:206-211): midprice, then the intensities, which jump on arrivals (ARR:110-119)
+  double mid_new;
+  if (V::USER_MID) {
+#ifdef MBT_JIT_USER_CODE
+    mid_new = mid + mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, P.user_mid_p);
+#else
+    mid_new = mid;
+#endif
+  } else {
+    mid_new = midprice_step_exact(mid, z, n_bid, n_ask, X);
+  }
+  double lam_bid_new = 0.0, lam_ask_new = 0.0;
+  if (V::ARR == kArrHawkes) {
+    lam_bid_new = (lam_bid + X.hawkes_speed * (X.hawkes_base_bid - lam_bid) * X.arr_dt) + X.hawkes_jump * static_cast<double>(D.arr_bid);
+    lam_ask_new = (lam_ask + X.hawkes_speed * (X.hawkes_base_ask - lam_ask) * X.arr_dt) + X.hawkes_jump * static_cast<double>(D.arr_ask);
+  }
+  // reward
+  if (V::USER_REWARD) {
+#ifdef MBT_JIT_USER_CODE
+    UserRewardArgs u;  // RewardFunction.calculate(current_state, action, next_state, is_terminal_step) (RW:10-13) on the float64 states
+    u.cash = cash; u.q = q; u.t = t_now; u.mid = mid;
+    u.cash_next = c_clip; u.q_next = q_clip; u.t_next = t_next; u.mid_next = mid_new;
+    u.a0 = act.x; u.a1 = act.y; u.a2 = act.z; u.a3 = act.w;
+    u.pnl = (c_clip + q_clip * mid_new) - (cash + q * mid);
+    u.dt = t_next - t_now; u.is_terminal = is_terminal ? 1.0 : 0.0; u.q0 = q_init; u.episode_length = X.episode_length;
+    r.reward = static_cast<float>(X.reward_scale * mbt_user_reward(u, P.user_reward_p));
+#else
+    r.reward = 0.0f;
+#endif
+  } else {
+    r.reward = static_cast<float>(reward_exact(cash, q, mid, c_clip, q_clip, mid_new, q_init, 0.0, is_terminal, t_now, t_next, P));
+  }
+  float c_hi, m_hi, lb_hi = 0.0f, la_hi = 0.0f;
+  r.lo = make_int4(0, 0, 0, 0);
+  exact_split(c_clip, c_hi, r.lo.x);
+  exact_split(mid_new, m_hi, r.lo.y);
+  if (V::ARR == kArrHawkes) {
+    exact_split(lam_bid_new, lb_hi, r.lo.z);
+    exact_split(lam_ask_new, la_hi, r.lo.w);
+  }
+  r.core = make_float4(c_hi, static_cast<float>(q_clip), static_cast<float>(t_next), m_hi);
+  r.lam = make_float2(lb_hi, la_hi);
+  return r;
+}
+
 // Sum over the 64 lanes of a wave with DPP row operations + 4 readlanes (no LDS traffic).
 __device__ __forceinline__ float wave_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -597,11 +728,13 @@ struct LaneLoads {
   float2 ua, uf;  // injected noise
   float z;
   float qi;     // per-lane initial inventory (CjMm)
-  float2 resid; // precise_state residuals
+  int4 lo;      // precise_state: the int32 remainders of [cash, midprice, bid intensity, ask intensity] (exact_join)
 };
 
 typedef float ld4_t __attribute__((ext_vector_type(4)));
 typedef float ld2_t __attribute__((ext_vector_type(2)));
+typedef int ldi4_t __attribute__((ext_vector_type(4)));
+typedef int ldi2_t __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ float4 load4(const float* p) {
   const ld4_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const ld4_t*>(p)) : *reinterpret_cast<const ld4_t*>(p);
@@ -640,7 +773,14 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
     L.z = B.z[lane];
   }
   L.qi = P.q_init_scalar;
-  L.resid = V::PRECISE ? load2<NT>(B.resid + static_cast<size_t>(lane) * 2) : make_float2(0.f, 0.f);
+  L.lo = make_int4(0, 0, 0, 0);
+  if (V::RES == 4) {
+    const ldi4_t v = *reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
+    L.lo = make_int4(v.x, v.y, v.z, v.w);
+  } else if (V::RES == 2) {
+    const ldi2_t v = *reinterpret_cast<const ldi2_t*>(B.resid + static_cast<size_t>(lane) * 2);
+    L.lo = make_int4(v.x, v.y, 0, 0);
+  }
   return L;
 }
 
@@ -689,14 +829,11 @@ __device__ __forceinline__ void store_through(float* p, const float v) {
   asm volatile("s_nop 0\n\tglobal_store_dword %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
 }
 
-// one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
+// one state row as given
 // THROUGH: write the row through the L2 (what the NEXT launch reads); a trajectory recording, which nobody reads back soon
 // and which streams ~4 TB/s, is better left to the write-back L2 (1.52e11 vs 1.40e11 env-steps/s recorded)
 template <class V, bool THROUGH = true>
-__device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
-  if (normalise) normalise_row(core, lam, P);
-  float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);  // the exogenous best depths never move (FILL:168-170)
-  if (V::EXO && normalise && P.norm_obs) best = make_float2(normalise_column(best.x, V::EXO_COL, P), normalise_column(best.y, V::EXO_COL + 1, P));
+__device__ __forceinline__ void store_row_values(float* base, uint32_t lane, const float4 core, const float2 lam, const float2 best) {
   if (V::DIM == 8) {
     float4* row = reinterpret_cast<float4*>(base) + static_cast<size_t>(lane) * 2;
     row[0] = core;  // (rows wider than 16 bytes are written by several instructions that each cover PART of a cache line:
@@ -713,12 +850,49 @@ __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 cor
   }
 }
 
+// one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
+template <class V, bool THROUGH = true>
+__device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
+  if (normalise) normalise_row(core, lam, P);
+  float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);  // the exogenous best depths never move (FILL:168-170)
+  if (V::EXO && normalise && P.norm_obs) best = make_float2(normalise_column(best.x, V::EXO_COL, P), normalise_column(best.y, V::EXO_COL + 1, P));
+  store_row_values<V, THROUGH>(base, lane, core, lam, best);
+}
+
+// precise_state: the normalised observation (TE:112-118) is formed from the float64 state like the reference forms it -
+// (x - low) / gradient - 1 in double, the float32 Box bounds promoted - and rounded once.
+__device__ __forceinline__ float normalise_column_exact(double x, int col, const StepParams& P) {
+  return static_cast<float>((x - static_cast<double>(P.obs_lo[col])) / static_cast<double>(P.obs_grad[col]) - 1.0);
+}
+
+// the observation row of the precise_state tier: normalised (when the environment normalises) from the float64 state,
+// `t`: the float64 clock the row's time column stands for
+template <class V, bool THROUGH = true>
+__device__ __forceinline__ void store_row_exact(float* base, uint32_t lane, float4 core, float2 lam, const int4 lo, const double t, const StepParams& P) {
+  float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);
+  if (P.norm_obs) {
+    core.x = normalise_column_exact(exact_join(core.x, lo.x), 0, P);
+    core.y = normalise_column_exact(core.y, 1, P);
+    core.z = normalise_column_exact(t, 2, P);
+    core.w = normalise_column_exact(exact_join(core.w, lo.y), 3, P);
+    if (V::ARR == kArrHawkes) lam = make_float2(normalise_column_exact(exact_join(lam.x, lo.z), 4, P), normalise_column_exact(exact_join(lam.y, lo.w), 5, P));
+    if (V::EXO) best = make_float2(normalise_column_exact(P.exo_depth_f64[0], V::EXO_COL, P), normalise_column_exact(P.exo_depth_f64[1], V::EXO_COL + 1, P));
+  }
+  store_row_values<V, THROUGH>(base, lane, core, lam, best);
+}
+
+__device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int4 lo, int res) {
+  if (res == 4) store_through(reinterpret_cast<float4*>(base) + lane, make_float4(__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y), __builtin_bit_cast(float, lo.z), __builtin_bit_cast(float, lo.w)));
+  else store_through(reinterpret_cast<float2*>(base) + lane, make_float2(__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y)));
+}
+
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f) {
-  const LaneResult r = lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, L.resid, z, P.t_now);
-  if (V::PRECISE) store_through(reinterpret_cast<float2*>(B.resid) + lane, r.resid);
+  const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64)
+                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now);
+  if (V::PRECISE) store_lo(B.resid, lane, r.lo, V::RES);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
   } else {  // rows wider than 16 bytes go through LDS (see step_kernel): this lane's row, 8-byte pieces
@@ -734,7 +908,10 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   }
   store_through(B.reward + lane, r.reward);
   // -- optional outputs (wave-uniform branches)
-  if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lane, r.core, r.lam, true, P);
+  if (V::NORM && B.obs != nullptr) {
+    if (V::PRECISE) store_row_exact<V>(B.obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
+    else store_row<V>(B.obs, lane, r.core, r.lam, true, P);
+  }
   if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));
   if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
   clipped = r.clipped_q | r.clipped_c;
@@ -846,7 +1023,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
   const size_t n_pad = static_cast<size_t>(P.n_pairs) * 2;
   float4 core[2];
   float2 lam[2];
-  float2 resid[2];
+  int4 lo[2];
   float qi[2], ret[2] = {0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -854,8 +1031,11 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     core[l] = L.core;
     lam[l] = L.lam;
     qi[l] = L.qi;
-    resid[l] = L.resid;
-    if (R.obs_traj != nullptr) store_row<V, false>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
+    lo[l] = L.lo;
+    if (R.obs_traj != nullptr) {
+      if (V::PRECISE) store_row_exact<V, false>(R.obs_traj, lanes[l], core[l], lam[l], lo[l], R.t_start, P);
+      else store_row<V, false>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
+    }
   }
   load_initial_inventories<V>(B, lanes[0], lanes[1], qi[0], qi[1]);
   float4 held[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -934,15 +1114,20 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      const LaneResult r = lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, resid[l], nz[l].z, t_now);
+      const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t)
+                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now);
       core[l] = r.core;
       lam[l] = r.lam;
-      resid[l] = r.resid;
+      lo[l] = r.lo;
       ret[l] += r.reward;
       clips += (lanes[l] < P.n && (r.clipped_q | r.clipped_c)) ? 1u : 0u;
       last_reward[l] = r.reward;
       if (B.events != nullptr) last_events[l] = event_byte(r);
-      if (R.obs_traj != nullptr) store_row<V, false>(R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM, lanes[l], core[l], lam[l], V::NORM, P);
+      if (R.obs_traj != nullptr) {
+        float* slice = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
+        if (V::PRECISE) store_row_exact<V, false>(slice, lanes[l], core[l], lam[l], lo[l], t, P);
+        else store_row<V, false>(slice, lanes[l], core[l], lam[l], V::NORM, P);
+      }
       if (R.act_traj != nullptr) {
         float* dst = R.act_traj + static_cast<size_t>(k) * n_pad * A;
         if (A == 2) reinterpret_cast<float2*>(dst)[lanes[l]] = make_float2(act[l].x, act[l].y);
@@ -955,8 +1140,11 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
 #pragma unroll
   for (int l = 0; l < 2; ++l) {  // what step() leaves behind: final state, last rewards (and events) of the final step
     store_row<V>(B.state_out, lanes[l], core[l], lam[l], false, P);
-    if (V::PRECISE) reinterpret_cast<float2*>(B.resid)[lanes[l]] = resid[l];
-    if (V::NORM && B.obs != nullptr) store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
+    if (V::PRECISE) store_lo(B.resid, lanes[l], lo[l], V::RES);
+    if (V::NORM && B.obs != nullptr) {
+      if (V::PRECISE) store_row_exact<V>(B.obs, lanes[l], core[l], lam[l], lo[l], t, P);
+      else store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
+    }
     if (R.n_steps > 0) {
       B.reward[lanes[l]] = last_reward[l];
       if (B.events != nullptr) B.events[lanes[l]] = static_cast<uint8_t>(last_events[l]);
@@ -1021,20 +1209,33 @@ __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs,
 struct ResetRow {
   float cash0, t0, s0, q0_scalar;
   float extra[4];  // columns 4..: Hawkes baselines (ARR:103), exogenous best depths (FILL:148-154), or the impact model's initial state (IMP:81, IMP:121)
+  // precise_state: the same row as the reference's float64 values (column order of the state row; [1] is unused when the
+  // initial inventories are per lane) and the int32 remainders of the residual columns (exact_split on the host)
+  double exact[8];
+  int32_t lo[4];
+  int32_t res;  // residual columns per lane: 0 (float32 tiers), 2 or 4
 };
 
 __global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0, const ResetRow row0,
-                             uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P, float* resid, float2 resid0) {
+                             uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P, int32_t* resid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
-  if (resid != nullptr) reinterpret_cast<float2*>(resid)[i] = resid0;  // what float32 lost of the initial cash / price
+  if (resid != nullptr)
+    for (int j = 0; j < row0.res; ++j) resid[static_cast<size_t>(i) * row0.res + j] = row0.lo[j];  // what float32 left of the initial values
   float* row = state + static_cast<size_t>(i) * dim;
   float* orow = obs != nullptr ? obs + static_cast<size_t>(i) * dim : nullptr;
   for (int j = 0; j < dim; ++j) {
     const float v = j == 0 ? row0.cash0 : j == 1 ? (q0 != nullptr ? q0[i] : row0.q0_scalar) : j == 2 ? row0.t0 : j == 3 ? row0.s0 : row0.extra[j - 4];
     row[j] = v;
-    if (orow != nullptr) orow[j] = P.norm_obs ? normalise_column(v, j, P) : v;
+    if (orow != nullptr) {
+      if (row0.res != 0) {  // precise_state: normalised from the float64 value, like the reference (TE:112-118)
+        const double x = (j == 1 && q0 != nullptr) ? static_cast<double>(q0[i]) : row0.exact[j];
+        orow[j] = P.norm_obs ? normalise_column_exact(x, j, P) : v;
+      } else {
+        orow[j] = P.norm_obs ? normalise_column(v, j, P) : v;
+      }
+    }
   }
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
@@ -1052,12 +1253,13 @@ __global__ void export_step_kernel(const float* obs, const float* reward, float*
 }
 
 // un-normalised state rows -> normalised observation rows (after set_state)
-__global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n_pad, int dim, const StepParams P) {
+// (`exact`: the precise_state tier normalises in double, like the reference; a state set from float32 rows has no remainders)
+__global__ void normalise_rows_kernel(const float* state, float* obs, uint32_t n_pad, int dim, const StepParams P, int exact) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   const float* r = state + static_cast<size_t>(i) * dim;
   float* o = obs + static_cast<size_t>(i) * dim;
-  for (int j = 0; j < dim; ++j) o[j] = P.norm_obs ? normalise_column(r[j], j, P) : r[j];
+  for (int j = 0; j < dim; ++j) o[j] = !P.norm_obs ? r[j] : (exact ? normalise_column_exact(r[j], j, P) : normalise_column(r[j], j, P));
 }
 
 // [sum of wave_sums, sum of lane_returns^2 (NaN when per-lane returns are not tracked), lane count] -> out[0..2]; one block.

@@ -515,6 +515,16 @@ class TradingEnvironment(_EnvBase):
         _native.check(_native.load_library().mbt_env_get_state_host(self._handle, _native.fptr(out)))
         return out
 
+    @property
+    def state64(self) -> np.ndarray:
+        """The un-normalised (N, D) state as float64 - the dtype of the reference's `state` (TE:142-144).  With
+        `precise_state=True` these ARE the reference's float64 values (the kernels carry every real-valued column as its
+        float32 rounding plus an exact int32 remainder and step it in the reference's own float64 operation order);
+        otherwise the float32 state widened."""
+        out = np.empty((self.num_trajectories, self.observation_dim), dtype=np.float64)
+        _native.check(_native.load_library().mbt_env_get_state_f64_host(self._handle, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def set_state(self, state: np.ndarray, time: float = None, philox_step: int = None):
         st = _native.as_f32(state, (self.num_trajectories, self.observation_dim))
         t_now, _, ph = self.clock

@@ -34,6 +34,8 @@ def test_device_expressions_compile_without_a_gpu(no_device):
             env.check_device_expressions()
     finally:
         ExponentialInventoryCost.device_expression = good
+    precise = make_env(_cfg(64, arrival="hawkes", intensity=(15.0, 10.0), hawkes_speed=20.0), precise_state=True)
+    precise.check_device_expressions()  # the same plugins around the float64 (precise_state) instantiation
     built_in = make_env(_cfg(64, fill="exponential", reward="pnl"))
     built_in.check_device_expressions()  # nothing to compile: a no-op
     all_three = make_env(_cfg(64, arrival="user_seasonal", intensity=(40.0, 30.0), seasonal_amplitude=0.8, seasonal_period=0.5))
@@ -117,5 +119,5 @@ def test_user_plugin_refusals_and_cache():
     t2 = time.perf_counter()
     assert (t2 - t1) < 0.5 * (t1 - t0) + 0.2
     first.close(), second.close()
-    with pytest.raises(NativeError, match="precise_state"):
-        make_env(_cfg(64), precise_state=True)
+    with pytest.raises(NativeError, match="speed|order-book"):
+        make_env(_cfg(64, dynamics="speed", arrival="none", impact="temp_perm", fill="exponential"))  # user plugins run on the order-book kernels
