@@ -12,7 +12,10 @@ constant quote (0.7, 0.7) resident in HBM, in-kernel Philox noise keyed on the G
 One "step" = one env.step() = one launch of the fused kernel over every lane of the rank; the episode restarts
 (reset kernel) whenever it ends, inside the timed region, exactly like a VecEnv consumer would.
 No data-path collective; the only RCCL traffic is the 3-double all-reduce of the episode-return sums, enqueued on the
-environment's stream through the C ABI (mbt_env_set_communicator), one per finished episode.
+environment's stream through the C ABI (mbt_env_set_communicator), one per finished episode.  For N > 1 the line says how
+many ranks RCCL itself reports (`rccl_ranks_seen`, ncclCommCount), checks one all-reduce against its known answer and
+reports the collective's own latency (`collective`), measured after the timed region: at the driver's --steps 20 no
+1000-step episode ends inside the timed region, and forcing one in would charge 20 steps with a cost paid once per 1000.
 
 Timed region: barrier; t0; ONE call into the library that enqueues the K launches (mbt_env_step_many_device); wait for the
 stream; torch.cuda.synchronize(); t1.  Nothing else is inside it.  Before the W warm-up steps the GPU's clocks are
@@ -33,7 +36,6 @@ import re
 import socket
 import subprocess
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -142,11 +144,12 @@ def _cpu_worker(args):
     return t0, time.time(), done
 
 
-def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32)):
+def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32, 64, 128, 256)):
     """The reference's algorithm (oracle = NumPy restatement, bit-matched to the reference, float64, PCG64 noise like the
     reference) on this host, same model and N = 2^20 lanes: (i) one process / one core, like the reference itself;
     (ii) K processes x N/K lanes - the sharding the reference's MultiprocessTradingEnv intended
-    (gym/MultiprocessTradingEnv.py:74-80).  A bounded sample: about 10 s + two times ~5 s."""
+    (gym/MultiprocessTradingEnv.py:74-80) - for every K in `process_counts` the host has cores for; (iii) BASELINE.json
+    configs[0], the reference's own CPU-runnable case (N = 1000, 200 steps), one core.  A bounded sample: about 10 s + ~5 s per K."""
     import multiprocessing as mp
 
     n = LANES_PER_GPU
@@ -187,8 +190,24 @@ def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32)):
         except Exception as exc:  # noqa: BLE001 - a host that cannot spawn still reports the one-core figure
             multi[k] = f"failed: {exc}"
     best_k = max((k for k, v in multi.items() if isinstance(v, float)), key=lambda k: multi[k], default=None)
+    # (iii) configs[0]: N = 1000, n_steps = 200, the AS agent's closed form on the host like the reference's notebook (NB1:68-99)
+    from oracle.mbt_oracle import avellaneda_stoikov_action
+
+    cfg0 = OracleConfig(num_trajectories=1000, n_steps=200, terminal_time=1.0, midprice="bm", drift=0.0, volatility=2.0, initial_price=100.0,
+                        arrival="poisson", intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0,
+                        max_inventory=200, seed=SEED, normalise_action_space=False, normalise_observation_space=False)
+    env0 = OracleEnv(cfg0, NumpyProtocolNoise(SEED))
+    t0, episodes0 = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 1.0:
+        obs0 = env0.reset()
+        for _ in range(cfg0.n_steps):
+            obs0, _, _ = env0.step(avellaneda_stoikov_action(cfg0, 0.1, obs0))
+        episodes0 += 1
+    cfg0_rate = 1000 * 200 * episodes0 / (time.perf_counter() - t0)
     out = {
         "value": single, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "configs0": {"value": cfg0_rate, "unit": "env-steps/s", "cores": 1,
+                     "sample": f"{episodes0} episodes of BASELINE.json configs[0] (N = 1000, n_steps = 200, AS agent on the host), the same oracle"},
         "sample": f"{steps} steps x {n} lanes of the same workload, oracle/mbt_oracle.py (NumPy float64, PCG64 noise), "
                   f"{cores} host cores present, 1 used",
     }
@@ -261,10 +280,11 @@ def spawn_ranks(args):
     return rc
 
 
-def rccl_probe_child(rank, world, gpu, id_path):
-    """`bench.py --probe-rccl rank world gpu path`: one rank of a throw-away job that makes a C-ABI RCCL communicator (the
-    128-byte id travels by file, like examples/sharded_returns.c) and all-reduces three doubles on an environment's stream.
-    Exit code 0 = the sum is right."""
+def rccl_probe(rank, world, gpu, id_path):
+    """`bench.py --probe rank world gpu path`: a DIAGNOSTIC, not part of the measured job - one rank of a throw-away job that
+    makes a C-ABI RCCL communicator (the 128-byte id travels by file, like examples/sharded_returns.c) and all-reduces three
+    doubles on an environment's stream.  Exit code 0 = the sum is right.  Start one per GPU by hand when a multi-GPU run
+    misbehaves; the benchmark itself uses ONE communicator strategy (main: make_communicator)."""
     from mbt_gym_amd.distributed import RcclCommunicator
 
     def exchange(payload):
@@ -284,33 +304,112 @@ def rccl_probe_child(rank, world, gpu, id_path):
     env = build_env(1024, rank * 1024, gpu)
     comm = RcclCommunicator(rank, world, gpu, exchange=exchange)
     sums = env.allreduce_return_sums(comm, [float(rank + 1), 0.0, 1.0])
-    ok = sums[0] == world * (world + 1) / 2 and sums[2] == world
+    ok = sums[0] == world * (world + 1) / 2 and sums[2] == world and comm.count() == world
+    print(f"rank {rank}: ranks seen {comm.count()}, sums {sums.tolist()} -> {'ok' if ok else 'WRONG'}", file=sys.stderr)
     env.close()
     comm.close()
     return 0 if ok else 4
 
 
-def probe_c_abi_rccl(rank, world, gpu, id_path, timeout_s=120.0):
-    """Before the measured job binds its one collective to the C ABI's own RCCL communicator, the same thing is tried in a
-    child process with a deadline: a collective that never completes cannot be cancelled from inside the process it hangs,
-    but a child can be killed - and the job then takes the torch.distributed transport instead of hanging the run."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--probe-rccl", str(rank), str(world), str(gpu), id_path]
+class Watchdog:
+    """A hard deadline around the steps of a multi-GPU run that can block inside native code (communicator creation, a
+    collective): nothing inside a process can cancel those, so when the deadline passes the process says which step hung
+    and exits - the launcher then stops the other ranks - instead of hanging the run for the caller's whole time limit."""
+
+    def __init__(self, seconds, what, rank):
+        import threading
+
+        self.what, self.rank, self.seconds = what, rank, seconds
+        self.timer = threading.Timer(seconds, self.expire)
+        self.timer.daemon = True
+
+    def expire(self):
+        print(f"[rank {self.rank}] bench.py: '{self.what}' did not finish within {self.seconds:.0f} s - giving up (exit 17)", file=sys.stderr, flush=True)
+        os._exit(17)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def pin_to_gpu_numa_node(gpu):
+    """Keep this rank's host threads on the cores of its GPU's NUMA node (the launch path is one host thread per GPU; a
+    cross-socket hop adds to every launch).  Best effort: returns a description, or the reason nothing was done."""
     try:
-        child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    except OSError as exc:
-        return False, f"probe could not start: {exc}"
-    try:
-        _, err = child.communicate(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        child.kill()  # exactly the process started here
-        child.communicate()
-        return False, f"probe did not finish within {timeout_s:.0f} s"
-    return child.returncode == 0, (err.decode("utf-8", "replace")[-400:] if child.returncode != 0 else "")
+        import torch
+
+        props = torch.cuda.get_device_properties(gpu)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return f"GPU {gpu} ({bdf}): no NUMA affinity reported"
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return f"GPU {gpu} ({bdf}): NUMA node {node} has no core this process may use"
+        os.sched_setaffinity(0, allowed)
+        return f"GPU {gpu} ({bdf}): NUMA node {node}, {len(allowed)} cores"
+    except Exception as exc:  # noqa: BLE001 - affinity is an optimisation, never a requirement
+        return f"not pinned: {exc}"
+
+
+def gpu_cfg0_figures(device):
+    """BASELINE.json configs[0] (N = 1000, n_steps = 200) on the GPU, the two ways a caller runs it: the reference's loop
+    (host agent + env.step(ndarray): latency-bound at this size) and the fused rollout (the agent's closed form on the device)."""
+    from mbt_gym_amd.agents.BaselineAgents import AvellanedaStoikovAgent
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
+    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+
+    n, n_steps = 1000, 200
+    dt = 1.0 / n_steps
+    dynamics = LimitOrderModelDynamics(
+        midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
+        arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
+        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n), num_trajectories=n)
+    env = TradingEnvironment(terminal_time=1.0, n_steps=n_steps, model_dynamics=dynamics, initial_inventory=0, max_inventory=200, seed=SEED,
+                             num_trajectories=n, normalise_action_space=False, normalise_observation_space=False, device=device)
+    agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
+
+    def loop_episode():
+        obs = env.reset()
+        while True:
+            obs, _, done, _ = env.step(agent.get_action(obs))
+            if done[0]:
+                return
+
+    def fused_episode():
+        env.reset_device()
+        env.rollout(agent, record=False)
+        env.synchronize()
+
+    out = {}
+    for name, episode in (("host_api_loop", loop_episode), ("fused_rollout", fused_episode)):
+        episode()
+        t0, count = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.5:
+            episode()
+            count += 1
+        out[name + "_env_steps_per_s"] = n * n_steps * count / (time.perf_counter() - t0)
+    env.close()
+    out["note"] = "N = 1000 x 200 steps: a launch-latency regime (140 KB of state), not a bandwidth one; reported beside the CPU port's configs0 figure"
+    return out
 
 
 def main():
-    if len(sys.argv) == 6 and sys.argv[1] == "--probe-rccl":
-        sys.exit(rccl_probe_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]))
+    if len(sys.argv) == 6 and sys.argv[1] == "--probe":
+        sys.exit(rccl_probe(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
@@ -321,6 +420,8 @@ def main():
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--force-distributed", action="store_true", help="testing: take the multi-rank code path (process group, C-ABI communicator, collective check) even with one rank")
+    ap.add_argument("--comm-timeout", type=float, default=180.0, help="hard deadline (s) for creating the RCCL communicator and for each collective check")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -339,22 +440,28 @@ def main():
     if rank == 0:
         build_native()  # no-op unless the library is missing or was built from other sources
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_distributed  # the multi-rank code path (a world of one takes it only when asked to: tests)
+    if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     visible = torch.cuda.device_count()
     if world > 1 and not args.single_device and visible < world and args.backend == "nccl":
         raise SystemExit(f"--gpus {world} needs {world} visible GPUs, {visible} present (functional test on one GPU: --backend gloo --single-device)")
     # one process per GPU; a launcher that narrows each rank's visible devices leaves fewer ordinals than ranks
     gpu = 0 if args.single_device else local_rank % max(1, visible)
     torch.cuda.set_device(gpu)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
-        else:
-            dist.init_process_group(backend=args.backend)
-        dist.barrier()  # every rank waits for rank 0's build check before it loads the library
+    affinity = pin_to_gpu_numa_node(gpu) if multi else "not pinned (1 rank)"
+    if multi:
+        with Watchdog(args.comm_timeout, "torch.distributed rendezvous + first barrier", rank):
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
+            else:
+                dist.init_process_group(backend=args.backend)
+            dist.barrier()  # every rank waits for rank 0's build check before it loads the library
     lib = _native.load_library()
 
     n = args.lanes
@@ -362,43 +469,35 @@ def main():
     assert count == n and offset == rank * n
     env = build_env(n, offset, gpu)
 
-    # the one collective of the path: through the C ABI's RCCL binding when the launcher-side backend is RCCL too, else
-    # (gloo, single-device testing: RCCL refuses two ranks on one GPU) through torch.distributed after the fact
-    comm, transport = None, "none (1 rank)"
+    # The one collective of the path, ONE strategy: an RCCL communicator made through the C ABI (mbt_comm_init_rank; the
+    # 128-byte id travels over the launcher's process group) and attached to the environment, so that episode ends enqueue
+    # their 24-byte all-reduce on the environment's stream.  Creation runs under a hard deadline.  If it FAILS (an error, not
+    # a hang) every rank agrees to take torch.distributed for the return sums instead - on every rank or on none.  With the
+    # gloo backend (single-device testing: RCCL refuses two ranks on one GPU) torch.distributed is the transport from the start.
+    comm, transport, ranks_seen = None, "none (1 rank)", 1
     tdev = torch.device("cuda", gpu) if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if multi:
         transport = f"torch.distributed/{args.backend}"
+        ranks_seen = dist.get_world_size()
         if args.backend == "nccl":
-            # (i) the same communicator + collective in throw-away child processes, with a deadline (probe_c_abi_rccl)
-            box = [os.path.join(tempfile.gettempdir(), f"mbt_rccl_probe_{os.getpid()}_{time.time_ns()}")]
-            dist.broadcast_object_list(box, src=0)
-            try:
-                ok, why = probe_c_abi_rccl(rank, world, gpu, box[0])
-            except Exception as exc:  # noqa: BLE001
-                ok, why = False, str(exc)
-            if not ok:
-                print(f"[rank {rank}] C-ABI RCCL probe failed ({why}); using torch.distributed", file=sys.stderr)
-            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if rank == 0 and os.path.exists(box[0]):
-                os.remove(box[0])
-            # (ii) every rank's probe came back: the measured job makes its own
-            ok = flag.item() >= 1.0
-            if ok:
+            ok = True
+            with Watchdog(args.comm_timeout, "mbt_comm_init_rank (C-ABI RCCL communicator)", rank):
                 try:
                     comm = RcclCommunicator(rank, world, gpu)
                     env.set_communicator(comm)
-                except Exception as exc:  # noqa: BLE001 - fall back to torch.distributed on EVERY rank, or on none
+                except Exception as exc:  # noqa: BLE001
                     print(f"[rank {rank}] C-ABI RCCL communicator unavailable ({exc}); using torch.distributed", file=sys.stderr)
                     ok = False
-            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=tdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() < 1.0:
                 if comm is not None:
                     env.set_communicator(None)
+                    comm.close()
                 comm = None
             else:
                 transport = "RCCL via mbt_env_set_communicator (C ABI), enqueued on the environment's stream"
+                ranks_seen = comm.count()  # ncclCommCount: what RCCL itself says
 
     def sync_all(barrier=True):
         env.synchronize()
@@ -412,20 +511,21 @@ def main():
             sums = env.episode_log_pop(wait=True)
             if sums is None:
                 return out
-            out.append(sums if (comm is not None or world == 1) else allreduce_return_sums(sums, device=tdev))
+            out.append(sums if (comm is not None or not multi) else allreduce_return_sums(sums, device=tdev))
 
     # clocks up (untimed, not part of --warmup), then the warm-up the caller asked for
     prewarm, prewarm_target = 0, args.prewarm_steps if args.prewarm_steps >= 0 else default_prewarm_steps(n)
-    while prewarm < prewarm_target:
-        prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
-        env.synchronize()
-    if args.warmup > 0:
-        env.step_many_device(args.warmup, auto_reset=True)
-    sync_all()
-    drain_log()
+    with Watchdog(max(args.comm_timeout, 600.0), "warm-up steps (including the all-reduces of the episodes that end in them)", rank):
+        while prewarm < prewarm_target:
+            prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
+            env.synchronize()
+        if args.warmup > 0:
+            env.step_many_device(args.warmup, auto_reset=True)
+        sync_all()
+        warm_episodes = drain_log()
 
-    wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
-    episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
+        wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
+        episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([wall, event_s], dtype=torch.float64, device=tdev)
@@ -435,9 +535,29 @@ def main():
     # mean return of the last finished episode over ALL shards (or of the partial episode if none finished)
     if episode_returns:
         sums = episode_returns[-1]
+    elif warm_episodes:
+        sums = warm_episodes[-1]
     else:
         local = env.episode_return_sums()
         sums = env.allreduce_return_sums(comm, local) if comm is not None else allreduce_return_sums(local, device=tdev)
+
+    # the collective on its own (N > 1): a known-answer all-reduce through the same communicator - every rank contributes
+    # [rank + 1, 0, 1], the sum must be [N (N + 1) / 2, 0, N] - and its latency (blocking form: copy in, all-reduce, copy out, wait)
+    collective = None
+    if multi:
+        with Watchdog(args.comm_timeout, "known-answer all-reduce", rank):
+            reduce_once = (lambda v: env.allreduce_return_sums(comm, v)) if comm is not None else (lambda v: allreduce_return_sums(v, device=tdev))
+            got = reduce_once([float(rank + 1), 0.0, 1.0])
+            correct = bool(got[0] == world * (world + 1) / 2 and got[2] == world)
+            sync_all()
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                reduce_once([1.0, 0.0, 1.0])
+            per_call = (time.perf_counter() - t0) / reps
+        collective = {"what": "24-byte all-reduce of [sum R, sum R^2, lanes], blocking form (H2D 24 B + all-reduce + D2H 24 B + wait)",
+                      "us": per_call * 1e6, "known_answer_ok": correct, "per_episode_share_of_stepping": per_call / (N_STEPS * wall / args.steps),
+                      "episodes_all_reduced_before_the_timed_region": len(warm_episodes)}
 
     if rank == 0:
         total_lanes = n * world
@@ -454,8 +574,10 @@ def main():
                 "num_trajectories_per_gpu": n, "num_trajectories_total": total_lanes, "n_steps": N_STEPS,
                 "action": "constant quote (0.7, 0.7) resident in HBM", "noise": "in-kernel Philox4x32-10",
                 "parallelism": f"trajectory axis sharded over {world} GPU(s), no data-path collective",
-                "return_allreduce": transport,
+                "return_allreduce": transport, "rccl_ranks_seen": ranks_seen, "host_affinity_rank0": affinity,
                 "episodes_finished_in_timed_region": episodes, "prewarm_steps": prewarm,
+                "kernel_tuning": "this kernel (Brownian / Poisson / limit / PnL) runs capped at 5 workgroups per CU from 2^20 lanes "
+                                 "up (mbt_env.hip: tune_for_size): measured +2.5 % for it, a loss for every heavier kernel, which keep full occupancy",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -469,6 +591,8 @@ def main():
             "event_env_steps_per_s": total_lanes * args.steps / event_s,
             "mean_episode_return": return_statistics(sums)[0],
         }
+        if collective is not None:
+            out["collective"] = collective
     env.close()
     if rank == 0:
         if world == 1 and not args.no_hbm_resident:
@@ -478,11 +602,16 @@ def main():
                 out["roofline"]["hbm_resident"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"]["configs0"]["gpu"] = gpu_cfg0_figures(gpu)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"]["configs0"]["gpu"] = {"error": str(exc)}
     if comm is not None:
         comm.close()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with Watchdog(args.comm_timeout, "final barrier", rank):
+            dist.barrier()
+            dist.destroy_process_group()
     if rank == 0:  # the very last thing written to stdout (RCCL prints its version banner there when communicators are made)
         print(json.dumps(out), flush=True)
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 4u
+#define MBT_ABI_VERSION 5u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -141,13 +141,23 @@ typedef struct mbt_config {
   double exogenous_depth[2];
   double base_fill_probability;              /* FILL:132 */
 
-  /* ---- ABI 4 ---- */
+  /* ---- ABI 4 (ABI 5 added entry points only) ---- */
   double reward_terminal_time;               /* CjMmCriterion / CjOeCriterion keep their OWN terminal_time (RW:88, RW:74, RW:113); 0 = terminal_time */
   double mid_coef_add, mid_coef_mul;         /* MBT_MID_LINEAR_SDE only */
-  /* 1 = keep cash and midprice as float32 PAIRS (value + residual, two more floats per lane in a side buffer, +16 B of
-   * traffic per env-step): the state follows the float64 reference to ~1e-12 instead of accumulating float32 roundings,
-   * so rewards stay within 1e-5 of it even on lane-steps where the clip of TE:283-289 turns the state's level into
-   * reward.  Observations are unchanged (the rounded float32 value).  Order-book dynamics only. */
+  /* Numerics tier.
+   * 0 (default): float32 state, the 44 B / env-step kernels.  Decisions (arrivals, fills, inventory) are bit-exact against
+   *   the float64 reference on the same draws - except that Hawkes intensities are float32 STATE, so a draw within the
+   *   float32 error of lambda dt can decide differently (3e-9 per draw) - and rewards are within 1e-5 + 1e-6 |r| on
+   *   lane-steps where the clip of TE:283-289 does not fire, within 1.2e-4 where it does (the reward then carries the level
+   *   of the float32 cash / midprice); real-valued inventory (speed dynamics) accumulates float32 rounding.
+   * 1: the reference's float64 state, EXACTLY - every real-valued column (cash, midprice, Hawkes intensities, the inventory
+   *   and impact state of speed dynamics) is its float32 rounding in the state row plus an int32 remainder in a side
+   *   buffer (mbt_exact_split: the same 8 bytes as a float32 pair, all 53 bits) - stepped in double in the reference's own
+   *   order of operations: state, rewards and every decision ARE the reference's on the same draws (rewards rounded once
+   *   to float32; a transcendental in the path - a fractional impact exponent, exponential utility, a user expression -
+   *   agrees to an ulp instead of to the bit).  Every plugin family, user-defined (mbt_env_create_jit) included.
+   *   +8 B per remainder column and env-step: 60 B instead of 44 (limit orders), 92 instead of 60 (Hawkes), 80 instead of
+   *   48 (speed dynamics with an impact state).  Observations are unchanged in layout: float32 rows. */
   int32_t precise_state;
   /* The Hawkes intensity recursion lambda += speed (base - lambda) dt + jump (ARR:110-119) is a contraction only for
    * hawkes_speed * arrival_step_size < 1; from 1 it oscillates and from 2 it diverges (in the float64 reference as well),
@@ -167,6 +177,16 @@ const char* mbt_last_error(void);
 int mbt_device_count(void);
 /* Writes the device name ("gfx950...") into buf; returns MBT_OK or an error. */
 int mbt_device_name(int device, char* buf, size_t buf_len);
+
+/* ---- pinned host memory for the "*_host" entry points ------------------------------------------ */
+/* The "*_host" entry points move actions in and observations / rewards out with DMA copies, which read and write PINNED
+ * host memory directly; pageable memory has to be staged (by the library through a pinned bounce buffer: one more pass
+ * over the bytes, and page faults if the destination is fresh).  A caller that steps large batches through the host API
+ * allocates its action / observation / reward buffers here once and re-uses them: the copies then run at the PCIe rate
+ * (28 B per lane and step for the Avellaneda-Stoikov workload).  Every host pointer is accepted either way - the library
+ * recognises these blocks (and foreign pinned memory, through hipPointerGetAttributes).  Returns NULL on failure. */
+void* mbt_host_alloc(size_t bytes);
+void mbt_host_free(void* ptr);
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
 /* Replaces TradingEnvironment.__init__ (TE:27-94) for the numeric part: validates the plugin combination,
@@ -399,6 +419,8 @@ int mbt_env_set_communicator(mbt_env* env, void* nccl_comm);
 #define MBT_COMM_ID_BYTES 128
 int mbt_comm_unique_id(void* id_out);
 int mbt_comm_init_rank(int device, int n_ranks, const void* id, int rank, void** comm_out);
+/* ncclCommCount: how many ranks the communicator spans, as RCCL itself reports it (evidence for a multi-GPU run's log). */
+int mbt_comm_count(void* comm, int* n_ranks);
 int mbt_comm_destroy(void* comm);
 
 /* ---- RewardFunction.calculate on caller-supplied matrices (RW:23-33, RW:96-109, RW:128-138) ---------------------

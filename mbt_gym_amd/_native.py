@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER = 0, 1, 2, 3, 4, 5, 6, 7
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER = 0, 1, 2, 3, 4
@@ -167,6 +167,8 @@ SIGNATURES = {
     "mbt_last_error": (C.c_char_p, []),
     "mbt_device_count": (C.c_int, []),
     "mbt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "mbt_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "mbt_host_free": (None, [C.c_void_p]),
     "mbt_env_create": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(_ENV)]),
     "mbt_env_destroy": (None, [_ENV]),
     "mbt_env_create_jit": (C.c_int, [C.POINTER(MbtConfig), C.POINTER(MbtUserCode), C.POINTER(_ENV)]),
@@ -212,6 +214,7 @@ SIGNATURES = {
     "mbt_env_set_communicator": (C.c_int, [_ENV, C.c_void_p]),
     "mbt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mbt_comm_init_rank": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mbt_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mbt_comm_destroy": (C.c_int, [C.c_void_p]),
     "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
@@ -331,6 +334,82 @@ def as_f32(a, shape=None):
     if shape is not None and out.shape != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {out.shape}")
     return out
+
+
+class PinnedBuffer:
+    """A block of pinned host memory from libmbtenv (mbt_host_alloc) shaped as a float32 array: what the host API's DMA
+    copies read and write directly.  `array()` makes a NumPy array over it whose base chain ends HERE, so the number of
+    references to this object tells whether any array (or view, or torch tensor made from one) still looks at the block -
+    which is how TradingEnvironment.step() re-uses its output buffers without ever overwriting one a caller still holds."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = load_library().mbt_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise NativeError(-3, load_library().mbt_last_error().decode("utf-8", "replace"))
+
+    @property
+    def __array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def array(self) -> np.ndarray:
+        return np.asarray(self)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr and _lib is not None:
+            try:
+                _lib.mbt_host_free(ptr)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+
+class OutputPool:
+    """Output buffers of the host API (observations, rewards, dones) in pinned memory, re-used across steps WITHOUT changing
+    what the caller sees: a buffer is handed out again only once no array over it is referenced any more (the reference
+    returns fresh arrays, TE:101, TE:110 - a caller that keeps one keeps its values).  In the usual loop
+    `obs, rew, done, info = env.step(action)` the previous step's arrays die when the names are rebound, so two buffers
+    alternate and nothing is allocated after the first two steps (a fresh 16 MB np.empty per step - and the page faults of
+    the DMA that fills it - were most of a 2^20-lane step).  A caller that holds on to many outputs makes the pool grow, up to
+    `max_bytes` of pinned memory; beyond that it gets ordinary (pageable) arrays, as before."""
+
+    def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30):
+        self.shape, self.dtype, self.max_bytes = tuple(shape), np.dtype(dtype), max_bytes
+        self._cursor = 0
+        self._pinned_unavailable = False
+        self.buffers = [_RefProbe()]
+        self._idle_refs = self._refs(0)  # references a buffer has when only this pool looks at it (counted exactly as acquire() counts)
+        self.buffers = []
+
+    def _refs(self, index):
+        import sys
+
+        buf = self.buffers[index]
+        return sys.getrefcount(buf)
+
+    def acquire(self):
+        """(array, is_pinned): an array nobody else references, preferably over pinned memory."""
+        for _ in range(len(self.buffers)):
+            index = self._cursor
+            self._cursor = (self._cursor + 1) % len(self.buffers)
+            if self._refs(index) <= self._idle_refs:
+                return self.buffers[index].array(), True
+        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if not self._pinned_unavailable and (len(self.buffers) + 1) * nbytes <= max(self.max_bytes, 2 * nbytes):
+            try:
+                self.buffers.append(PinnedBuffer(self.shape, self.dtype))
+            except (NativeError, RuntimeError, OSError):  # no pinned memory to be had (no device, a locked-memory limit):
+                self._pinned_unavailable = True          # pageable arrays work everywhere, only slower
+            else:
+                self._cursor = 0
+                return self.buffers[-1].array(), True
+        return np.empty(self.shape, dtype=self.dtype), False
+
+
+class _RefProbe:
+    """(calibrates OutputPool's reference count without allocating anything)"""
 
 
 class DeviceView:

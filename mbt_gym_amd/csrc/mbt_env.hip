@@ -81,6 +81,31 @@ void exact_split_host(double x, float& hi, int32_t& lo) {
 }
 double exact_join_host(float hi, int32_t lo) { return static_cast<double>(hi) + std::ldexp(static_cast<double>(lo), f32_biased_exponent_host(hi) - (127 + 53)); }
 
+// Pinned host memory handed to callers (mbt_host_alloc): a host pointer inside one of these blocks is DMA-able as it is, so
+// the "*_host" entry points copy straight into / out of it; any other host pointer is pageable as far as the library knows
+// (a foreign pinned allocation is recognised through hipPointerGetAttributes) and goes through a pinned bounce buffer.
+std::mutex g_pinned_mutex;
+std::map<uintptr_t, size_t> g_pinned_blocks;  // base address -> bytes
+
+bool is_pinned_host(const void* p, size_t bytes) {
+  if (p == nullptr) return false;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  {
+    std::lock_guard<std::mutex> guard(g_pinned_mutex);
+    auto it = g_pinned_blocks.upper_bound(a);
+    if (it != g_pinned_blocks.begin()) {
+      --it;
+      if (a >= it->first && a + bytes <= it->first + it->second) return true;
+    }
+  }
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary malloc'ed pointer: not an error of ours
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 // up to this many lanes the host API stages through device-mapped pinned memory (mbt_env_step_host); measured per step,
 // DMA path vs mapped staging: 52 vs 33 us at 8192 lanes, 85 vs 70 at 32768, 138 vs 131 at 65536, 149 vs 228 at 131072.
 // MBT_HOST_FAST_PATH_LANES overrides it (measurement knob).
@@ -304,6 +329,9 @@ struct mbt_env {
   uint32_t log_head = 0, log_count = 0;  // oldest entry, entries in flight
   void* comm = nullptr;            // ncclComm_t of the episode log (mbt_env_set_communicator)
   // staging of mbt_env_rollout_host trajectories (grow-only)
+  // pinned bounce buffers of the host API for callers that pass pageable memory: [actions | observation | rewards] (grow-only)
+  float* h_bounce = nullptr;
+  size_t bounce_floats = 0;
   float* traj_stage[3] = {nullptr, nullptr, nullptr};
   size_t traj_stage_floats[3] = {0, 0, 0};
 };
@@ -1054,6 +1082,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
   bool ok = false;
   std::string why;
@@ -1083,6 +1112,7 @@ const RcclApi& rccl() {
     a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
     a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
     a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(h, "ncclCommCount"));
     a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
     a.ok = a.all_reduce != nullptr && a.get_unique_id != nullptr && a.comm_init_rank != nullptr && a.comm_destroy != nullptr;
     if (!a.ok) a.why = "librccl is loaded but lacks ncclAllReduce / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy";
@@ -1400,6 +1430,7 @@ void mbt_env_destroy(mbt_env* e) {
   for (hipEvent_t ev : e->log_event)
     if (ev != nullptr) (void)hipEventDestroy(ev);
   if (e->h_stage != nullptr) (void)hipHostFree(e->h_stage);
+  if (e->h_bounce != nullptr) (void)hipHostFree(e->h_bounce);
   if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);
   if (e->ev_end != nullptr) (void)hipEventDestroy(e->ev_end);
   if (e->ev_sums != nullptr) (void)hipEventDestroy(e->ev_sums);
@@ -1493,14 +1524,39 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
     if (reward_host != nullptr) std::memcpy(reward_host, e->h_stage + e->stage_reward, size_t(e->n) * sizeof(float));
     return MBT_OK;
   }
-  HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  // Larger batches: three DMA copies around the launch, bandwidth-bound (28 B per lane over PCIe for the AS workload).  A
+  // copy engine can only read / write PINNED host memory directly; handed pageable memory the runtime stages it piecewise
+  // through its own small pinned buffers (2.2 GB/s effective at 2^20 lanes, profiles/r02_host_path.json).  So: buffers from
+  // mbt_host_alloc (or any pinned memory) are used as they are - the Python binding keeps its output arrays in such
+  // memory and re-uses them - and pageable ones bounce through a pinned buffer of the environment's own.
+  const size_t act_floats = size_t(e->n) * e->act_dim, obs_floats = size_t(e->n) * e->dim, rew_floats = e->n;
+  const bool act_direct = is_pinned_host(action_host, act_floats * sizeof(float));
+  const bool obs_direct = obs_host == nullptr || is_pinned_host(obs_host, obs_floats * sizeof(float));
+  const bool rew_direct = reward_host == nullptr || is_pinned_host(reward_host, rew_floats * sizeof(float));
+  if (!(act_direct && obs_direct && rew_direct)) {
+    const size_t want = act_floats + obs_floats + rew_floats;
+    if (want > e->bounce_floats) {
+      if (e->h_bounce != nullptr) (void)hipHostFree(e->h_bounce);
+      e->h_bounce = nullptr;
+      e->bounce_floats = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_bounce), want * sizeof(float), hipHostMallocDefault));
+      e->bounce_floats = want;
+    }
+  }
+  float* bounce_act = e->h_bounce;
+  float* bounce_obs = e->h_bounce != nullptr ? e->h_bounce + act_floats : nullptr;
+  float* bounce_rew = e->h_bounce != nullptr ? e->h_bounce + act_floats + obs_floats : nullptr;
+  if (!act_direct) std::memcpy(bounce_act, action_host, act_floats * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(e->action, act_direct ? action_host : bounce_act, act_floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
   int rc = launch_step(e, nullptr, done);
   if (rc != MBT_OK) return rc;
   if (obs_host != nullptr)
-    HIP_TRY(hipMemcpyAsync(obs_host, current_obs(e), size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(obs_direct ? obs_host : bounce_obs, current_obs(e), obs_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (reward_host != nullptr)
-    HIP_TRY(hipMemcpyAsync(reward_host, e->reward, size_t(e->n) * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(rew_direct ? reward_host : bounce_rew, e->reward, rew_floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (obs_host != nullptr && !obs_direct) std::memcpy(obs_host, bounce_obs, obs_floats * sizeof(float));
+  if (reward_host != nullptr && !rew_direct) std::memcpy(reward_host, bounce_rew, rew_floats * sizeof(float));
   return MBT_OK;
 }
 
@@ -1594,6 +1650,16 @@ int mbt_comm_init_rank(int device, int n_ranks, const void* id_bytes, int rank, 
   ncclResult_t r = api.comm_init_rank(&comm, n_ranks, id, rank);
   if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
   *comm_out = comm;
+  return MBT_OK;
+}
+
+int mbt_comm_count(void* comm, int* n_ranks) {
+  if (comm == nullptr || n_ranks == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  const RcclApi& api = rccl();
+  if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+  if (api.comm_count == nullptr) return fail(MBT_ERR_HIP, "librccl lacks ncclCommCount");
+  ncclResult_t r = api.comm_count(static_cast<ncclComm_t>(comm), n_ranks);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclCommCount");
   return MBT_OK;
 }
 
@@ -1715,6 +1781,28 @@ int mbt_env_get_state_host(mbt_env* e, float* state_host) {
   HIP_TRY(hipMemcpyAsync(state_host, e->state[e->cur], size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
+}
+
+void* mbt_host_alloc(size_t bytes) {
+  if (bytes == 0) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(MBT_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> guard(g_pinned_mutex);
+  g_pinned_blocks[reinterpret_cast<uintptr_t>(p)] = bytes;
+  return p;
+}
+
+void mbt_host_free(void* p) {
+  if (p == nullptr) return;
+  {
+    std::lock_guard<std::mutex> guard(g_pinned_mutex);
+    g_pinned_blocks.erase(reinterpret_cast<uintptr_t>(p));
+  }
+  (void)hipHostFree(p);
 }
 
 void mbt_exact_split(double x, float* hi, int32_t* lo) {

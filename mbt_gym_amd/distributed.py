@@ -50,6 +50,16 @@ class RcclCommunicator:
         _native.check(lib.mbt_comm_init_rank(int(device), int(world_size), C.create_string_buffer(raw, _native.COMM_ID_BYTES), int(rank), C.byref(handle)))
         self.handle, self.rank, self.world_size, self._lib = handle, rank, world_size, lib
 
+    def count(self) -> int:
+        """The number of ranks RCCL itself says the communicator spans (ncclCommCount)."""
+        import ctypes as C
+
+        from mbt_gym_amd import _native
+
+        out = C.c_int(0)
+        _native.check(self._lib.mbt_comm_count(self.handle, C.byref(out)))
+        return int(out.value)
+
     def close(self):
         if self.handle is not None:
             self._lib.mbt_comm_destroy(self.handle)

@@ -280,17 +280,23 @@ class TradingEnvironment(_EnvBase):
 
     def reset(self):
         """Re-initialise every lane (TE:96-101) and return the (N, D) float32 observation."""
-        obs = np.empty((self.num_trajectories, self.observation_dim), dtype=np.float32)
+        obs = self._host_buffers()["obs"].acquire()[0]
         self._reset_device(obs)
         return obs
 
     def step(self, action: np.ndarray):
         """One environment step for all lanes: ONE kernel launch.  Returns (obs, rewards, dones, infos) with the
-        reference's shapes (TE:103-110): (N, D) float32, (N,) float32, (N,) bool, list of N dicts."""
+        reference's shapes (TE:103-110): (N, D) float32, (N,) float32, (N,) bool, list of N dicts.
+
+        The three arrays live in pinned host memory that the step's DMA copies write directly and that is RE-USED - but only
+        once the caller has let go of an array (`_native.OutputPool`): like the reference's, an array you keep keeps its
+        values.  The action may be any array-like of shape (N, A); handing over `env.action_buffer` (pinned) after writing
+        the action into it saves the one pass that stages other arrays into pinned memory."""
         n = self.num_trajectories
-        act = _native.as_f32(action, (n, self.action_dim))
-        obs = np.empty((n, self.observation_dim), dtype=np.float32)
-        rewards = np.empty((n,), dtype=np.float32)
+        pools = self._host_buffers()
+        act = self._stage_action(action, pools)
+        obs = pools["obs"].acquire()[0]
+        rewards = pools["rewards"].acquire()[0]
         done = C.c_int32(0)
         lib = _native.load_library()
         _native.check(lib.mbt_env_step_host(self._handle, _native.fptr(act), _native.fptr(obs), _native.fptr(rewards), C.byref(done)))
@@ -298,8 +304,46 @@ class TradingEnvironment(_EnvBase):
             ev = np.empty((n,), dtype=np.uint8)
             _native.check(lib.mbt_env_get_events_host(self._handle, ev.ctypes.data_as(C.POINTER(C.c_uint8))))
             self._last_events = ev
-        dones = np.full((n,), bool(done.value), dtype=bool)
+        dones = pools["dones"].acquire()[0]
+        dones.fill(bool(done.value))
         return obs, rewards, dones, self._infos()
+
+    # -- host buffers of step() / reset() ---------------------------------------------------------------------------------
+    def _host_buffers(self):
+        pools = getattr(self, "_pools", None)
+        if pools is None or pools["n"] != self.num_trajectories:
+            n = self.num_trajectories
+            pools = {"n": n, "obs": _native.OutputPool((n, self.observation_dim)), "rewards": _native.OutputPool((n,)),
+                     "dones": _native.OutputPool((n,), dtype=np.bool_), "action": None}
+            self._pools = pools
+        return pools
+
+    @property
+    def action_buffer(self) -> np.ndarray:
+        """A pinned (N, A) float32 array owned by the environment: an agent that writes its action into it (e.g. with a
+        ufunc's `out=`) and calls `env.step(env.action_buffer)` has it DMA-copied as it is - any other array is first copied
+        (and converted to float32) into this one."""
+        pools = self._host_buffers()
+        if pools["action"] is None:
+            try:
+                pools["action"] = _native.PinnedBuffer((self.num_trajectories, self.action_dim))
+                pools["action_array"] = pools["action"].array()
+            except (_native.NativeError, RuntimeError, OSError):  # no pinned memory: an ordinary array (staged by the library)
+                pools["action"] = False
+                pools["action_array"] = np.empty((self.num_trajectories, self.action_dim), dtype=np.float32)
+        return pools["action_array"]
+
+    def _stage_action(self, action, pools):
+        staged = self.action_buffer
+        if action is staged:
+            return staged
+        a = np.asarray(action)
+        if a.shape != staged.shape:
+            raise ValueError(f"expected shape {staged.shape}, got {a.shape}")
+        if a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size * 4 <= (1 << 17):
+            return a  # small batches: the library's own staging (mapped memory) reads the caller's array directly
+        np.copyto(staged, a, casting="unsafe")  # one pass: conversion to float32 and the move into pinned memory
+        return staged
 
     def seed(self, seed: int = None):
         """Re-key the generators (TE:345-348): environment generator <- default_rng(seed), Philox key <- seed,

@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[0] (the reference's own CPU-runnable case: Avellaneda-Stoikov, N = 1000, 200 steps) through
-the three ways a caller can run an episode, in wall-clock per episode:
-  gym loop   - the reference's usage: agent.get_action(obs) on the host + env.step(action), NumPy in / NumPy out
-               (one H2D copy, one launch, two D2H copies and a stream sync per step: latency-bound, not bandwidth)
-  rollout    - the fused rollout kernel with the agent's closed form on the device (generate_trajectory)
-  oracle     - the float64 NumPy port of the reference on one host core (cpu baseline)
-Also at N = 2^16 and 2^20 to show where the host path turns bandwidth-bound (PCIe)."""
+"""The reference-compatible host API - `env.step(np.ndarray)` - measured piece by piece (PCIe-inclusive; never the bench
+line's `value`).  BASELINE.json configs[0] (Avellaneda-Stoikov, N = 1000, 200 steps: the reference's own CPU-runnable
+case) and the same model at N = 2^16 and 2^20 lanes:
+
+  env_step_*        env.step() ALONE, K steps with a fixed action, auto-reset at episode ends like a VecEnv consumer:
+                      pinned   - the action written into `env.action_buffer` (pinned): three DMA copies + one launch
+                      pageable - an ordinary float32 ndarray: one more pass (np.copyto into the pinned action buffer)
+                      float64  - the reference's dtype: the same pass also converts
+  agent_get_action  the host agent's NumPy arithmetic alone (AvellanedaStoikovAgent.get_action on an (N, 4) observation)
+  gym_loop          agent + env.step() as the reference's users write it
+  sb3_vec_env       the same steps through StableBaselinesTradingEnvironment.step() (auto-reset, terminal observations)
+  pcie              what the box's link does for the step's three copies alone (pinned torch tensors, same sizes): the
+                    wire time a step cannot beat
+  rollout / oracle  the fused rollout kernel (generate_trajectory) and the NumPy port of the reference, for scale"""
 import json
 import os
 import sys
@@ -15,6 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np  # noqa: E402
 
 from mbt_gym_amd.agents.BaselineAgents import AvellanedaStoikovAgent  # noqa: E402
+from mbt_gym_amd.gym.StableBaselinesTradingEnvironment import StableBaselinesTradingEnvironment  # noqa: E402
 from mbt_gym_amd.gym.helpers.generate_trajectory import generate_trajectory  # noqa: E402
 from oracle.mbt_oracle import NumpyProtocolNoise, OracleConfig, OracleEnv, avellaneda_stoikov_action  # noqa: E402
 from tests.env_factory import make_env  # noqa: E402
@@ -30,24 +38,96 @@ def episode_gym_loop(env, agent):
             return total
 
 
+def env_only(env, action, steps):
+    """`steps` env.step(action) calls, resetting at episode ends; seconds per step."""
+    env.reset()
+    for _ in range(3):
+        obs, rew, done, _ = env.step(action)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, rew, done, _ = env.step(action)
+        if done[0]:
+            obs = env.reset()
+    return (time.perf_counter() - t0) / steps
+
+
+def pcie_wire(n, obs_dim, act_dim, reps=20):
+    """Seconds for the step's three copies alone (action H2D, observation + reward D2H) between pinned host tensors and HBM."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    h_act, h_obs, h_rew = (torch.empty(shape, dtype=torch.float32).pin_memory() for shape in ((n, act_dim), (n, obs_dim), (n,)))
+    d_act, d_obs, d_rew = (torch.empty_like(t, device=dev) for t in (h_act, h_obs, h_rew))
+    for _ in range(3):
+        d_act.copy_(h_act, non_blocking=True), h_obs.copy_(d_obs, non_blocking=True), h_rew.copy_(d_rew, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d_act.copy_(h_act, non_blocking=True), h_obs.copy_(d_obs, non_blocking=True), h_rew.copy_(d_rew, non_blocking=True)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def main():
     out = {}
-    for log2n, reps in ((None, 20), (16, 5), (20, 2)):
+    for log2n, reps, steps in ((None, 20, 2000), (16, 5, 600), (20, 2, 120)):
         n = 1000 if log2n is None else 1 << log2n
         cfg = OracleConfig(num_trajectories=n, n_steps=200, terminal_time=1.0, volatility=2.0, initial_price=100.0, intensity=(140.0, 140.0),
                            fill_exponent=1.5, initial_inventory=0, max_inventory=200, seed=50, normalise_action_space=False,
                            normalise_observation_space=False)
         env = make_env(cfg)
         agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
+        bytes_per_step = 4 * n * (env.action_dim + env.observation_dim + 1)
+        row = {"bytes_over_pcie_per_step": bytes_per_step}
+
+        # env.step() alone
+        env.action_buffer[:] = 0.7
+        t = env_only(env, env.action_buffer, steps)
+        row["env_step_pinned_action"] = {"us_per_step": t * 1e6, "env_steps_per_s": n / t, "GBps": bytes_per_step / t / 1e9}
+        pageable = np.full((n, env.action_dim), 0.7, np.float32)
+        t = env_only(env, pageable, steps)
+        row["env_step_pageable_action"] = {"us_per_step": t * 1e6, "env_steps_per_s": n / t, "GBps": bytes_per_step / t / 1e9}
+        t = env_only(env, pageable.astype(np.float64), steps)
+        row["env_step_float64_action"] = {"us_per_step": t * 1e6, "env_steps_per_s": n / t, "GBps": bytes_per_step / t / 1e9}
+        row["output_buffers_in_pool"] = len(env._host_buffers()["obs"].buffers)
+        try:
+            wire = pcie_wire(n, env.observation_dim, env.action_dim)
+            row["pcie"] = {"us_per_step": wire * 1e6, "GBps": bytes_per_step / wire / 1e9, "env_steps_per_s": n / wire}
+        except Exception as exc:  # noqa: BLE001 - torch missing: the split above stands on its own
+            row["pcie"] = {"error": str(exc)}
+
+        # the agent alone, then both (the reference's loop)
+        obs = env.reset()
+        agent.get_action(obs)
+        t0 = time.perf_counter()
+        for _ in range(max(5, steps // 10)):
+            agent.get_action(obs)
+        t = (time.perf_counter() - t0) / max(5, steps // 10)
+        row["agent_get_action"] = {"us_per_call": t * 1e6}
         episode_gym_loop(env, agent)
         t0 = time.perf_counter()
         for _ in range(reps):
             total = episode_gym_loop(env, agent)
         gym_s = (time.perf_counter() - t0) / reps
+        row["gym_loop"] = {"ms_per_episode": gym_s * 1e3, "us_per_step": gym_s / cfg.n_steps * 1e6, "env_steps_per_s": n * cfg.n_steps / gym_s,
+                           "mean_episode_return": float(total.mean())}
+
+        # the SB3 VecEnv adapter (SBE:22-37): auto-reset and terminal observations inside step()
+        venv = StableBaselinesTradingEnvironment(env)
+        venv.reset()
+        for _ in range(3):
+            venv.step(pageable)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            obs, rew, done, infos = venv.step(pageable)
+        t = (time.perf_counter() - t0) / steps
+        row["sb3_vec_env_step"] = {"us_per_step": t * 1e6, "env_steps_per_s": n / t}
+
+        # fused paths and the CPU port, for scale
         generate_trajectory(env, agent)
         t0 = time.perf_counter()
         for _ in range(reps):
-            obs, act, rew = generate_trajectory(env, agent)
+            generate_trajectory(env, agent)
         roll_s = (time.perf_counter() - t0) / reps
         env.reset()
         env.rollout(agent, record=False)
@@ -57,10 +137,8 @@ def main():
             env.rollout(agent, record=False)
             env.synchronize()
         fused_s = (time.perf_counter() - t0) / reps
-        row = {"gym_loop_ms_per_episode": gym_s * 1e3, "gym_loop_us_per_step": gym_s / cfg.n_steps * 1e6, "gym_loop_env_steps_per_s": n * cfg.n_steps / gym_s,
-               "generate_trajectory_ms_per_episode": roll_s * 1e3, "generate_trajectory_env_steps_per_s": n * cfg.n_steps / roll_s,
-               "rollout_returns_only_ms_per_episode": fused_s * 1e3, "rollout_returns_only_env_steps_per_s": n * cfg.n_steps / fused_s,
-               "mean_episode_return": float(total.mean())}
+        row["generate_trajectory"] = {"ms_per_episode": roll_s * 1e3, "env_steps_per_s": n * cfg.n_steps / roll_s}
+        row["rollout_returns_only"] = {"ms_per_episode": fused_s * 1e3, "env_steps_per_s": n * cfg.n_steps / fused_s}
         if n <= 1 << 16:
             o = OracleEnv(cfg, NumpyProtocolNoise(50))
             t0 = time.perf_counter()
@@ -68,7 +146,7 @@ def main():
             for _ in range(cfg.n_steps):
                 obs_o, _, _ = o.step(avellaneda_stoikov_action(cfg, 0.1, obs_o))
             orc_s = time.perf_counter() - t0
-            row.update({"oracle_ms_per_episode": orc_s * 1e3, "oracle_env_steps_per_s": n * cfg.n_steps / orc_s})
+            row["oracle"] = {"ms_per_episode": orc_s * 1e3, "env_steps_per_s": n * cfg.n_steps / orc_s}
         out[f"N={n}"] = row
         env.close()
     print(json.dumps(out, indent=1))

@@ -4,6 +4,7 @@ calibration of normalise_rewards against the reference, and the refusals that re
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -143,31 +144,33 @@ def test_a_process_that_made_a_communicator_without_torch_exits_cleanly():
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
 
 
-def test_the_bounded_time_rccl_probe(tmp_path):
-    """bench.py tries the C ABI's communicator + collective in a child process with a deadline before the measured job
-    relies on it (a hung collective cannot be cancelled in-process; a child can be killed).  World of one: succeeds.  A
-    deadline that cannot be met: reported as failed, child gone.  Two ranks on ONE GPU - which RCCL refuses - fail on both
-    sides within the deadline instead of hanging: the path the job then takes is torch.distributed."""
-    import threading
+def test_the_rccl_probe_diagnostic_and_the_ranks_rccl_reports(tmp_path):
+    """`bench.py --probe rank world gpu id-file` (a diagnostic, not part of the measured job): a world of one makes the C-ABI
+    communicator, all-reduces a known answer on an environment's stream and reads ncclCommCount back."""
+    from mbt_gym_amd.distributed import RcclCommunicator
 
-    sys.path.insert(0, ROOT)
-    import bench
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--probe", "0", "1", "0", str(tmp_path / "id")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "ranks seen 1" in out.stderr, out.stderr[-2000:]
+    comm = RcclCommunicator(rank=0, world_size=1, device=0)
+    assert comm.count() == 1
+    comm.close()
 
-    ok, why = bench.probe_c_abi_rccl(0, 1, 0, str(tmp_path / "id1"))
-    assert ok, why
-    ok, why = bench.probe_c_abi_rccl(0, 1, 0, str(tmp_path / "id2"), timeout_s=0.05)
-    assert not ok and "did not finish" in why
-    results = {}
 
-    def one(rank):
-        results[rank] = bench.probe_c_abi_rccl(rank, 2, 0, str(tmp_path / "id3"), timeout_s=90.0)
-
-    threads = [threading.Thread(target=one, args=(r,)) for r in (0, 1)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    assert not results[0][0] and not results[1][0], results
+def test_the_watchdog_ends_a_process_whose_native_call_never_returns():
+    """A collective (or communicator creation) that hangs cannot be cancelled from inside its process; bench.py's deadline
+    says which step hung and exits with code 17 - the launcher then stops the other ranks - instead of hanging the run."""
+    code = ("import sys, time\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "import bench\n"
+            "with bench.Watchdog(0.3, 'a step that hangs', 3):\n"
+            "    time.sleep(30)\n")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 17 and "a step that hangs" in out.stderr and "rank 3" in out.stderr, (out.returncode, out.stderr[-500:])
+    assert time.time() - t0 < 25
+    with __import__("bench").Watchdog(5.0, "a step that returns", 0):
+        pass  # cancelled on exit: nothing fires later
 
 
 def _bench(*args):
@@ -224,6 +227,30 @@ def test_two_ranks_at_the_drivers_arguments_finish_the_same_number_of_episodes()
     one = _bench("--gpus", "1", "--lanes", str(1 << 21), "--steps", "20", "--warmup", "5", "--prewarm-steps", "8192")
     assert line["mean_episode_return"] == pytest.approx(one["mean_episode_return"], rel=1e-12)
     assert 10.0 < line["mean_episode_return"] < 20.0  # about 67 * 0.217
+
+
+@pytest.mark.timeout(600)
+def test_the_multi_rank_code_path_of_bench_runs_on_rccl_with_a_world_of_one():
+    """Everything `bench.py --gpus 8` does that a one-rank run does not - the nccl process group, the NUMA pinning, the C-ABI
+    RCCL communicator made from an id broadcast over that group, the every-rank-or-none agreement, the per-episode
+    all-reduce enqueued in-stream, ncclCommCount in the line, the known-answer all-reduce and its latency - forced onto the
+    one GPU a test box has (`--force-distributed`: a world of one).  Nothing in the 8-rank path differs but the world size."""
+    line = _bench("--gpus", "1", "--force-distributed", "--steps", "1100", "--warmup", "5", "--prewarm-steps", "64")
+    assert line["config"]["return_allreduce"].startswith("RCCL via mbt_env_set_communicator"), line["config"]
+    assert line["config"]["rccl_ranks_seen"] == 1
+    assert line["config"]["episodes_finished_in_timed_region"] == 1  # one in-stream reduce + all-reduce + reset inside the timed region
+    c = line["collective"]
+    assert c["known_answer_ok"] is True and 0.0 < c["us"] < 5000.0 and c["per_episode_share_of_stepping"] < 0.2
+    assert 60.0 < line["mean_episode_return"] < 75.0
+    plain = _bench("--gpus", "1", "--steps", "1100", "--warmup", "5", "--prewarm-steps", "64")
+    assert "collective" not in plain and plain["mean_episode_return"] == pytest.approx(line["mean_episode_return"], rel=1e-12)
+
+
+@pytest.mark.timeout(600)
+def test_two_gloo_ranks_report_the_collective_and_the_world_size():
+    line = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--lanes", str(1 << 16), "--steps", "50", "--warmup", "5", "--prewarm-steps", "64")
+    assert line["config"]["rccl_ranks_seen"] == 2 and line["config"]["return_allreduce"] == "torch.distributed/gloo"
+    assert line["collective"]["known_answer_ok"] is True
 
 
 def test_reward_scaling_matches_the_reference_calibration(repo_root):
