@@ -153,14 +153,26 @@ StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, bool stre
 }
 // `staged` = the instantiation that loads 20-byte rows through LDS (cache-resident sizes, only with an impact state);
 // `stream` = non-temporal direct loads (sizes beyond the Infinity Cache); see speed_step_kernel
+// POW: the instantiation that can raise to arbitrary powers (speed_powers below); every reference configuration runs without
+template <bool STATE, bool POW>
+StepKernel pick_speed_pow(bool norm, bool inject, bool stream) {
+  if (inject) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, false, POW>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true, false, POW>>;
+  if (stream) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>, false, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>, false, true>;
+  if (STATE) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>, true>;
+  return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>>;
+}
 template <bool STATE>
-StepKernel pick_speed(bool norm, bool inject, bool stream) {
-  if (inject) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true>>;
-  if (stream) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, false, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, false, true>;
-  if (STATE) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>, true>;
-  return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false>>;
+StepKernel pick_speed(bool powers, bool norm, bool inject, bool stream) {
+  return powers ? pick_speed_pow<STATE, true>(norm, inject, stream) : pick_speed_pow<STATE, false>(norm, inject, stream);
 }
 bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
+// does this speed-dynamics configuration raise anything to a power other than 1 (impact, IMP:55) or 2 (inventory penalty,
+// RW:59-68), or use the exponential utility?  (No reference configuration does; the kernels without are a quarter the code.)
+bool speed_powers(const mbt_config& c) {
+  return (c.impact_kind == MBT_IMPACT_TEMPORARY_POWER && c.impact_exponent != 1.0) || (c.reward_kind != MBT_REW_PNL && c.inventory_exponent != 2.0) ||
+         c.reward_kind == MBT_REW_EXP_UTILITY;
+}
+
 
 // ExogenousMmFillProbabilityModel: the general tier only (runtime midprice coefficients, every reward, runtime
 // normalisation flags), 8 step + 4 rollout kernels.
@@ -199,7 +211,7 @@ StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
     if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(inject) : pick_speed_precise<false>(inject);
-    return impact_has_state(c) ? pick_speed<true>(norm, inject, stream) : pick_speed<false>(norm, inject, stream);
+    return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, stream) : pick_speed<false>(speed_powers(c), norm, inject, stream);
   }
   if (c.precise_state)
     return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), inject)
@@ -216,6 +228,10 @@ StepKernel pick_kernel(const mbt_config& c, bool stream) {
 }
 
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
+template <bool STATE, bool POW>
+RolloutKernel pick_speed_rollout(bool norm) {
+  return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>>;
+}
 
 template <int ARR, int DYN, bool BM>
 RolloutKernel rpick_rew(int rew, bool norm) {
@@ -250,8 +266,8 @@ RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   if (c.dynamics_kind == MBT_DYN_SPEED) {
     if (c.precise_state)
       return impact_has_state(c) ? mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<true, true, false, true>> : mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<false, true, false, true>>;
-    if (impact_has_state(c)) return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<true, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<true, false, false>>;
-    return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<false, true, false>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<false, false, false>>;
+    if (impact_has_state(c)) return speed_powers(c) ? pick_speed_rollout<true, true>(norm) : pick_speed_rollout<true, false>(norm);
+    return speed_powers(c) ? pick_speed_rollout<false, true>(norm) : pick_speed_rollout<false, false>(norm);
   }
   if (c.precise_state)
     return c.arrival_kind == MBT_ARR_HAWKES ? rpick_precise<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c)) : rpick_precise<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c));

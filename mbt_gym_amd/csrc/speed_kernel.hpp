@@ -23,9 +23,14 @@
 
 namespace mbt {
 
-template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false>
+template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false, bool POWERS_ = true>
 struct SpeedVariant {
   static constexpr bool HAS_IMPACT_STATE = HAS_IMPACT_STATE_, NORM = NORM_, INJECT = INJECT_;
+  // POWERS: the instantiation can raise to arbitrary powers (a temporary impact with exponent != 1, IMP:55; an inventory
+  // penalty with exponent != 2, RW:59-68; exponential utility).  Every reference configuration has exponent 1 / 2: the host
+  // picks the instantiation WITHOUT them then (mbt_env.hip: pick_speed) - four inlined powf bodies made the kernel 3300
+  // instructions (20 KB of code for a 40-byte-per-lane copy), 740 without.
+  static constexpr bool POWERS = POWERS_;
   // precise_state: [cash, inventory, midprice, impact state] held exactly as the reference's float64 values (the row's
   // float32 + an int32 remainder each, step_kernel.hpp: exact_join) and stepped in double in the reference's operation order
   static constexpr bool PRECISE = PRECISE_;
@@ -66,7 +71,7 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
   if (V::NORM && P.norm_act) v = static_cast<float>((static_cast<double>(a_raw) + 1.0) * P.act_grad[0] + P.act_lo[0]);  // TE:124
   float impact, y_new = s.y;
   switch (P.impact_kind) {
-    case kImpactTempPower: impact = P.temp_coef * (P.impact_exponent_is_one ? v : powf(v, P.impact_exponent)); break;
+    case kImpactTempPower: impact = P.temp_coef * ((!V::POWERS || P.impact_exponent_is_one) ? v : powf(v, P.impact_exponent)); break;
     case kImpactTempPerm:
       impact = P.temp_coef * v + s.y;
       y_new = s.y + P.perm_coef * v * P.impact_dt;
@@ -91,7 +96,8 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
   const float pnl = -volume * impact + q_clip * d_mid + dq_clip * s.mid + dc_clip;
   SpeedResult r;
   r.next = SpeedLane{c_clip, q_clip, mid_new, y_new};
-  r.reward = finish_reward(pnl, s.q, q_clip, c_clip, mid_new, q_init, v, is_terminal, P);
+  r.reward = V::POWERS ? finish_reward(pnl, s.q, q_clip, c_clip, mid_new, q_init, v, is_terminal, P)
+                       : finish_reward_squares(pnl, s.q, q_clip, q_init, v, is_terminal, P);
   r.events = (dq_clip != 0.0f ? 64u : 0u) | (dc_clip != 0.0f ? 128u : 0u);
   return r;
 }
@@ -171,30 +177,51 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
   }
 }
 
-// STAGED (D = 5 only): the tile's 1024 twenty-byte rows are LOADED as 1280 whole-line float4 into LDS and read from there,
-// instead of five dword loads per lane that walk the same cache lines.  Measured with the traffic-only kernels of
-// tools/microbench/mb_floor.hip (48 B/lane, 2^20 lanes): 7.94 us for the dword loads, 7.50 us staged - but at 2^24 lanes,
-// where every byte crosses HBM, 134.9 vs 144.3 us the other way round.  The host picks the instantiation by size
-// (mbt_env.hip: tune_for_size).  STREAM: beyond the Infinity Cache the direct loads carry the non-temporal bit, as in
-// step_kernel.
+// Rows of 20 bytes (D = 5) through LDS, PER WAVE.  Thread t of wave w owns the lanes 64 w + t + {0, 256, 512, 768} of the
+// tile: four spans of 64 consecutive rows = 4 x 1280 B, each a whole number of 64-byte lines.  The wave moves each span as
+// 80 float4 (every thread one, the first 16 a second) between HBM and ITS OWN 5 KB of LDS and picks its rows out of that -
+// whole-line accesses on the memory side (five dword accesses per row walk the same lines: 7.9 vs 7.5 us for the traffic
+// alone at 2^20 lanes, tools/microbench/mb_floor.hip; written through the L2 piecewise they double the step time,
+// step_kernel.hpp: store_through) with NO workgroup barrier: a wave's LDS operations are executed in order, so only the
+// compiler has to be told (the round-2 kernel staged the whole tile through three __syncthreads: with four workgroups on a
+// CU at 2^20 lanes, waves waiting at barriers are what kept it 8 % above its floor).
+constexpr int kSpanFloat4 = 64 * 5 / 4;  // float4 per span of 64 rows
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// STAGED (D = 5 only): rows LOADED through LDS as above instead of five dword loads per lane - better while the launch's
+// working set is cache-resident (2^20 lanes: 7.94 us for the dword loads, 7.50 us staged, traffic alone), worse beyond
+// (2^24 lanes: 134.9 vs 144.3 us the other way round).  The host picks the instantiation by size (mbt_env.hip:
+// tune_for_size).  STREAM: beyond the Infinity Cache the direct loads carry the non-temporal bit, as in step_kernel.
 template <class V, bool STAGED = false, bool STREAM = false>
 __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuffers B, const StepParams P) {
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
   const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
   const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
-  // 20-byte rows (D = 5) would leave the thread as five 4-byte stores per lane, each covering part of a cache line: such
-  // stores cannot be written through the L2 (step_kernel.hpp: store_through).  The workgroup therefore assembles its
-  // 1024 x 5 floats in LDS (20 KB; consecutive threads write at a stride of 5 words: no bank conflicts) and writes them
-  // out as 1280 contiguous, whole-line float4 - through the L2.
-  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];
+  __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];  // 20 KB: 5 KB per wave
+  const uint32_t wave = threadIdx.x >> 6, t = threadIdx.x & 63u;
+  // float4 index of the first row of this wave's span k, in the tile (global: + tile base) and in LDS alike
+  const uint32_t span0 = (64u * wave) * 5u / 4u;  // + k * 320
   SpeedLane s[4];
   float act[4], qi[4], z[4];
-  float4 tile_in[kStaged ? 5 : 1];
   if (kStaged) {
     const float4* in4 = reinterpret_cast<const float4*>(B.state_in) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+    float4* lds4 = reinterpret_cast<float4*>(staged_rows);
+    float4 a[4], b[4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) tile_in[k] = in4[threadIdx.x + k * kBlockThreads];
+    for (int k = 0; k < 4; ++k) {
+      a[k] = in4[span0 + k * 320 + t];
+      b[k] = in4[span0 + k * 320 + 64u + (t & 15u)];  // (every thread loads: the upper 48 repeat addresses the first 16 fetch anyway)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lds4[span0 + k * 320 + t] = a[k];
+      if (t < 16u) lds4[span0 + k * 320 + 64u + t] = b[k];
+    }
   }
 #pragma unroll
   for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
@@ -214,16 +241,13 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
   }
   if (kStaged) {
-    float4* staged4 = reinterpret_cast<float4*>(staged_rows);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) staged4[threadIdx.x + k * kBlockThreads] = tile_in[k];
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       const float* row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
       s[l] = SpeedLane{row[0], row[1], row[3], row[4]};
     }
-    __syncthreads();  // every row has been read before results overwrite the tile
+    wave_lds_fence();  // every row of the wave's spans has been read before its results overwrite them
   }
   float r_sum = 0.0f;
   bool clipped = false;
@@ -247,18 +271,21 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     clipped = real && r.events != 0u;
     n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped));
   }
-  if (V::DIM == 5) {
-    __syncthreads();
-    const float4* staged = reinterpret_cast<const float4*>(staged_rows);
-    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+  if (V::DIM == 5) {  // the wave's four spans leave as whole lines, through the L2
+    wave_lds_fence();
+    const float4* lds4 = reinterpret_cast<const float4*>(staged_rows);
+    float4* out4 = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
+    for (int k = 0; k < 4; ++k) {
+      store_through(out4 + span0 + k * 320 + t, lds4[span0 + k * 320 + t]);
+      if (t < 16u) store_through(out4 + span0 + k * 320 + 64u + t, lds4[span0 + k * 320 + 64u + t]);
+    }
   }
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
-    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
-    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
-    if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
+    const uint32_t wave_id = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    unsafeAtomicAdd(&B.wave_sums[wave_id], static_cast<double>(total));
+    if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave_id & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
 }
 

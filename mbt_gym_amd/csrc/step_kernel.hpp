@@ -351,6 +351,26 @@ __device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_n
   return reward * P.reward_scale;
 }
 
+// The same for the rewards every reference configuration uses - inventory exponent 2, no exponential utility - without a
+// single transcendental: what the speed kernels inline four times per thread when the host knows the exponents
+// (SpeedVariant::POWERS = false).  Rounds exactly like finish_reward's exponent_is_two paths.
+__device__ __forceinline__ float finish_reward_squares(float pnl, float q_old, float q_new, float q_init, float speed, bool is_terminal,
+                                                       const StepParams& P) {
+  float reward = pnl;
+  if (P.reward_kind != kRewPnl) {
+    const float qp = q_new * q_new, qp_old = q_old * q_old, qp_init = q_init * q_init;
+    reward -= P.dt * P.phi * qp;
+    if (P.reward_kind == kRewRunning) {
+      reward -= is_terminal ? P.alpha * qp : 0.0f;
+    } else if (P.reward_kind != kRewCjOe) {
+      reward -= P.alpha * ((qp - qp_old) + P.dt_over_episode * qp_init);
+    } else {
+      reward -= P.dt * P.alpha * (P.exponent * speed * q_old + qp_init * P.episode_length);
+    }
+  }
+  return reward * P.reward_scale;
+}
+
 // ---- precise_state: the reference's float64 state, exactly, in 8 bytes per value ---------------------------------------
 // A double x is kept as  hi = float32(x)  (round to nearest: what the observation shows, np.float32(x)) in the state row
 // and  lo = (x - hi) * 2^(53 - e)  as an int32 in a side buffer, e = the exponent of hi.  x - hi is exact in double, at most
