@@ -24,9 +24,12 @@ CASES = {
     "speed temp+perm impact, CjOe 2^20 (D=5,A=1,48B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5]),
     "speed power impact, PnL 2^20 (D=4,A=1,40B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.0, reward="pnl", initial_inventory=10), 20, [0.5]),
     "default normalised 2^20 (60B incl. obs)": (dict(midprice="bm", arrival="poisson", intensity=(100.0, 100.0), reward="pnl", normalise_action_space=True, normalise_observation_space=True, max_inventory=10000), 20, [-0.5, -0.5]),
-    # precise_state: cash / midprice as float32 pairs (+16 B per env-step), general tier
+    "speed power impact ^1.5, running penalty 2^20 (40B, the instantiation with powf)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.5, reward="running", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5]),
+    # precise_state: the reference's float64 state (float32 row + int32 remainders: +8 B per remainder column and env-step), float64 arithmetic
     "cfg1 AS 2^20, precise_state (60B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="pnl"), 20, [0.7, 0.7], dict(precise_state=True)),
+    "cfg3 Hawkes+OU 2^22, precise_state (92B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7], dict(precise_state=True)),
     "cfg4 limit+market 2^21, precise_state (68B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), dynamics="limit_and_market", reward="pnl", initial_inventory=10), 21, [0.7, 0.7, 0.0, 1.0], dict(precise_state=True)),
+    "speed temp+perm impact, CjOe 2^20, precise_state (80B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5], dict(precise_state=True)),
 }
 
 
@@ -40,10 +43,10 @@ def main():
         env = make_env(cfg, **env_kw)
         env.set_action_host(np.tile(np.array([action], np.float32), (n, 1)))
         env.reset()
-        for _ in range(50):
+        for _ in range(int(os.environ.get("MBT_BENCH_WARMUP", "1500"))):  # clocks up, like bench.py's prewarm
             env.step_device()
         env.synchronize()
-        steps = int(os.environ.get("MBT_BENCH_STEPS", "400"))
+        steps = int(os.environ.get("MBT_BENCH_STEPS", "1000"))
         _native.check(lib.mbt_env_timer_begin(env._handle))
         for _ in range(steps):
             env.step_device()
@@ -51,7 +54,7 @@ def main():
         _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
         us = ms.value * 1e3 / steps
         d, a = env.observation_dim, env.action_dim
-        bytes_step = 4 * (d + a + d + 1) + (4 * d if cfg.normalise_observation_space else 0) + (16 if env_kw.get("precise_state") else 0)
+        bytes_step = 4 * (d + a + d + 1) + (4 * d if cfg.normalise_observation_space else 0) + (8 * (4 if (cfg.dynamics == "speed" or cfg.arrival == "hawkes") else 2) if env_kw.get("precise_state") else 0)
         out[name] = {"us_per_step": round(us, 2), "env_steps_per_s": n / us * 1e6, "algorithmic_GBps": bytes_step * n / us * 1e-3,
                      "frac_of_8TBps": bytes_step * n / us * 1e-3 / 8000}
         env.close()
