@@ -454,7 +454,7 @@ def main():
     # one process per GPU; a launcher that narrows each rank's visible devices leaves fewer ordinals than ranks
     gpu = 0 if args.single_device else local_rank % max(1, visible)
     torch.cuda.set_device(gpu)
-    affinity = pin_to_gpu_numa_node(gpu) if multi else "not pinned (1 rank)"
+    affinity = pin_to_gpu_numa_node(gpu) if (multi and os.environ.get("MBT_BENCH_PIN", "1") != "0") else "not pinned"
     if multi:
         with Watchdog(args.comm_timeout, "torch.distributed rendezvous + first barrier", rank):
             if args.backend == "nccl":

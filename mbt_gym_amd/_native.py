@@ -377,7 +377,6 @@ class OutputPool:
 
     def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30):
         self.shape, self.dtype, self.max_bytes = tuple(shape), np.dtype(dtype), max_bytes
-        self._cursor = 0
         self._pinned_unavailable = False
         self.buffers = [_RefProbe()]
         self._idle_refs = self._refs(0)  # references a buffer has when only this pool looks at it (counted exactly as acquire() counts)
@@ -391,9 +390,7 @@ class OutputPool:
 
     def acquire(self):
         """(array, is_pinned): an array nobody else references, preferably over pinned memory."""
-        for _ in range(len(self.buffers)):
-            index = self._cursor
-            self._cursor = (self._cursor + 1) % len(self.buffers)
+        for index in range(len(self.buffers)):  # the first idle one: the usual loop then alternates between buffers 0 and 1
             if self._refs(index) <= self._idle_refs:
                 return self.buffers[index].array(), True
         nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
@@ -403,7 +400,6 @@ class OutputPool:
             except (NativeError, RuntimeError, OSError):  # no pinned memory to be had (no device, a locked-memory limit):
                 self._pinned_unavailable = True          # pageable arrays work everywhere, only slower
             else:
-                self._cursor = 0
                 return self.buffers[-1].array(), True
         return np.empty(self.shape, dtype=self.dtype), False
 

@@ -222,11 +222,12 @@ def test_two_ranks_at_the_drivers_arguments_finish_the_same_number_of_episodes()
     assert line["n_gpus"] == 2 and line["config"]["prewarm_steps"] == 8192
     assert line["config"]["num_trajectories_total"] == 1 << 21
     assert line["config"]["episodes_finished_in_timed_region"] == 0
-    # no episode ends inside the 20 timed steps: the line reports the running episode (217 steps old), over both shards -
-    # the same number one rank stepping all 2^21 lanes for as long reports
+    # no episode ends inside the 20 timed steps: the line reports the last episode that finished during the warm-up (the
+    # eighth), over both shards - the same number one rank stepping all 2^21 lanes for as long reports
     one = _bench("--gpus", "1", "--lanes", str(1 << 21), "--steps", "20", "--warmup", "5", "--prewarm-steps", "8192")
     assert line["mean_episode_return"] == pytest.approx(one["mean_episode_return"], rel=1e-12)
-    assert 10.0 < line["mean_episode_return"] < 20.0  # about 67 * 0.217
+    assert 60.0 < line["mean_episode_return"] < 75.0  # a whole episode of the AS market at a constant quote of 0.7: about 67
+    assert line["collective"]["episodes_all_reduced_before_the_timed_region"] == 8
 
 
 @pytest.mark.timeout(600)
