@@ -19,6 +19,22 @@ def _to_numpy(tensor) -> np.ndarray:
     return np.asarray(tensor.detach().cpu().numpy() if hasattr(tensor, "detach") else tensor, dtype=np.float32)
 
 
+FP16_OBSERVATION_BOUND = 4.0  # csrc/policy_mlp.hpp: kMlpMaxObservationBound
+
+
+def observations_fit_fp16(env) -> bool:
+    """True when the in-kernel MLP may read `env`'s observations: they are normalised to [-1, 1] (TE:112-118), or every column
+    of the raw Box is bounded by FP16_OBSERVATION_BOUND (the library refuses anything else: mbt_env.hip, prepare_learned_policy).
+    An object that is not one of our environments (no observation Box to inspect) is given the benefit of the doubt - the
+    library checks again when the policy is handed over."""
+    if env is None or not hasattr(env, "original_observation_space"):
+        return True
+    if getattr(env, "normalise_observation_space_", False):
+        return True
+    space = env.original_observation_space
+    return bool(np.all(np.maximum(np.abs(space.low), np.abs(space.high)) <= FP16_OBSERVATION_BOUND))
+
+
 class SbAgent(Agent):
     def __init__(self, model, reduced_training_indices: list = None, num_trajectories: int = None):
         self.model = model
@@ -70,11 +86,15 @@ class SbAgent(Agent):
 
     @property
     def has_device_policy(self) -> bool:
+        """Can the fused rollout evaluate this actor AND read this environment's observations?  The matrix cores take the
+        observation row as fp16 (11 bits, nothing beyond 65504): fine for normalised observations, not for a raw midprice of
+        100 or raw cash - there `generate_trajectory` and the results table keep the host loop (`model.predict` in float32)."""
         try:
             self.actor_layers(observation_dim=max(self.reduced_training_indices) + 1 if self.reduced_training else None)
-            return True
         except ValueError:
             return False
+        env = getattr(self.model, "env", None)
+        return observations_fit_fp16(getattr(env, "env", env))
 
     def device_policy(self, deterministic: bool = True):
         """deterministic=False adds the policy's exploration noise (SB3: std = exp(policy.log_std), state independent) in the

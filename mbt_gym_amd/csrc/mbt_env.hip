@@ -651,6 +651,17 @@ int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPol
   } else {
     const int H = static_cast<int>(policy->table_rows);
     if (H < 1 || H > mbt::kMlpHidden) return fail(MBT_ERR_INVALID, "MLP policies have a hidden width of 1..64 (got %d)", H);
+    // The matrix cores take the observation row as fp16: 11 significant bits, nothing beyond 65504.  Normalised observations
+    // ([-1, 1], TE:112-118) are resolved to 5e-4 or better; a raw midprice of 100 would be quantised to 0.0625 and raw cash
+    // overflows - the actions would silently differ from the network's.  Refused instead (a linear policy is float32 and
+    // takes any observation; a host loop with the network in float32 takes any network).
+    if (!c.normalise_observation)
+      for (int j = 0; j < D; ++j) {
+        const float bound = std::fmax(std::fabs(c.obs_lo[j]), std::fabs(c.obs_hi[j]));
+        if (!(bound <= mbt::kMlpMaxObservationBound))
+          return fail(MBT_ERR_INVALID, "MLP policies read the observation as fp16: column %d is bounded by %g (> %g) - use normalise_observation_space=True "
+                      "(or evaluate the network on the host)", j, bound, mbt::kMlpMaxObservationBound);
+      }
     if (D + 1 > mbt::kMlpInPad) return fail(MBT_ERR_INVALID, "MLP policies take observations of at most 15 columns");
     const size_t floats = size_t(H) * D + H + size_t(H) * H + H + size_t(A) * H + A;
     if (policy->table_cols != floats) return fail(MBT_ERR_INVALID, "an MLP policy of width %d holds %zu floats for D = %d, A = %d (got %u)", H, floats, D, A, policy->table_cols);
@@ -1484,6 +1495,9 @@ int mbt_env_synchronize(mbt_env* e) {
 int mbt_env_set_step_size(mbt_env* e, double step_size) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (!(step_size > 0.0)) return fail(MBT_ERR_INVALID, "step_size must be positive");
+  if (e->cfg.arrival_kind == MBT_ARR_HAWKES && !e->cfg.allow_stiff_hawkes && !(e->cfg.hawkes_speed * step_size < 1.0))  // the same domain mbt_env_create enforces
+    return fail(MBT_ERR_INVALID, "Hawkes mean_reversion_speed * step_size = %g >= 1 with the new step size: the intensity recursion (ARR:110-119) "
+                "oscillates (>= 2: diverges); set allow_stiff_hawkes to run it anyway", e->cfg.hawkes_speed * step_size);
   // TE:158-167: the environment's clock and every process continue with the new value; like the reference, nothing else
   // (n_steps, terminal_time, max_cash, Box bounds) is re-derived.  The kernel parameters are host-side data.
   e->dt = e->mid_dt = e->arr_dt = e->imp_dt = step_size;

@@ -33,6 +33,9 @@ typedef float acc4_t __attribute__((ext_vector_type(4)));
 constexpr int kMlpHidden = 64;              // hidden width (narrower networks are zero-padded by the host)
 constexpr int kMlpTiles = kMlpHidden / 16;  // 16-feature tiles per hidden layer
 constexpr int kMlpInPad = 16;               // observation features + the constant one, padded to one K step
+// the observation row is an fp16 operand: a column bounded by this is resolved to 2e-3 or better (normalised ones, in [-1, 1],
+// to 5e-4); anything wider is refused by the host (mbt_env.hip: prepare_learned_policy)
+constexpr float kMlpMaxObservationBound = 4.0f;
 constexpr int kMlpRowsPerWave = 128;        // 64 threads x 2 lanes
 enum : int { kActTanh = 0, kActRelu = 1 };
 

@@ -79,6 +79,11 @@ class MultiDeviceTradingEnvironment:
         q0 = self.initial_inventory
         if isinstance(q0, tuple) and len(q0) == 2:
             return self.rng.integers(*q0, size=self._num_trajectories).astype(np.float32)
+        if callable(q0):  # evaluated ONCE for every lane, like the reference (TE:275-279) - not once per shard
+            value = q0()
+            if self.shards[0].model_dynamics.round_initial_inventory:
+                value = int(np.round(value))
+            return np.full((self._num_trajectories,), value, dtype=np.float32)
         return None
 
     def _map(self, fn, *per_shard):

@@ -766,11 +766,19 @@ class TradingEnvironment(_EnvBase):
         finally:
             self.normalise_observation_space_, self._philox_key, self._num_trajectories, self.rng = saved
         handle = C.c_void_p()
-        _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        code = self._user_code()  # a user-defined reward / midprice travels with the calibration environment (hiprtc, cached)
+        if code is None:
+            _native.check(lib.mbt_env_create(C.byref(cfg), C.byref(handle)))
+        else:
+            _native.check(lib.mbt_env_create_jit(C.byref(cfg), C.byref(code), C.byref(handle)))
+        fill_exponent = getattr(self.model_dynamics.fill_probability_model, "fill_exponent", None)
+        if fill_exponent is None:
+            lib.mbt_env_destroy(handle)
+            raise UnsupportedOnDevice("normalise_rewards calibrates with the fixed action 1 / fill_exponent (TE:330): the fill model has no fill_exponent")
         try:
             _native.check(lib.mbt_env_reset(handle, 0.0, _native.fptr(q0)))
             policy = _native.MbtPolicy(kind=_native.POLICY_FIXED)  # the constant action 1/kappa on both sides (TE:330)
-            policy.params[0] = policy.params[1] = 1.0 / self.model_dynamics.fill_probability_model.fill_exponent
+            policy.params[0] = policy.params[1] = 1.0 / fill_exponent
             steps, done = C.c_uint32(0), C.c_int32(0)
             _native.check(lib.mbt_env_rollout_device(handle, C.byref(policy), self.n_steps, None, None, None, C.byref(steps), C.byref(done)))
             assert done.value and steps.value == self.n_steps

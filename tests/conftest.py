@@ -25,12 +25,13 @@ def pytest_sessionstart(session):
 
 
 def _gfx950_visible() -> bool:
-    try:
-        from mbt_gym_amd import _native
+    """Is there a gfx950 device to run the `gpu` tests on?  "No device" is a reason to SKIP them; a library that does not
+    load (missing, stale, ABI mismatch, a symbol the header declares and the .so lacks) is not - that raises here and fails
+    the session, on a GPU box and on the build container alike."""
+    from mbt_gym_amd import _native
 
-        return _native.device_count() > 0 and _native.device_name(0).startswith("gfx950")
-    except Exception:  # noqa: BLE001 - no library, no runtime, no device
-        return False
+    _native.load_library()
+    return _native.device_count() > 0 and _native.device_name(0).startswith("gfx950")
 
 
 def pytest_collection_modifyitems(config, items):

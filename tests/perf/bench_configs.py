@@ -43,13 +43,13 @@ def main():
         env = make_env(cfg, **env_kw)
         env.set_action_host(np.tile(np.array([action], np.float32), (n, 1)))
         env.reset()
-        for _ in range(int(os.environ.get("MBT_BENCH_WARMUP", "1500"))):  # clocks up, like bench.py's prewarm
-            env.step_device()
+        # k launches per call into the library (mbt_env_step_many_device), like bench.py: a Python loop of step_device() calls
+        # costs 4-6 us of interpreter + ctypes per launch - as much as the lighter kernels take - and would be what is measured
+        env.step_many_device(int(os.environ.get("MBT_BENCH_WARMUP", "1500")), auto_reset=True)  # clocks up, like bench.py's prewarm
         env.synchronize()
         steps = int(os.environ.get("MBT_BENCH_STEPS", "1000"))
         _native.check(lib.mbt_env_timer_begin(env._handle))
-        for _ in range(steps):
-            env.step_device()
+        env.step_many_device(steps, auto_reset=True)
         ms = C.c_float(0)
         _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
         us = ms.value * 1e3 / steps

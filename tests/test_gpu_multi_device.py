@@ -92,3 +92,24 @@ def test_fused_rollout_and_the_sb3_adapter_over_shards():
         if d_s[0]:
             np.testing.assert_array_equal(i_m[17]["terminal_observation"], i_s[17]["terminal_observation"])
     vec_s.close(), vec_m.close()
+
+
+def test_a_random_callable_initial_inventory_is_drawn_once_for_all_shards():
+    """TE:275-279: a callable `initial_inventory` is evaluated ONCE per reset and every lane gets that value.  Sharded, each
+    shard used to evaluate it for itself - a random callable then gave lanes that depended on the number of devices."""
+    draws = np.random.default_rng(8)
+    calls = []
+
+    def random_inventory():
+        calls.append(1)
+        return float(draws.integers(-3, 4))
+
+    cfg = _cfg(3072, initial_inventory=0, reward="running")
+    env = _sharded(cfg, [0, 0, 0])
+    env.initial_inventory = random_inventory
+    for _ in range(6):
+        before = len(calls)
+        obs = env.reset()
+        assert len(calls) == before + 1
+        assert np.unique(obs[:, 1]).size == 1  # one value, in every shard
+    env.close()

@@ -55,7 +55,7 @@ def _action_space(env):
 @pytest.mark.parametrize("activation", ["tanh", "relu"])
 @pytest.mark.parametrize("kw,hidden", [(dict(), 64), (dict(dynamics="limit_and_market", market_half_spread=0.4), 64),
                                        (dict(arrival="hawkes", intensity=(10.0, 10.0), hawkes_speed=20.0, midprice="ou", ou_level=100.0, ou_speed=0.02), 32),
-                                       (dict(normalise_action_space=False, normalise_observation_space=False), 48)])
+                                       (dict(normalise_action_space=False), 48)])
 def test_mlp_policy_kernel_matches_the_numpy_restatement(kw, hidden, activation):
     n = 3000  # not a multiple of the 512-lane tile: pad rows are evaluated and never reported
     cfg = _cfg(n, **kw)
@@ -183,6 +183,36 @@ def test_learned_policy_refusals():
     touch.close()
 
 
+def test_raw_observations_are_refused_by_the_mlp_kernel_and_sent_to_the_host_loop_by_the_agents():
+    """The matrix cores read the observation row as fp16: a raw midprice of 100 would be quantised to 0.0625, raw cash
+    overflows at 65504.  The library refuses an MLP policy on an environment whose observations are not normalised (nor
+    bounded by 4); the agents that would have routed to it (`has_device_policy`) keep the reference's host loop instead,
+    with the network in float32.  A linear policy is float32 arithmetic and takes raw observations."""
+    from mbt_gym_amd._native import NativeError
+    from mbt_gym_amd.agents.SbAgent import SbAgent
+    from mbt_gym_amd.gym.helpers.generate_trajectory import generate_trajectory
+    from tests.test_host_logic import _fake_sb3_model
+
+    n = 1024
+    cfg = _cfg(n, n_steps=12, normalise_action_space=False, normalise_observation_space=False)
+    env = make_env(cfg)
+    env.reset()
+    rng = np.random.default_rng(4)
+    with pytest.raises(NativeError, match="fp16"):
+        env.policy_device(_native.mlp_policy(_random_mlp(rng, 4, 64, 2, scale=0.05)))
+    with pytest.raises(NativeError, match="fp16"):
+        env.rollout(_native.mlp_policy(_random_mlp(rng, 4, 64, 2, scale=0.05)))
+    env.policy_device(_native.linear_policy(rng.normal(0, 0.01, size=(2, 4)).astype(np.float32), np.array([0.5, 0.5], np.float32)))
+    env.synchronize()
+    agent = SbAgent(_fake_sb3_model(4, 64, 2, "Tanh", seed=3, env=env))
+    assert not agent.has_device_policy
+    obs_t, act_t, rew_t = generate_trajectory(env, agent)  # the reference's loop: model.predict on the host
+    for k in (0, 5, 11):
+        np.testing.assert_allclose(act_t[:, :, k], agent.get_action(np.ascontiguousarray(obs_t[:, :, k])), rtol=0, atol=1e-6)
+    assert SbAgent(_fake_sb3_model(4, 64, 2, "Tanh", seed=3, env=make_env(_cfg(n)))).has_device_policy
+    env.close()
+
+
 def test_generate_trajectory_with_an_sb3_shaped_agent_runs_fused_and_agrees_with_the_host_loop():
     """The reference's caller, unchanged: generate_trajectory(env, SbAgent(model)) (GT:8-38, agents/SbAgent.py).  With an
     SB3-shaped MlpPolicy actor the episode runs in one launch with the policy in-kernel; the actions it records are what
@@ -298,6 +328,7 @@ def test_learned_policy_rollout_on_environments_without_a_fused_kernel(kind):
     else:
         cfg, _ = load_case("user_fill_and_reward")
         cfg.num_trajectories, kw = n, {}
+        cfg.normalise_observation_space = cfg.normalise_action_space = True  # (the matrix cores read the observation as fp16)
     recorded, loop = make_env(cfg, **kw), make_env(cfg, **kw)
     rng = np.random.default_rng(31)
     d, a = recorded.observation_dim, recorded.action_dim

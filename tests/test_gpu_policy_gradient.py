@@ -67,6 +67,33 @@ def test_reference_loop_for_actors_the_kernels_do_not_evaluate_and_the_two_paths
     env.close()
 
 
+def test_sampled_actions_are_scored_around_the_mean_the_kernel_used():
+    """The fused rollout samples a ~ N(kernel mean, std) with the network on fp16 operands; REINFORCE scores those actions
+    with log N(a | mean, std).  `kernel_mean` restates the kernel's evaluation in torch (differentiable, straight-through for
+    the weight rounding): it reproduces the kernel's deterministic actions ten times closer than the float32 network does,
+    so the score has no systematic (kernel mean - float32 mean) / std^2 term - at std = 0.01 that term would be O(1)."""
+    env = _env(2048, horizon=10)
+    net = _actor().to("cuda")
+    agent = PolicyGradientAgent(net, action_std=0.01, env=env)
+    obs = env.reset()
+    for _ in range(4):
+        obs, _, _, _ = env.step(np.zeros((2048, 2), np.float32))
+    env.policy_device(agent.device_policy(deterministic=True))
+    env.synchronize()
+    kernel = torch.as_tensor(env.action_device, device="cuda")
+    o = torch.as_tensor(obs, device="cuda")
+    restated, plain = agent.kernel_mean(o), net(o)
+    err_restated, err_plain = float((restated - kernel).abs().max()), float((plain - kernel).abs().max())
+    assert err_restated <= 2e-4 and err_restated < 0.25 * err_plain, (err_restated, err_plain)
+    restated.sum().backward()  # gradients reach the float32 parameters through the rounding
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in net.parameters())
+    # and the score of sampled actions is centred: (a - kernel mean) / std has mean ~ 0 (it had a bias of ~ err_plain / std)
+    r, lp = agent._sample_on_device()
+    z_mean = float(((-2 * 0.01 ** 2 * (lp + np.log(0.01 * np.sqrt(2 * np.pi)))).clamp(min=0).sqrt()).mean())  # E|z| of a standard normal: 0.798
+    assert z_mean == pytest.approx(np.sqrt(2 / np.pi), abs=0.02)
+    env.close()
+
+
 def test_rewards_to_go():
     r = torch.tensor([[[1.0, 2.0, 3.0]], [[0.5, 0.0, -1.0]]])
     np.testing.assert_allclose(PolicyGradientAgent._calculate_future_rewards(r).numpy(), [[[6.0, 5.0, 3.0]], [[-0.5, -1.0, -1.0]]])

@@ -293,3 +293,9 @@ def test_row_width_disagreements_and_stiff_hawkes_are_refused():
     with pytest.raises(NativeError, match="Hawkes"):
         make_env(stiff)
     make_env(stiff, allow_stiff_hawkes=True).close()
+    # ... and the step_size setter (TE:158-167) re-checks the same domain: 20 * 0.025 is fine, 20 * 0.06 is not
+    soft = make_env(_cfg(n, arrival="hawkes", intensity=(10.0, 10.0), hawkes_speed=20.0))
+    soft.step_size = 0.03
+    with pytest.raises(NativeError, match="Hawkes"):
+        soft.step_size = 0.06
+    soft.close()

@@ -121,3 +121,27 @@ def test_user_plugin_refusals_and_cache():
     first.close(), second.close()
     with pytest.raises(NativeError, match="speed|order-book"):
         make_env(_cfg(64, dynamics="speed", arrival="none", impact="temp_perm", fill="exponential"))  # user plugins run on the order-book kernels
+
+
+@pytest.mark.gpu
+def test_normalise_rewards_calibrates_an_environment_with_a_user_defined_reward():
+    """TE:329-343 rolls a copy of the environment out under the fixed action 1 / kappa; with a user-defined reward (or
+    midprice) that copy is a run-time compiled environment too.  The scale it finds is 1 / (mean episode return) of exactly
+    that rollout, and a fill model without a `fill_exponent` is refused with a message instead of an AttributeError."""
+    from mbt_gym_amd.gym.TradingEnvironment import UnsupportedOnDevice
+
+    cfg = _cfg(4096, fill="exponential", fill_exponent=1.5)
+    plain = make_env(cfg)
+    scaled = make_env(cfg, normalise_rewards=True)
+    assert np.isfinite(scaled.reward_scaling) and scaled.reward_scaling > 0
+    action = np.tile(np.array([[1 / 1.5, 1 / 1.5]], np.float32), (4096, 1))
+    plain.reset(), scaled.reset()
+    total_plain = total_scaled = 0.0
+    for _ in range(cfg.n_steps):
+        total_plain += plain.step(action)[1].astype(np.float64).mean()
+        total_scaled += scaled.step(action)[1].astype(np.float64).mean()
+    assert total_scaled == pytest.approx(total_plain * scaled.reward_scaling, rel=1e-4)
+    assert total_scaled == pytest.approx(1.0, abs=0.1)  # the calibration's own rollout (100 000 lanes, another key) has mean return 1 / scale
+    plain.close(), scaled.close()
+    with pytest.raises((UnsupportedOnDevice, AssertionError)):
+        make_env(_cfg(64), normalise_rewards=True)  # the power-law fill model has no fill_exponent (and is not the exponential model TE:90-93 asserts)
