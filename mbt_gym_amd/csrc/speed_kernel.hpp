@@ -204,32 +204,29 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
   const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
   __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];  // 20 KB: 5 KB per wave
   const uint32_t wave = threadIdx.x >> 6, t = threadIdx.x & 63u;
-  // float4 index of the first row of this wave's span k, in the tile (global: + tile base) and in LDS alike
-  const uint32_t span0 = (64u * wave) * 5u / 4u;  // + k * 320
-  // Schedule, as in step_kernel: every load is issued first, the generator (which depends on nothing in memory) runs while
-  // they are in flight, and an empty asm ties the loaded registers to the finished draws so that the compiler cannot pull a
-  // consumer of the loads - and its s_waitcnt - above the generator (it did: the kernel waited for all eight loads before
-  // the first Philox round, 6.98 instead of 6.5 us at 2^20 lanes).
+  // float4 index of the first row of this wave's span l, in the tile (global: + tile base) and in LDS alike: span0 + 320 l
+  const uint32_t span0 = (64u * wave) * 5u / 4u;
+  // Schedule: every load of the quad is issued first, lane by lane; the generator (which depends on nothing in memory) runs
+  // while they are in flight; then the four lanes are CONSUMED IN LOAD ORDER, each behind an empty asm that ties its own
+  // loaded registers to its draw - the compiler can neither pull a consumer (and its s_waitcnt) above the generator nor
+  // wait for all four lanes at once: lane l is computed and stored while the data of lanes l+1.. are still arriving.  (One
+  // tie over all lanes made every wave wait for its last load before its first store: 7.3 instead of 6.8 us at 2^20 lanes.)
   SpeedLane s[4];
   float act[4], qi[4], z[4];
-  ld4_t row4[4];               // D = 4: the four rows as loaded (whole vectors are tied below: a dead component - the time column - would
-                               // otherwise be re-used as a temporary by the generator, behind a wait for the load that wrote it)
-  ld4_t span_a[4], span_b[4];  // kStaged: the wave's four spans of 64 rows, 80 float4 each (clang vectors: tying a MEMBER of HIP's float4 struct routes it through scratch)
-  if (kStaged) {
-    const ld4_t* in4 = reinterpret_cast<const ld4_t*>(B.state_in) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      span_a[k] = in4[span0 + k * 320 + t];
-      span_b[k] = in4[span0 + k * 320 + 64u + (t & 15u)];  // (every thread loads: the upper 48 repeat addresses the first 16 fetch anyway)
-    }
-  }
+  ld4_t row4[4];               // D = 4: the rows as loaded (whole vectors are tied: a dead component - the time column - would otherwise
+                               // be re-used as a temporary by the generator, behind a wait for the load that wrote it)
+  ld4_t span_a[4], span_b[4];  // kStaged: the wave's four spans of 64 rows, 80 float4 each
 #pragma unroll
   for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
     const uint32_t lane = lane0 + l * kBlockThreads;
-    if (V::DIM == 4) {
+    if (kStaged) {
+      const ld4_t* in4 = reinterpret_cast<const ld4_t*>(B.state_in) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+      span_a[l] = in4[span0 + l * 320 + t];
+      span_b[l] = in4[span0 + l * 320 + 64u + (t & 15u)];  // (every thread loads: the upper 48 repeat addresses the first 16 fetch anyway)
+    } else if (V::DIM == 4) {
       const ld4_t* src = reinterpret_cast<const ld4_t*>(B.state_in) + lane;
       row4[l] = STREAM ? __builtin_nontemporal_load(src) : *src;
-    } else if (!kStaged) {
+    } else {
       s[l] = load_speed_row<V, STREAM>(B.state_in, lane);
     }
     act[l] = STREAM ? __builtin_nontemporal_load(B.action + lane) : B.action[lane];
@@ -240,53 +237,40 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
 #pragma unroll
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
-    if (kStaged) {
-      asm volatile("; loads are first consumed below this line"
-                   : "+v"(span_a[0]), "+v"(span_a[1]), "+v"(span_a[2]), "+v"(span_a[3]), "+v"(span_b[0]), "+v"(span_b[1]), "+v"(span_b[2]),
-                     "+v"(span_b[3]), "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]), "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-    } else if (V::DIM == 4) {
-      asm volatile("; loads are first consumed below this line"
-                   : "+v"(row4[0]), "+v"(row4[1]), "+v"(row4[2]), "+v"(row4[3]), "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]), "+v"(z[0]), "+v"(z[1]),
-                     "+v"(z[2]), "+v"(z[3]));
-    } else {
-      asm volatile("; loads are first consumed below this line"
-                   : "+v"(s[0].cash), "+v"(s[1].cash), "+v"(s[2].cash), "+v"(s[3].cash), "+v"(s[0].mid), "+v"(s[1].mid), "+v"(s[2].mid), "+v"(s[3].mid),
-                     "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]), "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-    }
   }
-  if (V::DIM == 4) {
-#pragma unroll
-    for (int l = 0; l < 4; ++l) s[l] = SpeedLane{row4[l].x, row4[l].y, row4[l].w, 0.0f};
-  }
-  if (kStaged) {
-    ld4_t* lds4 = reinterpret_cast<ld4_t*>(staged_rows);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      lds4[span0 + k * 320 + t] = span_a[k];
-      if (t < 16u) lds4[span0 + k * 320 + 64u + t] = span_b[k];
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const float* row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
-      s[l] = SpeedLane{row[0], row[1], row[3], row[4]};
-    }
-    wave_lds_fence();  // every row of the wave's spans has been read before its results overwrite them
-  }
-  if (B.q_init != nullptr) {  // (per-lane initial inventories: after the tie - a pointer test between the loads would put a wait there)
+  if (B.q_init != nullptr) {  // (per-lane initial inventories: after the generator - a pointer test between the loads would put a wait there)
 #pragma unroll
     for (int l = 0; l < 4; ++l) qi[l] = B.q_init[lane0 + l * kBlockThreads];
   }
   float r_sum = 0.0f;
-  bool clipped = false;
   uint32_t n_clipped = 0;
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
     const uint32_t lane = lane0 + l * kBlockThreads;
+    float* lds_row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
+    if (!V::INJECT) {
+      if (kStaged) asm volatile("; lane is first consumed below this line" : "+v"(span_a[l]), "+v"(span_b[l]), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
+      else if (V::DIM == 4) asm volatile("; lane is first consumed below this line" : "+v"(row4[l]), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
+      else asm volatile("; lane is first consumed below this line" : "+v"(s[l].cash), "+v"(s[l].q), "+v"(s[l].mid), "+v"(s[l].y), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
+    }
+    if (kStaged) {  // span l: into the wave's LDS, this thread's row out of it
+      ld4_t* lds4 = reinterpret_cast<ld4_t*>(staged_rows);
+      lds4[span0 + l * 320 + t] = span_a[l];
+      if (t < 16u) lds4[span0 + l * 320 + 64u + t] = span_b[l];
+      wave_lds_fence();
+      s[l] = SpeedLane{lds_row[0], lds_row[1], lds_row[3], lds_row[4]};
+      wave_lds_fence();  // every row of the span has been read before results overwrite it
+    } else if (V::DIM == 4) {
+      s[l] = SpeedLane{row4[l].x, row4[l].y, row4[l].w, 0.0f};
+    }
     const SpeedResult r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
-    if (V::DIM == 5) {
-      float* row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
-      row[0] = r.next.cash; row[1] = r.next.q; row[2] = P.t_next; row[3] = r.next.mid; row[4] = r.next.y;
+    if (V::DIM == 5) {  // the wave's span l leaves as whole lines, through the L2
+      lds_row[0] = r.next.cash; lds_row[1] = r.next.q; lds_row[2] = P.t_next; lds_row[3] = r.next.mid; lds_row[4] = r.next.y;
+      wave_lds_fence();
+      const float4* lds4 = reinterpret_cast<const float4*>(staged_rows);
+      float4* out4 = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
+      store_through(out4 + span0 + l * 320 + t, lds4[span0 + l * 320 + t]);
+      if (t < 16u) store_through(out4 + span0 + l * 320 + 64u + t, lds4[span0 + l * 320 + 64u + t]);
     } else {
       store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
     }
@@ -296,18 +280,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
     const bool real = lane < P.n;
     r_sum += real ? r.reward : 0.0f;
-    clipped = real && r.events != 0u;
-    n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(clipped));
-  }
-  if (V::DIM == 5) {  // the wave's four spans leave as whole lines, through the L2
-    wave_lds_fence();
-    const float4* lds4 = reinterpret_cast<const float4*>(staged_rows);
-    float4* out4 = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      store_through(out4 + span0 + k * 320 + t, lds4[span0 + k * 320 + t]);
-      if (t < 16u) store_through(out4 + span0 + k * 320 + 64u + t, lds4[span0 + k * 320 + 64u + t]);
-    }
+    n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && r.events != 0u));
   }
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
