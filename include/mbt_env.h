@@ -238,6 +238,26 @@ typedef struct mbt_user_code {
   const char* midprice_increment;  /* NULL unless cfg.midprice_kind == MBT_MID_USER */
   const char* midprice_param_names;
   double midprice_params[8];
+  /* ---- ABI 5: user processes that OWN state (SP:8-53: a subclass carries its own (N, d) current_state) ----------------
+   * state_columns = 1 or 2 adds that many columns x0 (, x1) to the state row right after the midprice, in the reference's
+   * registry order (a second midprice factor first, then the arrival model's columns, TE:303-318); Poisson-type or user
+   * arrivals and no exogenous-depth fill model (the columns take the place of the built-in Hawkes intensities).  Each
+   * column is advanced by its own expression  state_update[j]  for the NEXT value, of type double, in
+   *     S, t, dt (the step size of the process that owns the column, state_owner), x0, x1 (the columns BEFORE the step), z (the lane's midprice normal), z1, z2,
+   *     arr_bid, arr_ask (1.0 where an order arrived), fills_bid, fills_ask (1.0 where the agent's quote was executed)
+   * and the named state parameters - evaluated, like the reference's update() calls, from the state before the step.  The
+   * midprice_increment and arrival_probability expressions may read x0, x1 (and z1, z2) too: a two-factor midprice
+   * (dS = alpha dt + sigma dW, alpha its own OU process), a Hawkes variant with cross-excitation, a stochastic intensity.
+   * extra_normals = 1 draws z1, z2 - two more standard normals per lane and step, a third Philox block per pair of lanes
+   * (mbt_rng_fill_user_host exports them; injected-noise mode takes them through mbt_env_set_user_noise_host) - otherwise
+   * they read 0.  state_initial: the columns after reset (SP:30-31); their observation bounds travel in cfg.obs_lo / obs_hi. */
+  int32_t state_columns;
+  int32_t extra_normals;
+  const char* state_update[2];
+  const char* state_param_names;
+  double state_params[8];
+  double state_initial[2];
+  int32_t state_owner[2];  /* 0 = the midprice model's column (dt = its step size), 1 = the arrival model's */
 } mbt_user_code;
 int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out);
 const char* mbt_jit_log(void);    /* thread local; "" when the last compilation had nothing to say */
@@ -350,6 +370,9 @@ uint64_t mbt_env_padded_lanes(mbt_env* env); /* N rounded up to whole 512-lane t
 /* u_arr, u_fill: (N, 2) float32 in [0, 1) (ignored, may be NULL, for speed dynamics); z: (N) float32.
  * Consumed by the next step. */
 int mbt_env_set_noise_host(mbt_env* env, const float* u_arr, const float* u_fill, const float* z);
+/* z_user: (N, 2) float32, the two extra normals of user processes (mbt_user_code.extra_normals); consumed by the next step,
+ * together with the arrays of mbt_env_set_noise_host. */
+int mbt_env_set_user_noise_host(mbt_env* env, const float* z_user);
 
 /* ---- device buffers (zero-copy consumers) ------------------------------------------------------ */
 float* mbt_env_action_ptr(mbt_env* env);   /* (N, A) staging buffer a device policy may write */
@@ -432,11 +455,28 @@ int mbt_reward_calculate_host(int device, int reward_kind, double phi, double al
                               const double* q_init, const double* episode_length, const double* action /* (n), CJ_OE */,
                               double risk_aversion /* EXP_UTILITY */, double* out);
 
+/* ---- StochasticProcessModel.update / get_arrivals / get_fills for host callers (SP:33-35, ARR:27-29, FILL:28-34) ----
+ * The plugin objects of the reference can be driven on their own, outside an environment (a midprice path, an arrival
+ * stream).  There is no CPU implementation of their arithmetic here either: one call evaluates one such method on
+ * caller-supplied float64 arrays on the device, in double and in the reference's order of operations, with the draws the
+ * CALLER supplies (the Python descriptors draw them from the same numpy Generator the reference's classes own, so a seeded
+ * process object walks the reference's path).  cfg: only the fields of the process in question are read (kinds, parameters,
+ * *_step_size).  Arrays are row-major; booleans come back as 0.0 / 1.0.
+ *   MBT_PROCESS_MIDPRICE_UPDATE  a = S (n), b = z (n), c / d = the agent's bid / ask fills (n) or NULL   -> out = S' (n)
+ *   MBT_PROCESS_HAWKES_UPDATE    a = intensities (n, 2), b = arrivals (n, 2)                              -> out (n, 2)
+ *   MBT_PROCESS_ARRIVALS         a = uniforms (n, 2), b = intensities (n, 2) for Hawkes, else NULL       -> out (n, 2)
+ *   MBT_PROCESS_FILLS            a = uniforms (n, 2), b = depths (n, 2)                                   -> out (n, 2) */
+enum { MBT_PROCESS_MIDPRICE_UPDATE = 0, MBT_PROCESS_HAWKES_UPDATE = 1, MBT_PROCESS_ARRIVALS = 2, MBT_PROCESS_FILLS = 3 };
+int mbt_process_evaluate_host(int device, int op, const mbt_config* cfg, uint64_t n, const double* a, const double* b, const double* c,
+                              const double* d, double* out);
+
 /* ---- the generator itself (so tests can pin it) ------------------------------------------------ */
 /* Writes the noise lane ids [trajectory_offset, trajectory_offset + n) would draw at philox step `step`
  * under `seed` into host arrays (any may be NULL): u_arr (n,2), u_fill (n,2), z (n). */
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n,
                       float* u_arr, float* u_fill, float* z);
+/* The extra normals of user processes (mbt_user_code.extra_normals): z_user (n, 2); offset a multiple of 512. */
+int mbt_rng_fill_user_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z_user);
 /* Same for the speed-dynamics stream (one normal per lane, drawn per quad of lanes 256 apart in a 1024-lane tile): z (n); offset multiple of 1024. */
 int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z);
 /* Raw Philox4x32-10 block function on the device: out[4] = philox(ctr[4], key[2]) (known-answer tests). */

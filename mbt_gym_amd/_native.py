@@ -60,12 +60,29 @@ class MbtUserCode(C.Structure):
     _fields_ = [("fill_probability", C.c_char_p), ("fill_param_names", C.c_char_p), ("fill_params", C.c_double * 8),
                 ("reward", C.c_char_p), ("reward_param_names", C.c_char_p), ("reward_params", C.c_double * 8),
                 ("arrival_probability", C.c_char_p), ("arrival_param_names", C.c_char_p), ("arrival_params", C.c_double * 8),
-                ("midprice_increment", C.c_char_p), ("midprice_param_names", C.c_char_p), ("midprice_params", C.c_double * 8)]
+                ("midprice_increment", C.c_char_p), ("midprice_param_names", C.c_char_p), ("midprice_params", C.c_double * 8),
+                ("state_columns", C.c_int32), ("extra_normals", C.c_int32), ("state_update", C.c_char_p * 2),
+                ("state_param_names", C.c_char_p), ("state_params", C.c_double * 8), ("state_initial", C.c_double * 2), ("state_owner", C.c_int32 * 2)]
 
 
-def user_code(fill=None, reward=None, arrival=None, midprice=None) -> MbtUserCode:
-    """(expression, {name: value}) pairs -> struct mbt_user_code."""
+def user_code(fill=None, reward=None, arrival=None, midprice=None, state=None) -> MbtUserCode:
+    """(expression, {name: value}) pairs -> struct mbt_user_code.  `state`: (list of 1-2 update expressions, {name: value},
+    initial values, uses_extra_normals, owners (0 midprice / 1 arrival model per column)) for the state columns user processes own."""
     code = MbtUserCode()
+    if state is not None:
+        updates, params, initial, extra_normals, owners = state
+        if not 1 <= len(updates) <= 2 or len(initial) != len(updates):
+            raise ValueError("user processes own one or two state columns, each with an update expression and an initial value")
+        if len(params) > 8:
+            raise ValueError("a device expression takes at most 8 parameters")
+        code.state_columns, code.extra_normals = len(updates), int(bool(extra_normals))
+        for j, (expression, x0) in enumerate(zip(updates, initial)):
+            code.state_update[j] = expression.encode()
+            code.state_initial[j] = float(x0)
+            code.state_owner[j] = int(owners[j])
+        code.state_param_names = ",".join(params).encode()
+        for j, value in enumerate(params.values()):
+            code.state_params[j] = float(value)
     for prefix, part in (("fill", fill), ("reward", reward), ("arrival", arrival), ("midprice", midprice)):
         if part is None:
             continue
@@ -189,6 +206,7 @@ SIGNATURES = {
     "mbt_env_policy_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy)]),
     "mbt_env_padded_lanes": (C.c_uint64, [_ENV]),
     "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),
+    "mbt_env_set_user_noise_host": (C.c_int, [_ENV, _F]),
     "mbt_env_action_ptr": (C.c_void_p, [_ENV]),
     "mbt_env_obs_ptr": (C.c_void_p, [_ENV]),
     "mbt_env_reward_ptr": (C.c_void_p, [_ENV]),
@@ -219,8 +237,10 @@ SIGNATURES = {
     "mbt_reward_calculate_host": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),
+    "mbt_process_evaluate_host": (C.c_int, [C.c_int, C.c_int, C.POINTER(MbtConfig), C.c_uint64] + [C.POINTER(C.c_double)] * 5),
     "mbt_rng_fill_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F, _F, _F]),
     "mbt_rng_fill_quad_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F]),
+    "mbt_rng_fill_user_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _F]),
     "mbt_philox4x32_10_host": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_timer_begin": (C.c_int, [_ENV]),
     "mbt_env_timer_end": (C.c_int, [_ENV, C.POINTER(C.c_float)]),
@@ -438,6 +458,29 @@ def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_t
     return out
 
 
+PROCESS_MIDPRICE_UPDATE, PROCESS_HAWKES_UPDATE, PROCESS_ARRIVALS, PROCESS_FILLS = 0, 1, 2, 3
+
+
+def process_evaluate(op, params: dict, a, b=None, c=None, d=None, device=0):
+    """One update() / get_arrivals() / get_fills() of a plugin object on host arrays, evaluated on the device in double
+    (mbt_process_evaluate_host).  `params`: the mbt_config fields of the process (its `device_params()`)."""
+    cfg = MbtConfig()
+    cfg.abi_version = ABI_VERSION
+    for key, value in params.items():
+        if value is None:
+            continue
+        if key in ("intensity", "exogenous_depth"):
+            getattr(cfg, key)[0], getattr(cfg, key)[1] = value
+        else:
+            setattr(cfg, key, value)
+    arrays = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (a, b, c, d)]
+    n = arrays[0].shape[0]
+    out = np.empty_like(arrays[0])
+    ptr = lambda x: None if x is None else x.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    check(load_library().mbt_process_evaluate_host(device, op, C.byref(cfg), n, ptr(arrays[0]), ptr(arrays[1]), ptr(arrays[2]), ptr(arrays[3]), ptr(out)))
+    return out
+
+
 def device_count():
     return int(load_library().mbt_device_count())
 
@@ -461,6 +504,13 @@ def rng_fill_quad(seed, trajectory_offset, step, n, device=0):
     """The normals lanes [offset, offset+n) of a speed-dynamics environment draw at one step."""
     z = np.empty((n,), np.float32)
     check(load_library().mbt_rng_fill_quad_host(device, int(seed), int(trajectory_offset), int(step), int(n), fptr(z)))
+    return z
+
+
+def rng_fill_user(seed, trajectory_offset, step, n, device=0):
+    """The two extra normals (n, 2) user processes of lanes [offset, offset+n) draw at one step."""
+    z = np.empty((n, 2), np.float32)
+    check(load_library().mbt_rng_fill_user_host(device, int(seed), int(trajectory_offset), int(step), int(n), fptr(z)))
     return z
 
 

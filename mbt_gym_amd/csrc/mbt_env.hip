@@ -331,7 +331,12 @@ struct mbt_env {
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
   hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
-  double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {}, user_mid_p[8] = {};  // parameters of the user's device expressions
+  double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {}, user_mid_p[8] = {}, user_state_p[8] = {};  // parameters of the user's device expressions
+  int user_state_columns = 0;      // state columns owned by user processes (mbt_user_code.state_columns), after the midprice
+  bool user_draws = false;         // ... that read the two extra normals z1, z2
+  double user_state_initial[2] = {0.0, 0.0};
+  float* z_user = nullptr;         // injected-noise mode: (n_pad, 2) extra normals
+  bool user_noise_ready = false;
   char* learned_dev = nullptr;                               // packed weights of a learned policy (policy_mlp.hpp), device
   std::vector<char> learned_host;                            // what learned_dev holds (re-uploaded only when the policy changes)
   uint32_t step_dynamic_lds = 0;   // occupancy control of the step kernel, see tune_for_size()
@@ -354,6 +359,46 @@ struct mbt_env {
 
 namespace {
 
+// What the float64 code paths compute with (the precise_state tier; RewardFunction / process evaluation for host callers):
+// the constructor arguments as the reference holds them.
+void fill_precise_params(const mbt_config& c, double mid_dt, double arr_dt, double imp_dt, mbt::PreciseParams& X) {
+  const int mk = c.midprice_kind;
+  std::memset(&X, 0, sizeof X);
+  X.mid_kind = mk;
+  X.mu = c.drift;
+  X.sigma = c.volatility;
+  X.mid_dt = mid_dt;
+  X.sqrt_mid_dt = std::sqrt(mid_dt);
+  X.mu_dt = c.drift * mid_dt;                         // MID:63: self.drift * self.step_size
+  X.sigma_sqrt_dt = c.volatility * std::sqrt(mid_dt);  // MID:64, MID:143: self.volatility * sqrt(self.step_size)
+  X.mid_add = c.mid_coef_add;
+  X.mid_mul = c.mid_coef_mul;
+  X.ou_speed = c.ou_speed;
+  X.ou_level = c.ou_level;
+  X.jump_size = c.jump_size;
+  X.hawkes_speed = c.hawkes_speed;
+  X.hawkes_base_bid = c.intensity[0];
+  X.hawkes_base_ask = c.intensity[1];
+  X.hawkes_jump = c.hawkes_jump;
+  X.arr_dt = arr_dt;
+  X.half_spread = c.market_half_spread;
+  X.q_max = c.max_inventory;
+  X.c_max = c.max_cash;
+  X.phi = c.phi;
+  X.alpha = c.alpha;
+  X.exponent = c.inventory_exponent;
+  X.risk_aversion = c.risk_aversion;
+  X.reward_scale = c.reward_scale;
+  X.temp_coef = c.temporary_impact;
+  X.impact_exponent = c.impact_exponent;
+  X.perm_coef = c.permanent_impact;
+  X.trans_coef = c.transient_impact;
+  X.resilience = c.resilience;
+  X.kernel_coef = c.kernel_coefficient;
+  X.impact_dt = imp_dt;
+  X.speed_dt = mid_dt;
+}
+
 void fill_static_params(mbt_env* e) {
   const mbt_config& c = e->cfg;
   mbt::StepParams& P = e->params;
@@ -367,6 +412,7 @@ void fill_static_params(mbt_env* e) {
     P.user_reward_p[j] = e->user_reward_p[j];
     P.user_arrival_p[j] = e->user_arrival_p[j];
     P.user_mid_p[j] = e->user_mid_p[j];
+    P.user_state_p[j] = e->user_state_p[j];
   }
   P.dt = static_cast<float>(e->dt);
   // the midprice model as coefficients of midprice_increment() (step_kernel.hpp)
@@ -436,40 +482,7 @@ void fill_static_params(mbt_env* e) {
   P.trans_coef = static_cast<float>(c.transient_impact);
   P.resilience = static_cast<float>(c.resilience);
   P.kernel_coef = static_cast<float>(c.kernel_coefficient);
-  mbt::PreciseParams& X = P.X;  // what the precise_state tier computes with: the constructor arguments as the reference holds them
-  X.mid_kind = mk;
-  X.mu = c.drift;
-  X.sigma = c.volatility;
-  X.mid_dt = e->mid_dt;
-  X.sqrt_mid_dt = std::sqrt(e->mid_dt);
-  X.mu_dt = c.drift * e->mid_dt;                         // MID:63: self.drift * self.step_size
-  X.sigma_sqrt_dt = c.volatility * std::sqrt(e->mid_dt);  // MID:64, MID:143: self.volatility * sqrt(self.step_size)
-  X.mid_add = c.mid_coef_add;
-  X.mid_mul = c.mid_coef_mul;
-  X.ou_speed = c.ou_speed;
-  X.ou_level = c.ou_level;
-  X.jump_size = c.jump_size;
-  X.hawkes_speed = c.hawkes_speed;
-  X.hawkes_base_bid = c.intensity[0];
-  X.hawkes_base_ask = c.intensity[1];
-  X.hawkes_jump = c.hawkes_jump;
-  X.arr_dt = e->arr_dt;
-  X.half_spread = c.market_half_spread;
-  X.q_max = c.max_inventory;
-  X.c_max = c.max_cash;
-  X.phi = c.phi;
-  X.alpha = c.alpha;
-  X.exponent = c.inventory_exponent;
-  X.risk_aversion = c.risk_aversion;
-  X.reward_scale = c.reward_scale;
-  X.temp_coef = c.temporary_impact;
-  X.impact_exponent = c.impact_exponent;
-  X.perm_coef = c.permanent_impact;
-  X.trans_coef = c.transient_impact;
-  X.resilience = c.resilience;
-  X.kernel_coef = c.kernel_coefficient;
-  X.impact_dt = e->imp_dt;
-  X.speed_dt = e->mid_dt;
+  fill_precise_params(c, e->mid_dt, e->arr_dt, e->imp_dt, P.X);
   P.norm_act = c.normalise_action;
   P.norm_obs = c.normalise_observation;
   for (int j = 0; j < 4; ++j) {
@@ -543,6 +556,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
   const bool inject = e->cfg.noise_mode == MBT_NOISE_INJECTED;
   if (inject && !e->noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: set_noise() must precede every step()");
+  if (inject && e->user_draws && !e->user_noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: the user processes' extra normals (mbt_env_set_user_noise_host) must precede every step()");
   // host clock: t += dt (TE:216); done = t >= T - dt/2 (TE:218-220).  Committed only once the launch is known to be queued.
   const double t_next = e->time + e->dt;
   const bool terminal = t_next >= e->cfg.terminal_time - e->dt / 2;
@@ -562,6 +576,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   B.u_arr = e->u_arr;
   B.u_fill = e->u_fill;
   B.z = e->z;
+  B.z_user = e->z_user;
   B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
   B.resid = e->resid;
   B.events = e->record_events ? e->events : nullptr;
@@ -580,6 +595,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   e->philox_step += 1;
   e->episode_step += 1;
   e->noise_ready = false;
+  e->user_noise_ready = false;
   if (done != nullptr) *done = terminal ? 1 : 0;
   return MBT_OK;
 }
@@ -888,6 +904,7 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
       x[col++] = c.exogenous_depth[0];
       x[col++] = c.exogenous_depth[1];
     }
+    for (int j = 0; j < e->user_state_columns; ++j) x[col++] = e->user_state_initial[j];  // SP:30-31 of the user's own processes
   }
   row0.cash0 = static_cast<float>(x[0]);
   row0.q0_scalar = static_cast<float>(x[1]);
@@ -1065,7 +1082,11 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
 int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER, user_arrival = c.arrival_kind == MBT_ARR_USER;
   const bool user_mid = c.midprice_kind == MBT_MID_USER;
-  std::string fill_decl, reward_decl, arrival_decl, mid_decl;
+  std::string fill_decl, reward_decl, arrival_decl, mid_decl, state_decl;
+  if (int rc_state = param_declarations(u.state_param_names, state_decl); rc_state != MBT_OK) return rc_state;
+  const int user_state = u.state_columns;
+  // the symbols every process expression may read beyond its own arguments
+  const std::string process_symbols = "  const double x0 = u_.x0, x1 = u_.x1, z1 = u_.z1, z2 = u_.z2;\n  (void)x0; (void)x1; (void)z1; (void)z2;\n";
   if (int rc_mid = param_declarations(u.midprice_param_names, mid_decl); rc_mid != MBT_OK) return rc_mid;
   int rc = param_declarations(u.fill_param_names, fill_decl);
   if (rc != MBT_OK) return rc;
@@ -1086,13 +1107,19 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "  (void)cash; (void)q; (void)t; (void)mid; (void)cash_next; (void)q_next; (void)t_next; (void)mid_next; (void)a0; (void)a1; (void)a2;\n"
          "  (void)a3; (void)pnl; (void)dt; (void)is_terminal; (void)q0; (void)episode_length; (void)p;\n" +
          reward_decl + "  return static_cast<double>(" + std::string(user_reward ? u.reward : "0.0") + ");\n}\n";
-  src += "__device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p) {\n  (void)t; (void)side; (void)dt; (void)p;\n" + arrival_decl +
-         "  return static_cast<double>(" + std::string(user_arrival ? u.arrival_probability : "0.0") + ");\n}\n";
-  src += "__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const double* p) {\n"
-         "  (void)S; (void)t; (void)z; (void)dt; (void)fills_bid; (void)fills_ask; (void)p;\n" + mid_decl +
-         "  return static_cast<double>(" + std::string(user_mid ? u.midprice_increment : "0.0") + ");\n}\n}  // namespace mbt\n";
+  src += "__device__ double mbt_user_arrival_probability(double t, int side, double dt, const UserProcessState& u_, const double* p) {\n  (void)t; (void)side; (void)dt; (void)p;\n" +
+         process_symbols + arrival_decl + "  return static_cast<double>(" + std::string(user_arrival ? u.arrival_probability : "0.0") + ");\n}\n";
+  src += "__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const UserProcessState& u_, const double* p) {\n"
+         "  (void)S; (void)t; (void)z; (void)dt; (void)fills_bid; (void)fills_ask; (void)p;\n" + process_symbols + mid_decl +
+         "  return static_cast<double>(" + std::string(user_mid ? u.midprice_increment : "0.0") + ");\n}\n";
+  const auto owner_dt = [&](int j) { return std::string(u.state_owner[j] == 1 ? "dt_arr" : "dt_mid"); };  // each column advances with its owner's step size (SP:21)
+  src += "__device__ double mbt_user_state_next(int which, double S, double t, double dt_mid, double dt_arr, double z, double arr_bid, double arr_ask, double fills_bid, "
+         "double fills_ask, const UserProcessState& u_, const double* p) {\n  (void)which; (void)S; (void)t; (void)dt_mid; (void)dt_arr; (void)z; (void)arr_bid; (void)arr_ask; "
+         "(void)fills_bid; (void)fills_ask; (void)p;\n" + process_symbols + state_decl +
+         "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? u.state_update[0] : "0.0") + "); }\n"
+         "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? u.state_update[1] : "0.0") + "); }\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ">;\n";
+         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
@@ -1238,6 +1265,15 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (needs_jit) {
     if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill))
       return fail(MBT_ERR_INVALID, "user-defined plugins run on the order-book kernels (a fill model needs limit or limit + market dynamics)");
+    if (code->state_columns < 0 || code->state_columns > 2) return fail(MBT_ERR_INVALID, "user processes own at most two state columns (got %d)", code->state_columns);
+    if (code->state_columns > 0) {
+      if (!(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_ARR_USER)");
+      if (cfg->arrival_kind == MBT_ARR_HAWKES || exogenous_fill(*cfg))
+        return fail(MBT_ERR_INVALID, "user state columns take the place of the Hawkes intensities / exogenous depths: Poisson-type or user arrivals, exponential or user fills");
+      for (int j = 0; j < code->state_columns; ++j)
+        if (code->state_update[j] == nullptr || code->state_update[j][0] == 0) return fail(MBT_ERR_INVALID, "user state column %d has no update expression", j);
+    }
+    if (code->extra_normals && !(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "extra normals are drawn for user-defined midprice / arrival models");
   }
   if (cfg->abi_version != MBT_ABI_VERSION)
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
@@ -1299,7 +1335,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (e == nullptr) return fail(MBT_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
   e->speed = speed;
-  e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0);
+  e->user_state_columns = needs_jit ? code->state_columns : 0;
+  e->user_draws = needs_jit && code->extra_normals != 0;
+  for (int j = 0; j < 2; ++j) e->user_state_initial[j] = needs_jit ? code->state_initial[j] : 0.0;
+  e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0) + e->user_state_columns;
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
   e->n = static_cast<uint32_t>(cfg->num_trajectories);
   // a thread owns four lanes of a 1024-lane tile (speed) or two lanes of a 512-lane tile (order book): pad to whole tiles
@@ -1314,7 +1353,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
-  e->res = !cfg->precise_state ? 0 : speed ? 4 : (cfg->arrival_kind == MBT_ARR_HAWKES ? 4 : 2);
+  e->res = !cfg->precise_state ? 0 : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
   tune_for_size(e);
   if (needs_jit) {
     for (int j = 0; j < 8; ++j) {
@@ -1322,6 +1361,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
       e->user_reward_p[j] = code->reward_params[j];
       e->user_arrival_p[j] = code->arrival_params[j];
       e->user_mid_p[j] = code->midprice_params[j];
+      e->user_state_p[j] = code->state_params[j];
     }
     std::string source;
     JitKernels kernels;
@@ -1373,6 +1413,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
       ENV_TRY(dev_alloc(&e->u_fill, np * 2, e->stream));
     }
     ENV_TRY(dev_alloc(&e->z, np, e->stream));
+    if (e->user_draws) ENV_TRY(dev_alloc(&e->z_user, np * 2, e->stream));
   }
   ENV_TRY(dev_alloc(&e->q_init, np, e->stream));
   if (e->res != 0) ENV_TRY(dev_alloc(&e->resid, np * e->res, e->stream));
@@ -1448,7 +1489,7 @@ void mbt_env_destroy(mbt_env* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = {e->resid, e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
+  void* bufs[] = {e->z_user, e->resid, e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
                   e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
                   e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2], e->learned_dev};
   for (void* b : bufs)
@@ -1785,6 +1826,17 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
   return rc;
 }
 
+int mbt_env_set_user_noise_host(mbt_env* e, const float* z_user) {
+  if (e == nullptr || z_user == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
+  if (!e->user_draws || e->z_user == nullptr) return fail(MBT_ERR_STATE, "this environment's user processes draw no extra normals (mbt_user_code.extra_normals)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->z_user, z_user, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->user_noise_ready = true;
+  return MBT_OK;
+}
+
 int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, const float* z) {
   if (e == nullptr || z == nullptr || (!e->speed && (u_arr == nullptr || u_fill == nullptr))) return fail(MBT_ERR_INVALID, "null argument");
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
@@ -2025,6 +2077,47 @@ int mbt_reward_calculate_host(int device, int reward_kind, double phi, double al
   return MBT_OK;
 }
 
+int mbt_process_evaluate_host(int device, int op, const mbt_config* cfg, uint64_t n, const double* a, const double* b, const double* c, const double* d,
+                              double* out) {
+  if (cfg == nullptr || a == nullptr || out == nullptr || n == 0 || n > 0x7FFFFFFFull) return fail(MBT_ERR_INVALID, "bad argument");
+  if (op < MBT_PROCESS_MIDPRICE_UPDATE || op > MBT_PROCESS_FILLS) return fail(MBT_ERR_INVALID, "unknown process operation %d", op);
+  if ((op == MBT_PROCESS_MIDPRICE_UPDATE || op == MBT_PROCESS_HAWKES_UPDATE || op == MBT_PROCESS_FILLS) && b == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (op == MBT_PROCESS_ARRIVALS && cfg->arrival_kind == MBT_ARR_HAWKES && b == nullptr) return fail(MBT_ERR_INVALID, "Hawkes arrivals need the intensities");
+  if (op == MBT_PROCESS_MIDPRICE_UPDATE && (cfg->midprice_kind < MBT_MID_BROWNIAN || cfg->midprice_kind > MBT_MID_LINEAR_SDE))
+    return fail(MBT_ERR_INVALID, "midprice kind %d has no host-callable update (user expressions run inside an environment)", cfg->midprice_kind);
+  if (op == MBT_PROCESS_FILLS && cfg->fill_kind != MBT_FILL_EXPONENTIAL && cfg->fill_kind != MBT_FILL_EXOGENOUS_MM) return fail(MBT_ERR_INVALID, "fill kind %d has no host-callable get_fills", cfg->fill_kind);
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  const double dt = cfg->terminal_time > 0.0 && cfg->n_steps > 0 ? cfg->terminal_time / cfg->n_steps : 0.0;
+  const double mid_dt = cfg->midprice_step_size > 0.0 ? cfg->midprice_step_size : dt, arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : dt;
+  mbt::PreciseParams X;
+  fill_precise_params(*cfg, mid_dt, arr_dt, dt, X);
+  const bool nonlinear = cfg->arrival_kind == MBT_ARR_POISSON_NONLINEAR;
+  const double thr_bid = nonlinear ? 1.0 - std::exp(-cfg->intensity[0] * arr_dt) : cfg->intensity[0] * arr_dt;  // ARR:83 / ARR:56
+  const double thr_ask = nonlinear ? 1.0 - std::exp(-cfg->intensity[1] * arr_dt) : cfg->intensity[1] * arr_dt;
+  const size_t width = op == MBT_PROCESS_MIDPRICE_UPDATE ? 1 : 2, bytes = n * width * sizeof(double);
+  const double* in[4] = {a, b, c, d};
+  double* dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipError_t he = hipSuccess;
+  for (int k = 0; k < 5 && he == hipSuccess; ++k) {
+    if (k < 4 && in[k] == nullptr) continue;
+    he = hipMalloc(reinterpret_cast<void**>(&dev[k]), bytes);
+    if (he == hipSuccess && k < 4) he = hipMemcpy(dev[k], in[k], bytes, hipMemcpyHostToDevice);
+  }
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(mbt::process_evaluate_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, cfg->arrival_kind, cfg->fill_kind, X, thr_bid, thr_ask,
+                       cfg->fill_exponent, cfg->exogenous_depth[0], cfg->exogenous_depth[1], cfg->base_fill_probability, dev[0], dev[1], dev[2], dev[3],
+                       static_cast<uint32_t>(n), dev[4]);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipMemcpy(out, dev[4], bytes, hipMemcpyDeviceToHost);
+  for (double* p : dev)
+    if (p != nullptr) (void)hipFree(p);
+  if (he != hipSuccess) return fail(MBT_ERR_HIP, "process evaluation failed: %s", hipGetErrorString(he));
+  return MBT_OK;
+}
+
 int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* u_arr,
                       float* u_fill, float* z) {
   if (trajectory_offset % mbt::kTileLanes != 0) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 512");
@@ -2047,6 +2140,24 @@ int mbt_rng_fill_host(int device, uint64_t seed, uint64_t trajectory_offset, uin
   (void)hipFree(d_ua);
   (void)hipFree(d_uf);
   (void)hipFree(d_z);
+  return MBT_OK;
+}
+
+int mbt_rng_fill_user_host(int device, uint64_t seed, uint64_t trajectory_offset, uint32_t step, uint64_t n, float* z_user) {
+  if (trajectory_offset % mbt::kTileLanes != 0) return fail(MBT_ERR_INVALID, "trajectory_offset must be a multiple of 512");
+  if (n == 0 || n > 0x7FFFF000ull || z_user == nullptr) return fail(MBT_ERR_INVALID, "bad argument");
+  int rc = check_device(device);
+  if (rc != MBT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t tiles = (static_cast<uint32_t>(n) + mbt::kTileLanes - 1u) / mbt::kTileLanes, n_pad = tiles * mbt::kTileLanes;
+  float* d_z = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_z), size_t(n_pad) * 2 * sizeof(float)));
+  hipLaunchKernelGGL(mbt::rng_fill_user_kernel, dim3(tiles), dim3(mbt::kBlockThreads), 0, nullptr, trajectory_offset >> 1, step,
+                     static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), d_z);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipMemcpy(z_user, d_z, size_t(n) * 2 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_z);
+  if (he != hipSuccess) return fail(MBT_ERR_HIP, "rng_fill_user failed: %s", hipGetErrorString(he));
   return MBT_OK;
 }
 

@@ -101,4 +101,14 @@ __device__ __forceinline__ void philox_pair_noise(uint64_t pair, uint32_t step, 
   box_muller(low_bytes(wa), low_bytes(wb), a.z, b.z);
 }
 
+// Two more standard normals per lane for USER-DEFINED processes that draw noise of their own (a second midprice factor, a
+// stochastic intensity): a third block of the pair, ctr = (p.lo, p.hi, step, 2), words (0, 1) -> z1 of the pair's two lanes,
+// words (2, 3) -> z2.  Drawn only by the run-time compiled kernels that ask for it (Variant::USER_DRAWS).
+__device__ __forceinline__ void philox_pair_user_noise(uint64_t pair, uint32_t step, uint32_t k0, uint32_t k1, float& a_z1, float& a_z2,
+                                                       float& b_z1, float& b_z2) {
+  const PhiloxWords w = philox4x32_10(static_cast<uint32_t>(pair), static_cast<uint32_t>(pair >> 32), step, 2u, k0, k1);
+  box_muller(w.w0, w.w1, a_z1, b_z1);
+  box_muller(w.w2, w.w3, a_z2, b_z2);
+}
+
 }  // namespace mbt

@@ -57,7 +57,8 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
-          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false>
+          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false, int USER_STATE_ = 0,
+          bool USER_DRAWS_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -76,15 +77,25 @@ struct Variant {
   // and the step is evaluated in double in the reference's own order of operations (lane_step_exact): state and rewards
   // are the reference's float64 results, bit for bit, rounded once to float32 on the way out.  General tier only, like EXO.
   static constexpr bool PRECISE = PRECISE_;
-  static constexpr int RES = PRECISE_ ? (ARR_ == kArrHawkes ? 4 : 2) : 0;  // residual columns: [cash, midprice (, bid intensity, ask intensity)]
+  static constexpr int RES = PRECISE_ ? ((ARR_ == kArrHawkes || USER_STATE_ != 0) ? 4 : 2) : 0;  // residual columns: [cash, midprice (, the two columns after it)]
   // User-defined plugins (mbt_env_create_jit): this header is compiled at RUN TIME (hiprtc) together with the user's
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
   static constexpr bool USER_FILL = USER_FILL_, USER_REWARD = USER_REWARD_;
   static constexpr bool USER_MID = USER_MID_;  // MidpriceModel.update as an expression for S' - S (one column, one normal per step)
   static constexpr bool USER_ARRIVAL = USER_ARRIVAL_;  // a stateless ArrivalModel.get_arrivals (ARR:27-29) as an expression of time
-  static_assert(!(USER_ARRIVAL_ && ARR_ == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (no state columns)");
-  static constexpr int EXO_COL = (ARR_ == kArrHawkes) ? 6 : 4;
+  static_assert(!(USER_ARRIVAL_ && ARR_ == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (its state columns are USER_STATE)");
+  // State columns OWNED by user-defined processes (SP:8-53: a subclass carries its own (N, d) state): 0, 1 or 2 columns
+  // x0, x1 right after the midprice, in the reference's registry order (a second midprice factor first, then the arrival
+  // model's columns, TE:303-318).  They live where the Hawkes intensities of the built-in model live (`lam`), are advanced
+  // by the user's state_update expressions, and may be read by the user's midprice and arrival expressions.  USER_DRAWS:
+  // the user's processes consume two more standard normals per lane and step (a third Philox block per pair of lanes).
+  static constexpr int USER_STATE = USER_STATE_;
+  static constexpr bool USER_DRAWS = USER_DRAWS_;
+  static_assert(USER_STATE_ >= 0 && USER_STATE_ <= 2, "at most two user state columns");
+  static_assert(!(USER_STATE_ != 0 && (ARR_ == kArrHawkes || EXO_)), "user state columns take the place of the Hawkes intensities / exogenous depths");
+  static constexpr int EXTRA = (ARR_ == kArrHawkes) ? 2 : USER_STATE_;  // columns between the midprice and the exogenous depths
+  static constexpr int EXO_COL = 4 + EXTRA;
   static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
 };
 
@@ -158,10 +169,16 @@ struct StepParams {
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
   PreciseParams X;
-  double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8];  // parameters of the user's device expressions (mbt_user_code)
+  double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8], user_state_p[8];  // parameters of the user's device expressions (mbt_user_code)
   double mid_dt_f64;  // the midprice model's own step size (SP:21), for a user midprice expression
   double t_now;  // the clock BEFORE this step (TE:216 accumulates it in double on the host): what a user arrival model sees
   double t_next_f64;  // ... and after it: the precise_state tier's TIME column and the `dt` of its rewards (RW:99, RW:131)
+};
+
+// what the user's process expressions may read beyond their own arguments: the user state columns before the step and the
+// two extra normals of the step (zero when the configuration has none)
+struct UserProcessState {
+  double x0, x1, z1, z2;
 };
 
 #ifdef MBT_JIT_USER_CODE
@@ -175,8 +192,12 @@ struct UserRewardArgs {
   double dt, is_terminal, q0, episode_length;  // step size, 1.0 on the terminal step, initial inventory, T - t_start
 };
 __device__ double mbt_user_reward(const UserRewardArgs& s, const double* p);
-__device__ double mbt_user_arrival_probability(double t, int side, double dt, const double* p);
-__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const double* p);
+__device__ double mbt_user_arrival_probability(double t, int side, double dt, const UserProcessState& u, const double* p);
+__device__ double mbt_user_midprice_increment(double S, double t, double z, double dt, double fills_bid, double fills_ask, const UserProcessState& u, const double* p);
+// the user state columns after the step (which = 0, 1): StochasticProcessModel.update (SP:8-53) of the processes that own them
+// (dt_mid / dt_arr: the step sizes of the midprice and of the arrival model - each column is advanced with its owner's, SP:21)
+__device__ double mbt_user_state_next(int which, double S, double t, double dt_mid, double dt_arr, double z, double arr_bid, double arr_ask, double fills_bid,
+                                      double fills_ask, const UserProcessState& u, const double* p);
 #endif
 
 struct StepBuffers {
@@ -188,6 +209,7 @@ struct StepBuffers {
   const float* u_arr;      // injected noise (n_pad, 2), (n_pad, 2), (n_pad)
   const float* u_fill;
   const float* z;
+  const float* z_user;     // injected noise of user processes (n_pad, 2), or nullptr
   const float* q_init;     // CjMm per-lane initial inventory or nullptr
   int32_t* resid;          // precise_state: (n_pad, RES) int32 remainders of the float64 state (exact_join), updated in place; else nullptr
   uint8_t* events;         // nullptr unless recording
@@ -461,7 +483,7 @@ struct Decisions {
 // float32 state, the exact tier the reference's float64 value).
 template <class V>
 __device__ __forceinline__ Decisions decide(const float q, const float4 act, const LaneDraw& dr, const double lam_bid, const double lam_ask,
-                                            const double t_now, const bool norm_act, const StepParams& P) {
+                                            const double t_now, const bool norm_act, const StepParams& P, const UserProcessState& ups) {
   Decisions D;
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
   float arr_bid = dr.arr_bid, arr_ask = dr.arr_ask;
@@ -472,8 +494,8 @@ __device__ __forceinline__ Decisions decide(const float q, const float4 act, con
   if (V::USER_ARRIVAL) {
 #ifdef MBT_JIT_USER_CODE
     // the user's get_arrivals (ARR:27-29): u < p(t, side), in double, at the time stamp of the observation acted on
-    arr_bid = static_cast<double>(dr.arr_bid) < mbt_user_arrival_probability(t_now, 0, P.arr_dt_f64, P.user_arrival_p) ? 1.0f : 0.0f;
-    arr_ask = static_cast<double>(dr.arr_ask) < mbt_user_arrival_probability(t_now, 1, P.arr_dt_f64, P.user_arrival_p) ? 1.0f : 0.0f;
+    arr_bid = static_cast<double>(dr.arr_bid) < mbt_user_arrival_probability(t_now, 0, P.arr_dt_f64, ups, P.user_arrival_p) ? 1.0f : 0.0f;
+    arr_ask = static_cast<double>(dr.arr_ask) < mbt_user_arrival_probability(t_now, 1, P.arr_dt_f64, ups, P.user_arrival_p) ? 1.0f : 0.0f;
 #endif
   }
   D.arr_bid = arr_bid;
@@ -538,12 +560,13 @@ __device__ __forceinline__ Decisions decide(const float q, const float4 act, con
 template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
-                                                const StepParams& P, const float z = 0.f, const double t_now = 0.0) {
+                                                const StepParams& P, const float z = 0.f, const double t_now = 0.0, const float2 zu = make_float2(0.f, 0.f)) {
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
   r.lo = make_int4(0, 0, 0, 0);
   const bool norm_act = V::NORM && P.norm_act;
-  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P);
+  const UserProcessState ups{V::USER_STATE > 0 ? static_cast<double>(lam.x) : 0.0, V::USER_STATE > 1 ? static_cast<double>(lam.y) : 0.0, zu.x, zu.y};
+  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P, ups);
   const float arr_bid = D.arr_bid, arr_ask = D.arr_ask, n_bid = D.n_bid, n_ask = D.n_ask;
   r.arr_bid = arr_bid != 0.0f;
   r.arr_ask = arr_ask != 0.0f;
@@ -577,7 +600,7 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   float d_mid = V::BROWNIAN ? dr.dz : midprice_increment(mid, dr.dz, n_bid, n_ask, P);
   if (V::USER_MID) {
 #ifdef MBT_JIT_USER_CODE
-    d_mid = static_cast<float>(mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, P.user_mid_p));
+    d_mid = static_cast<float>(mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, ups, P.user_mid_p));
 #endif
   }
   const float mid_new = mid + d_mid;
@@ -585,6 +608,13 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   if (V::ARR == kArrHawkes) {
     r.lam.x = __builtin_fmaf(P.hawkes_jump, arr_bid, lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.arr_dt);
     r.lam.y = __builtin_fmaf(P.hawkes_jump, arr_ask, lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.arr_dt);
+  }
+  if (V::USER_STATE > 0) {
+#ifdef MBT_JIT_USER_CODE
+    // the user processes' own update() (SP:8-53), each from the state BEFORE the step, in double; the columns are float32
+    r.lam.x = static_cast<float>(mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, ups, P.user_state_p));
+    if (V::USER_STATE > 1) r.lam.y = static_cast<float>(mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, ups, P.user_state_p));
+#endif
   }
 
   // -- reward: the mark-to-market change (c'+q'S') - (c+qS) of RW:27-33 from the step's increments, then the reward
@@ -626,13 +656,14 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
 template <class V>
 __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const float2 lam, const int4 lo, const float4 act, const LaneDraw& dr,
                                                       const float q_init, const bool is_terminal, const StepParams& P, const float z,
-                                                      const double t_now, const double t_next) {
+                                                      const double t_now, const double t_next, const float2 zu = make_float2(0.f, 0.f)) {
   const PreciseParams& X = P.X;
   const double cash = exact_join(core.x, lo.x), mid = exact_join(core.w, lo.y), q = core.y;  // (order-book inventories are integers)
-  const double lam_bid = V::ARR == kArrHawkes ? exact_join(lam.x, lo.z) : 0.0, lam_ask = V::ARR == kArrHawkes ? exact_join(lam.y, lo.w) : 0.0;
+  const double lam_bid = V::EXTRA > 0 ? exact_join(lam.x, lo.z) : 0.0, lam_ask = V::EXTRA > 1 ? exact_join(lam.y, lo.w) : 0.0;  // (or the user state columns)
   LaneResult r;
   const bool norm_act = V::NORM && P.norm_act;
-  const Decisions D = decide<V>(core.y, act, dr, lam_bid, lam_ask, t_now, norm_act, P);
+  const UserProcessState ups{V::USER_STATE > 0 ? lam_bid : 0.0, V::USER_STATE > 1 ? lam_ask : 0.0, zu.x, zu.y};
+  const Decisions D = decide<V>(core.y, act, dr, lam_bid, lam_ask, t_now, norm_act, P, ups);
   r.arr_bid = D.arr_bid != 0.0f;
   r.arr_ask = D.arr_ask != 0.0f;
   r.fill_bid = D.fill_bid;
@@ -666,7 +697,7 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
   double mid_new;
   if (V::USER_MID) {
 #ifdef MBT_JIT_USER_CODE
-    mid_new = mid + mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, P.user_mid_p);
+    mid_new = mid + mbt_user_midprice_increment(mid, t_now, z, P.mid_dt_f64, n_bid, n_ask, ups, P.user_mid_p);
 #else
     mid_new = mid;
 #endif
@@ -677,6 +708,12 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
   if (V::ARR == kArrHawkes) {
     lam_bid_new = (lam_bid + X.hawkes_speed * (X.hawkes_base_bid - lam_bid) * X.arr_dt) + X.hawkes_jump * static_cast<double>(D.arr_bid);
     lam_ask_new = (lam_ask + X.hawkes_speed * (X.hawkes_base_ask - lam_ask) * X.arr_dt) + X.hawkes_jump * static_cast<double>(D.arr_ask);
+  }
+  if (V::USER_STATE > 0) {
+#ifdef MBT_JIT_USER_CODE
+    lam_bid_new = mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, ups, P.user_state_p);
+    if (V::USER_STATE > 1) lam_ask_new = mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, ups, P.user_state_p);
+#endif
   }
   // reward
   if (V::USER_REWARD) {
@@ -698,10 +735,8 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
   r.lo = make_int4(0, 0, 0, 0);
   exact_split(c_clip, c_hi, r.lo.x);
   exact_split(mid_new, m_hi, r.lo.y);
-  if (V::ARR == kArrHawkes) {
-    exact_split(lam_bid_new, lb_hi, r.lo.z);
-    exact_split(lam_ask_new, la_hi, r.lo.w);
-  }
+  if (V::EXTRA > 0) exact_split(lam_bid_new, lb_hi, r.lo.z);
+  if (V::EXTRA > 1) exact_split(lam_ask_new, la_hi, r.lo.w);
   r.core = make_float4(c_hi, static_cast<float>(q_clip), static_cast<float>(t_next), m_hi);
   r.lam = make_float2(lb_hi, la_hi);
   return r;
@@ -747,6 +782,7 @@ struct LaneLoads {
   float4 act;   // (bid depth, ask depth[, market buy, market sell])
   float2 ua, uf;  // injected noise
   float z;
+  float2 zu;    // injected noise of user processes (z1, z2)
   float qi;     // per-lane initial inventory (CjMm)
   int4 lo;      // precise_state: the int32 remainders of [cash, midprice, bid intensity, ask intensity] (exact_join)
 };
@@ -776,7 +812,11 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
     const float* row = B.state_in + static_cast<size_t>(lane) * 6;
     const float2 a = load2<NT>(row), b = load2<NT>(row + 2);
     L.core = make_float4(a.x, a.y, b.x, b.y);
-    L.lam = V::ARR == kArrHawkes ? load2<NT>(row + 4) : make_float2(0.f, 0.f);
+    L.lam = V::EXTRA == 2 ? load2<NT>(row + 4) : make_float2(0.f, 0.f);
+  } else if (V::DIM == 5) {  // one user state column: rows of 20 bytes, 4-byte aligned (run-time compiled kernels only)
+    const float* row = B.state_in + static_cast<size_t>(lane) * 5;
+    L.core = make_float4(row[0], row[1], row[2], row[3]);
+    L.lam = make_float2(row[4], 0.f);
   } else {
     L.core = load4<NT>(B.state_in + static_cast<size_t>(lane) * 4);
     L.lam = make_float2(0.f, 0.f);
@@ -792,6 +832,7 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
     L.uf = reinterpret_cast<const float2*>(B.u_fill)[lane];
     L.z = B.z[lane];
   }
+  L.zu = (V::INJECT && V::USER_DRAWS) ? reinterpret_cast<const float2*>(B.z_user)[lane] : make_float2(0.f, 0.f);
   L.qi = P.q_init_scalar;
   L.lo = make_int4(0, 0, 0, 0);
   if (V::RES == 4) {
@@ -863,7 +904,10 @@ __device__ __forceinline__ void store_row_values(float* base, uint32_t lane, con
     float2* row = reinterpret_cast<float2*>(base) + static_cast<size_t>(lane) * 3;
     row[0] = make_float2(core.x, core.y);
     row[1] = make_float2(core.z, core.w);
-    row[2] = V::ARR == kArrHawkes ? lam : best;
+    row[2] = V::EXTRA == 2 ? lam : best;
+  } else if (V::DIM == 5) {
+    float* row = base + static_cast<size_t>(lane) * 5;
+    row[0] = core.x; row[1] = core.y; row[2] = core.z; row[3] = core.w; row[4] = lam.x;
   } else {
     if (THROUGH) store_through(reinterpret_cast<float4*>(base) + lane, core);
     else reinterpret_cast<float4*>(base)[lane] = core;
@@ -895,7 +939,8 @@ __device__ __forceinline__ void store_row_exact(float* base, uint32_t lane, floa
     core.y = normalise_column_exact(core.y, 1, P);
     core.z = normalise_column_exact(t, 2, P);
     core.w = normalise_column_exact(exact_join(core.w, lo.y), 3, P);
-    if (V::ARR == kArrHawkes) lam = make_float2(normalise_column_exact(exact_join(lam.x, lo.z), 4, P), normalise_column_exact(exact_join(lam.y, lo.w), 5, P));
+    if (V::EXTRA > 0) lam.x = normalise_column_exact(exact_join(lam.x, lo.z), 4, P);
+    if (V::EXTRA > 1) lam.y = normalise_column_exact(exact_join(lam.y, lo.w), 5, P);
     if (V::EXO) best = make_float2(normalise_column_exact(P.exo_depth_f64[0], V::EXO_COL, P), normalise_column_exact(P.exo_depth_f64[1], V::EXO_COL + 1, P));
   }
   store_row_values<V, THROUGH>(base, lane, core, lam, best);
@@ -909,18 +954,20 @@ __device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
-                                             const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f) {
-  const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64)
-                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now);
+                                             const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f, const float2 zu = make_float2(0.f, 0.f)) {
+  const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu)
+                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu);
   if (V::PRECISE) store_lo(B.resid, lane, r.lo, V::RES);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
+  } else if (V::DIM == 5) {  // (20-byte rows are only 4-byte aligned in LDS too)
+    staged_row[0] = r.core.x; staged_row[1] = r.core.y; staged_row[2] = r.core.z; staged_row[3] = r.core.w; staged_row[4] = r.lam.x;
   } else {  // rows wider than 16 bytes go through LDS (see step_kernel): this lane's row, 8-byte pieces
     float2* row = reinterpret_cast<float2*>(staged_row);
     row[0] = make_float2(r.core.x, r.core.y);
     row[1] = make_float2(r.core.z, r.core.w);
     if (V::DIM == 6) {
-      row[2] = V::ARR == kArrHawkes ? r.lam : make_float2(P.exo_depth[0], P.exo_depth[1]);
+      row[2] = V::EXTRA == 2 ? r.lam : make_float2(P.exo_depth[0], P.exo_depth[1]);
     } else {
       row[2] = r.lam;
       row[3] = make_float2(P.exo_depth[0], P.exo_depth[1]);
@@ -952,6 +999,8 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
   load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
   LaneNoise nz0, nz1;
   LaneDraw d0, d1;
+  float2 zu0 = L0.zu, zu1 = L1.zu;
+  if (V::USER_DRAWS && !V::INJECT) philox_pair_user_noise(pair, P.philox_step, P.key0, P.key1, zu0.x, zu0.y, zu1.x, zu1.y);
   if (V::INJECT) {
     nz0 = LaneNoise{L0.ua.x, L0.ua.y, L0.uf.x, L0.uf.y, L0.z};
     nz1 = LaneNoise{L1.ua.x, L1.ua.y, L1.uf.x, L1.uf.y, L1.z};
@@ -968,15 +1017,17 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
   // in LDS instead (12 / 16 KB) and writes them out as contiguous whole-line float4 - through the L2.
   __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM > 4 ? kTileLanes * V::DIM : 4];
   bool clipped0, clipped1;
-  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM, nz0.z);
-  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM, nz1.z);
+  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM, nz0.z, zu0);
+  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM, nz1.z, zu1);
   if (V::DIM > 4) {
     __syncthreads();
-    constexpr int kVectors = kTileLanes * V::DIM / 4 / kBlockThreads;  // float4 per thread: 3 (D = 6) or 4 (D = 8)
+    constexpr int kTileVectors = kTileLanes * V::DIM / 4;  // float4 per tile: 3 (D = 6) or 4 (D = 8) per thread; 2.5 for D = 5
     const float4* staged = reinterpret_cast<const float4*>(staged_rows);
-    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * (kTileLanes * V::DIM / 4);
+    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * kTileVectors;
 #pragma unroll
-    for (int k = 0; k < kVectors; ++k) store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
+    for (int k = 0; k * kBlockThreads < kTileVectors; ++k)
+      if ((k + 1) * kBlockThreads <= kTileVectors || threadIdx.x + k * kBlockThreads < kTileVectors)
+        store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
   }
   if ((blockIdx.x + 1u) * kTileLanes > P.n) {  // only the last tile can hold pad lanes: computed, never reported
     const bool real0 = lane0 < P.n, real1 = lane1 < P.n;
@@ -1076,6 +1127,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
   for (uint32_t k = 0; k < R.n_steps; ++k) {
     LaneNoise nz[2];
     if (!LEARNED) philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);
+    float2 zu[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    if (V::USER_DRAWS) philox_pair_user_noise(pair, P.philox_step + k, P.key0, P.key1, zu[0].x, zu[0].y, zu[1].x, zu[1].y);
     float4 act[2];
     if (LEARNED) {
 #ifndef MBT_JIT_USER_CODE
@@ -1134,8 +1187,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t)
-                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now);
+      const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t, zu[l])
+                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l]);
       core[l] = r.core;
       lam[l] = r.lam;
       lo[l] = r.lo;
@@ -1342,6 +1395,36 @@ __global__ void reward_calculate_kernel(int kind, const double* cur, const doubl
   out[i] = r;
 }
 
+// StochasticProcessModel.update / ArrivalModel.get_arrivals / FillProbabilityModel.get_fills for HOST callers of the plugin
+// objects outside an environment (SP:33-35, ARR:27-29, FILL:28-34): the arithmetic of one call on caller-supplied float64
+// arrays, in the reference's order of operations - so a process object seeded like the reference's (its NumPy generator
+// supplies the draws on the host, as in the reference) walks the reference's path without a CPU implementation of the maths.
+enum : int { kProcessMidpriceUpdate = 0, kProcessHawkesUpdate = 1, kProcessArrivals = 2, kProcessFills = 3 };
+__global__ void process_evaluate_kernel(int op, int arrival_kind, int fill_kind, const PreciseParams X, double thr_bid, double thr_ask, double kappa,
+                                        double exo_bid, double exo_ask, double exo_base, const double* a, const double* b, const double* c, const double* d,
+                                        uint32_t n, double* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == kProcessMidpriceUpdate) {  // a: S (n), b: z (n), c / d: the agent's bid / ask fills (n) or null
+    out[i] = midprice_step_exact(a[i], b[i], c != nullptr ? c[i] : 0.0, d != nullptr ? d[i] : 0.0, X);
+    return;
+  }
+  for (int side = 0; side < 2; ++side) {
+    const size_t j = static_cast<size_t>(i) * 2 + side;
+    if (op == kProcessHawkesUpdate) {  // a: intensities (n, 2), b: arrivals (n, 2) as 0 / 1   (ARR:110-119)
+      const double base = side == 0 ? X.hawkes_base_bid : X.hawkes_base_ask;
+      out[j] = (a[j] + X.hawkes_speed * (base - a[j]) * X.arr_dt) + X.hawkes_jump * b[j];
+    } else if (op == kProcessArrivals) {  // a: uniforms (n, 2), b: intensities (n, 2) for Hawkes   (ARR:56, ARR:83, ARR:123)
+      const double threshold = arrival_kind == kArrHawkes ? b[j] * X.arr_dt : (side == 0 ? thr_bid : thr_ask);
+      out[j] = a[j] < threshold ? 1.0 : 0.0;
+    } else {  // fills - a: uniforms (n, 2), b: depths (n, 2)   (FILL:34, FILL:57-58, FILL:159-163)
+      const double best = side == 0 ? exo_bid : exo_ask;
+      const double p = fill_kind == 2 ? (b[j] > best ? exo_base * exp(-kappa * (b[j] - best)) : 1.0) : exp(-kappa * b[j]);
+      out[j] = a[j] < p ? 1.0 : 0.0;
+    }
+  }
+}
+
 // The production noise, written out in the step kernel's own lane <-> pair mapping (tests pin the generator and tie
 // Philox mode to injected mode with it).  One 256-thread block per tile.
 __global__ void rng_fill_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0, uint32_t k1, float* u_arr, float* u_fill, float* z) {
@@ -1360,6 +1443,15 @@ __global__ void rng_fill_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0
     z[lane0] = a.z;
     z[lane1] = b.z;
   }
+}
+
+// the extra normals of user processes (Variant::USER_DRAWS), in the step kernel's lane <-> pair mapping: z_user (n_pad, 2)
+__global__ void rng_fill_user_kernel(uint64_t pair_offset, uint32_t step, uint32_t k0, uint32_t k1, float* z_user) {
+  const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
+  float2 a, b;
+  philox_pair_user_noise(pair_offset + blockIdx.x * kBlockThreads + threadIdx.x, step, k0, k1, a.x, a.y, b.x, b.y);
+  reinterpret_cast<float2*>(z_user)[lane0] = a;
+  reinterpret_cast<float2*>(z_user)[lane1] = b;
 }
 
 __global__ void philox_kat_kernel(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {

@@ -234,6 +234,8 @@ class TradingEnvironment(_EnvBase):
 
     def _user_code(self):
         """struct mbt_user_code for the user-defined plugins of this environment (None when every plugin is built in)."""
+        import re
+
         fill, reward, arrival = self.model_dynamics.fill_probability_model, self.reward_function, self.model_dynamics.arrival_model
         fill_code = fill.device_code() if getattr(fill, "device_kind", None) == _native.FILL_USER else None
         reward_code = reward.device_code() if getattr(reward, "device_kind", None) == _native.REW_USER else None
@@ -242,7 +244,46 @@ class TradingEnvironment(_EnvBase):
         mid_code = mid.device_code() if getattr(mid, "device_kind", None) == _native.MID_USER else None
         if fill_code is None and reward_code is None and arrival_code is None and mid_code is None:
             return None
-        return _native.user_code(fill_code, reward_code, arrival_code, mid_code)
+        # State columns owned by user processes, in the registry order of TE:303-318 (the midprice's second factor, then the
+        # arrival model's columns).  Each process writes its expressions in terms of ITS OWN columns x0 (, x1); the kernel
+        # numbers the columns globally, so the arrival model's are shifted behind a midprice factor.
+        mid_state = mid.device_state() if mid_code is not None and hasattr(mid, "device_state") else None
+        arr_state = arrival.device_state() if arrival_code is not None and hasattr(arrival, "device_state") else None
+        state = None
+        if mid_state is not None or arr_state is not None:
+            updates, params, initial, extra, owners = [], {}, [], False, []
+            shift = 0
+            if mid_state is not None:
+                updates += mid_state[0]
+                params.update({k: v for k, v in mid_state[1].items() if re.search(rf"\b{re.escape(k)}\b", " ".join(mid_state[0]))})
+                initial += mid_state[2]
+                extra |= mid_state[3]
+                shift = len(mid_state[0])
+                owners += [0] * shift
+            if arr_state is not None:
+                if shift + len(arr_state[0]) > 2:
+                    raise UnsupportedOnDevice("user processes own at most two state columns between them (a second midprice factor and a one-column arrival model, or a two-column arrival model)")
+                rename = (lambda e: re.sub(r"\bx0\b", "x1", e)) if shift else (lambda e: e)
+                if shift and any(re.search(r"\bx1\b", e) for e in list(arr_state[0]) + [arrival_code[0]]):
+                    raise UnsupportedOnDevice("with a two-factor midprice the arrival model owns ONE column (x0)")
+                updates += [rename(e) for e in arr_state[0]]
+                clash = {k for k in arr_state[1] if k in params and params[k] != arr_state[1][k]}
+                if clash:
+                    raise UnsupportedOnDevice(f"parameter name(s) {sorted(clash)} are used by both the midprice and the arrival model with different values")
+                params.update({k: v for k, v in arr_state[1].items() if re.search(rf"\b{re.escape(k)}\b", " ".join(arr_state[0]))})
+                initial += arr_state[2]
+                extra |= arr_state[3]
+                owners += [1] * len(arr_state[0])
+                arrival_code = (rename(arrival_code[0]), arrival_code[1])
+            if mid_code is not None and mid_state is None and arr_state is not None:
+                pass  # (a one-column user midprice beside a stateful arrival model reads no state)
+            state = (updates, params, initial, extra, owners)
+        extra_normals = bool(getattr(mid, "uses_extra_normals", False) and mid_code is not None) or bool(getattr(arrival, "uses_extra_normals", False) and arrival_code is not None)
+        if state is None and extra_normals:
+            raise UnsupportedOnDevice("extra normals are drawn for user processes that own state columns")
+        if state is not None:
+            state = (state[0], state[1], state[2], extra_normals, state[4])
+        return _native.user_code(fill_code, reward_code, arrival_code, mid_code, state)
 
     def check_device_expressions(self):
         """Compile the user-defined plugins' device expressions without creating anything (needs no GPU); raises
@@ -489,10 +530,14 @@ class TradingEnvironment(_EnvBase):
     # ---------------------------------------------------------------------------------------------------
     # parity / diagnostics
     # ---------------------------------------------------------------------------------------------------
-    def set_noise(self, u_arr: np.ndarray, u_fill: np.ndarray, z: np.ndarray):
+    def set_noise(self, u_arr: np.ndarray, u_fill: np.ndarray, z: np.ndarray, z_user: np.ndarray = None):
         """Injected-noise mode: the uniforms/normal the next step consumes in place of the three numpy
-        generators of the reference (arrival_models.py:55, fill_probability_models.py:33, midprice_models.py:64)."""
+        generators of the reference (arrival_models.py:55, fill_probability_models.py:33, midprice_models.py:64).
+        `z_user` (N, 2): the two extra normals of user processes that draw noise of their own (`uses_extra_normals`)."""
         n = self.num_trajectories
+        if z_user is not None:
+            zu = _native.as_f32(z_user, (n, 2))
+            _native.check(_native.load_library().mbt_env_set_user_noise_host(self._handle, _native.fptr(zu)))
         ua = None if u_arr is None else _native.as_f32(u_arr, (n, 2))  # speed dynamics have no order flow: pass None
         uf = None if u_fill is None else _native.as_f32(u_fill, (n, 2))
         zz = _native.as_f32(np.asarray(z).reshape(-1), (n,))

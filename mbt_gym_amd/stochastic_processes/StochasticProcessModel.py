@@ -4,8 +4,12 @@ Same constructor surface and attributes as the reference's `StochasticProcessMod
 (mbt_gym/stochastic_processes/StochasticProcessModel.py:8-53) - `min_value`, `max_value` (shape (1, d)),
 `step_size`, `terminal_time`, `num_trajectories`, `initial_state` (1, d), `current_state` (N, d), `seed_` - but
 here a process is a DESCRIPTOR: it names a device implementation (`device_kind`) and carries its parameters
-(`device_params()`).  The numerics run inside the fused HIP step kernel (csrc/step_kernel.hpp); nothing is
-evaluated on the host, so `update()` on a descriptor raises instead of silently running a CPU path.
+(`device_params()`).  Inside an environment its numerics run in the fused HIP step kernel (csrc/step_kernel.hpp) and
+`update()` raises: the kernel, not the caller, advances it.  ON ITS OWN (not attached to an environment: a midprice path, an
+arrival stream - the reference's objects can be driven that way, SP:33-35) a built-in process keeps a host copy of its (N, d)
+state, draws from its own numpy Generator exactly like the reference's class does, and has the arithmetic of each call
+evaluated on the device in double (`mbt_process_evaluate_host`): there is no CPU implementation of the maths here either, and
+a process seeded like the reference's walks the reference's path.
 """
 import abc
 from typing import Optional
@@ -47,6 +51,7 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         self.rng = np.random.default_rng(seed)
         self._env = None  # set by TradingEnvironment: (env, first column, last column)
         self._columns = None
+        self._host_state = None  # stand-alone use: the (N, d) float64 state between update() calls
 
     # ---- descriptor side --------------------------------------------------------------------------------
     def device_params(self) -> dict:
@@ -67,15 +72,37 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         return np.repeat(self.initial_state, self.num_trajectories, axis=0)
 
     @property
+    def _stand_alone(self) -> bool:
+        return self._env is None  # not handed to a TradingEnvironment: driven by the caller
+
+    @property
     def current_state(self) -> np.ndarray:
-        """The process's columns of the device-resident state matrix (host copy)."""
-        if self._env is None or not self._env.has_device_state:
+        """Inside an environment: the process's columns of the device-resident state matrix (host copy).  On its own: the
+        (N, d) float64 state its update() calls have produced since reset() (SP:30-31)."""
+        if self._stand_alone:
+            if self._host_state is None or self._host_state.shape[0] != self.num_trajectories:
+                self._host_state = self.initial_vector_state.copy()
+            return self._host_state
+        if not self._env.has_device_state:
             return self.initial_vector_state
         lo, hi = self._columns
         return self._env.state[:, lo:hi]
 
+    @current_state.setter
+    def current_state(self, value):
+        if not self._stand_alone:
+            raise DeviceResidentError("inside an environment the state matrix lives in HBM: use env.set_state()")
+        self._host_state = np.array(value, dtype=np.float64)
+
     def reset(self):
-        """The device state is re-initialised by TradingEnvironment.reset(); nothing to do on the host."""
+        """SP:30-31 for stand-alone use; inside an environment TradingEnvironment.reset() re-initialises the device state."""
+        self._host_state = None
+
+    def _evaluate(self, op, a, b=None, c=None, d=None):
+        """One method call's arithmetic on host arrays, on the device in double (include/mbt_env.h: mbt_process_evaluate_host)."""
+        from mbt_gym_amd import _native
+
+        return _native.process_evaluate(op, self.device_params(), a, b, c, d)
 
     def seed(self, seed: int = None):
         # The reference gives process i its own generator seeded seed+i+1 (TE:345-348).  On the device all
@@ -85,6 +112,11 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         self.seed_ = seed
 
     def update(self, arrivals, fills, action, state=None):
-        raise DeviceResidentError(
-            f"{type(self).__name__}.update runs inside the fused HIP step kernel; call TradingEnvironment.step()."
-        )
+        if not self._stand_alone:
+            raise DeviceResidentError(
+                f"{type(self).__name__}.update runs inside the fused HIP step kernel; call TradingEnvironment.step()."
+            )
+        return self._update_stand_alone(arrivals, fills, action)
+
+    def _update_stand_alone(self, arrivals, fills, action):
+        raise DeviceResidentError(f"{type(self).__name__} has no host-callable update (its device form runs inside an environment only)")

@@ -19,17 +19,32 @@ from mbt_gym_amd.stochastic_processes.StochasticProcessModel import DeviceReside
 
 class ArrivalModel(StochasticProcessModel):
     def get_arrivals(self) -> np.ndarray:
-        raise DeviceResidentError(
-            "arrivals are drawn inside the fused HIP step kernel; enable env.record_events(True) and read "
-            "env.last_arrivals after a step."
-        )
+        """Inside an environment arrivals are drawn by the fused step kernel.  On its own (ARR:27-29) a built-in model draws
+        its (N, 2) uniforms from its generator like the reference's class and has them compared on the device, in double."""
+        if not self._stand_alone:
+            raise DeviceResidentError(
+                "arrivals are drawn inside the fused HIP step kernel; enable env.record_events(True) and read "
+                "env.last_arrivals after a step."
+            )
+        if self.device_kind not in (_native.ARR_POISSON, _native.ARR_POISSON_NONLINEAR, _native.ARR_HAWKES):
+            raise DeviceResidentError(f"{type(self).__name__} has no host-callable get_arrivals (its device form runs inside an environment only)")
+        unif = self.rng.uniform(size=(self.num_trajectories, 2))  # ARR:55, ARR:82, ARR:122
+        lam = self.current_state if self.device_kind == _native.ARR_HAWKES else None
+        return self._evaluate(_native.PROCESS_ARRIVALS, unif, lam) != 0.0
+
+    def _update_stand_alone(self, arrivals, fills, action):
+        if self.device_kind == _native.ARR_HAWKES:  # ARR:110-119
+            self.current_state = self._evaluate(_native.PROCESS_HAWKES_UPDATE, self.current_state, np.asarray(arrivals, dtype=np.float64))
+        elif self.device_kind not in (_native.ARR_POISSON, _native.ARR_POISSON_NONLINEAR):  # (ARR:51-52: Poisson models have no state to advance)
+            raise DeviceResidentError(f"{type(self).__name__} has no host-callable update (its device form runs inside an environment only)")
+        return self.current_state
 
 
 _EMPTY = np.array([[]])
 
 
 class DeviceExpressionArrivalModel(ArrivalModel):
-    """The device route for USER-DEFINED, stateless arrival models (the reference's plugin contract, ARR:9-29).
+    """The device route for USER-DEFINED arrival models (the reference's plugin contract, ARR:9-29).
 
     The reference asks a subclass for `get_arrivals()` in NumPy; there is no CPU path here to run NumPy code in the step,
     so a subclass states the probability of an arrival within one step as a C++ device expression in `t` (the time stamp of
@@ -41,17 +56,42 @@ class DeviceExpressionArrivalModel(ArrivalModel):
             def device_expression_params(self):
                 return {"base_bid": ..., "base_ask": ..., "amplitude": ..., "period": ...}
 
-    An arrival happens when the lane's uniform u < expression, compared in double.  The model adds no state columns (what it
-    needs of the past it must get from `t`); self-exciting models are `HawkesArrivalModel`.  Compiled into the step and rollout
-    kernels at run time (include/mbt_env.h, mbt_env_create_jit)."""
+    An arrival happens when the lane's uniform u < expression, compared in double.
+
+    A model WITH STATE (SP:8-53: `current_state` of shape (N, d), d = 1 or 2 - the built-in HawkesArrivalModel is the case
+    d = 2): pass `initial_state`, `min_value`, `max_value` of shape (1, d) and set `state_expressions` to d expressions for
+    the NEXT value of each column, in `x0`, `x1` (the model's columns before the step), `arr_bid`, `arr_ask` (1.0 where an
+    order arrived this step), `fills_bid`, `fills_ask`, `t`, `dt`, `S`, `z` and, with `uses_extra_normals = True`, `z1`, `z2`
+    (two more N(0, 1) draws per lane and step); `device_expression` reads `x0`, `x1` too.  E.g. Hawkes intensities that
+    also excite each other:
+
+        class CrossExcitingHawkes(DeviceExpressionArrivalModel):
+            device_expression = "(side == 0 ? x0 : x1) * dt"
+            state_expressions = ("x0 + beta * (base_bid - x0) * dt + eta * arr_bid + cross * arr_ask",
+                                 "x1 + beta * (base_ask - x1) * dt + eta * arr_ask + cross * arr_bid")
+
+    Compiled into the step and rollout kernels at run time (include/mbt_env.h, mbt_env_create_jit)."""
 
     device_kind = _native.ARR_USER
     device_expression: str = None
+    state_expressions: tuple = ()
+    uses_extra_normals: bool = False
 
-    def __init__(self, step_size: float = 0.001, num_trajectories: int = 1, seed: Optional[int] = None):
+    def __init__(self, step_size: float = 0.001, num_trajectories: int = 1, seed: Optional[int] = None, initial_state: np.ndarray = None,
+                 min_value: np.ndarray = None, max_value: np.ndarray = None, terminal_time: float = 0.0):
         if not self.device_expression:
             raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of get_arrivals)")
-        super().__init__(_EMPTY, _EMPTY, step_size, 0.0, _EMPTY, num_trajectories, seed)
+        d = len(self.state_expressions)
+        if d == 0:
+            super().__init__(_EMPTY, _EMPTY, step_size, terminal_time, _EMPTY, num_trajectories, seed)
+            return
+        if d > 2:
+            raise TypeError("a device arrival model owns at most two state columns")
+        if initial_state is None or min_value is None or max_value is None:
+            raise TypeError(f"{type(self).__name__} has {d} state column(s): pass initial_state, min_value and max_value of shape (1, {d})")
+        x0, lo, hi = (np.asarray(v, dtype=np.float64).reshape(1, -1) for v in (initial_state, min_value, max_value))
+        assert x0.shape == lo.shape == hi.shape == (1, d), f"initial_state / min_value / max_value must have shape (1, {d})"
+        super().__init__(lo, hi, step_size, terminal_time, x0, num_trajectories, seed)
 
     def device_expression_params(self) -> dict:
         return {}
@@ -61,6 +101,12 @@ class DeviceExpressionArrivalModel(ArrivalModel):
 
     def device_code(self):
         return self.device_expression, dict(self.device_expression_params())
+
+    def device_state(self):
+        """(update expressions, parameters, initial values, uses extra normals) of the model's own state columns, or None."""
+        if not self.state_expressions:
+            return None
+        return list(self.state_expressions), dict(self.device_expression_params()), [float(v) for v in self.initial_state[0]], bool(self.uses_extra_normals)
 
 
 class PoissonArrivalModel(ArrivalModel):

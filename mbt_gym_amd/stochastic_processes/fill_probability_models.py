@@ -20,10 +20,23 @@ _EMPTY = np.array([[]])
 
 class FillProbabilityModel(StochasticProcessModel):
     def get_fills(self, depths: np.ndarray) -> np.ndarray:
-        raise DeviceResidentError(
-            "fills are drawn inside the fused HIP step kernel; enable env.record_events(True) and read "
-            "env.last_fills after a step."
-        )
+        """Inside an environment fills are drawn by the fused step kernel.  On its own (FILL:28-34) a built-in model draws its
+        (N, 2) uniforms from its generator like the reference's class and has `u < p(depth)` evaluated on the device, in double."""
+        if not self._stand_alone:
+            raise DeviceResidentError(
+                "fills are drawn inside the fused HIP step kernel; enable env.record_events(True) and read "
+                "env.last_fills after a step."
+            )
+        if self.device_kind not in (_native.FILL_EXPONENTIAL, _native.FILL_EXOGENOUS_MM):
+            raise DeviceResidentError(f"{type(self).__name__} has no host-callable get_fills (its device form runs inside an environment only)")
+        depths = np.asarray(depths, dtype=np.float64)
+        assert depths.shape == (self.num_trajectories, 2), (  # FILL:29-32
+            "Depths must be a numpy array of shape " + f"({self.num_trajectories},2). Instead it is a numpy array of shape {depths.shape}.")
+        unif = self.rng.uniform(size=(self.num_trajectories, 2))  # FILL:33
+        return self._evaluate(_native.PROCESS_FILLS, unif, depths) != 0.0
+
+    def _update_stand_alone(self, arrivals, fills, action):
+        return self.current_state  # FILL:64-65, FILL:168-170: the fill models' own state never moves
 
     @property
     def max_depth(self) -> float:

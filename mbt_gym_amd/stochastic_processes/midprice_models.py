@@ -45,6 +45,26 @@ class _SymmetricBandMidprice(MidpriceModel):
     def initial_price(self) -> float:
         return float(self.initial_state[0, 0])
 
+    def _update_stand_alone(self, arrivals, fills, action):
+        return _midprice_update_stand_alone(self, arrivals, fills)
+
+
+def _midprice_update_stand_alone(model, arrivals, fills):
+    """update() of a built-in midprice model driven on its own (MID:60-65, :95-103, :140-143, :222-227, :264-270): one normal
+    (N, 1) from the model's generator - as the reference's class draws it - and the Euler step on the device in double."""
+    n = model.num_trajectories
+    state = model.current_state
+    if model.device_kind == _native.MID_CONSTANT:  # MID:32-33
+        return state
+    z = model.rng.normal(size=(n, 1))
+    jumps = model.device_kind in (_native.MID_BROWNIAN_JUMP, _native.MID_OU_JUMP) or (model.device_kind == _native.MID_LINEAR_SDE and model.jump_size != 0)
+    fills_bid = fills_ask = None
+    if jumps:  # MID:220-221: the agent's own executed quotes
+        fills_bid = np.asarray(fills, dtype=np.float64)[:, 0] * np.asarray(arrivals, dtype=np.float64)[:, 0]
+        fills_ask = np.asarray(fills, dtype=np.float64)[:, 1] * np.asarray(arrivals, dtype=np.float64)[:, 1]
+    model.current_state = model._evaluate(_native.PROCESS_MIDPRICE_UPDATE, state[:, 0], z[:, 0], fills_bid, fills_ask).reshape(n, 1)
+    return model.current_state
+
 
 class BrownianMotionMidpriceModel(_SymmetricBandMidprice):
     device_kind = _native.MID_BROWNIAN
@@ -238,6 +258,9 @@ class LinearSdeMidpriceModel(MidpriceModel):
     def initial_price(self) -> float:
         return float(self.initial_state[0, 0])
 
+    def _update_stand_alone(self, arrivals, fills, action):
+        return _midprice_update_stand_alone(self, arrivals, fills)
+
     def device_params(self):
         return dict(midprice_kind=self.device_kind, drift=self.drift, volatility=self.volatility, mid_coef_add=self.scale_constant,
                     mid_coef_mul=self.scale_proportional, ou_level=self.mean_reversion_level, ou_speed=self.mean_reversion_speed,
@@ -245,8 +268,8 @@ class LinearSdeMidpriceModel(MidpriceModel):
 
 
 class DeviceExpressionMidpriceModel(MidpriceModel):
-    """The device route for USER-DEFINED one-column midprice models whose increment is NOT of the linear-SDE form above: the
-    subclass states `update` (the reference's contract, SP:33-35) as a C++ device expression for S' - S in
+    """The device route for USER-DEFINED midprice models whose increment is NOT of the linear-SDE form above: the subclass
+    states `update` (the reference's contract, SP:33-35) as a C++ device expression for S' - S in
         S            the midprice before the step          t    the time at the beginning of the step
         z            this lane's N(0, 1) draw of the step   dt   this model's step size
         fills_bid, fills_ask   1.0 where the agent's bid / ask quote was filled this step (MID:220-221)
@@ -256,17 +279,37 @@ class DeviceExpressionMidpriceModel(MidpriceModel):
             device_expression = "mu * S * dt + sigma * pow(S, gamma) * sqrt(dt) * z"
 
     (the reference's own CEV class adds shape-(N,) noise to an (N, 1) state and is unusable for N > 1, MID:402-409).
-    Evaluated in double inside the fused step / rollout kernels, compiled at run time (include/mbt_env.h,
-    mbt_env_create_jit); the state column itself is float32.  min_value / max_value are the observation bounds."""
+
+    A SECOND FACTOR (the reference's plugin contract lets a process carry an (N, d) state, SP:8-53; its own two-column
+    midprices, MID:149-190, break for N > 1): set `factor_expression` to the NEXT value of the factor - the model's second
+    state column `x0` - as an expression in the same symbols plus `x0` (the factor before the step), `arr_bid`, `arr_ask`
+    (1.0 where an order arrived) and, with `uses_extra_normals = True`, `z1`, `z2` (two more N(0, 1) draws of the lane and
+    step); `device_expression` may read `x0`, `z1`, `z2` too.  E.g. a price with a mean-reverting short-term alpha:
+
+        class ShortTermAlphaMidprice(DeviceExpressionMidpriceModel):
+            device_expression = "x0 * dt + sigma * sqrt(dt) * z"
+            factor_expression = "x0 - kappa * x0 * dt + xi * sqrt(dt) * z1 + eps * (arr_ask - arr_bid)"
+            uses_extra_normals = True
+
+    Both are evaluated from the state BEFORE the step, like the reference's update().  Evaluated in double inside the fused
+    step / rollout kernels, compiled at run time (include/mbt_env.h, mbt_env_create_jit); the state columns themselves are
+    float32 (float64, exactly, with precise_state).  min_value / max_value (factor_min / factor_max) are observation bounds."""
 
     device_kind = _native.MID_USER
     device_expression: str = None
+    factor_expression: str = None
+    uses_extra_normals: bool = False
 
     def __init__(self, initial_price: float = 100.0, min_value: float = 0.0, max_value: float = 200.0, terminal_time: float = 1.0,
-                 step_size: float = 0.01, num_trajectories: int = 1, seed: Optional[int] = None):
+                 step_size: float = 0.01, num_trajectories: int = 1, seed: Optional[int] = None, initial_factor: float = 0.0,
+                 factor_min: float = -1.0, factor_max: float = 1.0):
         if not self.device_expression:
             raise TypeError(f"{type(self).__name__} must define `device_expression` (the device form of update: S' - S)")
-        super().__init__(np.array([[min_value]]), np.array([[max_value]]), step_size, terminal_time, np.array([[initial_price]]), num_trajectories, seed)
+        if self.factor_expression:
+            lo, hi, x0 = np.array([[min_value, factor_min]]), np.array([[max_value, factor_max]]), np.array([[initial_price, initial_factor]])
+        else:
+            lo, hi, x0 = np.array([[min_value]]), np.array([[max_value]]), np.array([[initial_price]])
+        super().__init__(lo, hi, step_size, terminal_time, x0, num_trajectories, seed)
 
     @property
     def initial_price(self) -> float:
@@ -280,3 +323,10 @@ class DeviceExpressionMidpriceModel(MidpriceModel):
 
     def device_code(self):
         return self.device_expression, dict(self.device_expression_params())
+
+    def device_state(self):
+        """(update expressions, parameters, initial values, uses extra normals) of the state columns this model owns BEYOND the
+        price itself - the second factor - or None."""
+        if not self.factor_expression:
+            return None
+        return [self.factor_expression], dict(self.device_expression_params()), [float(self.initial_state[0, 1])], bool(self.uses_extra_normals)

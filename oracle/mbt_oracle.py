@@ -54,7 +54,17 @@ class OracleConfig:
     # with its own observation bounds (midprice_lo, midprice_hi); the family every built-in midprice is a member of
     # "user_cev": a USER-DEFINED MidpriceModel with a non-linear increment (constant elasticity of variance):
     #   S <- S + drift S dt + volatility S^cev_gamma sqrt(dt) Z, bounds (midprice_lo, midprice_hi)
+    # "user_alpha": a USER-DEFINED TWO-COLUMN MidpriceModel (SP:8-53 lets a process carry (N, d) state; the reference's own
+    #   ShortTermOuAlphaMidpriceModel, MID:149-190, breaks for N > 1): [S, a] with
+    #   S <- S + a dt + volatility sqrt(dt) Z,   a <- a - alpha_kappa a dt + alpha_xi sqrt(dt) Z1 + alpha_eps (arr_ask - arr_bid),
+    #   both from the state before the step; Z, Z1 two normals of the model's generator; bounds (midprice_lo/hi, alpha_lo/hi)
     midprice: str = "bm"
+    alpha_kappa: float = 1.0
+    alpha_xi: float = 1.0
+    alpha_eps: float = 0.0
+    alpha_lo: float = -1.0
+    alpha_hi: float = 1.0
+    alpha_initial: float = 0.0
     cev_gamma: float = 1.0
     mid_coef_add: float = 1.0
     mid_coef_mul: float = 0.0
@@ -69,7 +79,10 @@ class OracleConfig:
     # arrivals: "poisson" (ARR:32-56), "poisson_nonlinear" (ARR:59-83), "hawkes" (ARR:86-126), "none" (speed dynamics)
     # "user_seasonal": a USER-DEFINED stateless ArrivalModel subclass (plugin contract ARR:9-29) with a time-of-day profile:
     #   p_side(t) = intensity_side (1 + seasonal_amplitude cos(2 pi t / seasonal_period)) dt, t = the time before the step
+    # "user_cross_hawkes": a USER-DEFINED ArrivalModel WITH STATE (two intensities, like ARR:86-126) in which an arrival on one
+    #   side also excites the other: lambda <- lambda + hawkes_speed (base - lambda) dt + hawkes_jump arrivals + hawkes_cross arrivals[::-1]
     arrival: str = "poisson"
+    hawkes_cross: float = 0.0
     seasonal_amplitude: float = 0.0
     seasonal_period: float = 1.0
     intensity: Sequence[float] = (140.0, 140.0)  # Poisson rate / Hawkes baseline (bid, ask)
@@ -140,8 +153,21 @@ class OracleConfig:
         return self.impact in ("temp_perm", "temp_transient", "transient")
 
     @property
+    def arrival_columns(self) -> int:
+        return 2 if self.arrival in ("hawkes", "user_cross_hawkes") else 0
+
+    @property
+    def midprice_columns(self) -> int:
+        return 2 if self.midprice == "user_alpha" else 1
+
+    @property
     def state_dim(self) -> int:
-        return 4 + (2 if self.arrival == "hawkes" else 0) + (2 if self.has_exogenous_fill else 0) + (1 if self.impact_has_state else 0)  # TE:311-318
+        return (3 + self.midprice_columns + self.arrival_columns + (2 if self.has_exogenous_fill else 0) + (1 if self.impact_has_state else 0))  # TE:311-318
+
+    @property
+    def arrival_column(self) -> int:
+        """First column of the arrival model's state: after the midprice model's columns (TE:303-318)."""
+        return 3 + self.midprice_columns
 
     @property
     def has_exogenous_fill(self) -> bool:
@@ -150,7 +176,7 @@ class OracleConfig:
     @property
     def exo_column(self) -> int:
         """First of the two best-depth columns: after the midprice and the arrival model's columns (TE:303-318)."""
-        return 4 + (2 if self.arrival == "hawkes" else 0)
+        return 3 + self.midprice_columns + self.arrival_columns
 
     @property
     def action_dim(self) -> int:
@@ -180,7 +206,7 @@ def midprice_bounds(cfg: OracleConfig) -> Tuple[float, float]:
         hi = cfg.initial_price * np.exp(cfg.drift * cfg.terminal_time) + 4 * stdev
     elif cfg.midprice == "constant":  # MID:21-23
         return float(cfg.initial_price), float(cfg.initial_price)
-    elif cfg.midprice in ("linear_sde", "user_cev"):  # the user's class states its own min_value / max_value (SP:11-12)
+    elif cfg.midprice in ("linear_sde", "user_cev", "user_alpha"):  # the user's class states its own min_value / max_value (SP:11-12)
         return float(cfg.midprice_lo), float(cfg.midprice_hi)
     else:
         raise ValueError(cfg.midprice)
@@ -215,7 +241,10 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
     mlo, mhi = midprice_bounds(cfg)
     lo.append(mlo)
     hi.append(mhi)
-    if cfg.arrival == "hawkes":
+    if cfg.midprice == "user_alpha":  # the second column of the user's midprice model
+        lo.append(float(cfg.alpha_lo))
+        hi.append(float(cfg.alpha_hi))
+    if cfg.arrival in ("hawkes", "user_cross_hawkes"):
         base = np.asarray(cfg.intensity, dtype=np.float64).reshape(-1)
         lo += [0.0, 0.0]  # ARR:100
         hi += list(base * 10)  # ARR:101, ARR:125-126
@@ -251,13 +280,16 @@ def action_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
 class InjectedNoise:
     """Replays pre-drawn noise: u_arr (K,N,2), u_fill (K,N,2), z (K,N)."""
 
-    def __init__(self, u_arr, u_fill, z):
+    def __init__(self, u_arr, u_fill, z, z_user=None):
         self.u_arr, self.u_fill, self.z = (np.asarray(a, dtype=np.float64) for a in (u_arr, u_fill, z))
+        self.z_user = None if z_user is None else np.asarray(z_user, dtype=np.float64)  # (K, N, 2): extra normals of user processes
         self.k = 0
+        self.last_user = None
 
     def draw(self, n: int):
         k = self.k
         self.k += 1
+        self.last_user = None if self.z_user is None else self.z_user[k]
         return self.u_arr[k], self.u_fill[k], self.z[k].reshape(n, 1)
 
 
@@ -325,7 +357,9 @@ class OracleEnv:
         s[:, TIME] = self._start_time() * np.ones((n,))
         s[:, INVENTORY] = self._initial_inventories()
         cols = [np.repeat(np.array([[cfg.initial_price]], dtype=np.float64), n, axis=0)]
-        if cfg.arrival == "hawkes":
+        if cfg.midprice == "user_alpha":
+            cols.append(np.repeat(np.array([[cfg.alpha_initial]], dtype=np.float64), n, axis=0))
+        if cfg.arrival in ("hawkes", "user_cross_hawkes"):
             cols.append(np.repeat(np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2), n, axis=0))
         if cfg.has_exogenous_fill:  # FILL:148-154
             cols.append(np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0))
@@ -401,8 +435,9 @@ class OracleEnv:
             elif cfg.arrival == "user_seasonal":  # the user's get_arrivals: the profile at the CURRENT time (the state's, before TE:216)
                 t_now = prev[0, TIME]
                 arrivals = u_arr < np.array(cfg.intensity) * (1.0 + cfg.seasonal_amplitude * np.cos(2 * np.pi * t_now / cfg.seasonal_period)) * adt
-            else:
-                arrivals = u_arr < st[:, 4:6] * adt
+            else:  # Hawkes (ARR:121-123) and the user's cross-exciting variant: the model's own two columns
+                ac = cfg.arrival_column
+                arrivals = u_arr < st[:, ac:ac + 2] * adt
             depths = action[:, 0:2]  # MD:50-51
             if cfg.dynamics == "touch":
                 fills = action[:, 0:2]  # the agent posts (or not) at the touch: MD:156-157
@@ -464,16 +499,29 @@ class OracleEnv:
             s_new = s_old + scale * (cfg.drift * mdt * np.ones((n, 1)) + noise_term) - cfg.ou_speed * (s_old - cfg.ou_level * np.ones((n, 1))) + jump
         elif cfg.midprice == "user_cev":  # the user's update(): per-trajectory CEV (what MID:401-409 meant)
             s_new = s_old + cfg.drift * s_old * mdt + cfg.volatility * s_old**cfg.cev_gamma * math.sqrt(mdt) * z
+        elif cfg.midprice == "user_alpha":  # the user's two-column update(): both columns from the state before the step
+            a_old = prev[:, 4].reshape(-1, 1)
+            z1 = self.noise.last_user[:, 0].reshape(-1, 1)
+            s_new = s_old + a_old * mdt + cfg.volatility * np.sqrt(mdt) * z
+            a_new = a_old - cfg.alpha_kappa * a_old * mdt + cfg.alpha_xi * np.sqrt(mdt) * z1 + cfg.alpha_eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
+            st[:, 4] = a_new[:, 0]
         else:  # constant, MID:32-33
             s_new = s_old
         st[:, PRICE] = s_new[:, 0]
         if cfg.arrival == "hawkes":  # ARR:110-119 (jumps on arrivals, not on fills)
-            lam = prev[:, 4:6]
+            ac = cfg.arrival_column
+            lam = prev[:, ac:ac + 2]
             base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
             adt = cfg.arrival_step_size or dt
-            st[:, 4:6] = (
+            st[:, ac:ac + 2] = (
                 lam + cfg.hawkes_speed * (np.ones((n, 2)) * base - lam) * adt * np.ones((n, 2)) + cfg.hawkes_jump * arrivals
             )
+        if cfg.arrival == "user_cross_hawkes":  # the user's update(): own jump and cross-excitation, from the intensities before the step
+            ac = cfg.arrival_column
+            lam = prev[:, ac:ac + 2]
+            base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
+            adt = cfg.arrival_step_size or dt
+            st[:, ac:ac + 2] = lam + cfg.hawkes_speed * (base - lam) * adt + cfg.hawkes_jump * arrivals + cfg.hawkes_cross * arrivals[:, ::-1]
         if cfg.impact_has_state:
             y = prev[:, -1].reshape(-1, 1)
             h = cfg.impact_step_size or dt

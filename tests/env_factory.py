@@ -57,6 +57,9 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
         "user_cev": lambda: __import__("tests.user_plugins", fromlist=["x"]).CevMidprice(
             drift=cfg.drift, volatility=cfg.volatility, gamma=cfg.cev_gamma, initial_price=cfg.initial_price, min_value=cfg.midprice_lo,
             max_value=cfg.midprice_hi, **common),
+        "user_alpha": lambda: __import__("tests.user_plugins", fromlist=["x"]).ShortTermAlphaMidprice(
+            volatility=cfg.volatility, kappa=cfg.alpha_kappa, xi=cfg.alpha_xi, eps=cfg.alpha_eps, alpha_lo=cfg.alpha_lo, alpha_hi=cfg.alpha_hi,
+            initial_price=cfg.initial_price, min_value=cfg.midprice_lo, max_value=cfg.midprice_hi, initial_factor=cfg.alpha_initial, **common),
     }[cfg.midprice]()
     arr = {
         "poisson": lambda: arr_m.PoissonArrivalModel(intensity=np.array(cfg.intensity), step_size=arr_dt, num_trajectories=n),
@@ -66,6 +69,8 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
         "none": lambda: None,
         "user_seasonal": lambda: __import__("tests.user_plugins", fromlist=["x"]).SeasonalArrivals(
             base=cfg.intensity, amplitude=cfg.seasonal_amplitude, period=cfg.seasonal_period, step_size=arr_dt, num_trajectories=n),
+        "user_cross_hawkes": lambda: __import__("tests.user_plugins", fromlist=["x"]).CrossExcitingHawkes(
+            baseline=cfg.intensity, speed=cfg.hawkes_speed, jump=cfg.hawkes_jump, cross=cfg.hawkes_cross, step_size=arr_dt, terminal_time=T, num_trajectories=n),
     }[cfg.arrival]()
     if cfg.fill == "exogenous":  # any two one-dimensional processes with these initial states and bounds (FILL:146-154)
         best = [_FixedBoundsProcess(cfg.exo_depth[s], cfg.exo_depth_lo[s], cfg.exo_depth_hi[s], dt, n, package) for s in range(2)]

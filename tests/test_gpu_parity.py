@@ -56,6 +56,8 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
     cash_tol = 1e-4 + 1e-6 * (np.abs(want[:, 0]) if cash_scale is None else cash_scale)
     assert np.all(np.abs(got[:, 0] - want[:, 0]) <= cash_tol), f"{name} step {k}: cash {np.max(np.abs(got[:, 0] - want[:, 0]))}"
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=2e-4, err_msg=f"{name} step {k}: midprice")
+    if want.shape[1] == 5 and not _is_speed(name):  # the second factor of a user's two-column midprice (float32 state, O(1) values)
+        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=2e-6, atol=2e-5, err_msg=f"{name} step {k}: second midprice factor")
     if want.shape[1] > 5:
         # float32 state: 2e-5 absolute around the baselines (10..50), float32 relative accuracy where arrivals have driven an
         # intensity to ~150 (ulp 1.5e-5 there)
@@ -67,7 +69,7 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
 def test_step_matches_reference_fixture(name, record):
     cfg, g = load_case(name)
     env = make_env(cfg, noise="injected")
-    oracle = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"]))
+    oracle = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"], g.get("z_user")))
     if record:
         env.record_events(True)
     obs0 = env.reset()
@@ -80,7 +82,7 @@ def test_step_matches_reference_fixture(name, record):
         if k in changes:  # the step_size setter in mid-episode (TE:158-167): host-side kernel parameters only
             env.step_size = changes[k]
             oracle.set_step_size(changes[k])
-        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k], g["z_user"][k] if "z_user" in g else None)
         obs, rew, dones, infos = env.step(g["actions"][k])
         o_obs, o_rew, o_done = oracle.step(g["actions"][k].astype(np.float64))
         # the live oracle and the stored reference outputs agree exactly (CPU test), so either is the target

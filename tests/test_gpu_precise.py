@@ -26,7 +26,9 @@ from tests.golden_io import CASES, load_case, step_size_changes
 pytestmark = pytest.mark.gpu
 
 # fixtures whose STATE passes through a transcendental function: x ** 1.5 in the temporary impact (IMP:55), the user's S ** gamma
-STATE_VIA_LIBM = {"speed_power_running", "user_cev_midprice"}
+# ... or a user's increment expression that associates differently from its NumPy original (S + (a dt + sigma sqrt(dt) z) on the
+# device - the expression IS the increment - against (S + a dt) + sigma sqrt(dt) z): one ulp of float64
+STATE_VIA_LIBM = {"speed_power_running", "user_cev_midprice", "user_two_factor_midprice", "user_two_factor_midprice_normalised"}
 # fixtures whose REWARD does: -exp(-gamma W) (RW:156-163), the user's exp(eta |q|) inventory cost
 REWARD_VIA_LIBM = {"bmjump_exputility", "user_fill_and_reward", "user_reward_touch"} | STATE_VIA_LIBM
 F32_ULP = 2.0 ** -23
@@ -55,7 +57,8 @@ def test_precise_state_reproduces_the_reference_fixture_bit_for_bit(name):
     for k in range(g["actions"].shape[0]):
         if k in changes:
             env.step_size = changes[k]
-        env.set_noise(None if _is_speed(name) else g["u_arr"][k], None if _is_speed(name) else g["u_fill"][k], g["z"][k])
+        env.set_noise(None if _is_speed(name) else g["u_arr"][k], None if _is_speed(name) else g["u_fill"][k], g["z"][k],
+                      g["z_user"][k] if "z_user" in g else None)
         obs, rew, dones, _ = env.step(g["actions"][k])
         want_obs, want_rew = g["obs"][k], g["rewards"][k]
         if not _is_speed(name):
@@ -63,7 +66,7 @@ def test_precise_state_reproduces_the_reference_fixture_bit_for_bit(name):
             np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"{name} step {k}: fills")
         _assert_reward(name, k, rew, want_rew)
         if name in STATE_VIA_LIBM:
-            np.testing.assert_allclose(obs, want_obs, rtol=2 * F32_ULP, atol=0, err_msg=f"{name} step {k}: observation")
+            np.testing.assert_allclose(obs, want_obs, rtol=2 * F32_ULP, atol=2e-7 if cfg.normalise_observation_space else 0, err_msg=f"{name} step {k}: observation")
             if not cfg.normalise_observation_space:
                 np.testing.assert_allclose(env.state64, want_obs, rtol=1e-12, atol=0, err_msg=f"{name} step {k}: float64 state")
         else:

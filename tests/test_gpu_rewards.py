@@ -70,3 +70,62 @@ def test_device_calculate_is_bitwise_the_float64_formula():
     np.testing.assert_allclose(cj.calculate(cur, None, nxt), want, rtol=0, atol=1e-12)
     with pytest.raises(Exception):
         CjMmCriterion().calculate(cur, None, nxt)  # before reset(): the reference fails too (None ** p)
+
+
+def test_process_objects_driven_on_their_own_walk_the_references_path():
+    """The reference's plugin objects can be used outside an environment (SP:33-35, ARR:27-29, FILL:28-34).  Ours then keep a
+    host copy of their state, draw from their own numpy Generator like the reference's classes, and have each call's
+    arithmetic evaluated on the device in double, in the reference's operation order: seeded alike they produce the values
+    the reference's NumPy statements produce (restated here line by line; exp() is the one libm call)."""
+    from mbt_gym_amd.stochastic_processes.arrival_models import HawkesArrivalModel, PoissonArrivalModel, PoissonArrivalNonLinearModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+    from mbt_gym_amd.stochastic_processes.midprice_models import (BrownianMotionMidpriceModel, GeometricBrownianMotionMidpriceModel, OuJumpMidpriceModel,
+                                                                 OuMidpriceModel)
+
+    n, dt, seed = 500, 0.01, 7
+    # midprices: MID:60-65, MID:140-143, MID:95-103, MID:264-270
+    bm = BrownianMotionMidpriceModel(drift=0.3, volatility=2.0, initial_price=100.0, step_size=dt, num_trajectories=n, seed=seed)
+    rng, s = np.random.default_rng(seed), np.full((n, 1), 100.0)
+    for _ in range(5):
+        s = s + 0.3 * dt * np.ones((n, 1)) + 2.0 * np.sqrt(dt) * rng.normal(size=(n, 1))
+        np.testing.assert_array_equal(bm.update(None, None, None), s)
+    bm.reset()
+    np.testing.assert_array_equal(bm.current_state, np.full((n, 1), 100.0))
+    ou = OuMidpriceModel(mean_reversion_level=99.0, mean_reversion_speed=0.05, volatility=1.5, initial_price=100.0, step_size=dt, num_trajectories=n, seed=seed)
+    rng, s = np.random.default_rng(seed), np.full((n, 1), 100.0)
+    for _ in range(5):
+        s = s + (-0.05 * (s - 99.0 * np.ones((n, 1))) + 1.5 * np.sqrt(dt) * rng.normal(size=(n, 1)))
+        np.testing.assert_array_equal(ou.update(None, None, None), s)
+    gbm = GeometricBrownianMotionMidpriceModel(drift=0.1, volatility=0.2, initial_price=50.0, step_size=dt, num_trajectories=n, seed=seed)
+    rng, s = np.random.default_rng(seed), np.full((n, 1), 50.0)
+    for _ in range(5):
+        s = s + 0.1 * s * dt + 0.2 * s * np.sqrt(dt) * rng.normal(size=(n, 1))
+        np.testing.assert_array_equal(gbm.update(None, None, None), s)
+    jump = OuJumpMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.02, volatility=1.0, jump_size=0.25, initial_price=100.0, step_size=dt,
+                               num_trajectories=n, seed=seed)
+    rng, s, events = np.random.default_rng(seed), np.full((n, 1), 100.0), np.random.default_rng(1)
+    for _ in range(5):
+        arrivals, fills = events.integers(0, 2, size=(n, 2)).astype(bool), events.integers(0, 2, size=(n, 2))
+        j = (0.25 * (fills[:, 1] * arrivals[:, 1]) - 0.25 * (fills[:, 0] * arrivals[:, 0])).reshape(-1, 1)
+        s = s - 0.02 * (s - 100.0 * np.ones((n, 1))) + 1.0 * np.sqrt(dt) * rng.normal(size=(n, 1)) + j
+        np.testing.assert_array_equal(jump.update(arrivals, fills, None), s)
+    # arrivals: ARR:54-56, ARR:81-83, ARR:110-123
+    for cls, thr in ((PoissonArrivalModel, np.array([140.0, 90.0]) * dt), (PoissonArrivalNonLinearModel, 1.0 - np.exp(-np.array([140.0, 90.0]) * dt))):
+        model, rng = cls(intensity=np.array([140.0, 90.0]), step_size=dt, num_trajectories=n, seed=seed), np.random.default_rng(seed)
+        for _ in range(3):
+            np.testing.assert_array_equal(model.get_arrivals(), rng.uniform(size=(n, 2)) < thr)
+    hawkes = HawkesArrivalModel(baseline_arrival_rate=np.array([[10.0, 14.0]]), step_size=dt, jump_size=40.0, mean_reversion_speed=60.0, num_trajectories=n, seed=seed)
+    rng, lam = np.random.default_rng(seed), np.repeat(np.array([[10.0, 14.0]]), n, axis=0)
+    for _ in range(6):
+        arrivals = rng.uniform(size=(n, 2)) < lam * dt
+        np.testing.assert_array_equal(hawkes.get_arrivals(), arrivals)
+        lam = lam + 60.0 * (np.ones((n, 2)) * np.array([[10.0, 14.0]]) - lam) * dt * np.ones((n, 2)) + 40.0 * arrivals
+        np.testing.assert_array_equal(hawkes.update(arrivals, None, None), lam)
+    # fills: FILL:28-34, FILL:57-58 (exp: device libm against NumPy's - a draw within an ulp of the probability may differ)
+    fill, rng = ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n, seed=seed), np.random.default_rng(seed)
+    depths = np.random.default_rng(2).uniform(0.0, 2.0, size=(n, 2))
+    unif = rng.uniform(size=(n, 2))
+    got, want = fill.get_fills(depths), unif < np.exp(-1.5 * depths)
+    assert np.all((got == want) | (np.abs(unif - np.exp(-1.5 * depths)) < 1e-15))
+    with pytest.raises(AssertionError):
+        fill.get_fills(depths[:, :1])

@@ -25,13 +25,14 @@ def test_fixture_set_is_complete():
         "speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transient_pnl", "speed_transient_pnl",
         "step_size_change_hawkes", "step_size_change_speed", "user_linear_sde_midprice",
         "user_fill_and_reward", "user_fill_hawkes_market_normalised", "user_reward_touch", "user_seasonal_arrivals", "user_cev_midprice",
+        "user_cross_hawkes", "user_two_factor_midprice", "user_two_factor_midprice_normalised",
     }
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_reproduces_reference_bit_for_bit(name):
     cfg, g = load_case(name)
-    env = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"]))
+    env = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"], g.get("z_user")))
     np.testing.assert_array_equal(env.obs_lo, g["obs_lo"])
     np.testing.assert_array_equal(env.obs_hi, g["obs_hi"])
     np.testing.assert_array_equal(env.act_lo, g["act_lo"])

@@ -75,7 +75,15 @@ def test_a_plugin_class_without_a_device_form_is_refused(no_device):
                                      dynamics="touch", market_half_spread=0.25),
                                 dict(midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0, midprice_hi=80.0),
                                 dict(midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0, midprice_hi=80.0,
-                                     fill="exponential", reward="pnl")])
+                                     fill="exponential", reward="pnl"),
+                                # processes that OWN state columns: a two-column arrival model, a two-column midprice (with two more normals per step), both
+                                dict(arrival="user_cross_hawkes", intensity=(18.0, 12.0), hawkes_speed=25.0, hawkes_jump=14.0, hawkes_cross=6.0),
+                                dict(arrival="user_cross_hawkes", intensity=(18.0, 12.0), hawkes_speed=25.0, hawkes_jump=14.0, hawkes_cross=6.0, fill="exponential",
+                                     reward="cjmm", dynamics="limit_and_market", market_half_spread=0.4, normalise_action_space=True, normalise_observation_space=True),
+                                dict(midprice="user_alpha", volatility=1.2, alpha_kappa=8.0, alpha_xi=3.0, alpha_eps=0.75, midprice_lo=90.0, midprice_hi=110.0,
+                                     alpha_lo=-10.0, alpha_hi=10.0, fill="exponential", reward="running"),
+                                dict(midprice="user_alpha", volatility=1.2, alpha_kappa=8.0, alpha_xi=3.0, alpha_eps=0.75, midprice_lo=90.0, midprice_hi=110.0,
+                                     alpha_lo=-10.0, alpha_hi=10.0, dynamics="touch", market_half_spread=0.25, fill="exponential", reward="pnl")])
 def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw):
     from mbt_gym_amd import _native
 
@@ -88,12 +96,20 @@ def test_user_plugins_on_philox_noise_match_the_oracle_and_the_fused_rollout(kw)
         action = np.tile(np.array([[1.0, 1.0]], np.float32), (n, 1))  # post on both sides
     env, fused = make_env(cfg), make_env(cfg)
     draws = [_native.rng_fill(seed, 0, k, n) for k in range(steps)]
-    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    z_user = np.stack([_native.rng_fill_user(seed, 0, k, n) for k in range(steps)]) if cfg.midprice == "user_alpha" else None
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)], z_user))
+    if cfg.normalise_action_space:
+        action = np.tile(np.array([[-0.6, -0.4, -1.0, 0.3][:a_dim]], np.float32), (n, 1))
     env.reset(), fused.reset(), oracle.reset()
+    assert env.observation_dim == cfg.state_dim
     for k in range(steps):
         obs, rew, dones, _ = env.step(action)
         o_obs, o_rew, _ = oracle.step(action.astype(np.float64))
-        np.testing.assert_array_equal(obs[:, 1], o_obs[:, 1], err_msg=f"step {k}: inventory")
+        if cfg.normalise_observation_space:
+            np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-4, err_msg=f"step {k}: normalised observation")
+        else:
+            np.testing.assert_array_equal(obs[:, 1], o_obs[:, 1], err_msg=f"step {k}: inventory")
+            np.testing.assert_allclose(obs[:, 4:], o_obs[:, 4:], rtol=3e-6, atol=3e-5, err_msg=f"step {k}: process state columns")
         clipped = oracle.last_clipped
         err = np.abs(rew - o_rew)
         assert np.all(err[~clipped] <= 1e-5 + 1e-6 * np.abs(o_rew[~clipped])), f"step {k}: reward {err[~clipped].max()}"

@@ -68,3 +68,38 @@ class CevMidprice(DeviceExpressionMidpriceModel):
 
     def device_expression_params(self):
         return {"mu": self.drift, "sigma": self.volatility, "gamma": self.gamma}
+
+
+class CrossExcitingHawkes(DeviceExpressionArrivalModel):
+    """An arrival model WITH STATE (two intensities, like the reference's Hawkes model) in which an arrival on one side also
+    excites the other.  The two state expressions restate, operation for operation, the update() of the reference-API class
+    the fixture `user_cross_hawkes` was produced with (tools/refgen/make_golden.py: UserCrossExcitingHawkes)."""
+
+    device_expression = "(side == 0 ? x0 : x1) * dt"
+    state_expressions = ("x0 + beta * (base_bid - x0) * dt + eta * arr_bid + cross * arr_ask",
+                         "x1 + beta * (base_ask - x1) * dt + eta * arr_ask + cross * arr_bid")
+
+    def __init__(self, baseline=(18.0, 12.0), speed: float = 25.0, jump: float = 14.0, cross: float = 6.0, step_size: float = 0.01,
+                 terminal_time: float = 1.0, num_trajectories: int = 1, seed=None):
+        self.baseline, self.speed, self.jump, self.cross = np.asarray(baseline, dtype=np.float64).reshape(1, 2), speed, jump, cross
+        super().__init__(step_size=step_size, num_trajectories=num_trajectories, seed=seed, initial_state=self.baseline, min_value=np.zeros((1, 2)),
+                         max_value=self.baseline * 10, terminal_time=terminal_time)
+
+    def device_expression_params(self):
+        return {"base_bid": self.baseline[0, 0], "base_ask": self.baseline[0, 1], "beta": self.speed, "eta": self.jump, "cross": self.cross}
+
+
+class ShortTermAlphaMidprice(DeviceExpressionMidpriceModel):
+    """A TWO-COLUMN midprice: the price and a mean-reverting short-term alpha that order flow pushes and the price drifts
+    with (what the reference's ShortTermOuAlphaMidpriceModel describes, MID:149-190, per trajectory); two normals per step."""
+
+    device_expression = "x0 * dt + sigma * sqrt(dt) * z"
+    factor_expression = "x0 - kappa * x0 * dt + xi * sqrt(dt) * z1 + eps * (arr_ask - arr_bid)"
+    uses_extra_normals = True
+
+    def __init__(self, volatility: float = 1.2, kappa: float = 8.0, xi: float = 3.0, eps: float = 0.75, alpha_lo: float = -10.0, alpha_hi: float = 10.0, **kw):
+        self.volatility, self.kappa, self.xi, self.eps = volatility, kappa, xi, eps
+        super().__init__(factor_min=alpha_lo, factor_max=alpha_hi, **kw)
+
+    def device_expression_params(self):
+        return {"sigma": self.volatility, "kappa": self.kappa, "xi": self.xi, "eps": self.eps}

@@ -120,8 +120,12 @@ def draw_actions(rng, k, n, a_dim, max_depth, normalised, kind="depths", max_spe
 
 
 def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, kappa=1.5, poisson_thr=None, action_kind="depths",
-             fill_prob=None, action_hook=None, step_size_changes=None):
-    """step_size_changes: {step index: new step size} - `env.step_size = value` (TE:158-167) before that step."""
+             fill_prob=None, action_hook=None, step_size_changes=None, user_normals=False):
+    """step_size_changes: {step index: new step size} - `env.step_size = value` (TE:158-167) before that step.
+    user_normals: the midprice model draws TWO normals per lane and step in one call, rng.normal(size=(N, 2)): column 0 is the
+    fixture's `z`, column 1 is saved as `z_user[..., 0]` (the extra normals of user processes; `z_user[..., 1]` is not consumed)."""
+    if ONLY is not None and name not in ONLY:
+        return
     rng = np.random.default_rng(1000 + seed)
     with contextlib.redirect_stdout(io.StringIO()):
         env = build_env()
@@ -142,7 +146,12 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         lo, c, hi = f32_neighbours(p)
         for j, v in enumerate((lo, c, hi)):
             u_fill[1::4, (3 + j) % n, :] = v[1::4, (3 + j) % n, :]
-    md.midprice_model.rng = Replay(normals=z)
+    z_user = None
+    if user_normals:
+        z_user = rng.normal(size=(k_steps, n, 2)).astype(np.float32)
+        md.midprice_model.rng = Replay(normals=np.stack([z, z_user[:, :, 0]], axis=-1))
+    else:
+        md.midprice_model.rng = Replay(normals=z)
     if md.arrival_model is not None:
         md.arrival_model.rng = Replay(uniforms=u_arr)
     if md.fill_probability_model is not None:
@@ -194,6 +203,7 @@ def run_case(name, build_env, k_steps, n, a_dim, seed, cfg, normalised=False, ka
         obs_lo=lo, obs_hi=hi, act_lo=np.float32(alo), act_hi=np.float32(ahi), max_cash=float(env.max_cash),
         process_indices=np.array([v for v in env.stochastic_process_indices.values()]),
         config_json=json.dumps(dict(cfg, num_trajectories=n)),
+        **({"z_user": z_user} if z_user is not None else {}),
         **({"step_size_at": np.array(sorted(step_size_changes)), "step_size_to": np.array([step_size_changes[k] for k in sorted(step_size_changes)])}
            if step_size_changes else {}),
     )
@@ -592,8 +602,13 @@ def round2_cases():
         poisson_thr=55.0 / ns)
 
 
-def user_plugin_cases():
+ONLY = None  # when set: the names of the cases run_case still runs (regenerating some fixtures leaves the others' bytes untouched)
+
+
+def user_plugin_cases(only=None):
     """User-defined FillProbabilityModel and RewardFunction subclasses written against the reference's plugin API."""
+    global ONLY
+    ONLY = only
     from mbt_gym.gym.index_names import CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX
     from mbt_gym.rewards.RewardFunctions import RewardFunction
     from mbt_gym.stochastic_processes.fill_probability_models import FillProbabilityModel
@@ -737,6 +752,72 @@ def user_plugin_cases():
              initial_inventory=2, max_inventory=8, seed=65, **common),
         poisson_thr=50.0 / ns)
 
+    # Z1. a user-defined ArrivalModel WITH STATE (SP:8-53: a subclass carries its own (N, d) current_state): two intensities
+    #     like the reference's Hawkes model (ARR:86-126) in which an arrival on one side also excites the other
+    class UserCrossExcitingHawkes(ArrivalModel):
+        def __init__(self, baseline, speed, jump, cross, step_size, terminal_time, num_trajectories, seed=None):
+            self.baseline, self.speed, self.jump, self.cross = np.array(baseline, dtype=float).reshape(1, 2), speed, jump, cross
+            super().__init__(min_value=np.zeros((1, 2)), max_value=self.baseline * 10, step_size=step_size, terminal_time=terminal_time,
+                             initial_state=self.baseline, num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            lam = self.current_state
+            self.current_state = lam + self.speed * (self.baseline - lam) * self.step_size + self.jump * arrivals + self.cross * arrivals[:, ::-1]
+
+        def get_arrivals(self):
+            unif = self.rng.uniform(size=(self.num_trajectories, 2))
+            return unif < self.current_state * self.step_size
+
+    n, ns = 32, 90
+    run_case(
+        "user_cross_hawkes",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=66, initial_inventory=(-2, 3), max_inventory=6, num_trajectories=n,
+            reward_function=CjMmCriterion(0.02, 0.05, terminal_time=1.0),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                OuMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.02, volatility=1.5, initial_price=100.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                UserCrossExcitingHawkes([18.0, 12.0], 25.0, 14.0, 6.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n)),
+            **common),
+        ns, n, 2, 66,
+        dict(n_steps=ns, terminal_time=1.0, midprice="ou", ou_level=100.0, ou_speed=0.02, volatility=1.5, initial_price=100.0, arrival="user_cross_hawkes",
+             intensity=[18.0, 12.0], hawkes_speed=25.0, hawkes_jump=14.0, hawkes_cross=6.0, fill_exponent=1.5, dynamics="limit", reward="cjmm", phi=0.02,
+             alpha=0.05, initial_inventory=[-2, 3], max_inventory=6, seed=66, **common))
+
+    # Z2. a user-defined TWO-COLUMN MidpriceModel: price + a mean-reverting short-term alpha that order flow pushes (what the
+    #     reference's ShortTermOuAlphaMidpriceModel, MID:149-190, describes and cannot run for N > 1); two normals per step
+    class UserShortTermAlphaMidprice(MidpriceModel):
+        def __init__(self, volatility, kappa, xi, eps, initial_price, lo, hi, alpha_lo, alpha_hi, terminal_time, step_size, num_trajectories, seed=None):
+            self.volatility, self.kappa, self.xi, self.eps = volatility, kappa, xi, eps
+            super().__init__(min_value=np.array([[lo, alpha_lo]]), max_value=np.array([[hi, alpha_hi]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[initial_price, 0.0]]), num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            s, a = self.current_state[:, 0:1], self.current_state[:, 1:2]
+            z = self.rng.normal(size=(self.num_trajectories, 2))
+            dt = self.step_size
+            s_new = s + a * dt + self.volatility * np.sqrt(dt) * z[:, 0:1]
+            a_new = a - self.kappa * a * dt + self.xi * np.sqrt(dt) * z[:, 1:2] + self.eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
+            self.current_state = np.append(s_new, a_new, axis=1)
+
+    n, ns = 32, 80
+    alpha = dict(volatility=1.2, alpha_kappa=8.0, alpha_xi=3.0, alpha_eps=0.75, initial_price=100.0, midprice_lo=90.0, midprice_hi=110.0, alpha_lo=-10.0, alpha_hi=10.0)
+    for tag, norm in (("user_two_factor_midprice", common), ("user_two_factor_midprice_normalised", dict(normalise_action_space=True, normalise_observation_space=True))):
+        run_case(
+            tag,
+            lambda norm=norm: TradingEnvironment(
+                terminal_time=1.0, n_steps=ns, seed=67, initial_inventory=1, max_inventory=5, num_trajectories=n,
+                reward_function=RunningInventoryPenalty(0.01, 0.05),
+                model_dynamics=lo_dynamics(
+                    n, 1 / ns, 1.0,
+                    UserShortTermAlphaMidprice(1.2, 8.0, 3.0, 0.75, 100.0, 90.0, 110.0, -10.0, 10.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                    PoissonArrivalModel(intensity=np.array([45.0, 60.0]), step_size=1 / ns, num_trajectories=n)),
+                **norm),
+            ns, n, 2, 67,
+            dict(n_steps=ns, terminal_time=1.0, midprice="user_alpha", arrival="poisson", intensity=[45.0, 60.0], fill_exponent=1.5, dynamics="limit",
+                 reward="running", phi=0.01, alpha=0.05, initial_inventory=1, max_inventory=5, seed=67, **alpha, **norm),
+            poisson_thr=45.0 / ns, user_normals=True, normalised=norm["normalise_observation_space"])
+
     # W. user reward with the built-in exponential fill, at the touch
     n, ns = 24, 60
     run_case(
@@ -761,6 +842,8 @@ if __name__ == "__main__":
         user_plugin_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
         exogenous_fill_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--only-round3":  # the stateful user processes (leaves the other fixtures' bytes untouched)
+        user_plugin_cases(only=("user_cross_hawkes", "user_two_factor_midprice", "user_two_factor_midprice_normalised"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-round2":
         round2_cases()
     else:
