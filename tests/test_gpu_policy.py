@@ -63,6 +63,8 @@ def test_mlp_policy_kernel_matches_the_numpy_restatement(kw, hidden, activation)
     rng = np.random.default_rng(11)
     raw = not cfg.normalise_observation_space
     layers = _random_mlp(rng, env.observation_dim, hidden, env.action_dim, scale=0.05 if raw else 1.5)
+    if not cfg.normalise_action_space:  # raw depths live in [0, max_depth]: centre the outputs inside the Box instead of on its lower edge
+        layers[2] = (layers[2][0], layers[2][1] + np.float32(1.5))
     policy = _native.mlp_policy(layers, activation)
     env.reset()
     warm = np.tile(np.array([[0.0] * env.action_dim], np.float32), (n, 1)) if not raw else np.tile(np.array([[0.5] * env.action_dim], np.float32), (n, 1))

@@ -70,7 +70,7 @@ def test_reference_loop_for_actors_the_kernels_do_not_evaluate_and_the_two_paths
 def test_sampled_actions_are_scored_around_the_mean_the_kernel_used():
     """The fused rollout samples a ~ N(kernel mean, std) with the network on fp16 operands; REINFORCE scores those actions
     with log N(a | mean, std).  `kernel_mean` restates the kernel's evaluation in torch (differentiable, straight-through for
-    the weight rounding): it reproduces the kernel's deterministic actions ten times closer than the float32 network does,
+    the weight rounding): it reproduces the kernel's deterministic actions several times closer than the float32 network does,
     so the score has no systematic (kernel mean - float32 mean) / std^2 term - at std = 0.01 that term would be O(1)."""
     env = _env(2048, horizon=10)
     net = _actor().to("cuda")
@@ -84,7 +84,7 @@ def test_sampled_actions_are_scored_around_the_mean_the_kernel_used():
     o = torch.as_tensor(obs, device="cuda")
     restated, plain = agent.kernel_mean(o), net(o)
     err_restated, err_plain = float((restated - kernel).abs().max()), float((plain - kernel).abs().max())
-    assert err_restated <= 2e-4 and err_restated < 0.25 * err_plain, (err_restated, err_plain)
+    assert err_restated <= 1e-4 and err_restated < 0.5 * err_plain, (err_restated, err_plain)  # (what is left: tanh implementations, fp16 rounding ties)
     restated.sum().backward()  # gradients reach the float32 parameters through the rounding
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in net.parameters())
     # and the score of sampled actions is centred: (a - kernel mean) / std has mean ~ 0 (it had a bias of ~ err_plain / std)
