@@ -434,13 +434,16 @@ void fill_static_params(mbt_env* e) {
     P.arr_thr_bid = round_up_f32(c.intensity[0] * e->arr_dt);
     P.arr_thr_ask = round_up_f32(c.intensity[1] * e->arr_dt);
   }
-  {  // the Philox uniforms are k * 2^-24, k integer: u < thr <=> k < ceil(thr * 2^24) (the product is exact in double)
+  {  // the Philox uniforms are (w >> 8) * 2^-24: u < thr <=> (w >> 8) < K = ceil(thr * 2^24) (exact in double) <=> w < (K << 8)
     const auto as_count = [](float thr) -> uint32_t {
       const double x = std::ceil(static_cast<double>(thr) * 16777216.0);
       return x <= 0.0 ? 0u : (x >= 16777216.0 ? 16777216u : static_cast<uint32_t>(x));
     };
-    P.arr_thr_k_bid = as_count(P.arr_thr_bid);
-    P.arr_thr_k_ask = as_count(P.arr_thr_ask);
+    const uint32_t k_bid = as_count(P.arr_thr_bid), k_ask = as_count(P.arr_thr_ask);
+    P.arr_always_bid = k_bid >= 16777216u ? 1 : 0;
+    P.arr_always_ask = k_ask >= 16777216u ? 1 : 0;
+    P.arr_thr_w_bid = P.arr_always_bid ? 0xFFFFFFFFu : (k_bid << 8);
+    P.arr_thr_w_ask = P.arr_always_ask ? 0xFFFFFFFFu : (k_ask << 8);
   }
   P.arr_dt_f64 = e->arr_dt;
   P.arr_dt = static_cast<float>(e->arr_dt);

@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t low_bytes(const PhiloxWords& w) {
 
 struct LaneNoise {
   float ua_bid, ua_ask, uf_bid, uf_ask, z;
-  uint32_t ka_bid, ka_ask;  // the arrival uniforms as 24-bit integers (u = k * 2^-24): a Poisson arrival is decided on these
+  uint32_t wa_bid, wa_ask;  // the generator's own 32-bit words behind the arrival uniforms (u = (w >> 8) * 2^-24): a Poisson arrival is decided on these
 };
 
 // Noise of the pair `pair` (global pair index) at `step`: a = its lower lane, b = the lane 256 above.
@@ -97,7 +97,7 @@ __device__ __forceinline__ void philox_pair_noise(uint64_t pair, uint32_t step, 
   const PhiloxWords wb = philox4x32_10(plo, phi, step, 1u, k0, k1);
   a.ua_bid = uniform24(wa.w0); a.ua_ask = uniform24(wa.w1); a.uf_bid = uniform24(wa.w2); a.uf_ask = uniform24(wa.w3);
   b.ua_bid = uniform24(wb.w0); b.ua_ask = uniform24(wb.w1); b.uf_bid = uniform24(wb.w2); b.uf_ask = uniform24(wb.w3);
-  a.ka_bid = wa.w0 >> 8; a.ka_ask = wa.w1 >> 8; b.ka_bid = wb.w0 >> 8; b.ka_ask = wb.w1 >> 8;
+  a.wa_bid = wa.w0; a.wa_ask = wa.w1; b.wa_bid = wb.w0; b.wa_ask = wb.w1;
   box_muller(low_bytes(wa), low_bytes(wb), a.z, b.z);
 }
 
