@@ -652,97 +652,6 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   return r;
 }
 
-// The two lanes of a thread advanced TOGETHER, for the loops that are bound by vector instruction issue (the fused rollout):
-// everything after the Bernoulli decisions is the same float32 arithmetic on two independent lanes, so it is written on
-// 2-vectors - gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on a register pair as ONE instruction.  Expression by
-// expression this is lane_step (a packed operation rounds each half like the scalar one, and the fused multiply-adds sit
-// where lane_step has them), so the results are bit-identical to two lane_step calls - which the rollout-against-step-loop
-// tests assert.  What cannot be packed stays per lane: compares, selects, v_med3.
-typedef float v2f_pk __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f_pk pk_fma(v2f_pk a, v2f_pk b, v2f_pk c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f_pk pk_splat(float x) { return v2f_pk{x, x}; }
-
-#ifndef MBT_PACKED_PAIR_STEP
-#define MBT_PACKED_PAIR_STEP 1  // 0: the fused rollouts advance the pair with two lane_step calls (measurement knob)
-#endif
-template <class V>
-struct PairStepIsPacked {
-  static constexpr bool value = MBT_PACKED_PAIR_STEP != 0 && !V::PRECISE && !V::USER_MID && !V::USER_REWARD && V::USER_STATE == 0 && V::REWARD != kRewardGeneral;
-};
-
-__device__ __forceinline__ void copy_decisions(const Decisions& D, LaneResult& r) {
-  r.lo = make_int4(0, 0, 0, 0);
-  r.arr_bid = D.arr_bid != 0.0f;
-  r.arr_ask = D.arr_ask != 0.0f;
-  r.fill_bid = D.fill_bid;
-  r.fill_ask = D.fill_ask;
-  r.mo_buy = D.mo_buy;
-  r.mo_sell = D.mo_sell;
-}
-
-template <class V>
-__device__ __forceinline__ void pair_step(const float4 core0, const float4 core1, const float2 lam0, const float2 lam1, const float4 act0, const float4 act1,
-                                          const LaneDraw& dr0, const LaneDraw& dr1, const float q_init0, const float q_init1, const float t_next,
-                                          const bool is_terminal, const StepParams& P, const double t_now, LaneResult& r0, LaneResult& r1) {
-  const bool norm_act = V::NORM && P.norm_act;
-  const UserProcessState none{0.0, 0.0, 0.0, 0.0};
-  const Decisions D0 = decide<V>(core0.y, act0, dr0, static_cast<double>(lam0.x), static_cast<double>(lam0.y), t_now, norm_act, P, none);
-  const Decisions D1 = decide<V>(core1.y, act1, dr1, static_cast<double>(lam1.x), static_cast<double>(lam1.y), t_now, norm_act, P, none);
-  copy_decisions(D0, r0);
-  copy_decisions(D1, r1);
-  const v2f_pk cash = {core0.x, core1.x}, q = {core0.y, core1.y}, mid = {core0.w, core1.w};
-  const v2f_pk n_bid = {D0.n_bid, D1.n_bid}, n_ask = {D0.n_ask, D1.n_ask};
-  const v2f_pk off_bid = {D0.off_bid, D1.off_bid}, off_ask = {D0.off_ask, D1.off_ask};
-  // -- cash / inventory with the OLD midprice (lane_step: MD:108-116, MD:208-222, MD:146-154)
-  v2f_pk dq = n_bid - n_ask;
-  v2f_pk gain = pk_fma(n_ask, off_ask, n_bid * off_bid);
-  if (V::DYN == kDynLimitAndMarket) {
-    const v2f_pk mb = {D0.mo_buy ? 1.0f : 0.0f, D1.mo_buy ? 1.0f : 0.0f}, ms = {D0.mo_sell ? 1.0f : 0.0f, D1.mo_sell ? 1.0f : 0.0f};
-    dq += mb - ms;
-    gain = pk_fma(pk_splat(-P.half_spread), mb + ms, gain);
-  }
-  const v2f_pk q_new = q + dq;
-  const v2f_pk cash_new = pk_fma(-dq, mid, cash + gain);
-  // -- clip (TE:283-289): v_med3_f32 has no packed form
-  const v2f_pk q_clip = {__builtin_amdgcn_fmed3f(q_new.x, -P.q_max, P.q_max), __builtin_amdgcn_fmed3f(q_new.y, -P.q_max, P.q_max)};
-  const v2f_pk c_clip = {__builtin_amdgcn_fmed3f(cash_new.x, -P.c_max, P.c_max), __builtin_amdgcn_fmed3f(cash_new.y, -P.c_max, P.c_max)};
-  const v2f_pk dq_clip = q_clip - q_new, dc_clip = c_clip - cash_new;
-  // -- midprice, then the Hawkes intensities (ARR:110-119)
-  const v2f_pk dz = {dr0.dz, dr1.dz};
-  v2f_pk d_mid = dz;
-  if (!V::BROWNIAN) {  // midprice_increment()
-    const v2f_pk scale = pk_fma(pk_splat(P.mid_mul), mid, pk_splat(P.mid_add));
-    const v2f_pk pull = pk_splat(P.ou_speed) * (mid - pk_splat(P.ou_level));
-    d_mid = pk_fma(pk_splat(P.jump_size), n_ask - n_bid, pk_fma(scale, dz, -pull));
-  }
-  const v2f_pk mid_new = mid + d_mid;
-  v2f_pk lam_bid = {lam0.x, lam1.x}, lam_ask = {lam0.y, lam1.y};
-  if (V::ARR == kArrHawkes) {
-    const v2f_pk arr_bid = {D0.arr_bid, D1.arr_bid}, arr_ask = {D0.arr_ask, D1.arr_ask};
-    lam_bid = pk_fma(pk_splat(P.hawkes_jump), arr_bid, lam_bid + pk_splat(P.hawkes_speed) * (pk_splat(P.hawkes_base_bid) - lam_bid) * pk_splat(P.arr_dt));
-    lam_ask = pk_fma(pk_splat(P.hawkes_jump), arr_ask, lam_ask + pk_splat(P.hawkes_speed) * (pk_splat(P.hawkes_base_ask) - lam_ask) * pk_splat(P.arr_dt));
-  }
-  // -- reward (RW:27-33 from the step's increments; the quadratic inventory penalties of RW:96-109 / RW:128-138)
-  const v2f_pk pnl = pk_fma(dq_clip, mid, pk_fma(q_clip, d_mid, gain)) + dc_clip;
-  v2f_pk reward;
-  if (V::REWARD == kRewardPnl) {
-    reward = pnl * pk_splat(P.reward_scale);
-  } else {
-    const float c_new = P.quad_new + (is_terminal ? P.alpha_running : 0.0f);
-    const v2f_pk qi = {q_init0, q_init1};
-    const v2f_pk pen = pk_fma(pk_splat(-P.alpha_cjmm), q * q, pk_fma(pk_splat(c_new), q_clip * q_clip, pk_splat(P.quad_init) * (qi * qi)));
-    reward = (pnl - pen) * pk_splat(P.reward_scale);
-  }
-  r0.clipped_q = dq_clip.x != 0.0f; r1.clipped_q = dq_clip.y != 0.0f;
-  r0.clipped_c = dc_clip.x != 0.0f; r1.clipped_c = dc_clip.y != 0.0f;
-  r0.core = make_float4(c_clip.x, q_clip.x, t_next, mid_new.x);
-  r1.core = make_float4(c_clip.y, q_clip.y, t_next, mid_new.y);
-  r0.lam = make_float2(lam_bid.x, lam_ask.x);
-  r1.lam = make_float2(lam_bid.y, lam_ask.y);
-  r0.reward = reward.x;
-  r1.reward = reward.y;
-}
-
 // precise_state: the same lane-step on the reference's float64 state, in the reference's float64 arithmetic.  Every
 // expression below is written in the operation order of the NumPy statement it cites (the library is compiled with
 // -ffp-contract=off, IEEE double add / multiply / divide round like NumPy's), so cash, inventory, midprice, intensities and
@@ -1282,20 +1191,14 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     const double t_now = t;
     t += R.dt_f64;
     const bool terminal = (k + 1 == R.n_steps) && R.last_is_terminal != 0;
-    LaneResult r0, r1;
-    if constexpr (PairStepIsPacked<V>::value && !LEARNED) {
-      pair_step<V>(core[0], core[1], lam[0], lam[1], act[0], act[1], make_draw<V>(nz[0], P), make_draw<V>(nz[1], P), qi[0], qi[1], static_cast<float>(t), terminal, P,
-                   t_now, r0, r1);
-    } else if constexpr (V::PRECISE) {
-      r0 = lane_step_exact<V>(core[0], lam[0], lo[0], act[0], make_draw<V>(nz[0], P), qi[0], terminal, P, nz[0].z, t_now, t, zu[0]);
-      r1 = lane_step_exact<V>(core[1], lam[1], lo[1], act[1], make_draw<V>(nz[1], P), qi[1], terminal, P, nz[1].z, t_now, t, zu[1]);
-    } else {
-      r0 = lane_step<V>(core[0], lam[0], act[0], make_draw<V>(nz[0], P), qi[0], static_cast<float>(t), terminal, P, nz[0].z, t_now, zu[0]);
-      r1 = lane_step<V>(core[1], lam[1], act[1], make_draw<V>(nz[1], P), qi[1], static_cast<float>(t), terminal, P, nz[1].z, t_now, zu[1]);
-    }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      const LaneResult& r = l == 0 ? r0 : r1;
+      // (Advancing the pair TOGETHER on 2-vectors - v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for everything after the Bernoulli
+      // decisions - was built and measured in round 3: 15 fewer arithmetic instructions per pair and step, 23 more v_mov to put
+      // lane values into adjacent registers and SGPR spills from the longer live ranges: 3.48e11 instead of 3.62e11 env-steps/s at
+      // 2^20 lanes.  profiles/r03_experiments.txt.  The compiler already packs the two SIDES of a lane where that is free.)
+      const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t, zu[l])
+                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l]);
       core[l] = r.core;
       lam[l] = r.lam;
       lo[l] = r.lo;
