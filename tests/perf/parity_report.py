@@ -16,7 +16,7 @@ from tests.golden_io import CASES, load_case, step_size_changes  # noqa: E402
 def run(name, **env_kw):
     cfg, g = load_case(name)
     env = make_env(cfg, noise="injected", **env_kw)
-    oracle = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"]))  # only for the lanes the reference would print (clip)
+    oracle = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"], g.get("z_user")))  # only for the lanes the reference would print (clip)
     env.record_events(True)
     env.reset(), oracle.reset()
     changes = step_size_changes(g)
@@ -26,7 +26,8 @@ def run(name, **env_kw):
         if k in changes:
             env.step_size = changes[k]
             oracle.set_step_size(changes[k])
-        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        speed = cfg.dynamics == "speed"
+        env.set_noise(None if speed else g["u_arr"][k], None if speed else g["u_fill"][k], g["z"][k], g["z_user"][k] if "z_user" in g else None)
         obs, rew, done, _ = env.step(g["actions"][k])
         oracle.step(g["actions"][k].astype(np.float64))
         clipped = oracle.last_clipped
@@ -60,9 +61,45 @@ print("== float32 state (default) ==   dr = reward error vs the reference; 'clip
 print(HEADER)
 for name in CASES:
     run(name)
-print("\n== precise_state=True (cash / midprice as float32 pairs, double arithmetic) ==")
-print(HEADER)
+
+
+def run_precise(name):
+    """precise_state=True: the device carries the reference's float64 state exactly and steps it in the reference's order of
+    operations.  Counts of entries that are NOT bit-equal, and the largest deviations where any exist."""
+    cfg, g = load_case(name)
+    env = make_env(cfg, noise="injected", precise_state=True)
+    env.record_events(True)
+    env.reset()
+    changes = step_size_changes(g)
+    speed = cfg.dynamics == "speed"
+    bad_ev = bad_state = bad_rew = bad_obs = n_state = 0
+    e_state = e_rew = 0.0
+    for k in range(g["actions"].shape[0]):
+        if k in changes:
+            env.step_size = changes[k]
+        env.set_noise(None if speed else g["u_arr"][k], None if speed else g["u_fill"][k], g["z"][k], g["z_user"][k] if "z_user" in g else None)
+        obs, rew, done, _ = env.step(g["actions"][k])
+        if not speed:
+            bad_ev += int(np.sum(env.last_arrivals != g["arrivals"][k])) + int(np.sum(env.last_fills != g["fills"][k]))
+        want = g["obs"][k]
+        bad_obs += int(np.sum(obs != want.astype(np.float32)) - np.sum(np.isnan(obs) & np.isnan(want)))
+        if not cfg.normalise_observation_space:
+            state = env.state64
+            n_state += state.size
+            bad_state += int(np.sum(state != want))
+            e_state = max(e_state, float(np.max(np.abs(state - want) / np.maximum(1.0, np.abs(want)))))
+        bad_rew += int(np.sum(rew != g["rewards"][k].astype(np.float32)))
+        e_rew = max(e_rew, float(np.max(np.abs(rew.astype(np.float64) - g["rewards"][k]))))
+    env.close()
+    shape = f"{cfg.num_trajectories} x {g['actions'].shape[0]}"
+    rmax = float(np.abs(g["rewards"]).max())
+    print(f"{name:36s} {shape:>10s} {bad_ev:9d} {bad_state:12d} {e_state:12.3e} {bad_obs:10d} {bad_rew:12d} {e_rew:12.3e} {rmax:9.3g}")
+
+
+print("\n== precise_state=True: float64 state held exactly (float32 + int32 remainder), stepped in the reference's operation order ==")
+print("   counts are entries that differ in ANY bit from the reference (state64 vs its float64 state, observation vs np.float32 of its observation, reward vs")
+print("   np.float32 of its reward); non-zero only where a transcendental or a user's own expression sits in the path (pow in speed_power_running, exp in")
+print("   bmjump_exputility / the user rewards, the association of a user's increment expression: user_cev / user_two_factor)")
+print(f"{'fixture':36s} {'lanes x k':>10s} {'arr/fill':>9s} {'state64 !=':>12s} {'max rel d':>12s} {'obs32 !=':>10s} {'reward32 !=':>12s} {'max|dr|':>12s} {'max|r|':>9s}")
 for name in CASES:
-    if name.startswith(("speed_", "exo_fill", "user_fill", "user_reward", "user_seasonal", "user_cev")) or name.endswith("_speed"):
-        continue
-    run(name, precise_state=True)
+    run_precise(name)

@@ -4,7 +4,7 @@
 # rocprofv3 passes: kernel trace + stats alone; FETCH_SIZE and WRITE_SIZE each in its own --pmc pass (the MI355X guide's
 # HBM recipe); never combined with hip/hsa/sys tracing.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -39,12 +39,16 @@ python tests/perf/bench_regimes.py > "$OUT/${TAG}_regimes.json" 2> /dev/null; st
 python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null; stamp "rollout"
 python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; stamp "policy rollout"
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
+python tools/dbg/gym_loop_breakdown.py > "$OUT/${TAG}_gym_loop_breakdown.json" 2> /dev/null; stamp "gym loop breakdown"
+# the multi-rank code path of bench.py with a world of one (RCCL communicator through the C ABI, collective check): what an 8-GPU run adds
+python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
 python tests/perf/bench_timed_region.py > "$OUT/${TAG}_timed_region.json" 2> /dev/null; stamp "timed region"
 
 # per-kernel statistics of the other kernel families (every BASELINE config's step kernel, the fused rollouts, the learned
 # policies) and the HBM-side traffic of every config's step kernel
 stats() {  # stats <name> <script>
-  rm -rf /tmp/prof_$1 && (cd /tmp && MBT_BENCH_STEPS=200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python "$ROOT/$2" > /dev/null 2> "$ROOT/$OUT/rocprof_$1.stderr")
+  rm -rf /tmp/prof_$1 && (cd /tmp && MBT_BENCH_STEPS=2000 MBT_BENCH_WARMUP=500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python "$ROOT/$2" > /dev/null 2> "$ROOT/$OUT/rocprof_$1.stderr")
   find /tmp/prof_$1 -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_$1_kernel_stats.csv"
   stamp "kernel stats $1"
 }
