@@ -89,7 +89,7 @@ def test_sampled_actions_are_scored_around_the_mean_the_kernel_used():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in net.parameters())
     # and the score of sampled actions is centred: (a - kernel mean) / std has mean ~ 0 (it had a bias of ~ err_plain / std)
     r, lp = agent._sample_on_device()
-    z_mean = float(((-2 * 0.01 ** 2 * (lp + np.log(0.01 * np.sqrt(2 * np.pi)))).clamp(min=0).sqrt()).mean())  # E|z| of a standard normal: 0.798
+    z_mean = float(((-2 * (lp.detach() + np.log(0.01 * np.sqrt(2 * np.pi)))).clamp(min=0).sqrt()).mean())  # log N = -z^2 / 2 - log(std sqrt(2 pi)); E|z| = 0.798
     assert z_mean == pytest.approx(np.sqrt(2 / np.pi), abs=0.02)
     env.close()
 
