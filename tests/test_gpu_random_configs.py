@@ -95,7 +95,9 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
                 inventory = o_obs[:, 1] if not cfg.normalise_observation_space else (o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory
                 tol = tol + cfg.ou_speed * np.abs(inventory) * 1e-4
             err = np.abs(rew - o_rew)
-            assert np.all(err[clipped] <= 5e-4), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
+            # clipped lane-steps: the reward carries the level of the float32 cash / midprice.  Measured over 600 random configurations
+            # (tools/dbg/fuzz_clip_maxima.py -> profiles/r03_fuzz_clip_maxima.json): 4.4e-5; over the fixtures: 5.8e-5.  Bound: 2x the latter
+            assert np.all(err[clipped] <= 1.2e-4), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
             assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]
@@ -227,7 +229,9 @@ def test_random_speed_configuration_matches_the_oracle(case):
         # shows in it times the price move - which is several units per step in the wilder draws (17 % per step)
         move = np.nan_to_num(np.abs(o_obs[:, 3] - o_prev[:, 3]), nan=0.0)  # (constant midprice, normalised: a zero-width Box column is NaN on both sides)
         tol = tol + 1.5 * move * (np.abs(obs[:, 1] - o_obs[:, 1]) + 1e-6)
-        assert np.all(err[clipped] <= 5e-3 + 1e-5 * np.abs(o_rew[clipped])), f"{tag} step {k}: reward on clipped lanes"
+        # measured over 240 random configurations (profiles/r03_fuzz_clip_maxima.json): 1.03e-3 (4.6e-4 of |r|) - cash of ~1e4 and a
+        # real-valued inventory at its limit, both float32 state marked to market; bound: 2x
+        assert np.all(err[clipped] <= 2e-3 + 1e-5 * np.abs(o_rew[clipped])), f"{tag} step {k}: reward on clipped lanes"
         assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()} (allowed {tol[~clipped][np.argmax((err - tol)[~clipped])]})"
         prev, o_prev = obs, o_obs
         assert bool(dones[0]) == bool(o_dones[0])
