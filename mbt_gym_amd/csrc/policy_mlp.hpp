@@ -97,38 +97,48 @@ __device__ __forceinline__ void explore_and_clip(const LearnedPolicyParams& L, u
   }
 }
 
-// the weights of one wave, in registers
-struct MlpRegisters {
-  half4_t w1[kMlpTiles];
-  half8_t w2[kMlpTiles][kMlpTiles / 2];
-  half8_t w3[kMlpTiles / 2];
-  acc4_t b2[kMlpTiles];
-  acc4_t b3;
-};
+// The network as the workgroup keeps it in LDS (12.3 KB, staged once per launch): the fragments in the host's order, so a
+// lane's operand of one MFMA is ONE ds_read_b64 / ds_read_b128 at [fragment][lane].  The tile loop streams fragments from
+// there just before the instruction that consumes them - a tile then holds ~40 registers of network state instead of
+// 68 for the whole step - and the bias reads land directly in the accumulators.
+constexpr int kMlpLdsW1 = 0;                                              // [4][64] half4
+constexpr int kMlpLdsW2 = kMlpLdsW1 + kMlpTiles * 64 * 8;                 // [4][2][64] half8
+constexpr int kMlpLdsW3 = kMlpLdsW2 + kMlpTiles * (kMlpTiles / 2) * 64 * 16;  // [2][64] half8
+constexpr int kMlpLdsB2 = kMlpLdsW3 + (kMlpTiles / 2) * 64 * 16;          // [64] float
+constexpr int kMlpLdsB3 = kMlpLdsB2 + kMlpHidden * 4;                     // [16] float
+constexpr int kMlpLdsWeightBytes = kMlpLdsB3 + 16 * 4;
 
-__device__ __forceinline__ MlpRegisters load_mlp(const MlpDeviceWeights& w) {
-  const int lane = threadIdx.x & 63;
-  MlpRegisters r;
-#pragma unroll
-  for (int mt = 0; mt < kMlpTiles; ++mt) {
-    r.w1[mt] = w.w1[mt * 64 + lane];
-    if (mt < kMlpTiles / 2) r.w3[mt] = w.w3[mt * 64 + lane];
-#pragma unroll
-    for (int c = 0; c < kMlpTiles / 2; ++c) r.w2[mt][c] = w.w2[(mt * (kMlpTiles / 2) + c) * 64 + lane];
-    const float* b = w.b2 + 16 * mt + 4 * (lane >> 4);  // accumulator rows of this lane: 4 (lane / 16) + r
-    r.b2[mt] = acc4_t{b[0], b[1], b[2], b[3]};
-  }
-  const float* b = w.b3 + 4 * (lane >> 4);
-  r.b3 = acc4_t{b[0], b[1], b[2], b[3]};
-  return r;
+// every thread of the workgroup (kBlockThreads = 256) calls this once, before the first evaluation
+__device__ __forceinline__ void stage_mlp_weights(const MlpDeviceWeights& w, char* lds) {
+  const int t = threadIdx.x;
+  reinterpret_cast<half4_t*>(lds + kMlpLdsW1)[t] = w.w1[t];
+  reinterpret_cast<half8_t*>(lds + kMlpLdsW2)[t] = w.w2[t];
+  reinterpret_cast<half8_t*>(lds + kMlpLdsW2)[t + 256] = w.w2[t + 256];
+  if (t < (kMlpTiles / 2) * 64) reinterpret_cast<half8_t*>(lds + kMlpLdsW3)[t] = w.w3[t];
+  if (t < kMlpHidden) reinterpret_cast<float*>(lds + kMlpLdsB2)[t] = w.b2[t];
+  if (t < 16) reinterpret_cast<float*>(lds + kMlpLdsB3)[t] = w.b3[t];
+  __syncthreads();
 }
 
 template <int ACT>
 __device__ __forceinline__ float activate(float x) {
   if (ACT == kActRelu) return __builtin_fmaxf(x, 0.0f);
-  // tanh(x) = 1 - 2 / (1 + e^{2x}) on the hardware exp2 / rcp (two quarter-rate instructions); saturates cleanly at +-1
+  // tanh(x) = 1 - 2 / (1 + e^{2x}) on the hardware exp2 / rcp (two transcendental instructions); saturates cleanly at +-1
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// The same tanh on two values: what is not a transcendental runs on the packed fp32 forms (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32: two values per issue slot).  Every operation is the IEEE operation of `activate` - 2r is exact, so
+// fma(r, -2, 1) rounds once exactly like 1 - 2r - hence the SAME bits; per value 2 plain + 2 transcendental issue slots
+// instead of 3.5 + 2 (the compiler packs only the tail of the scalar form: a literal cannot be a packed operand).
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2_t tanh_pair(float2_t x) {
+  const float2_t two_log2e = {2.8853900817779268f, 2.8853900817779268f};
+  const float2_t t = x * two_log2e;
+  const float2_t e = float2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + float2_t{1.0f, 1.0f};
+  const float2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+  return __builtin_elementwise_fma(r, float2_t{-2.0f, -2.0f}, float2_t{1.0f, 1.0f});
 }
 
 // Two accumulator tiles (features 16 (2c) .. and 16 (2c + 1) ..) -> activation -> ONE 8-half operand of the K = 32 instruction.
@@ -140,9 +150,10 @@ __device__ __forceinline__ half8_t activate_pair(acc4_t lo, acc4_t hi) {
     const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_elementwise_max(h, zero);
   }
-  return half8_t{static_cast<_Float16>(activate<ACT>(lo.x)), static_cast<_Float16>(activate<ACT>(lo.y)), static_cast<_Float16>(activate<ACT>(lo.z)),
-                 static_cast<_Float16>(activate<ACT>(lo.w)), static_cast<_Float16>(activate<ACT>(hi.x)), static_cast<_Float16>(activate<ACT>(hi.y)),
-                 static_cast<_Float16>(activate<ACT>(hi.z)), static_cast<_Float16>(activate<ACT>(hi.w))};
+  const float2_t a = tanh_pair(float2_t{lo.x, lo.y}), b = tanh_pair(float2_t{lo.z, lo.w});
+  const float2_t c = tanh_pair(float2_t{hi.x, hi.y}), d = tanh_pair(float2_t{hi.z, hi.w});
+  return half8_t{static_cast<_Float16>(a.x), static_cast<_Float16>(a.y), static_cast<_Float16>(b.x), static_cast<_Float16>(b.y),
+                 static_cast<_Float16>(c.x), static_cast<_Float16>(c.y), static_cast<_Float16>(d.x), static_cast<_Float16>(d.y)};
 }
 
 // Two 16-feature fragments side by side = the 8-element operand of the K = 32 instruction.  The hardware pairs element
@@ -157,9 +168,14 @@ constexpr int kMlpLdsBytesPerWave = kMlpRowsPerWave * (kMlpInPad * 2 + 16);
 // obs[l][c]: the observation rows of this thread's two lanes (columns >= obs_dim ignored).  act[l][a]: the actor's mean (unclipped).
 // Every lane of the wave must call this together (MFMA and the wave-level LDS exchange).
 template <int ACT>
-__device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
+__device__ __forceinline__ void mlp_forward_wave_act(const char* W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
                                                      char* lds_wave) {
   const int lane = threadIdx.x & 63;
+  const half4_t* w1 = reinterpret_cast<const half4_t*>(W + kMlpLdsW1) + lane;
+  const half8_t* w2 = reinterpret_cast<const half8_t*>(W + kMlpLdsW2) + lane;
+  const half8_t* w3 = reinterpret_cast<const half8_t*>(W + kMlpLdsW3) + lane;
+  const acc4_t* b2 = reinterpret_cast<const acc4_t*>(W + kMlpLdsB2) + (lane >> 4);  // accumulator rows of this lane: 4 (lane / 16) + r
+  const acc4_t* b3 = reinterpret_cast<const acc4_t*>(W + kMlpLdsB3) + (lane >> 4);
   _Float16* x_rows = reinterpret_cast<_Float16*>(lds_wave);                                // [128][16]
   float* a_rows = reinterpret_cast<float*>(lds_wave + kMlpRowsPerWave * kMlpInPad * 2);      // [128][4]
   // 1. observations -> fp16 rows [features | 1 | 0...] in LDS (row = l * 64 + lane)
@@ -181,20 +197,40 @@ __device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, cons
   // 2. eight tiles of 16 rows through the three layers, activations in registers
 #pragma unroll 1
   for (int t = 0; t < kMlpRowsPerWave / 16; ++t) {
+    asm volatile("" ::: "memory");  // the fragments are STREAMED: read here, every tile, not hoisted into 68 registers held across the loop
     // B operand of layer 1: k = 4 (lane / 16) + j of row n = lane % 16
     const half4_t x = *reinterpret_cast<const half4_t*>(x_rows + (16 * t + (lane & 15)) * kMlpInPad + 4 * (lane >> 4));
+    // Software pipeline over the LDS reads: the fragments of the NEXT group of matrix instructions are requested before the
+    // current group is issued (LDS returns in order, so the wait before a group leaves the newer requests in flight), and the
+    // scheduler may not sink them back down to their use (sched_barrier): without this every one of the 14 instructions of
+    // a tile waited for its own round trip to LDS.
+    half4_t f1[kMlpTiles];
+#pragma unroll
+    for (int mt = 0; mt < kMlpTiles; ++mt) f1[mt] = w1[mt * 64];
+    half8_t fa = w2[0], fb = w2[64];
+    acc4_t fc = b2[0];
+    __builtin_amdgcn_sched_barrier(0);
     acc4_t a1[kMlpTiles], a2[kMlpTiles];
 #pragma unroll
-    for (int mt = 0; mt < kMlpTiles; ++mt) a1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(W.w1[mt], x, acc4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    for (int mt = 0; mt < kMlpTiles; ++mt) a1[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(f1[mt], x, acc4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     const half8_t h1_lo = activate_pair<ACT>(a1[0], a1[1]), h1_hi = activate_pair<ACT>(a1[2], a1[3]);
 #pragma unroll
     for (int mt = 0; mt < kMlpTiles; ++mt) {
-      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w2[mt][0], h1_lo, W.b2[mt], 0, 0, 0);
-      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w2[mt][1], h1_hi, a2[mt], 0, 0, 0);
+      // next: the fragments of hidden tile mt + 1, or the output layer's
+      const half8_t na = mt + 1 < kMlpTiles ? w2[((mt + 1) * (kMlpTiles / 2) + 0) * 64] : w3[0];
+      const half8_t nb = mt + 1 < kMlpTiles ? w2[((mt + 1) * (kMlpTiles / 2) + 1) * 64] : w3[64];
+      const acc4_t nc = mt + 1 < kMlpTiles ? b2[4 * (mt + 1)] : b3[0];
+      __builtin_amdgcn_sched_barrier(0);
+      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, h1_lo, fc, 0, 0, 0);
+      a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, h1_hi, a2[mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fa = na;
+      fb = nb;
+      fc = nc;
     }
     const half8_t h2_lo = activate_pair<ACT>(a2[0], a2[1]), h2_hi = activate_pair<ACT>(a2[2], a2[3]);
-    acc4_t out = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w3[0], h2_lo, W.b3, 0, 0, 0);
-    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w3[1], h2_hi, out, 0, 0, 0);
+    acc4_t out = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, h2_lo, fc, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, h2_hi, out, 0, 0, 0);
     // lanes 0..15 hold output rows 0..3 (= the action components) of batch row 16 t + lane
     if (lane < 16) *reinterpret_cast<acc4_t*>(a_rows + (16 * t + lane) * 4) = out;
   }
@@ -214,7 +250,7 @@ __device__ __forceinline__ void mlp_forward_wave_act(const MlpRegisters& W, cons
 }
 
 // (the activation is a template parameter: chosen once per call, outside the tile loop, instead of per value)
-__device__ __forceinline__ void mlp_forward_wave(const MlpRegisters& W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
+__device__ __forceinline__ void mlp_forward_wave(const char* W, const LearnedPolicyParams& L, const float (&obs)[2][8], float (&act)[2][4],
                                                  char* lds_wave) {
   if (L.activation == kActRelu) mlp_forward_wave_act<kActRelu>(W, L, obs, act, lds_wave);
   else mlp_forward_wave_act<kActTanh>(W, L, obs, act, lds_wave);

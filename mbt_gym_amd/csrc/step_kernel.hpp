@@ -1128,7 +1128,9 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
   float last_reward[2] = {0.f, 0.f};  // what step() leaves behind for the final step: its rewards and event bytes
   uint32_t last_events[2] = {0u, 0u};
 #ifndef MBT_JIT_USER_CODE
-  __shared__ __attribute__((aligned(16))) char policy_lds[LEARNED ? (kBlockThreads / 64) * kMlpLdsBytesPerWave : 16];
+  constexpr int kMlpLdsWaveBytesPerBlock = (kBlockThreads / 64) * kMlpLdsBytesPerWave;
+  __shared__ __attribute__((aligned(16))) char policy_lds[LEARNED ? kMlpLdsWaveBytesPerBlock + kMlpLdsWeightBytes : 16];
+  if (LEARNED && !LP->is_linear) stage_mlp_weights(LP->w, policy_lds + kMlpLdsWaveBytesPerBlock);  // (uniform branch: the barrier inside is reached by all or none)
 #endif
   for (uint32_t k = 0; k < R.n_steps; ++k) {
     LaneNoise nz[2];
@@ -1151,12 +1153,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
         linear_forward(*LP, o[0], a[0]);
         linear_forward(*LP, o[1], a[1]);
       } else {
-        // The weight fragments (68 registers) are re-read every step - 12 KB that stay in the L1 / L2 - instead of being
-        // held across the environment step, whose own peak is ~130 registers in this tier: the kernel then fits 3 waves
-        // per SIMD instead of 2 (the barrier keeps the compiler from hoisting the loads out of the loop again).
-        asm volatile("" ::: "memory");
-        const MlpRegisters mlp_w = load_mlp(LP->w);
-        mlp_forward_wave(mlp_w, *LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
+        // (the network lives in LDS, staged before the loop; the tile loop streams its fragments from there - policy_mlp.hpp)
+        mlp_forward_wave(policy_lds + kMlpLdsWaveBytesPerBlock, *LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
       }
       explore_and_clip(*LP, pair, P.philox_step + k, P.key0, P.key1, a);
 #pragma unroll
@@ -1259,7 +1257,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void learned_rollout_kernel(const
 // the step kernel's lane <-> thread mapping (so the wave-level MLP sees the same rows in the same places as the rollout).
 __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs, float* action, int dim, int act_dim, const LearnedPolicyParams LP,
                                                               uint64_t pair_offset, uint32_t philox_step, uint32_t key0, uint32_t key1) {
-  __shared__ __attribute__((aligned(16))) char policy_lds[(kBlockThreads / 64) * kMlpLdsBytesPerWave];
+  constexpr int kMlpLdsWaveBytesPerBlock = (kBlockThreads / 64) * kMlpLdsBytesPerWave;
+  __shared__ __attribute__((aligned(16))) char policy_lds[kMlpLdsWaveBytesPerBlock + kMlpLdsWeightBytes];
   const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
   float o[2][8], a[2][4];
 #pragma unroll
@@ -1272,8 +1271,8 @@ __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs,
     linear_forward(LP, o[0], a[0]);
     linear_forward(LP, o[1], a[1]);
   } else {
-    const MlpRegisters w = load_mlp(LP.w);
-    mlp_forward_wave(w, LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
+    stage_mlp_weights(LP.w, policy_lds + kMlpLdsWaveBytesPerBlock);
+    mlp_forward_wave(policy_lds + kMlpLdsWaveBytesPerBlock, LP, o, a, policy_lds + (threadIdx.x >> 6) * kMlpLdsBytesPerWave);
   }
   // exploration noise of the step that is about to be taken: the same (pair, philox step) the fused rollout would use
   explore_and_clip(LP, pair_offset + blockIdx.x * kBlockThreads + threadIdx.x, philox_step, key0, key1, a);
