@@ -5,7 +5,7 @@
 // This is the one dense contraction on the path, hence the one use of the matrix cores: per environment step a wave
 // evaluates 128 rows (64 threads x the 2 lanes each owns) x [D -> 64 -> 64 -> A] = 8960 flop per row on
 // v_mfma_f32_16x16x16_f16 (first layer) and v_mfma_f32_16x16x32_f16 (the other two): fp16 operands, fp32 accumulate.  Formulated TRANSPOSED, H^T = W X^T: the weights are the
-// A operand (M = output features, held in registers for the whole rollout - 48 VGPRs), the batch rows are N, and the
+// A operand (M = output features; the fragments live in LDS and are streamed into the tile loop), the batch rows are N, and the
 // accumulator layout of one layer (lane L: rows m = 4 (L / 16) + r, r = 0..3, column n = L % 16) IS the B-operand layout
 // of the next (lane L: k = 4 (L / 16) + j, n = L % 16), so hidden activations never leave registers: activation,
 // convert to fp16, feed the next MFMA.  Only the observations (in) and the actions (out) cross lanes, through 6 KB of
