@@ -456,7 +456,8 @@ def main():
     torch.cuda.set_device(gpu)
     affinity = pin_to_gpu_numa_node(gpu) if (multi and os.environ.get("MBT_BENCH_PIN", "1") != "0") else "not pinned"
     if multi:
-        with Watchdog(args.comm_timeout, "torch.distributed rendezvous + first barrier", rank):
+        # (generous: on a fresh box the ranks finish their first `import torch` minutes apart, and the early ones wait here)
+        with Watchdog(max(args.comm_timeout, 480.0), "torch.distributed rendezvous + first barrier", rank):
             if args.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
             else:
