@@ -187,7 +187,7 @@ StepKernel pick_exogenous(bool inject) {
 
 // precise_state: the general tier again (every midprice model, every reward, runtime normalisation flags) on the
 // reference's float64 state: {Poisson-type, Hawkes} x {limit, limit + market, touch} + the exogenous-depth fill model on
-// {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 4 + 2 for speed dynamics.
+// {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 6 + 2 for speed dynamics (the float32 kernel with a precise branch).
 template <int ARR, int DYN, bool EXO>
 StepKernel pick_precise(bool inject) {
   return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>
@@ -201,16 +201,20 @@ StepKernel pick_precise_dyn(int dyn, bool exo, bool inject) {
     default: return pick_precise<ARR, mbt::kDynTouch, false>(inject);
   }
 }
+// (the precise_state tier of the speed family is the same kernel: `staged` / `stream` as above)
 template <bool STATE>
-StepKernel pick_speed_precise(bool inject) {
-  return inject ? mbt::speed_step_exact_kernel<mbt::SpeedVariant<STATE, true, true, true>> : mbt::speed_step_exact_kernel<mbt::SpeedVariant<STATE, true, false, true>>;
+StepKernel pick_speed_precise(bool inject, bool stream) {
+  using V = mbt::SpeedVariant<STATE, true, false, true>;
+  if (inject) return mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, true>>;
+  if (stream) return mbt::speed_step_kernel<V, false, true>;
+  return STATE ? mbt::speed_step_kernel<V, true> : mbt::speed_step_kernel<V>;
 }
 
 StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
-    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(inject) : pick_speed_precise<false>(inject);
+    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(inject, stream) : pick_speed_precise<false>(inject, stream);
     return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, stream) : pick_speed<false>(speed_powers(c), norm, inject, stream);
   }
   if (c.precise_state)

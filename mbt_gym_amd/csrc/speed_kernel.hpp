@@ -177,6 +177,41 @@ __device__ __forceinline__ void store_speed_row(float* base, uint32_t lane, cons
   }
 }
 
+// ---- precise_state (SpeedVariant<..., PRECISE = true>) -----------------------------------------------------------------
+// Same lane <-> thread mapping and the same Philox quad stream as the float32 kernels; the state row holds the float32
+// rounding of the reference's float64 state and B.resid (n_pad, 4) int32 the remainders of [cash, inventory, midprice, y].
+template <class V>
+__device__ __forceinline__ SpeedExact load_speed_exact(const StepBuffers& B, uint32_t lane) {
+  const SpeedLane f = load_speed_row<V>(B.state_in, lane);
+  const ldi4_t lo = *reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
+  return SpeedExact{exact_join(f.cash, lo.x), exact_join(f.q, lo.y), exact_join(f.mid, lo.z), V::DIM == 5 ? exact_join(f.y, lo.w) : 0.0};
+}
+
+// row (float32 roundings) [+ remainders] of one lane; `obs`: the normalised observation row from the float64 values (TE:112-118)
+template <class V, bool THROUGH>
+__device__ __forceinline__ void store_speed_exact(float* state, int32_t* resid, float* obs, uint32_t lane, const SpeedExact& s, double t, const StepParams& P) {
+  const double x[5] = {s.cash, s.q, t, s.mid, s.y};
+  float hi[5];
+  int32_t lo[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) exact_split(x[c], hi[c], lo[c]);
+  hi[2] = static_cast<float>(t);
+  if (state != nullptr) store_speed_row<V, THROUGH>(state, lane, SpeedLane{hi[0], hi[1], hi[3], hi[4]}, hi[2], false, P);
+  if (resid != nullptr) store_through(reinterpret_cast<float4*>(resid) + lane, make_float4(__builtin_bit_cast(float, lo[0]), __builtin_bit_cast(float, lo[1]), __builtin_bit_cast(float, lo[3]), __builtin_bit_cast(float, V::DIM == 5 ? lo[4] : 0)));
+  if (obs != nullptr) {
+    float row[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) row[c] = P.norm_obs ? normalise_column_exact(x[c], c, P) : hi[c];
+    if (V::DIM == 4) {
+      reinterpret_cast<float4*>(obs)[lane] = make_float4(row[0], row[1], row[2], row[3]);
+    } else {
+      float* r = obs + static_cast<size_t>(lane) * 5;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) r[c] = row[c];
+    }
+  }
+}
+
 // Rows of 20 bytes (D = 5) through LDS, PER WAVE.  Thread t of wave w owns the lanes 64 w + t + {0, 256, 512, 768} of the
 // tile: four spans of 64 consecutive rows = 4 x 1280 B, each a whole number of 64-byte lines.  The wave moves each span as
 // 80 float4 (every thread one, the first 16 a second) between HBM and ITS OWN 5 KB of LDS and picks its rows out of that -
@@ -216,9 +251,14 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
   ld4_t row4[4];               // D = 4: the rows as loaded (whole vectors are tied: a dead component - the time column - would otherwise
                                // be re-used as a temporary by the generator, behind a wait for the load that wrote it)
   ld4_t span_a[4], span_b[4];  // kStaged: the wave's four spans of 64 rows, 80 float4 each
+  ldi4_t lo4[4];               // precise_state: the int32 remainders of [cash, inventory, midprice, y] (one 16-byte row per lane, updated in place)
 #pragma unroll
   for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
     const uint32_t lane = lane0 + l * kBlockThreads;
+    if (V::PRECISE) {
+      const ldi4_t* src = reinterpret_cast<const ldi4_t*>(B.resid) + lane;
+      lo4[l] = STREAM ? __builtin_nontemporal_load(src) : *src;
+    }
     if (kStaged) {
       const ld4_t* in4 = reinterpret_cast<const ld4_t*>(B.state_in) + static_cast<size_t>(blockIdx.x) * (kSpeedTileLanes * 5 / 4);
       span_a[l] = in4[span0 + l * 320 + t];
@@ -252,6 +292,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
       if (kStaged) asm volatile("; lane is first consumed below this line" : "+v"(span_a[l]), "+v"(span_b[l]), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
       else if (V::DIM == 4) asm volatile("; lane is first consumed below this line" : "+v"(row4[l]), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
       else asm volatile("; lane is first consumed below this line" : "+v"(s[l].cash), "+v"(s[l].q), "+v"(s[l].mid), "+v"(s[l].y), "+v"(act[l]), "+v"(z[l]), "+v"(z[(l + 1) & 3]), "+v"(z[(l + 2) & 3]), "+v"(z[(l + 3) & 3]));
+      if (V::PRECISE) asm volatile("" : "+v"(lo4[l]));
     }
     if (kStaged) {  // span l: into the wave's LDS, this thread's row out of it
       ld4_t* lds4 = reinterpret_cast<ld4_t*>(staged_rows);
@@ -263,7 +304,24 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     } else if (V::DIM == 4) {
       s[l] = SpeedLane{row4[l].x, row4[l].y, row4[l].w, 0.0f};
     }
-    const SpeedResult r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
+    SpeedResult r;
+    SpeedExact exact_next = {0.0, 0.0, 0.0, 0.0};
+    if (V::PRECISE) {  // the reference's float64 arithmetic on the exactly held state (speed_lane_exact); the row keeps the float32 roundings
+      const SpeedExact e = {exact_join(s[l].cash, lo4[l].x), exact_join(s[l].q, lo4[l].y), exact_join(s[l].mid, lo4[l].z), V::DIM == 5 ? exact_join(s[l].y, lo4[l].w) : 0.0};
+      const SpeedResultExact rx = speed_lane_exact<V>(e, act[l], z[l], qi[l], P.is_terminal != 0, P.t_now, P.t_next_f64, P);
+      exact_next = rx.next;
+      int32_t lo_c, lo_q, lo_m, lo_y = 0;
+      exact_split(rx.next.cash, r.next.cash, lo_c);
+      exact_split(rx.next.q, r.next.q, lo_q);
+      exact_split(rx.next.mid, r.next.mid, lo_m);
+      r.next.y = 0.0f;
+      if (V::DIM == 5) exact_split(rx.next.y, r.next.y, lo_y);
+      r.reward = rx.reward;
+      r.events = rx.events;
+      store_through(reinterpret_cast<float4*>(B.resid) + lane, make_float4(__builtin_bit_cast(float, lo_c), __builtin_bit_cast(float, lo_q), __builtin_bit_cast(float, lo_m), __builtin_bit_cast(float, lo_y)));
+    } else {
+      r = speed_lane<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P);
+    }
     if (V::DIM == 5) {  // the wave's span l leaves as whole lines, through the L2
       lds_row[0] = r.next.cash; lds_row[1] = r.next.q; lds_row[2] = P.t_next; lds_row[3] = r.next.mid; lds_row[4] = r.next.y;
       wave_lds_fence();
@@ -275,7 +333,10 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
       store_speed_row<V>(B.state_out, lane, r.next, P.t_next, false, P);
     }
     store_through(B.reward + lane, r.reward);
-    if (V::NORM && B.obs != nullptr) store_speed_row<V>(B.obs, lane, r.next, P.t_next, P.norm_obs != 0, P);
+    if (V::NORM && B.obs != nullptr) {
+      if (V::PRECISE) store_speed_exact<V, false>(nullptr, nullptr, B.obs, lane, exact_next, P.t_next_f64, P);  // normalised from the float64 values (TE:112-118)
+      else store_speed_row<V>(B.obs, lane, r.next, P.t_next, P.norm_obs != 0, P);
+    }
     if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
     if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
     const bool real = lane < P.n;
@@ -355,83 +416,6 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
-  }
-}
-
-// ---- precise_state (SpeedVariant<..., PRECISE = true>) -----------------------------------------------------------------
-// Same lane <-> thread mapping and the same Philox quad stream as the float32 kernels; the state row holds the float32
-// rounding of the reference's float64 state and B.resid (n_pad, 4) int32 the remainders of [cash, inventory, midprice, y].
-template <class V>
-__device__ __forceinline__ SpeedExact load_speed_exact(const StepBuffers& B, uint32_t lane) {
-  const SpeedLane f = load_speed_row<V>(B.state_in, lane);
-  const ldi4_t lo = *reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
-  return SpeedExact{exact_join(f.cash, lo.x), exact_join(f.q, lo.y), exact_join(f.mid, lo.z), V::DIM == 5 ? exact_join(f.y, lo.w) : 0.0};
-}
-
-// row (float32 roundings) [+ remainders] of one lane; `obs`: the normalised observation row from the float64 values (TE:112-118)
-template <class V, bool THROUGH>
-__device__ __forceinline__ void store_speed_exact(float* state, int32_t* resid, float* obs, uint32_t lane, const SpeedExact& s, double t, const StepParams& P) {
-  const double x[5] = {s.cash, s.q, t, s.mid, s.y};
-  float hi[5];
-  int32_t lo[5];
-#pragma unroll
-  for (int c = 0; c < 5; ++c) exact_split(x[c], hi[c], lo[c]);
-  hi[2] = static_cast<float>(t);
-  if (state != nullptr) store_speed_row<V, THROUGH>(state, lane, SpeedLane{hi[0], hi[1], hi[3], hi[4]}, hi[2], false, P);
-  if (resid != nullptr) store_through(reinterpret_cast<float4*>(resid) + lane, make_float4(__builtin_bit_cast(float, lo[0]), __builtin_bit_cast(float, lo[1]), __builtin_bit_cast(float, lo[3]), __builtin_bit_cast(float, V::DIM == 5 ? lo[4] : 0)));
-  if (obs != nullptr) {
-    float row[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) row[c] = P.norm_obs ? normalise_column_exact(x[c], c, P) : hi[c];
-    if (V::DIM == 4) {
-      reinterpret_cast<float4*>(obs)[lane] = make_float4(row[0], row[1], row[2], row[3]);
-    } else {
-      float* r = obs + static_cast<size_t>(lane) * 5;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) r[c] = row[c];
-    }
-  }
-}
-
-template <class V>
-__global__ __launch_bounds__(kBlockThreads) void speed_step_exact_kernel(const StepBuffers B, const StepParams P) {
-  static_assert(V::PRECISE, "the float32 tiers use speed_step_kernel");
-  const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;
-  const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
-  SpeedExact s[4];
-  float act[4], qi[4], z[4];
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const uint32_t lane = lane0 + l * kBlockThreads;
-    s[l] = load_speed_exact<V>(B, lane);
-    act[l] = B.action[lane];
-    if (V::INJECT) z[l] = B.z[lane];
-    qi[l] = B.q_init != nullptr ? B.q_init[lane] : P.q_init_scalar;
-  }
-  if (!V::INJECT) {
-    const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
-#pragma unroll
-    for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
-  }
-  float r_sum = 0.0f;
-  uint32_t n_clipped = 0;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const uint32_t lane = lane0 + l * kBlockThreads;
-    const SpeedResultExact r = speed_lane_exact<V>(s[l], act[l], z[l], qi[l], P.is_terminal != 0, P.t_now, P.t_next_f64, P);
-    store_speed_exact<V, false>(B.state_out, B.resid, B.obs, lane, r.next, P.t_next_f64, P);
-    B.reward[lane] = r.reward;
-    if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
-    if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
-    const bool real = lane < P.n;
-    r_sum += real ? r.reward : 0.0f;
-    n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && r.events != 0u));
-  }
-  const float total = wave_sum(r_sum);
-  if ((threadIdx.x & 63u) == 0u) {
-    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
-    unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
-    if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
 }
 

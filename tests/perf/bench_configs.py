@@ -36,7 +36,10 @@ CASES = {
 def main():
     lib = _native.load_library()
     out = {}
+    only = os.environ.get("MBT_BENCH_ONLY", "")  # substring of a case name: one case (for counter collection)
     for name, (kw, log2n, action, *extra) in CASES.items():
+        if only and only not in name:
+            continue
         n = 1 << log2n
         cfg = OracleConfig(**{**BASE, **kw, "num_trajectories": n})
         env_kw = extra[0] if extra else {}
