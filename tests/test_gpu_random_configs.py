@@ -96,7 +96,7 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
                 tol = tol + cfg.ou_speed * np.abs(inventory) * 1e-4
             err = np.abs(rew - o_rew)
             # clipped lane-steps: the reward carries the level of the float32 cash / midprice.  Measured over 600 random configurations
-            # (tools/dbg/fuzz_clip_maxima.py -> profiles/r03_fuzz_clip_maxima.json): 4.4e-5; over the fixtures: 5.8e-5.  Bound: 2x the latter
+            # (tests/dbg/fuzz_clip_maxima.py -> profiles/r03_fuzz_clip_maxima.json): 4.4e-5; over the fixtures: 5.8e-5.  Bound: 2x the latter
             assert np.all(err[clipped] <= 1.2e-4), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
             assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
         assert bool(dones[0]) == bool(o_dones[0])

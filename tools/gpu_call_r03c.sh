@@ -16,5 +16,5 @@ for pin in 1 0 1 0; do
 MBT_BENCH_PIN=$pin timeout 300 python bench.py --gpus 1 --force-distributed --steps 2000 --warmup 5 --no-cpu-baseline --no-hbm-resident > "$OUT/bench_forced_pin${pin}_$RANDOM.json" 2>> "$OUT/bench_forced.err"; stamp "forced distributed pin=$pin rc=$?"
 done
 timeout 300 python bench.py --steps 2000 --warmup 5 --no-cpu-baseline --no-hbm-resident > "$OUT/bench_plain_2000.json" 2>> "$OUT/bench_forced.err"; stamp "plain rc=$?"
-timeout 300 python tools/dbg/gym_loop_breakdown.py > "$OUT/gym_loop_breakdown.json" 2> "$OUT/gym_loop_breakdown.err"; stamp "gym loop breakdown rc=$?"
+timeout 300 python tests/dbg/gym_loop_breakdown.py > "$OUT/gym_loop_breakdown.json" 2> "$OUT/gym_loop_breakdown.err"; stamp "gym loop breakdown rc=$?"
 tail -8 "$OUT/pytest.log"

@@ -39,7 +39,7 @@ python tests/perf/bench_regimes.py > "$OUT/${TAG}_regimes.json" 2> /dev/null; st
 python tools/bench_rollout.py > "$OUT/${TAG}_rollout_kernel.json" 2> /dev/null; stamp "rollout"
 python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; stamp "policy rollout"
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
-python tools/dbg/gym_loop_breakdown.py > "$OUT/${TAG}_gym_loop_breakdown.json" 2> /dev/null; stamp "gym loop breakdown"
+python tests/dbg/gym_loop_breakdown.py > "$OUT/${TAG}_gym_loop_breakdown.json" 2> /dev/null; stamp "gym loop breakdown"
 # the multi-rank code path of bench.py with a world of one (RCCL communicator through the C ABI, collective check): what an 8-GPU run adds
 python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
