@@ -128,3 +128,25 @@ def test_a_missing_extension_fails_loudly(monkeypatch, tmp_path):
             "assert not any(n == 'oracle' or n.startswith('oracle.') for n in sys.modules), 'the package imports the oracle'\n")
     out = sp.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
     assert out.returncode == 0, out.stderr[-1500:]
+
+
+def test_only_the_checkers_name_the_oracle():
+    """`oracle/` is test infrastructure: outside tests/ only bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
+    Every other Python file of the repository (the package, tools/, examples/) is searched for an import of it."""
+    import re
+
+    pattern = re.compile(r"^\s*(from\s+oracle[.\s]|import\s+oracle\b)", re.M)
+    offenders = []
+    for top in ("mbt_gym_amd", "tools", "examples"):
+        for folder, _, files in os.walk(os.path.join(ROOT, top)):
+            for name in files:
+                if name.endswith(".py"):
+                    path = os.path.join(folder, name)
+                    if pattern.search(open(path, encoding="utf-8").read()):
+                        offenders.append(os.path.relpath(path, ROOT))
+    assert offenders == []
+    bench = open(os.path.join(ROOT, "bench.py"), encoding="utf-8").read()
+    for match in pattern.finditer(bench):  # every import in bench.py sits inside the cpu_baseline leg
+        before = bench[:match.start()]
+        enclosing = re.findall(r"^def (\w+)\(", before, re.M)[-1]
+        assert enclosing in ("_cpu_worker", "cpu_baseline", "_cpu_configs0"), enclosing
