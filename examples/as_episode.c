@@ -49,9 +49,11 @@ int main(void) {
 
   mbt_env* env = NULL;
   CHECK(mbt_env_create(&cfg, &env));
-  float* obs = malloc(sizeof(float) * N * 4);
-  float* act = malloc(sizeof(float) * N * 2);
-  float* rew = malloc(sizeof(float) * N);
+  /* host buffers of the step: pinned memory from the library, which its DMA copies then read and write directly (any host
+     pointer works - pageable ones go through a bounce buffer) */
+  float* obs = mbt_host_alloc(sizeof(float) * N * 4);
+  float* act = mbt_host_alloc(sizeof(float) * N * 2);
+  float* rew = mbt_host_alloc(sizeof(float) * N);
   double* total = calloc(N, sizeof(double));
   if (!obs || !act || !rew || !total) return 1;
 
@@ -90,7 +92,7 @@ int main(void) {
   printf("rollout   : %u steps, mean episode return %.4f\n", steps_done, sums[0] / sums[2]);
   if (steps_done != STEPS || !done || fabs(mean - sums[0] / sums[2]) > 0.02) return 3; /* the device policy rounds its quotes in float32: a fill may flip */
 
-  free(obs); free(act); free(rew); free(total);
+  mbt_host_free(obs); mbt_host_free(act); mbt_host_free(rew); free(total);
   mbt_env_destroy(env);
   return 0;
 }
