@@ -110,6 +110,7 @@ constexpr int kMlpLdsWeightBytes = kMlpLdsB3 + 16 * 4;
 
 // every thread of the workgroup (kBlockThreads = 256) calls this once, before the first evaluation
 __device__ __forceinline__ void stage_mlp_weights(const MlpDeviceWeights& w, char* lds) {
+  static_assert(kMlpTiles * 64 == 256 && kMlpTiles * (kMlpTiles / 2) * 64 == 512, "the copy below is laid out for 256 threads and a 64-wide network");
   const int t = threadIdx.x;
   reinterpret_cast<half4_t*>(lds + kMlpLdsW1)[t] = w.w1[t];
   reinterpret_cast<half8_t*>(lds + kMlpLdsW2)[t] = w.w2[t];

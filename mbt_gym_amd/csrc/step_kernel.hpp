@@ -1130,6 +1130,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
 #ifndef MBT_JIT_USER_CODE
   constexpr int kMlpLdsWaveBytesPerBlock = (kBlockThreads / 64) * kMlpLdsBytesPerWave;
   __shared__ __attribute__((aligned(16))) char policy_lds[LEARNED ? kMlpLdsWaveBytesPerBlock + kMlpLdsWeightBytes : 16];
+  static_assert(!LEARNED || kBlockThreads == 256, "stage_mlp_weights copies with 256 threads");
   if (LEARNED && !LP->is_linear) stage_mlp_weights(LP->w, policy_lds + kMlpLdsWaveBytesPerBlock);  // (uniform branch: the barrier inside is reached by all or none)
 #endif
   for (uint32_t k = 0; k < R.n_steps; ++k) {
