@@ -230,8 +230,12 @@ def test_random_speed_configuration_matches_the_oracle(case):
         move = np.nan_to_num(np.abs(o_obs[:, 3] - o_prev[:, 3]), nan=0.0)  # (constant midprice, normalised: a zero-width Box column is NaN on both sides)
         tol = tol + 1.5 * move * (np.abs(obs[:, 1] - o_obs[:, 1]) + 1e-6)
         # measured over 240 random configurations (profiles/r03_fuzz_clip_maxima.json): 1.03e-3 (4.6e-4 of |r|) - cash of ~1e4 and a
-        # real-valued inventory at its limit, both float32 state marked to market; bound: 2x
-        assert np.all(err[clipped] <= 2e-3 + 1e-5 * np.abs(o_rew[clipped])), f"{tag} step {k}: reward on clipped lanes"
+        # real-valued inventory at its limit, both float32 state marked to market; bound: 2x.  The 6 000 speed configurations of
+        # the round-3 soak (profiles/r03_soak.txt) found the tail of it: every lane pinned at BOTH limits for the whole episode
+        # (cash -9882: one float32 ulp is 9.8e-4), rewards of hundreds per step, errors up to 5.6e-3 = 5.7 ulp of that cash - so
+        # the bound carries the ulp of the cash the episode reaches, the quantity the error is made of
+        cash_ulp = float(np.spacing(np.float32(cash_scale)))
+        assert np.all(err[clipped] <= 2e-3 + 1e-5 * np.abs(o_rew[clipped]) + 8 * cash_ulp), f"{tag} step {k}: reward on clipped lanes"
         assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()} (allowed {tol[~clipped][np.argmax((err - tol)[~clipped])]})"
         prev, o_prev = obs, o_obs
         assert bool(dones[0]) == bool(o_dones[0])
