@@ -587,10 +587,10 @@ def main():
                 "note": "algorithmic bytes (44 B/env-step x lanes per launch) / mean launch-to-launch time from HIP events on "
                         "the kernel's stream over the timed region.  At 2^20 lanes the 46 MB a launch touches stay in the 256 MB "
                         "Infinity Cache between launches, so this is NOT an HBM rate (it can exceed the ~6.3 TB/s HBM sustains); "
-                        "`hbm_resident` is the same kernel where every byte crosses HBM.  Cross-check: rocprofv3 --kernel-trace "
-                        "(launches stay back to back) gives the same per-kernel time within 2-4 %; with --stats the tracer makes the "
-                        "host the bottleneck, every kernel starts on an idle chip and the average is 5-12 % higher "
-                        "(profiles/r03_bench_kernel_trace_hist*.txt).",
+                        "`hbm_resident` is the same kernel where every byte crosses HBM.  Cross-check: per-dispatch durations under "
+                        "rocprofv3 agree within 1-4 % in runs where the traced launches stay back to back; the tracer raises the host's "
+                        "cost per launch to about the kernel's duration, and in runs where the queue runs dry kernels start on an idle "
+                        "chip and take 0.5-1.8 us longer (profiles/r03_bench_kernel_trace_hist*.txt).",
             },
             "event_env_steps_per_s": total_lanes * args.steps / event_s,
             "mean_episode_return": return_statistics(sums)[0],
