@@ -13,7 +13,8 @@
  *   - plain C types only; no exceptions cross the boundary; every call returns 0 or a negative
  *     mbt_status and leaves a message for mbt_last_error() (thread local).
  *   - the library owns all device memory of an environment; callers own every pointer they pass.
- *   - "*_host" entry points take pageable host pointers and are synchronous (NumPy semantics);
+ *   - "*_host" entry points take any host pointer (pinned memory - mbt_host_alloc, or the caller's own - is read and
+ *     written by DMA directly, pageable memory through a bounce buffer) and are synchronous (NumPy semantics);
  *     "*_device" entry points take device pointers (or NULL = the library's own buffers), only enqueue
  *     work on the environment's HIP stream and return immediately.
  *   - one host thread per environment handle at a time.
