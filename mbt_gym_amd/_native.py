@@ -395,8 +395,8 @@ class OutputPool:
     the DMA that fills it - were most of a 2^20-lane step).  A caller that holds on to many outputs makes the pool grow, up to
     `max_bytes` of pinned memory; beyond that it gets ordinary (pageable) arrays, as before."""
 
-    def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30):
-        self.shape, self.dtype, self.max_bytes = tuple(shape), np.dtype(dtype), max_bytes
+    def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30, min_buffers=2):
+        self.shape, self.dtype, self.max_bytes, self.min_buffers = tuple(shape), np.dtype(dtype), max_bytes, min_buffers
         self._pinned_unavailable = False
         self.buffers = [_RefProbe()]
         self._idle_refs = self._refs(0)  # references a buffer has when only this pool looks at it (counted exactly as acquire() counts)
@@ -414,7 +414,7 @@ class OutputPool:
             if self._refs(index) <= self._idle_refs:
                 return self.buffers[index].array(), True
         nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        if not self._pinned_unavailable and (len(self.buffers) + 1) * nbytes <= max(self.max_bytes, 2 * nbytes):
+        if not self._pinned_unavailable and (len(self.buffers) + 1) * nbytes <= max(self.max_bytes, self.min_buffers * nbytes):
             try:
                 self.buffers.append(PinnedBuffer(self.shape, self.dtype))
             except (NativeError, RuntimeError, OSError):  # no pinned memory to be had (no device, a locked-memory limit):

@@ -1789,7 +1789,7 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
   // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends); the buffers
-  // are kept by the environment (grow-only, up to 1 GiB each), so a consumer that records every episode allocates once
+  // are kept by the environment (grow-only, up to 8 GiB each), so a consumer that records every episode allocates once
   const uint32_t remaining = static_cast<uint32_t>(std::ceil((e->cfg.terminal_time - e->time) / e->dt)) + 1;
   const size_t k_max = max_steps < remaining ? max_steps : remaining;
   const size_t np = e->n_pad;
@@ -1816,14 +1816,20 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
     // compact the padded time slices (n_pad lanes) into the caller's (n lanes) with strided copies
     const size_t n = e->n;
     hipError_t he = hipSuccess;
-    if (d_obs != nullptr) he = hipMemcpy2DAsync(obs_traj, n * e->dim * sizeof(float), d_obs, np * e->dim * sizeof(float), n * e->dim * sizeof(float), steps + 1, hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess && d_act != nullptr) he = hipMemcpy2DAsync(act_traj, n * e->act_dim * sizeof(float), d_act, np * e->act_dim * sizeof(float), n * e->act_dim * sizeof(float), steps, hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess && d_rew != nullptr) he = hipMemcpy2DAsync(rew_traj, n * sizeof(float), d_rew, np * sizeof(float), n * sizeof(float), steps, hipMemcpyDeviceToHost, e->stream);
+    // (a batch that fills its tiles has no pad rows: one linear copy per array - the 2-D form is the slower path of the runtime)
+    auto copy_out = [&](float* dst, const float* src, size_t width, size_t rows) {
+      if (np == n) return hipMemcpyAsync(dst, src, rows * n * width * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+      return hipMemcpy2DAsync(dst, n * width * sizeof(float), src, np * width * sizeof(float), n * width * sizeof(float), rows, hipMemcpyDeviceToHost, e->stream);
+    };
+    if (d_obs != nullptr) he = copy_out(obs_traj, d_obs, e->dim, steps + 1);
+    if (he == hipSuccess && d_act != nullptr) he = copy_out(act_traj, d_act, e->act_dim, steps);
+    if (he == hipSuccess && d_rew != nullptr) he = copy_out(rew_traj, d_rew, 1, steps);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) rc = fail(MBT_ERR_HIP, "trajectory copy failed: %s", hipGetErrorString(he));
   }
-  for (int j = 0; j < 3; ++j)  // what is kept between calls is bounded: a recording of gigabytes is released again
-    if (e->traj_stage_floats[j] * sizeof(float) > (size_t(1) << 30)) {
+  for (int j = 0; j < 3; ++j)  // what is kept between calls is bounded (8 GiB per array of the 288 GB: a 2^20-lane, 200-step recording
+                               // stays - allocating and freeing its 5.9 GB every episode cost as much as copying it out)
+    if (e->traj_stage_floats[j] * sizeof(float) > (size_t(8) << 30)) {
       (void)hipStreamSynchronize(e->stream);
       (void)hipFree(e->traj_stage[j]);
       e->traj_stage[j] = nullptr;

@@ -21,6 +21,7 @@ Differences from the reference, all deliberate:
   * clipping of cash/inventory is counted on the device (`clip_count`) instead of printing whole arrays.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Callable, Tuple, Union
 
@@ -488,15 +489,27 @@ class TradingEnvironment(_EnvBase):
         n = self.num_trajectories
         obs = act = rew = None
         if record:
-            obs = np.empty((k + 1, n, self.observation_dim), dtype=np.float32)
-            act = np.empty((k, n, self.action_dim), dtype=np.float32)
-            rew = np.empty((k, n), dtype=np.float32)
+            obs, act, rew = self._trajectory_buffers(k)
         steps, done = C.c_uint32(0), C.c_int32(0)
         _native.check(_native.load_library().mbt_env_rollout_host(
             self._handle, C.byref(pol), k, _native.fptr(obs), _native.fptr(act), _native.fptr(rew), C.byref(steps), C.byref(done)))
         if record:
             obs, act, rew = obs[: steps.value + 1], act[: steps.value], rew[: steps.value]
         return obs, act, rew, int(steps.value), bool(done.value)
+
+    def _trajectory_buffers(self, k):
+        """The three host arrays of a recorded rollout.  Like the outputs of step() they live in pinned memory that the
+        device-to-host copies write directly and that is re-used once the caller has dropped the previous recording
+        (`_native.OutputPool`; a fresh np.empty of this size is page-faulted in by the copy at a fifth of the PCIe rate) -
+        up to MBT_PINNED_TRAJECTORY_BYTES (default 8 GiB: two recordings of 2^20 lanes x 200 steps) of pinned memory per
+        array; beyond that, or where the host refuses to pin that much, ordinary arrays."""
+        n = self.num_trajectories
+        shapes = ((k + 1, n, self.observation_dim), (k, n, self.action_dim), (k, n))
+        pools = getattr(self, "_trajectory_pools", None)
+        if pools is None or tuple(p.shape for p in pools) != shapes:  # another length: the old recordings' buffers go with their last reference
+            cap = int(os.environ.get("MBT_PINNED_TRAJECTORY_BYTES", str(8 << 30)))
+            pools = self._trajectory_pools = tuple(_native.OutputPool(shape, max_bytes=cap, min_buffers=0) for shape in shapes)
+        return tuple(pool.acquire()[0] for pool in pools)
 
     def rollout_device(self, policy, max_steps: int = None, obs_ptr: int = None, act_ptr: int = None, rew_ptr: int = None):
         """Asynchronous variant: optional device pointers to time-major trajectory buffers sized for

@@ -129,6 +129,14 @@ def main():
         for _ in range(reps):
             generate_trajectory(env, agent)
         roll_s = (time.perf_counter() - t0) / reps
+        held = generate_trajectory(env, agent)  # the caller keeps each episode until the next one has arrived: two recordings alive
+        held = generate_trajectory(env, agent)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            held = generate_trajectory(env, agent)
+        roll_held_s = (time.perf_counter() - t0) / reps
+        recorded_bytes = sum(a.nbytes for a in held)
+        del held
         env.reset()
         env.rollout(agent, record=False)
         t0 = time.perf_counter()
@@ -137,7 +145,9 @@ def main():
             env.rollout(agent, record=False)
             env.synchronize()
         fused_s = (time.perf_counter() - t0) / reps
-        row["generate_trajectory"] = {"ms_per_episode": roll_s * 1e3, "env_steps_per_s": n * cfg.n_steps / roll_s}
+        row["generate_trajectory"] = {"ms_per_episode": roll_s * 1e3, "env_steps_per_s": n * cfg.n_steps / roll_s, "recorded_MB": recorded_bytes / 1e6,
+                                      "GBps_device_to_host": recorded_bytes / roll_s / 1e9,
+                                      "ms_per_episode_result_kept_until_the_next": roll_held_s * 1e3}
         row["rollout_returns_only"] = {"ms_per_episode": fused_s * 1e3, "env_steps_per_s": n * cfg.n_steps / fused_s}
         if n <= 1 << 16:
             o = OracleEnv(cfg, NumpyProtocolNoise(50))

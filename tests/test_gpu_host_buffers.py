@@ -131,3 +131,40 @@ def test_sb3_adapter_auto_reset_hands_out_terminal_observations_that_stay_valid(
     infos, want = terminal  # kept across later steps: still the terminal observation of that episode
     np.testing.assert_array_equal(np.stack([infos[i]["terminal_observation"] for i in (0, 7, n - 1)]), want[[0, 7, n - 1]])
     venv.close(), ref.close()
+
+
+def test_recorded_rollouts_reuse_pinned_arrays_only_after_the_caller_dropped_them():
+    """env.rollout(record=True) hands out arrays over pooled pinned memory: a recording the caller keeps keeps its values, one that
+    was dropped lends its memory to the next (no fresh gigabytes per episode)."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedSpreadAgent
+
+    n = 3000
+    env, ref = make_env(_cfg(n, n_steps=25), noise="philox"), make_env(_cfg(n, n_steps=25), noise="philox")
+    agent = FixedSpreadAgent(env, half_spread=0.7)
+    env.reset()
+    kept = env.rollout(agent, record=True)[:3]          # episode 1, kept
+    kept_copy = [a.copy() for a in kept]
+    env.reset()
+    second = env.rollout(agent, record=True)[:3]        # episode 2 (Philox counters moved on): other memory than episode 1
+    assert all(a.ctypes.data != b.ctypes.data for a, b in zip(kept, second))
+    for a, b in zip(kept, kept_copy):
+        np.testing.assert_array_equal(a, b)
+    address = [a.ctypes.data for a in second]
+    second_copy = [a.copy() for a in second]
+    del second
+    env.reset()
+    third = env.rollout(agent, record=True)[:3]         # the dropped recording's memory comes back
+    assert [a.ctypes.data for a in third] == address
+    for a, b in zip(kept, kept_copy):
+        np.testing.assert_array_equal(a, b)
+    # and the values are those of the step loop on a second environment with the same seed (which pools nothing of this kind)
+    action = np.tile(np.array([[0.7, 0.7]], np.float32), (n, 1))
+    for recorded in (kept, second_copy, third):
+        obs = ref.reset()
+        np.testing.assert_array_equal(recorded[0][0], obs)
+        for k in range(25):
+            obs, rew, done, _ = ref.step(action)
+            np.testing.assert_array_equal(recorded[0][k + 1], obs)
+            np.testing.assert_array_equal(recorded[2][k], rew)
+            np.testing.assert_array_equal(recorded[1][k], action)
+    env.close(), ref.close()
