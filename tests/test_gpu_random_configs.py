@@ -51,6 +51,7 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
     np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-5, err_msg=tag)
     scale = np.maximum(1.0, np.abs(o_obs[:, 0])) if not cfg.normalise_observation_space else None
     alive = np.ones(n, dtype=bool)
+    cash_scale = 0.0  # the largest |cash| the episode reaches (raw units): clipped lanes mark float32 state of that magnitude to market
     for k in range(steps):
         alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0])
         if cfg.midprice == "gbm":  # raw (un-normalised) states before the step, for the reward bound below
@@ -59,11 +60,14 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
         o_rew = np.broadcast_to(np.asarray(o_rew, dtype=np.float64), (n,))
         clipped = oracle.last_clipped
+        cash_scale = max(cash_scale, float(np.abs(oracle.state[:, 0]).max()))
         if scale is not None:
             scale = np.maximum(scale, np.abs(o_obs[:, 0]))
         obs, rew, o_obs, o_rew, clipped, scale_k = obs[alive], rew[alive], o_obs[alive], o_rew[alive], clipped[alive], (scale[alive] if scale is not None else None)
         if cfg.normalise_observation_space:
-            np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-4, err_msg=f"{tag} step {k}")
+            # (rtol: a geometric midprice may leave its Box by orders of magnitude - 53 in normalised units in the round-3 soak -
+            # and is then float32-accurate RELATIVE to that)
+            np.testing.assert_allclose(obs, o_obs, rtol=2e-6, atol=1e-4, err_msg=f"{tag} step {k}")
             q = np.rint((obs[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)
             np.testing.assert_array_equal(q, np.rint((o_obs[:, 1] + 1) * cfg.max_inventory - cfg.max_inventory), err_msg=f"{tag} step {k}: inventory")
         else:
@@ -78,9 +82,16 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
             if not dones[0]:
                 assert np.all(rew == 0.0) and np.all(o_rew == 0.0)
             else:
-                w_got, w_want = -np.log(-rew.astype(np.float64)) / cfg.risk_aversion, -np.log(-o_rew) / cfg.risk_aversion
+                w_want = -np.log(-o_rew) / cfg.risk_aversion
+                # a utility beyond the float32 range (gamma W < -85: losses of hundreds at a large risk aversion; seen in the
+                # round-3 soak) is -inf, or within a rounding of the largest float32, on both sides: nothing to compare through W
+                overflow = -cfg.risk_aversion * w_want > 85.0
+                assert np.all(rew[overflow] < -1e36), f"{tag} step {k}: utility beyond the float32 range"
+                with np.errstate(divide="ignore"):
+                    w_got = -np.log(-rew.astype(np.float64)) / cfg.risk_aversion
                 wealth_tol = 1e-3 + 4e-6 * (np.abs(w_want) + (scale_k if scale_k is not None else 0.0)) + 1e-2 * clipped
-                assert np.all(np.abs(w_got - w_want) <= wealth_tol), f"{tag} step {k}: terminal wealth off by {np.max(np.abs(w_got - w_want))}"
+                ok = (np.abs(w_got - w_want) <= wealth_tol) | overflow
+                assert np.all(ok), f"{tag} step {k}: terminal wealth off by {np.max(np.abs(w_got - w_want)[~overflow])}"
         else:
             # rewards: 1e-5, except where the reward itself carries float32 state (a clip; state-proportional diffusion)
             tol = 1e-5 + (2e-6 * np.abs(o_rew) if cfg.midprice == "gbm" else 0.0)
@@ -97,7 +108,10 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
             err = np.abs(rew - o_rew)
             # clipped lane-steps: the reward carries the level of the float32 cash / midprice.  Measured over 600 random configurations
             # (tests/dbg/fuzz_clip_maxima.py -> profiles/r03_fuzz_clip_maxima.json): 4.4e-5; over the fixtures: 5.8e-5.  Bound: 2x the latter
-            assert np.all(err[clipped] <= 1.2e-4), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
+            # ... plus the float32 spacing of the cash the episode reaches (the round-3 soak of 30 000 configurations: 1.36e-4 with
+            # geometric midprices and cash in the thousands, where one ulp is 1.2e-4 to 4.9e-4)
+            clip_tol = 1.2e-4 + 2 * float(np.spacing(np.float32(cash_scale)))
+            assert np.all(err[clipped] <= clip_tol), f"{tag} step {k}: reward on clipped lanes {err[clipped].max() if clipped.any() else 0}"
             assert np.all((err <= tol)[~clipped]), f"{tag} step {k}: rewards off by {err[~clipped].max()}"
         assert bool(dones[0]) == bool(o_dones[0])
     assert dones[0]
@@ -285,7 +299,9 @@ def test_random_configuration_rollout_equals_the_step_loop(case):
     # lanes in double): equal up to float32 rounding of the TERMS - a sum of returns of either sign can cancel to ~1 while
     # sum |R| <= sqrt(n sum R^2) is 1e4 (seen: 3e-4 on a sum of 1.3 with sum R^2 = 1.2e6)
     magnitude = float(np.abs(rew_r).sum())  # (per-step rewards of +-300 can cancel to an episode return of 0.1: the roundings do not)
-    np.testing.assert_allclose(sums_a[0], sums_b[0], rtol=1e-5, atol=1e-5 + 2e-7 * magnitude)
+    # (a lane's own float32 accumulation over k steps is good to k eps / 2 of its sum |r| at worst, sqrt(k) typically; the
+    # round-3 soak of 12 000 such configurations saw 3.4e-7 of the magnitude on 3 lanes, where nothing averages out)
+    np.testing.assert_allclose(sums_a[0], sums_b[0], rtol=1e-5, atol=1e-5 + 1e-6 * magnitude)
     np.testing.assert_allclose(sums_a[1], sums_b[1], rtol=1e-5, atol=1e-5)
     assert env_a.clip_count == env_b.clip_count
     env_a.close()
