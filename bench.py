@@ -61,29 +61,101 @@ def default_prewarm_steps(lanes):
     return int(min(PREWARM_STEPS_AT_2_20, max(64, PREWARM_STEPS_AT_2_20 * LANES_PER_GPU // max(1, lanes))))
 
 
-def build_env(n, offset, device):
-    """The environment through the public plugin API, one shard of the trajectory axis per rank."""
-    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+# BASELINE.json configs[1..4] as the public plugin API builds them (sizes, parameters, credited bytes).
+# `kernel`: the template arguments of the step kernel the library picks (mbt_env.hip: pick_kernel) - arrival layout, dynamics,
+# Brownian, reward tier, normalised, injected noise, exogenous fill - to which the tier (precise_state) and the load policy
+# (STREAM beyond 320 MB per launch) are appended: the name a rocprofv3 kernel-stats row carries.
+WORKLOADS = {
+    "cfg1": dict(label="cfg1 Avellaneda-Stoikov (BM, Poisson, exponential fills, PnL)", lanes=1 << 20, dim=4, act=2, kernel=(0, 0, True, 0)),
+    "cfg2_cjmm": dict(label="cfg2 Cartea-Jaimungal-Penalva, CjMmCriterion(0.01, 0.001)", lanes=1 << 20, dim=4, act=2, kernel=(0, 0, True, 1)),
+    "cfg2_running": dict(label="cfg2 Cartea-Jaimungal-Penalva, RunningInventoryPenalty(0.01, 0.001)", lanes=1 << 20, dim=4, act=2, kernel=(0, 0, True, 1)),
+    "cfg3": dict(label="cfg3 Hawkes arrivals + OU midprice, PnL", lanes=1 << 22, dim=6, act=2, kernel=(1, 0, False, 0)),
+    "cfg4": dict(label="cfg4 limit + market orders, Bernoulli(0.01) market-order flags, PnL", lanes=1 << 21, dim=4, act=4, kernel=(0, 1, True, 0)),
+}
+
+
+def credited_bytes(key):
+    """ALGORITHMIC bytes per env-step, SURVEY.md section 8d: state read + action read + next-state write + reward write in
+    float32 - 44 / 60 / 52 B.  The int32 remainders the precise_state tier also moves (+16 / +32 B) are overhead, not credit."""
+    w = WORKLOADS[key]
+    return 4 * (w["dim"] + w["act"] + w["dim"] + 1)
+
+
+def moved_bytes(key, precise):
+    w = WORKLOADS[key]
+    return credited_bytes(key) + (0 if not precise else 16 * (4 if w["kernel"][0] == 1 else 2))  # remainder columns: read + written
+
+
+def kernel_name(key, precise, lanes):
+    arr, dyn, bm, rew = WORKLOADS[key]["kernel"]
+    stream = lanes * moved_bytes(key, precise) > (320 << 20)
+    b = lambda x: "true" if x else "false"  # noqa: E731
+    return (f"mbt::step_kernel<mbt::Variant<{arr}, {dyn}, {b(bm)}, {rew}, false, false, false, {b(precise)}, false, false, false, false, 0, false, 0>, "
+            f"{b(stream)}>")
+
+
+def build_env(n, offset, device, workload="cfg1", precise=False):
+    """One shard of the trajectory axis of a BASELINE workload, through the public plugin API."""
+    from mbt_gym_amd.gym.ModelDynamics import LimitAndMarketOrderModelDynamics, LimitOrderModelDynamics
     from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
-    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.rewards.RewardFunctions import CjMmCriterion, PnL, RunningInventoryPenalty
+    from mbt_gym_amd.stochastic_processes.arrival_models import HawkesArrivalModel, PoissonArrivalModel
     from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
-    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel, OuMidpriceModel
 
     dt = 1.0 / N_STEPS
-    dynamics = LimitOrderModelDynamics(
-        midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
-        arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
-        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n),
-        num_trajectories=n,
-    )
+    if workload == "cfg3":
+        midprice = OuMidpriceModel(mean_reversion_level=100.0, mean_reversion_speed=0.01, volatility=2.0, initial_price=100.0, terminal_time=1.0,
+                                   step_size=dt, num_trajectories=n)
+        arrivals = HawkesArrivalModel(baseline_arrival_rate=np.array([[10.0, 10.0]]), step_size=dt, jump_size=40.0, mean_reversion_speed=60.0,
+                                      terminal_time=1.0, num_trajectories=n)
+    else:
+        midprice = BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n)
+        arrivals = PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n)
+    fills = ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n)
+    dynamics_class = LimitAndMarketOrderModelDynamics if workload == "cfg4" else LimitOrderModelDynamics
+    dynamics = dynamics_class(midprice_model=midprice, arrival_model=arrivals, fill_probability_model=fills, num_trajectories=n)
+    reward = {"cfg2_cjmm": lambda: CjMmCriterion(0.01, 0.001, terminal_time=1.0), "cfg2_running": lambda: RunningInventoryPenalty(0.01, 0.001)}.get(workload, PnL)()
     env = TradingEnvironment(
-        terminal_time=1.0, n_steps=N_STEPS, model_dynamics=dynamics, initial_inventory=0, max_inventory=N_STEPS,
-        seed=SEED, num_trajectories=n, normalise_action_space=False, normalise_observation_space=False,
-        device=device, trajectory_offset=offset,
+        terminal_time=1.0, n_steps=N_STEPS, model_dynamics=dynamics, reward_function=reward, initial_inventory=10 if workload == "cfg4" else 0,
+        max_inventory=100 if workload.startswith("cfg2") else N_STEPS, seed=SEED + (360 if workload.startswith("cfg2") else 0), num_trajectories=n,
+        normalise_action_space=False, normalise_observation_space=False, device=device, trajectory_offset=offset, precise_state=precise,
     )
-    env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
+    if workload == "cfg4":
+        # (bid depth, ask depth, market buy, market sell): the flags ~ Bernoulli(0.01), drawn ON THE DEVICE straight into the
+        # library's action buffer (zero copy) - keyed on the global lane id, so the action of a lane does not depend on the sharding
+        import torch
+
+        view = torch.as_tensor(env.action_device, device=f"cuda:{device}")
+        lane = torch.arange(offset, offset + n, device=f"cuda:{device}", dtype=torch.int64)
+
+        def uniform(column):  # a counter-based draw per (global lane, column): an integer hash (wrapping int64 arithmetic) -> [0, 1)
+            mask = (1 << 62) - 1
+            x = (lane * 2 + column + 0x1E3779B97F4A7C15) & mask
+            x = ((x ^ (x >> 30)) * 0x1CE4E5B9 + 0x133111EB) & mask
+            x = ((x ^ (x >> 27)) * 0x2545F491) & mask
+            x = x ^ (x >> 31)
+            return (x & ((1 << 24) - 1)).to(torch.float32) / float(1 << 24)
+
+        view[:, 0] = QUOTE[0]
+        view[:, 1] = QUOTE[1]
+        view[:, 2] = (uniform(0) < 0.01).to(torch.float32)
+        view[:, 3] = (uniform(1) < 0.01).to(torch.float32)
+        torch.cuda.synchronize(device)
+    else:
+        env.set_action_host(np.tile(np.array([QUOTE], dtype=np.float32), (n, 1)))
+    if TRACED_LAUNCH_GATE:
+        env.set_launch_gate(TRACED_LAUNCH_GATE)
     env.reset_device()
     return env
+
+
+# Under rocprofv3 the host needs ~11 us per traced launch - more than the 7 us kernels here take - so the queue runs dry and
+# a kernel that starts on an idle chip runs 0.5-1.8 us LONGER than in the untraced run the profile is meant to describe
+# (profiles/r03_bench_kernel_trace_hist*.txt).  When a tracer is attached the launches are therefore enqueued in bursts behind
+# a gate kernel (include/mbt_env.h: mbt_env_set_launch_gate) and run back to back, as they do untraced; the line says so.
+TRACED = "ROCP_TOOL_LIBRARIES" in os.environ  # what rocprofv3 sets for the process it launches
+TRACED_LAUNCH_GATE = int(os.environ.get("MBT_BENCH_GATE", "1024" if TRACED else "0") or 0)  # MBT_BENCH_GATE=0: never
 
 
 def timed_steps(env, lib, k, sync_all):
@@ -116,6 +188,69 @@ def pmc_traffic(n):
         if "step_kernel" in name:
             return row["hbm_bytes_per_launch"]
     return None
+
+
+def rocprof_reference():
+    """{kernel name: average duration (ns)} from the newest committed `rocprofv3 --kernel-trace --stats` summary of THIS command
+    (profiles/rNN_bench_kernel_stats.csv, tools/refresh_profiles.sh) and the file's name - so that the line can say, per
+    kernel, what the tracked profile gives next to what the HIP events of this run give, and take the LOWER fraction."""
+    import csv
+
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")) if re.fullmatch(r"r\d+_bench_kernel_stats\.csv", os.path.basename(p)))
+    if not paths:
+        return {}, None
+    rows = {}
+    with open(paths[-1], newline="") as f:
+        for row in csv.DictReader(f):
+            rows[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
+    return rows, os.path.relpath(paths[-1], ROOT)
+
+
+def roofline_row(key, precise, lanes, launch_s, reference):
+    """One kernel against the HBM roofline in CREDITED bytes: `frac_events` from this run's HIP events, `frac_rocprof` from the
+    committed rocprofv3 summary (None when it has no row for this kernel), `frac` the lower of the two."""
+    name = kernel_name(key, precise, lanes)
+    credited = credited_bytes(key) * lanes
+    frac_events = credited / launch_s / 1e9 / HBM_PEAK_GBPS
+    hit = next((v for k, v in reference.items() if name in k), None)
+    frac_rocprof = None if hit is None else credited / (hit[0] * 1e-9) / 1e9 / HBM_PEAK_GBPS
+    frac = frac_events if frac_rocprof is None else min(frac_events, frac_rocprof)
+    return {"config": WORKLOADS[key]["label"], "tier": "precise_state (the reference's float64 arithmetic)" if precise else "float32",
+            "lanes": lanes, "credited_bytes_per_env_step": credited_bytes(key), "moved_bytes_per_env_step": moved_bytes(key, precise),
+            "avg_launch_us": launch_s * 1e6, "avg_launch_us_rocprof": None if hit is None else hit[0] / 1e3,
+            "frac_events": frac_events, "frac_rocprof": frac_rocprof, "frac": frac, "achieved": frac * HBM_PEAK_GBPS,
+            "env_steps_per_s_kernel": lanes / launch_s, "kernel": name}
+
+
+def configs_block(lib, device, reference, steps_budget_s=0.06):
+    """Every other BASELINE configuration's step kernel, and the contract tier (`precise_state`) of all four, measured on THIS box
+    exactly like the headline: K launches in one library call, HIP events on the kernel's stream, about 0.06 s of launches each
+    (parity-test cases, not bench lines - they never enter `value`)."""
+    import torch
+
+    rows = []
+    cases = [("cfg2_cjmm", False), ("cfg2_running", False), ("cfg3", False), ("cfg4", False),
+             ("cfg1", True), ("cfg2_cjmm", True), ("cfg3", True), ("cfg4", True)]
+    for key, precise in cases:
+        lanes = WORKLOADS[key]["lanes"]
+        try:
+            env = build_env(lanes, 0, device, workload=key, precise=precise)
+
+            def sync_all(barrier=True, env=env):
+                env.synchronize()
+                torch.cuda.synchronize()
+
+            rough_us = moved_bytes(key, precise) * lanes / 5.5e6  # at ~5.5 TB/s: only sizes the launch counts
+            steps = int(max(200, min(4000, steps_budget_s * 1e6 / rough_us)))
+            env.step_many_device(max(100, steps // 2), auto_reset=True)
+            _, event_s, _ = timed_steps(env, lib, steps, sync_all)
+            env.close()
+            row = roofline_row(key, precise, lanes, event_s / steps, reference)
+            row["steps_timed"] = steps
+            rows.append(row)
+        except Exception as exc:  # noqa: BLE001 - one configuration failing must not take the line down
+            rows.append({"config": WORKLOADS[key]["label"], "tier": "precise_state" if precise else "float32", "error": str(exc)})
+    return rows
 
 
 def _cpu_worker(args):
@@ -220,7 +355,7 @@ def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32, 6
     return out
 
 
-def hbm_resident_measurement(lib, device, steps=600, warmup=100):
+def hbm_resident_measurement(lib, device, reference, steps=600, warmup=100):
     """The same kernel on 2^24 lanes: 738 MB of state + actions + rewards per launch, beyond the 256 MB Infinity Cache,
     so every byte comes from / goes to HBM.  Reported beside the headline (cache-resident) figure, never instead of it."""
     import torch
@@ -237,10 +372,11 @@ def hbm_resident_measurement(lib, device, steps=600, warmup=100):
     finally:
         env.close()
     launch_s = event_s / steps
-    achieved = BYTES_PER_ENV_STEP * HBM_RESIDENT_LANES / launch_s / 1e9
+    row = roofline_row("cfg1", False, HBM_RESIDENT_LANES, launch_s, reference)
     return {
         "lanes": HBM_RESIDENT_LANES, "steps": steps, "bytes_per_launch": BYTES_PER_ENV_STEP * HBM_RESIDENT_LANES,
-        "avg_launch_us": launch_s * 1e6, "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
+        "avg_launch_us": launch_s * 1e6, "avg_launch_us_rocprof": row["avg_launch_us_rocprof"], "achieved": row["achieved"], "frac": row["frac"],
+        "frac_events": row["frac_events"], "frac_rocprof": row["frac_rocprof"], "kernel": row["kernel"],
         "env_steps_per_s": HBM_RESIDENT_LANES * steps / wall,
         "note": "working set 738 MB per launch > 256 MB Infinity Cache: HBM-resident; the achievable copy rate of the chip "
                 "is ~6.3 TB/s (0.79 of the spec peak)",
@@ -402,6 +538,20 @@ def gpu_cfg0_figures(device):
             episode()
             count += 1
         out[name + "_env_steps_per_s"] = n * n_steps * count / (time.perf_counter() - t0)
+    # env.step(ndarray) on its own (a fixed action: no agent), and through the SB3 VecEnv adapter with its auto-reset (SBE:28-37)
+    from mbt_gym_amd.gym.StableBaselinesTradingEnvironment import StableBaselinesTradingEnvironment
+
+    action = np.tile(np.array([QUOTE], dtype=np.float32), (n, 1))
+    vec_env = StableBaselinesTradingEnvironment(trading_env=env)
+    for name, reset, step in (("env_step_us", env.reset, env.step), ("sb3_vec_env_step_us", vec_env.reset, vec_env.step)):
+        reset()
+        for _ in range(50):
+            step(action)
+        reset()
+        t0 = time.perf_counter()
+        for _ in range(150):
+            step(action)
+        out[name] = (time.perf_counter() - t0) / 150 * 1e6
     env.close()
     out["note"] = "N = 1000 x 200 steps: a launch-latency regime (140 KB of state), not a bandwidth one; reported beside the CPU port's configs0 figure"
     return out
@@ -417,6 +567,11 @@ def main():
     ap.add_argument("--lanes", type=int, default=LANES_PER_GPU, help="trajectories per GPU (default 2^20)")
     ap.add_argument("--prewarm-steps", type=int, default=-1, help="untimed clock warm-up before --warmup; -1 = ~55 ms worth, a fixed count for the size (default), 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration block (cfg2/3/4 and the precise_state tier; N = 1 only)")
+    ap.add_argument("--cfg4-total-lanes", type=int, default=1 << 24,
+                    help="N > 1: BASELINE.json configs[4] (limit + market orders) with this many lanes in TOTAL, sharded over the ranks "
+                         "(strong scaling: 2^21 per GPU at N = 8), reported as an extra block of the line; 0 = skip")
+    ap.add_argument("--cfg4-steps", type=int, default=400)
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
@@ -527,10 +682,12 @@ def main():
 
         wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
         episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
+    launch_us_min = launch_us_max = event_s / args.steps * 1e6  # per-rank mean launch-to-launch time: a straggler shows here
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([wall, event_s], dtype=torch.float64, device=tdev)
+        t = torch.tensor([wall, event_s, -event_s], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        launch_us_max, launch_us_min = float(t[1]) / args.steps * 1e6, -float(t[2]) / args.steps * 1e6
         wall, event_s = float(t[0]), float(t[1])
 
     # mean return of the last finished episode over ALL shards (or of the partial episode if none finished)
@@ -560,7 +717,39 @@ def main():
                       "us": per_call * 1e6, "known_answer_ok": correct, "per_episode_share_of_stepping": per_call / (N_STEPS * wall / args.steps),
                       "episodes_all_reduced_before_the_timed_region": len(warm_episodes)}
 
+    # BASELINE.json configs[4]: limit + market orders, --cfg4-total-lanes in TOTAL sharded over the ranks (strong scaling), the
+    # episode-return all-reduce on the same communicator; timed like the headline (barrier, K launches in one call, max over ranks)
+    cfg4 = None
+    if multi and args.cfg4_total_lanes > 0:
+        with Watchdog(max(args.comm_timeout, 300.0), "cfg4 (limit + market) sharded measurement", rank):
+            off4, n4 = shard_bounds(args.cfg4_total_lanes, rank, world)
+            env4 = build_env(n4, off4, gpu, workload="cfg4")
+            if comm is not None:
+                env4.set_communicator(comm)
+
+            def sync4(barrier=True):
+                env4.synchronize()
+                torch.cuda.synchronize()
+                if barrier and dist is not None:
+                    dist.barrier()
+
+            env4.step_many_device(max(50, args.cfg4_steps // 4), auto_reset=True)
+            wall4, event4, _ = timed_steps(env4, lib, args.cfg4_steps, sync4)
+            while env4.episode_log_pop(wait=True) is not None:
+                pass
+            t4 = torch.tensor([wall4, event4, -event4], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            env4.close()
+        launch4 = float(t4[1]) / args.cfg4_steps
+        cfg4 = {"workload": WORKLOADS["cfg4"]["label"] + ", BASELINE.json configs[4]", "scaling": "strong", "num_trajectories_total": args.cfg4_total_lanes,
+                "num_trajectories_per_gpu": n4, "steps": args.cfg4_steps, "value": args.cfg4_total_lanes * args.cfg4_steps / float(t4[0]), "unit": "env-steps/s",
+                "ms_per_step": float(t4[0]) / args.cfg4_steps * 1e3, "credited_bytes_per_env_step": credited_bytes("cfg4"),
+                "avg_launch_us_slowest_rank": launch4 * 1e6, "avg_launch_us_fastest_rank": -float(t4[2]) / args.cfg4_steps * 1e6,
+                "frac_per_gpu": credited_bytes("cfg4") * n4 / launch4 / 1e9 / HBM_PEAK_GBPS, "kernel": kernel_name("cfg4", False, n4)}
+
     if rank == 0:
+        reference, reference_file = rocprof_reference()
+        headline = roofline_row("cfg1", False, n, event_s / args.steps, reference)
         total_lanes = n * world
         value = total_lanes * args.steps / wall
         launch_s = event_s / args.steps  # includes the reset / reduction launches of finished episodes (2 per 1000 steps)
@@ -581,11 +770,16 @@ def main():
                                  "up (mbt_env.hip: tune_for_size): measured +2.5 % for it, a loss for every heavier kernel, which keep full occupancy",
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "bound": "hbm", "achieved": headline["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": headline["frac"],
+                "frac_events": achieved / HBM_PEAK_GBPS, "frac_rocprof": headline["frac_rocprof"], "rocprof_summary": reference_file,
+                "avg_launch_us_rocprof": headline["avg_launch_us_rocprof"], "kernel": headline["kernel"],
+                "avg_launch_us_per_rank": {"min": launch_us_min, "max": launch_us_max},
                 "traffic": pmc_traffic(n), "bytes_per_env_step": BYTES_PER_ENV_STEP, "avg_launch_us": launch_s * 1e6,
                 "regime": "Infinity-Cache resident" if n * BYTES_PER_ENV_STEP < (200 << 20) else "HBM resident",
-                "note": "algorithmic bytes (44 B/env-step x lanes per launch) / mean launch-to-launch time from HIP events on "
-                        "the kernel's stream over the timed region.  At 2^20 lanes the 46 MB a launch touches stay in the 256 MB "
+                "note": "`frac` = the LOWER of `frac_events` (algorithmic bytes, 44 B/env-step x lanes per launch, / mean launch-to-launch "
+                        "time from HIP events on the kernel's stream over the timed region of THIS run) and `frac_rocprof` (the same bytes / "
+                        "the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command, "
+                        "`rocprof_summary`); `achieved` = frac x peak.  At 2^20 lanes the 46 MB a launch touches stay in the 256 MB "
                         "Infinity Cache between launches, so this is NOT an HBM rate (it can exceed the ~6.3 TB/s HBM sustains); "
                         "`hbm_resident` is the same kernel where every byte crosses HBM.  Cross-check: per-dispatch durations under "
                         "rocprofv3 agree within 1-4 % in runs where the traced launches stay back to back; the tracer raises the host's "
@@ -595,15 +789,22 @@ def main():
             "event_env_steps_per_s": total_lanes * args.steps / event_s,
             "mean_episode_return": return_statistics(sums)[0],
         }
+        if TRACED_LAUNCH_GATE:
+            out["config"]["launch_gate"] = (f"launches enqueued in bursts of {TRACED_LAUNCH_GATE} behind a gate kernel (a tracer is attached: the host's "
+                                            "~11 us per traced launch would let the queue run dry); `value` is not a benchmark figure in this mode")
         if collective is not None:
             out["collective"] = collective
+        if cfg4 is not None:
+            out["cfg4_sharded"] = cfg4
     env.close()
     if rank == 0:
         if world == 1 and not args.no_hbm_resident:
             try:
-                out["roofline"]["hbm_resident"] = hbm_resident_measurement(lib, gpu)
+                out["roofline"]["hbm_resident"] = hbm_resident_measurement(lib, gpu, reference)
             except Exception as exc:  # noqa: BLE001 - e.g. a smaller device: the headline stands on its own
                 out["roofline"]["hbm_resident"] = {"error": str(exc)}
+        if world == 1 and not args.no_configs:
+            out["roofline"]["configs"] = configs_block(lib, gpu, reference)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:

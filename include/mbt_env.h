@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 5u
+#define MBT_ABI_VERSION 6u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -61,12 +61,14 @@ enum {
 enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
   MBT_ARR_NONE = 3 /* speed dynamics: no order flow (MD:47-48) */,
-  MBT_ARR_USER = 4 /* a user-defined, stateless ArrivalModel subclass (ARR:9-29): mbt_env_create_jit only */
+  MBT_ARR_USER = 4 /* a user-defined, stateless ArrivalModel subclass (ARR:9-29): mbt_env_create_jit only */,
+  MBT_ARR_HOST = 5 /* a stateless ArrivalModel subclass that only has HOST code: get_arrivals() runs in the caller, see "host-callback plugins" */
 };
 enum {
   MBT_FILL_EXPONENTIAL = 0 /* FILL:42-65 */, MBT_FILL_NONE = 1 /* at-the-touch and speed dynamics */,
   MBT_FILL_EXOGENOUS_MM = 2 /* FILL:126-170: certain inside an exogenous best depth, exponential beyond; adds two state columns */,
-  MBT_FILL_USER = 3 /* a user-defined FillProbabilityModel subclass (FILL:9-39): mbt_env_create_jit only */
+  MBT_FILL_USER = 3 /* a user-defined FillProbabilityModel subclass (FILL:9-39): mbt_env_create_jit only */,
+  MBT_FILL_HOST = 4 /* a FillProbabilityModel subclass that only has HOST code: _get_fill_probabilities runs in the caller */
 };
 enum {
   MBT_DYN_LIMIT = 0 /* MD:87-131 */, MBT_DYN_LIMIT_AND_MARKET = 1 /* MD:179-240 */, MBT_DYN_AT_THE_TOUCH = 2 /* MD:134-176 */,
@@ -75,7 +77,8 @@ enum {
 enum {
   MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */,
   MBT_REW_EXP_UTILITY = 3 /* RW:149-163 */, MBT_REW_CJ_OE = 4 /* RW:39-74, speed dynamics */,
-  MBT_REW_USER = 5 /* a user-defined RewardFunction subclass (RW:8-17): mbt_env_create_jit only */
+  MBT_REW_USER = 5 /* a user-defined RewardFunction subclass (RW:8-17): mbt_env_create_jit only */,
+  MBT_REW_HOST = 6 /* a RewardFunction subclass that only has HOST code: calculate() runs in the caller (order-book dynamics) */
 };
 enum {
   MBT_IMPACT_NONE = -1, MBT_IMPACT_TEMPORARY_POWER = 0 /* IMP:34-61 */, MBT_IMPACT_TEMPORARY_AND_PERMANENT = 1 /* IMP:64-96 */,
@@ -265,6 +268,32 @@ const char* mbt_jit_log(void);    /* thread local; "" when the last compilation 
 /* Compiles the kernels for (cfg, code) and discards them: "do these expressions compile?" - needs no GPU (hiprtc
  * cross-compiles), so a plugin can be checked where it is written. */
 int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
+/* ---- host-callback plugins: subclasses of the plugin contract that only have HOST code ----------------------------------
+ * A user of the reference writes FillProbabilityModel._get_fill_probabilities(depths) (FILL:22-34), ArrivalModel.get_arrivals()
+ * (ARR:27-29) or RewardFunction.calculate(current_state, action, next_state, is_terminal_step) (RW:10-13) in NumPy.  Such a
+ * class needs no device expression: with MBT_FILL_HOST / MBT_ARR_HOST / MBT_REW_HOST the caller's code keeps running on the
+ * host BETWEEN launches and the step kernel takes its results for the step - everything else of the step (max-inventory mask,
+ * cash / inventory, clip, midprice and Hawkes updates, normalisation, the draws themselves) stays on the device.  The slow
+ * path: one or two extra host round trips per step.  mbt_env_create serves these kinds (the kernel is still compiled at run
+ * time: one instantiation); they combine with built-in kinds and with device expressions of the OTHER families.  Per step:
+ *   1. MBT_FILL_HOST:  mbt_env_host_depths(action) -> the (N, 2) float64 depths the quotes stand for (the action
+ *      de-normalised in double exactly as the kernel does, TE:104 / TE:124); the caller evaluates its
+ *      _get_fill_probabilities(depths) and hands the (N, 2) float64 result to mbt_env_set_host_fill_probabilities: a fill is
+ *      u < p with u the lane's uniform (Philox, or injected), compared in double (FILL:33-34).
+ *   2. MBT_ARR_HOST:  the caller's get_arrivals() (which draws from the caller's own generator, ARR:55) -> (N, 2) 0.0f / 1.0f
+ *      -> mbt_env_set_host_arrivals.  Stateless models only (no state columns).
+ *   3. mbt_env_step_* as usual (refused with MBT_ERR_STATE if an input of this step is missing).
+ *   4. MBT_REW_HOST:  the step reports rewards of 0; the caller reads the float64 states (mbt_env_get_state_f64_host - before
+ *      and after the step; with precise_state they ARE the reference's float64 states), evaluates calculate() and files the
+ *      (N) float64 result with mbt_env_set_host_rewards: multiplied by cfg.reward_scale (TE:128-129), rounded once to float32,
+ *      written to the reward buffer, added to the episode-return sums; reward_out (N float32, may be NULL) receives what
+ *      env.step() returns.  The next step is refused until this happened.
+ * Fused rollouts are not available for such an environment (MBT_ERR_INVALID): the host is consulted every step. */
+int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_host);
+int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
+int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
+int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
+
 /* Every launch and copy of an environment is ordered on ONE stream: its own (created non-blocking, so it does not
  * synchronise with the null stream) until this call hands it another hipStream_t, e.g. torch's current stream.
  * mbt_env_create returns with all buffers allocated, zero-filled and idle.  A caller that reads or writes the device
@@ -294,7 +323,10 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
  *      FILL:28-34, FILL:57-58, TE:198-220, TE:283-289, TE:323-327, MID:60-65, MID:140-143, RW:23-33,
  *      RW:96-109, RW:128-138, TE:112-129) --------------------------------------------------------- */
 /* action: (N, A) float32 row-major, A = 2 (limit) or 4 (limit + market).  Outputs: obs (N, D), reward (N),
- * done (scalar; lane-invariant, TE:218-220).  Any output pointer may be NULL. */
+ * done (scalar; lane-invariant, TE:218-220).  Any output pointer may be NULL.
+ * Batches of up to 32768 lanes (the reference's own regime is N ~ 1000) take ONE launch and no interrupt: the step kernel
+ * reads the actions from, and mirrors observation rows and rewards into, pinned device-mapped host memory and raises a
+ * completion flag there that this call spins on. */
 int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);
 /* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
 int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);
@@ -306,6 +338,13 @@ int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done)
  * auto_reset the batch stops at the end of the episode.  steps_done / episodes_ended may be NULL. */
 int mbt_env_step_many_device(mbt_env* env, uint32_t k, const float* action_device, int32_t auto_reset, uint32_t* steps_done,
                              uint32_t* episodes_ended);
+/* Launch gate for mbt_env_step_many_device: with burst > 0 the launches of a call are enqueued in bursts of `burst` behind a
+ * one-thread kernel that waits for a word of host memory, which the library writes once the burst is queued - the kernels
+ * of a burst then run back to back however long the HOST needs per launch.  For runs under a tracer (rocprofv3 raises the
+ * host's cost per launch to ~11 us, above a 7 us kernel: the queue runs dry and kernels that start on an idle chip take
+ * 0.5-1.8 us longer than in the untraced run being profiled); not for production - the device idles while a burst is
+ * queued.  The gate kernel gives up by itself after 5 s.  burst <= 4096; 0 = off (default). */
+int mbt_env_set_launch_gate(mbt_env* env, uint32_t burst);
 
 /* ---- fused rollout: many steps in one launch with an on-device closed-form policy ---------------
  * Replaces the caller's per-time-step loop (gym/helpers/generate_trajectory.py:21-34) for policies that are closed

@@ -5,17 +5,19 @@ device is visible, environment construction raises - it never degrades to a CPU 
 """
 import ctypes as C
 import os
+import sys
+import time
 
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER = 0, 1, 2, 3, 4, 5, 6, 7
-ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER = 0, 1, 2, 3, 4
-FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER = 0, 1, 2, 3
+ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER, ARR_HOST = 0, 1, 2, 3, 4, 5
+FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER, FILL_HOST = 0, 1, 2, 3, 4
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
-REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE, REW_USER = 0, 1, 2, 3, 4, 5
+REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE, REW_USER, REW_HOST = 0, 1, 2, 3, 4, 5, 6
 IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT = -1, 0, 1, 2, 3
 NOISE_PHILOX, NOISE_INJECTED = 0, 1
 
@@ -197,8 +199,13 @@ SIGNATURES = {
     "mbt_env_seed": (C.c_int, [_ENV, C.c_uint64]),
     "mbt_env_reset": (C.c_int, [_ENV, C.c_double, _F]),
     "mbt_env_reset_host": (C.c_int, [_ENV, C.c_double, _F, _F]),
-    "mbt_env_step_host": (C.c_int, [_ENV, _F, _F, _F, C.POINTER(C.c_int32)]),
+    "mbt_env_step_host": (C.c_int, [_ENV, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),  # (float*: addresses are passed as they are)
     "mbt_env_step_device": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_int32)]),
+    "mbt_env_set_launch_gate": (C.c_int, [_ENV, C.c_uint32]),
+    "mbt_env_host_depths": (C.c_int, [_ENV, _F, C.POINTER(C.c_double)]),
+    "mbt_env_set_host_fill_probabilities": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
+    "mbt_env_set_host_arrivals": (C.c_int, [_ENV, _F]),
+    "mbt_env_set_host_rewards": (C.c_int, [_ENV, C.POINTER(C.c_double), _F]),
     "mbt_env_step_many_device": (C.c_int, [_ENV, C.c_uint32, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
@@ -386,6 +393,18 @@ class PinnedBuffer:
                 pass
 
 
+def _reference_counts_are_exact() -> bool:
+    """OutputPool decides that a buffer is idle from `sys.getrefcount`.  That is exact on standard (GIL) CPython only: on
+    PyPy, or a free-threaded build with deferred / biased counts, it says nothing reliable - there every output is a fresh
+    array, like the reference's.  MBT_FRESH_OUTPUTS=1 asks for that behaviour everywhere (see TradingEnvironment.step)."""
+    if os.environ.get("MBT_FRESH_OUTPUTS", "0") not in ("", "0"):
+        return False
+    if sys.implementation.name != "cpython" or not hasattr(sys, "getrefcount"):
+        return False
+    gil_enabled = getattr(sys, "_is_gil_enabled", None)
+    return True if gil_enabled is None else bool(gil_enabled())
+
+
 class OutputPool:
     """Output buffers of the host API (observations, rewards, dones) in pinned memory, re-used across steps WITHOUT changing
     what the caller sees: a buffer is handed out again only once no array over it is referenced any more (the reference
@@ -393,35 +412,70 @@ class OutputPool:
     `obs, rew, done, info = env.step(action)` the previous step's arrays die when the names are rebound, so two buffers
     alternate and nothing is allocated after the first two steps (a fresh 16 MB np.empty per step - and the page faults of
     the DMA that fills it - were most of a 2^20-lane step).  A caller that holds on to many outputs makes the pool grow, up to
-    `max_bytes` of pinned memory; beyond that it gets ordinary (pageable) arrays, as before."""
+    `max_bytes` of pinned memory; beyond that it gets ordinary (pageable) arrays, as before.
 
-    def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30, min_buffers=2):
+    What "referenced" means: PYTHON references - arrays, views, torch tensors made from them - which is what the count sees.
+    A consumer that keeps only a raw ADDRESS (`obs.ctypes.data`, a cffi / C-extension pointer cache) and drops the array is
+    invisible to it and will see the buffer overwritten two steps later; such a caller keeps a reference to the array, or
+    sets MBT_FRESH_OUTPUTS=1 (every output a fresh array, the reference's behaviour to the letter, at the cost described
+    above).  Where reference counts are not exact (not standard GIL CPython) that mode is the only one.
+
+    Memory: page-locked host memory is returned - `release()`, called by TradingEnvironment.close() - and does not pile up:
+    buffers beyond `min_buffers` that stayed idle for `idle_seconds` are freed the next time the pool is used."""
+
+    def __init__(self, shape, dtype=np.float32, max_bytes=1 << 30, min_buffers=2, idle_seconds=30.0):
         self.shape, self.dtype, self.max_bytes, self.min_buffers = tuple(shape), np.dtype(dtype), max_bytes, min_buffers
-        self._pinned_unavailable = False
+        self.idle_seconds = idle_seconds
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._pinned_unavailable = not _reference_counts_are_exact()
         self.buffers = [_RefProbe()]
-        self._idle_refs = self._refs(0)  # references a buffer has when only this pool looks at it (counted exactly as acquire() counts)
+        self._idle_refs = self._refs(0) if not self._pinned_unavailable else 0  # references a buffer has when only this pool looks at it (counted exactly as acquire() counts)
         self.buffers = []
+        self._last_used = []
 
     def _refs(self, index):
-        import sys
-
-        buf = self.buffers[index]
-        return sys.getrefcount(buf)
+        return sys.getrefcount(self.buffers[index])
 
     def acquire(self):
         """(array, is_pinned): an array nobody else references, preferably over pinned memory."""
-        for index in range(len(self.buffers)):  # the first idle one: the usual loop then alternates between buffers 0 and 1
-            if self._refs(index) <= self._idle_refs:
-                return self.buffers[index].array(), True
-        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        if not self._pinned_unavailable and (len(self.buffers) + 1) * nbytes <= max(self.max_bytes, self.min_buffers * nbytes):
+        array, pointer = self.acquire_with_pointer()
+        return array, pointer is not None
+
+    def acquire_with_pointer(self):
+        """(array, address of its pinned block or None for an ordinary array)."""
+        buffers, idle_refs, getrefcount = self.buffers, self._idle_refs, sys.getrefcount
+        for index in range(len(buffers)):  # the first idle one: the usual loop then alternates between buffers 0 and 1
+            if getrefcount(buffers[index]) <= idle_refs:
+                buf = buffers[index]
+                if len(buffers) > self.min_buffers:
+                    self._last_used[index] = time.monotonic()
+                    self._trim()  # (only ever removes buffers ABOVE the first idle one)
+                return buf.array(), buf.ptr
+        if not self._pinned_unavailable and (len(buffers) + 1) * self.nbytes <= max(self.max_bytes, self.min_buffers * self.nbytes):
             try:
-                self.buffers.append(PinnedBuffer(self.shape, self.dtype))
+                buffers.append(PinnedBuffer(self.shape, self.dtype))
+                self._last_used.append(time.monotonic())
             except (NativeError, RuntimeError, OSError):  # no pinned memory to be had (no device, a locked-memory limit):
                 self._pinned_unavailable = True          # pageable arrays work everywhere, only slower
             else:
-                return self.buffers[-1].array(), True
-        return np.empty(self.shape, dtype=self.dtype), False
+                return buffers[-1].array(), buffers[-1].ptr
+        return np.empty(self.shape, dtype=self.dtype), None
+
+    def _trim(self):
+        """Frees buffers beyond `min_buffers` that nobody references and that have not been handed out for `idle_seconds`
+        (a caller that once held many outputs - two recorded episodes, say - does not pin that memory for good)."""
+        now = time.monotonic()
+        for index in range(len(self.buffers) - 1, self.min_buffers - 1, -1):
+            if index < len(self.buffers) and self._refs(index) <= self._idle_refs and now - self._last_used[index] > self.idle_seconds:
+                del self.buffers[index], self._last_used[index]  # PinnedBuffer.__del__ returns the block (mbt_host_free)
+
+    def release(self):
+        """Gives back every buffer no caller references any more (the others go with their last array)."""
+        self.buffers, self._last_used = [], []
+
+    @property
+    def pinned_bytes(self) -> int:
+        return len(self.buffers) * self.nbytes
 
 
 class _RefProbe:

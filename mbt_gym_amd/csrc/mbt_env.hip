@@ -98,13 +98,33 @@ bool is_pinned_host(const void* p, size_t bytes) {
       if (a >= it->first && a + bytes <= it->first + it->second) return true;
     }
   }
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();  // an ordinary malloc'ed pointer: not an error of ours
-    return false;
+  // foreign memory: pinned only if the runtime knows BOTH ends of [p, p + bytes) as host memory (a registration may cover
+  // less than the caller's array)
+  const void* ends[2] = {p, static_cast<const char*>(p) + (bytes > 0 ? bytes - 1 : 0)};
+  for (const void* q : ends) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, q) != hipSuccess) {
+      (void)hipGetLastError();  // an ordinary malloc'ed pointer: not an error of ours
+      return false;
+    }
+    if (attr.type != hipMemoryTypeHost) return false;
   }
-  return attr.type == hipMemoryTypeHost;
+  return true;
 }
+
+// (per environment: callers pass the same buffers step after step, and for a pageable one the classification above costs
+// driver calls every time - the answer for the last (pointer, size) of each role is remembered)
+struct PinnedMemo {
+  const void* p = nullptr;
+  size_t bytes = 0;
+  bool pinned = false;
+  bool lookup(const void* q, size_t n) {
+    if (q == p && n == bytes) return pinned;
+    p = q;
+    bytes = n;
+    return pinned = is_pinned_host(q, n);
+  }
+};
 
 // up to this many lanes the host API stages through device-mapped pinned memory (mbt_env_step_host); measured per step,
 // DMA path vs mapped staging: 52 vs 33 us at 8192 lanes, 85 vs 70 at 32768, 138 vs 131 at 65536, 149 vs 228 at 131072.
@@ -188,38 +208,66 @@ StepKernel pick_exogenous(bool inject) {
 // precise_state: the general tier again (every midprice model, every reward, runtime normalisation flags) on the
 // reference's float64 state: {Poisson-type, Hawkes} x {limit, limit + market, touch} + the exogenous-depth fill model on
 // {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 6 + 2 for speed dynamics (the float32 kernel with a precise branch).
+// Round 4: like the float32 tier, the contract tier has SPECIALISED instantiations for what the BASELINE configurations run -
+// Brownian midprice x {plain PnL, the penalised rewards with exponent 2} x raw spaces (no pow / exp / normalisation code in the
+// instruction stream: reward_exact<TIER>) - and a STREAM (non-temporal loads) instantiation of every production-noise kernel for
+// launches beyond the Infinity Cache; same operations in the same order, so which one runs changes no bit.
 template <int ARR, int DYN, bool EXO>
-StepKernel pick_precise(bool inject) {
-  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>
-                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>;
+StepKernel pick_precise(bool inject, bool stream) {
+  using V = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>;
+  if (inject) return mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>;
+  return stream ? mbt::step_kernel<V, true> : mbt::step_kernel<V, false>;
 }
+template <int ARR, int DYN, int REW>
+StepKernel pick_precise_special(bool brownian, bool stream) {
+  using B = mbt::Variant<ARR, DYN, true, REW, false, false, false, true>;   // Brownian midprice (BASELINE configs 1, 2, 4)
+  using G = mbt::Variant<ARR, DYN, false, REW, false, false, false, true>;  // any other built-in midprice (config 3: OU)
+  if (brownian) return stream ? mbt::step_kernel<B, true> : mbt::step_kernel<B, false>;
+  return stream ? mbt::step_kernel<G, true> : mbt::step_kernel<G, false>;
+}
+template <int ARR, int DYN>
+StepKernel pick_precise_tier(int special_reward, bool brownian, bool inject, bool stream) {
+  if (special_reward == mbt::kRewardPnl) return pick_precise_special<ARR, DYN, mbt::kRewardPnl>(brownian, stream);
+  if (special_reward == mbt::kRewardQuadratic) return pick_precise_special<ARR, DYN, mbt::kRewardQuadratic>(brownian, stream);
+  return pick_precise<ARR, DYN, false>(inject, stream);
+}
+// special_reward: kRewardPnl / kRewardQuadratic when the specialised instantiation applies, kRewardGeneral otherwise
 template <int ARR>
-StepKernel pick_precise_dyn(int dyn, bool exo, bool inject) {
+StepKernel pick_precise_dyn(int dyn, bool exo, int special_reward, bool brownian, bool inject, bool stream) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject) : pick_precise<ARR, mbt::kDynLimit, false>(inject);
-    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject) : pick_precise<ARR, mbt::kDynLimitAndMarket, false>(inject);
-    default: return pick_precise<ARR, mbt::kDynTouch, false>(inject);
+    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject, stream) : pick_precise_tier<ARR, mbt::kDynLimit>(special_reward, brownian, inject, stream);
+    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject, stream) : pick_precise_tier<ARR, mbt::kDynLimitAndMarket>(special_reward, brownian, inject, stream);
+    default: return pick_precise_tier<ARR, mbt::kDynTouch>(special_reward, brownian, inject, stream);
   }
 }
-// (the precise_state tier of the speed family is the same kernel: `staged` / `stream` as above)
-template <bool STATE>
-StepKernel pick_speed_precise(bool inject, bool stream) {
-  using V = mbt::SpeedVariant<STATE, true, false, true>;
-  if (inject) return mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, true>>;
+// (the precise_state tier of the speed family is the same kernel: `staged` / `stream` as above; POW as for the float32 tier)
+template <bool STATE, bool POW>
+StepKernel pick_speed_precise_pow(bool inject, bool stream) {
+  using V = mbt::SpeedVariant<STATE, true, false, true, POW>;
+  if (inject) return mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, true, POW>>;
   if (stream) return mbt::speed_step_kernel<V, false, true>;
   return STATE ? mbt::speed_step_kernel<V, true> : mbt::speed_step_kernel<V>;
+}
+template <bool STATE>
+StepKernel pick_speed_precise(bool powers, bool inject, bool stream) {
+  return powers ? pick_speed_precise_pow<STATE, true>(inject, stream) : pick_speed_precise_pow<STATE, false>(inject, stream);
 }
 
 StepKernel pick_kernel(const mbt_config& c, bool stream) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
-    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(inject, stream) : pick_speed_precise<false>(inject, stream);
+    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(speed_powers(c), inject, stream) : pick_speed_precise<false>(speed_powers(c), inject, stream);
     return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, stream) : pick_speed<false>(speed_powers(c), norm, inject, stream);
   }
-  if (c.precise_state)
-    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), inject)
-                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), inject);
+  if (c.precise_state) {
+    const int tier = reward_weight(c);
+    const bool special = !inject && !norm && !exogenous_fill(c) && tier != mbt::kRewardGeneral;
+    const int special_reward = special ? tier : mbt::kRewardGeneral;
+    const bool brownian = c.midprice_kind == MBT_MID_BROWNIAN;
+    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, stream)
+                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, stream);
+  }
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
     if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject);
@@ -359,6 +407,23 @@ struct mbt_env {
   size_t bounce_floats = 0;
   float* traj_stage[3] = {nullptr, nullptr, nullptr};
   size_t traj_stage_floats[3] = {0, 0, 0};
+  PinnedMemo memo_action, memo_obs, memo_reward;  // what the caller's host buffers were found to be (mbt_env_step_host)
+  // small-batch host API: the step kernel mirrors its outputs into the stage and raises a flag there (step_kernel.hpp: signal_host)
+  uint32_t* done_counter = nullptr;  // device: workgroups of the launch that have finished
+  size_t stage_flag = 0;             // offset (in floats) of the flag word inside the stage
+  uint32_t flag_seq = 0;             // value the next mirrored launch writes there
+  bool action_in_stage = false;      // the newest actions sit in the stage, not (yet) in `action` (filed on demand: file_staged_action)
+  // launch gate (mbt_env_set_launch_gate): bursts of launches enqueued behind a kernel that waits for a host flag
+  uint32_t gate_chunk = 0, gate_seq = 0;
+  uint32_t* h_gate = nullptr;        // pinned, device-mapped
+  uint32_t* d_gate = nullptr;
+  bool gate_closed = false;
+  // host-callback plugins (Variant::HOST): per-step inputs computed by the caller's NumPy code
+  int host_mask = 0;                 // mbt::kHostFill | kHostArrival | kHostReward
+  double* host_fill_p = nullptr;     // (n_pad, 2) device
+  float* host_arrivals = nullptr;    // (n_pad, 2) device
+  double* host_scratch = nullptr;    // (n_pad, 2) device: depths out / rewards in
+  bool host_fill_ready = false, host_arrivals_ready = false, host_reward_pending = false;
 };
 
 namespace {
@@ -559,8 +624,37 @@ int dev_alloc(T** p, size_t count, hipStream_t stream) {
   return MBT_OK;
 }
 
-int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
+// Opens the launch gate: everything enqueued behind it starts to run.
+void gate_open(mbt_env* e) {
+  if (!e->gate_closed) return;
+  __atomic_store_n(e->h_gate, e->gate_seq, __ATOMIC_RELEASE);
+  e->gate_closed = false;
+}
+
+// The newest actions were handed over through the stage (mbt_env_step_host, small batches); anything that reads the
+// library's own action buffer afterwards - step_device(NULL), an action-repeat rollout, a consumer of mbt_env_action_ptr -
+// finds them there.
+int file_staged_action(mbt_env* e) {
+  if (!e->action_in_stage) return MBT_OK;
+  HIP_TRY(hipMemcpyAsync(e->action, e->h_stage + e->stage_action, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the stage is overwritten by the next host step
+  e->action_in_stage = false;
+  return MBT_OK;
+}
+
+// mirror: the launch also writes what env.step() returns into the stage and raises its flag (small-batch host API)
+int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror = false) {
   if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
+  if (action_dev == nullptr && e->action_in_stage) {
+    const int rc_file = file_staged_action(e);
+    if (rc_file != MBT_OK) return rc_file;
+  }
+  if ((e->host_mask & mbt::kHostFill) && !e->host_fill_ready)
+    return fail(MBT_ERR_STATE, "host-callback fill model: mbt_env_set_host_fill_probabilities must precede every step()");
+  if ((e->host_mask & mbt::kHostArrival) && !e->host_arrivals_ready)
+    return fail(MBT_ERR_STATE, "host-callback arrival model: mbt_env_set_host_arrivals must precede every step()");
+  if (e->host_reward_pending)
+    return fail(MBT_ERR_STATE, "host-callback reward: mbt_env_set_host_rewards must follow every step() before the next one");
   const bool inject = e->cfg.noise_mode == MBT_NOISE_INJECTED;
   if (inject && !e->noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: set_noise() must precede every step()");
   if (inject && e->user_draws && !e->user_noise_ready) return fail(MBT_ERR_STATE, "injected-noise mode: the user processes' extra normals (mbt_env_set_user_noise_host) must precede every step()");
@@ -575,9 +669,19 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   P.t_next_f64 = t_next;
 
   mbt::StepBuffers B;
+  std::memset(&B, 0, sizeof B);
   B.state_in = e->state[e->cur];
   B.state_out = e->state[e->cur ^ 1];
   B.action = action_dev != nullptr ? action_dev : e->action;
+  B.host_fill_p = e->host_fill_p;
+  B.host_arrivals = e->host_arrivals;
+  if (mirror) {
+    B.host_obs = e->d_stage + e->stage_obs;
+    B.host_reward = e->d_stage + e->stage_reward;
+    B.done_counter = e->done_counter;
+    B.host_flag = reinterpret_cast<uint32_t*>(e->d_stage + e->stage_flag);
+    B.flag_value = ++e->flag_seq;
+  }
   B.reward = e->reward;
   B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
   B.u_arr = e->u_arr;
@@ -603,6 +707,8 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done) {
   e->episode_step += 1;
   e->noise_ready = false;
   e->user_noise_ready = false;
+  e->host_fill_ready = e->host_arrivals_ready = false;
+  e->host_reward_pending = (e->host_mask & mbt::kHostReward) != 0;
   if (done != nullptr) *done = terminal ? 1 : 0;
   return MBT_OK;
 }
@@ -737,6 +843,11 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   if (!e->was_reset) return fail(MBT_ERR_STATE, "rollout() before reset()");
   if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "rollouts draw Philox noise; this environment is in injected-noise mode");
   if (policy == nullptr) return fail(MBT_ERR_INVALID, "null policy");
+  if (e->host_mask != 0) return fail(MBT_ERR_INVALID, "host-callback plugins (NumPy-only subclasses) are consulted between launches: this environment runs step by step, not as a fused rollout");
+  if (policy->kind == MBT_POLICY_ACTION_BUFFER) {
+    const int rc_file = file_staged_action(e);
+    if (rc_file != MBT_OK) return rc_file;
+  }
   mbt::RolloutParams R;
   std::memset(&R, 0, sizeof R);
   const bool learned = policy->kind == MBT_POLICY_LINEAR || policy->kind == MBT_POLICY_MLP;
@@ -1089,6 +1200,8 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
 int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   const bool user_fill = c.fill_kind == MBT_FILL_USER, user_reward = c.reward_kind == MBT_REW_USER, user_arrival = c.arrival_kind == MBT_ARR_USER;
   const bool user_mid = c.midprice_kind == MBT_MID_USER;
+  const int host_mask = (c.fill_kind == MBT_FILL_HOST ? mbt::kHostFill : 0) | (c.arrival_kind == MBT_ARR_HOST ? mbt::kHostArrival : 0) |
+                        (c.reward_kind == MBT_REW_HOST ? mbt::kHostReward : 0);
   std::string fill_decl, reward_decl, arrival_decl, mid_decl, state_decl;
   if (int rc_state = param_declarations(u.state_param_names, state_decl); rc_state != MBT_OK) return rc_state;
   const int user_state = u.state_columns;
@@ -1126,9 +1239,9 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? u.state_update[0] : "0.0") + "); }\n"
          "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? u.state_update[1] : "0.0") + "); }\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ">;\n";
+         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
-  if (!inject)
+  if (!inject && host_mask == 0)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
            "mbt::rollout_body<V>(B, P, R); }\n";
   return MBT_OK;
@@ -1217,6 +1330,7 @@ int log_push(mbt_env* e) {
 
 int log_wait_oldest(mbt_env* e, double sums[3]) {
   const uint32_t slot = e->log_head;
+  gate_open(e);  // (never block on work that sits behind a closed launch gate)
   HIP_TRY(hipEventSynchronize(e->log_event[slot]));
   for (int j = 0; j < 3; ++j) sums[j] = e->log_host[3 * slot + j];
   e->log_head = (e->log_head + 1) % mbt_env::kLogSlots;
@@ -1257,10 +1371,19 @@ int mbt_device_name(int device, char* buf, size_t buf_len) {
 static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
   if (cfg == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   *out = nullptr;
+  // first of all: a caller built against another ABI passes structs of another SIZE - nothing of *cfg beyond its first word,
+  // and nothing of *code, may be read before the versions are known to agree
+  if (cfg->abi_version != MBT_ABI_VERSION)
+    return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
   const bool user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
-  const bool needs_jit = user_fill || user_reward || user_arrival || user_mid;
+  const bool host_fill = cfg->fill_kind == MBT_FILL_HOST, host_arrival = cfg->arrival_kind == MBT_ARR_HOST, host_reward = cfg->reward_kind == MBT_REW_HOST;
+  const bool any_host = host_fill || host_arrival || host_reward;
+  const bool any_user = user_fill || user_reward || user_arrival || user_mid;
+  const bool needs_jit = any_user || any_host;
+  static const mbt_user_code kNoUserCode = {};  // host-callback kinds alone need no expressions: mbt_env_create serves them
+  if (code == nullptr && any_host && !any_user) code = &kNoUserCode;
   if (user_mid && (code == nullptr || code->midprice_increment == nullptr || code->midprice_increment[0] == 0))
     return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression (mbt_env_create_jit)");
   if (needs_jit && code == nullptr)
@@ -1270,8 +1393,9 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
   if (code != nullptr && !needs_jit) return fail(MBT_ERR_INVALID, "mbt_env_create_jit: no plugin kind of the configuration names a user-defined plugin");
   if (needs_jit) {
-    if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill))
+    if (cfg->dynamics_kind != MBT_DYN_LIMIT && cfg->dynamics_kind != MBT_DYN_LIMIT_AND_MARKET && !(cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH && !user_fill && !host_fill))
       return fail(MBT_ERR_INVALID, "user-defined plugins run on the order-book kernels (a fill model needs limit or limit + market dynamics)");
+    if (any_host && cfg->fill_kind == MBT_FILL_EXOGENOUS_MM && host_fill) return fail(MBT_ERR_INVALID, "a fill model is either built in or a host callback");
     if (code->state_columns < 0 || code->state_columns > 2) return fail(MBT_ERR_INVALID, "user processes own at most two state columns (got %d)", code->state_columns);
     if (code->state_columns > 0) {
       if (!(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_ARR_USER)");
@@ -1282,8 +1406,6 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     }
     if (code->extra_normals && !(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "extra normals are drawn for user-defined midprice / arrival models");
   }
-  if (cfg->abi_version != MBT_ABI_VERSION)
-    return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
   if (cfg->num_trajectories == 0 || cfg->num_trajectories > 0x7FFFF000ull)
     return fail(MBT_ERR_INVALID, "num_trajectories %llu out of range", (unsigned long long)cfg->num_trajectories);
   if (cfg->n_steps == 0 || !(cfg->terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "n_steps and terminal_time must be positive");
@@ -1293,7 +1415,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (cfg->reward_terminal_time != 0.0 && !(cfg->reward_terminal_time > 0.0)) return fail(MBT_ERR_INVALID, "reward_terminal_time must be positive (or 0 = terminal_time)");
   if (cfg->dynamics_kind < MBT_DYN_LIMIT || cfg->dynamics_kind > MBT_DYN_SPEED)
     return fail(MBT_ERR_INVALID, "dynamics kind %d has no device implementation", cfg->dynamics_kind);
-  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_USER)
+  if (cfg->reward_kind < MBT_REW_PNL || cfg->reward_kind > MBT_REW_HOST)
     return fail(MBT_ERR_INVALID, "reward kind %d has no device implementation", cfg->reward_kind);
   if (speed) {
     if (cfg->arrival_kind != MBT_ARR_NONE || cfg->fill_kind != MBT_FILL_NONE)
@@ -1307,12 +1429,12 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (cfg->trajectory_offset % mbt::kSpeedTileLanes != 0)
       return fail(MBT_ERR_INVALID, "speed dynamics draw noise per 1024-lane tile: trajectory_offset must be a multiple of 1024");
   } else {
-    if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR && !user_arrival)
+    if (cfg->arrival_kind != MBT_ARR_POISSON && cfg->arrival_kind != MBT_ARR_HAWKES && cfg->arrival_kind != MBT_ARR_POISSON_NONLINEAR && !user_arrival && !host_arrival)
       return fail(MBT_ERR_INVALID, "arrival kind %d has no device implementation for order-book dynamics", cfg->arrival_kind);
     if (cfg->dynamics_kind == MBT_DYN_AT_THE_TOUCH) {
       if (cfg->normalise_action) return fail(MBT_ERR_INVALID, "at-the-touch actions are binary: normalise_action_space must be False");
-    } else if (user_fill) {
-      // the expression is the model: no built-in parameter to validate
+    } else if (user_fill || host_fill) {
+      // the expression (or the caller's own code) is the model: no built-in parameter to validate
     } else if (!(cfg->fill_exponent > 0.0)) {
       return fail(MBT_ERR_INVALID, "fill_exponent must be positive (got %g)", cfg->fill_exponent);
     } else if (cfg->fill_kind == MBT_FILL_EXOGENOUS_MM) {
@@ -1360,6 +1482,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
+  e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | (host_reward ? mbt::kHostReward : 0);
   e->res = !cfg->precise_state ? 0 : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
   tune_for_size(e);
   if (needs_jit) {
@@ -1373,7 +1496,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     std::string source;
     JitKernels kernels;
     int jit_rc = jit_source(*cfg, *code, source);
-    if (jit_rc == MBT_OK) jit_rc = jit_build(cfg->device, source, cfg->noise_mode == MBT_NOISE_PHILOX, kernels);
+    if (jit_rc == MBT_OK) jit_rc = jit_build(cfg->device, source, cfg->noise_mode == MBT_NOISE_PHILOX && e->host_mask == 0, kernels);
     if (jit_rc != MBT_OK) {
       delete e;
       return jit_rc;
@@ -1428,6 +1551,12 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
   ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
   ENV_TRY(dev_alloc(&e->log_dev, 3 * mbt_env::kLogSlots, e->stream));
+  ENV_TRY(dev_alloc(&e->done_counter, 1, e->stream));
+  if (e->host_mask != 0) {
+    if (host_fill) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));
+    if (host_arrival) ENV_TRY(dev_alloc(&e->host_arrivals, np * 2, e->stream));
+    ENV_TRY(dev_alloc(&e->host_scratch, np * 2, e->stream));
+  }
   if (hipHostMalloc(reinterpret_cast<void**>(&e->log_host), 3 * mbt_env::kLogSlots * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     mbt_env_destroy(e);
     return fail(MBT_ERR_HIP, "hipHostMalloc failed");
@@ -1443,8 +1572,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     e->stage_action = 0;
     e->stage_obs = np * e->act_dim;
     e->stage_reward = e->stage_obs + size_t(e->n) * e->dim;
-    const size_t floats = e->stage_reward + e->n;
-    if (hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), floats * sizeof(float), hipHostMallocMapped) == hipSuccess) {
+    e->stage_flag = ((e->stage_reward + e->n + 15u) / 16u) * 16u;  // the completion flag of signal_host, on a cache line of its own
+    const size_t floats = e->stage_flag + 16u;
+    // (coherent: the host reads the flag, and then the mirror, while the GPU context is live - not after a synchronisation)
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(e->h_stage, 0, floats * sizeof(float));
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_stage), e->h_stage, 0) != hipSuccess) {
         (void)hipHostFree(e->h_stage);
@@ -1480,7 +1611,8 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   if (cfg == nullptr || code == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER, user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
-  if (!user_fill && !user_reward && !user_arrival && !user_mid) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
+  const bool any_host = cfg->fill_kind == MBT_FILL_HOST || cfg->arrival_kind == MBT_ARR_HOST || cfg->reward_kind == MBT_REW_HOST;
+  if (!user_fill && !user_reward && !user_arrival && !user_mid && !any_host) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
   if (user_mid && (code->midprice_increment == nullptr || code->midprice_increment[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression");
   if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
@@ -1504,6 +1636,9 @@ void mbt_env_destroy(mbt_env* e) {
   if (e->log_host != nullptr) (void)hipHostFree(e->log_host);
   for (hipEvent_t ev : e->log_event)
     if (ev != nullptr) (void)hipEventDestroy(ev);
+  for (void* b : {static_cast<void*>(e->done_counter), static_cast<void*>(e->host_fill_p), static_cast<void*>(e->host_arrivals), static_cast<void*>(e->host_scratch)})
+    if (b != nullptr) (void)hipFree(b);
+  if (e->h_gate != nullptr) (void)hipHostFree(e->h_gate);
   if (e->h_stage != nullptr) (void)hipHostFree(e->h_stage);
   if (e->h_bounce != nullptr) (void)hipHostFree(e->h_bounce);
   if (e->ev_begin != nullptr) (void)hipEventDestroy(e->ev_begin);
@@ -1583,21 +1718,28 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
   if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
   if (e->h_stage != nullptr) {
-    // Small batch (the reference's own regime, N ~ 1000): a pageable hipMemcpy costs ~15-25 us per call whatever its
-    // size, three of them dominate the step.  Instead the kernel reads the actions from, and one export launch
-    // writes observation + rewards into, pinned device-mapped host memory: 49 -> ~20 us per step at N = 1000.
+    // Small batch (the reference's own regime, N ~ 1000): a DMA copy costs ~15-25 us per call whatever its size, a second
+    // launch ~5 us, a blocking wait an interrupt round trip.  None of them here: the actions are read by the step kernel
+    // from, and its observation rows and rewards written by it into, pinned device-mapped host memory; the last workgroup
+    // to finish raises a flag there and this thread spins on it (step_kernel.hpp: signal_host).  ONE launch per env.step().
     const size_t n_obs = size_t(e->n) * e->dim;
     std::memcpy(e->h_stage + e->stage_action, action_host, size_t(e->n) * e->act_dim * sizeof(float));
-    int rc = launch_step(e, e->d_stage + e->stage_action, done);
+    e->action_in_stage = false;  // (set below: launch_step must not file the PREVIOUS stage contents first)
+    int rc = launch_step(e, e->d_stage + e->stage_action, done, /*mirror=*/true);
     if (rc != MBT_OK) return rc;
-    const uint32_t n_act = e->n * static_cast<uint32_t>(e->act_dim);
-    const uint32_t threads = 256, blocks = static_cast<uint32_t>((n_obs + threads - 1) / threads);  // D >= A: covers the actions too
-    hipLaunchKernelGGL(mbt::export_step_kernel, dim3(blocks), dim3(threads), 0, e->stream, current_obs(e), e->reward,
-                       obs_host != nullptr ? e->d_stage + e->stage_obs : nullptr,
-                       reward_host != nullptr ? e->d_stage + e->stage_reward : nullptr, static_cast<uint32_t>(n_obs), e->n,
-                       e->d_stage + e->stage_action, e->action, n_act);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->action_in_stage = true;
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(e->h_stage + e->stage_flag);
+    const uint32_t want = e->flag_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
+      if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+        // not a latency path any more (a clock ramp, a page migration - or a kernel that died): let the runtime wait and report
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(MBT_ERR_HIP, "the step kernel finished without raising its completion flag");
+        break;
+      }
+    }
     if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
     if (reward_host != nullptr) std::memcpy(reward_host, e->h_stage + e->stage_reward, size_t(e->n) * sizeof(float));
     return MBT_OK;
@@ -1608,9 +1750,9 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
   // mbt_host_alloc (or any pinned memory) are used as they are - the Python binding keeps its output arrays in such
   // memory and re-uses them - and pageable ones bounce through a pinned buffer of the environment's own.
   const size_t act_floats = size_t(e->n) * e->act_dim, obs_floats = size_t(e->n) * e->dim, rew_floats = e->n;
-  const bool act_direct = is_pinned_host(action_host, act_floats * sizeof(float));
-  const bool obs_direct = obs_host == nullptr || is_pinned_host(obs_host, obs_floats * sizeof(float));
-  const bool rew_direct = reward_host == nullptr || is_pinned_host(reward_host, rew_floats * sizeof(float));
+  const bool act_direct = e->memo_action.lookup(action_host, act_floats * sizeof(float));
+  const bool obs_direct = obs_host == nullptr || e->memo_obs.lookup(obs_host, obs_floats * sizeof(float));
+  const bool rew_direct = reward_host == nullptr || e->memo_reward.lookup(reward_host, rew_floats * sizeof(float));
   if (!(act_direct && obs_direct && rew_direct)) {
     const size_t want = act_floats + obs_floats + rew_floats;
     if (want > e->bounce_floats) {
@@ -1647,9 +1789,20 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     action_device = nullptr;
   }
-  uint32_t steps = 0, episodes = 0;
+  if (action_device == nullptr && e->action_in_stage) {
+    const int rc_file = file_staged_action(e);
+    if (rc_file != MBT_OK) return rc_file;
+  }
+  uint32_t steps = 0, episodes = 0, in_burst = 0;
   int rc = MBT_OK;
   while (steps < k) {
+    if (e->gate_chunk != 0 && !e->gate_closed) {  // a new burst: everything up to gate_open() is enqueued behind this kernel
+      e->gate_seq += 1;
+      hipLaunchKernelGGL(mbt::gate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_gate, e->gate_seq, 500000000ull /* 5 s of the 100 MHz clock */);
+      HIP_TRY(hipGetLastError());
+      e->gate_closed = true;
+      in_burst = 0;
+    }
     int32_t done = 0;
     rc = launch_step(e, action_device, &done);
     if (rc != MBT_OK) break;
@@ -1662,7 +1815,9 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
       rc = do_reset(e, e->start_time, nullptr, /*reuse_q0=*/true);
       if (rc != MBT_OK) break;
     }
+    if (e->gate_closed && ++in_burst >= e->gate_chunk) gate_open(e);
   }
+  gate_open(e);
   if (steps_done != nullptr) *steps_done = steps;
   if (episodes_ended != nullptr) *episodes_ended = episodes;
   return rc;
@@ -1747,6 +1902,71 @@ int mbt_comm_destroy(void* comm) {
   if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
   ncclResult_t r = api.comm_destroy(static_cast<ncclComm_t>(comm));
   if (r != ncclSuccess) return rccl_fail(r, "ncclCommDestroy");
+  return MBT_OK;
+}
+
+int mbt_env_set_launch_gate(mbt_env* e, uint32_t burst) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (burst > 4096u) return fail(MBT_ERR_INVALID, "a burst of more than 4096 launches may not fit the hardware queue behind a closed gate");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (burst != 0 && e->h_gate == nullptr) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_gate), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(e->h_gate, 0, 64);
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_gate), e->h_gate, 0));
+  }
+  gate_open(e);
+  e->gate_chunk = burst;
+  return MBT_OK;
+}
+
+// ---- host-callback plugins: the device side of what surrounds the caller's NumPy code (Variant::HOST) -------------------
+int mbt_env_host_depths(mbt_env* e, const float* action_host, double* depths_host) {
+  if (e == nullptr || action_host == nullptr || depths_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (e->speed || e->cfg.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "only limit-order dynamics quote depths (MD:104-106)");
+  if (e->host_scratch == nullptr) return fail(MBT_ERR_STATE, "this environment has no host-callback plugin (MBT_FILL_HOST / MBT_ARR_HOST / MBT_REW_HOST)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  e->action_in_stage = false;
+  hipLaunchKernelGGL(mbt::host_depths_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->action, e->act_dim, e->n, e->params, e->host_scratch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(depths_host, e->host_scratch, size_t(e->n) * 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_host) {
+  if (e == nullptr || probabilities_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!(e->host_mask & mbt::kHostFill)) return fail(MBT_ERR_STATE, "the fill model of this environment is not a host callback (MBT_FILL_HOST)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->host_fill_ready = true;
+  return MBT_OK;
+}
+
+int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
+  if (e == nullptr || arrivals_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!(e->host_mask & mbt::kHostArrival)) return fail(MBT_ERR_STATE, "the arrival model of this environment is not a host callback (MBT_ARR_HOST)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->host_arrivals_ready = true;
+  return MBT_OK;
+}
+
+int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* reward_out_host) {
+  if (e == nullptr || rewards_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!(e->host_mask & mbt::kHostReward)) return fail(MBT_ERR_STATE, "the reward function of this environment is not a host callback (MBT_REW_HOST)");
+  if (!e->host_reward_pending) return fail(MBT_ERR_STATE, "no step is waiting for its host-computed rewards");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->host_scratch, rewards_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  const uint32_t blocks = (e->n + 255u) / 256u;
+  hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
+                     e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves);
+  HIP_TRY(hipGetLastError());
+  if (reward_out_host != nullptr) HIP_TRY(hipMemcpyAsync(reward_out_host, e->reward, size_t(e->n) * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->host_reward_pending = false;
   return MBT_OK;
 }
 
@@ -1864,7 +2084,11 @@ int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, 
   return MBT_OK;
 }
 
-float* mbt_env_action_ptr(mbt_env* e) { return e != nullptr ? e->action : nullptr; }
+float* mbt_env_action_ptr(mbt_env* e) {
+  if (e == nullptr) return nullptr;
+  if (e->action_in_stage && hipSetDevice(e->cfg.device) == hipSuccess) (void)file_staged_action(e);  // a reader finds the newest actions
+  return e->action;
+}
 float* mbt_env_obs_ptr(mbt_env* e) { return e != nullptr ? current_obs(e) : nullptr; }
 float* mbt_env_reward_ptr(mbt_env* e) { return e != nullptr ? e->reward : nullptr; }
 int mbt_env_obs_dim(mbt_env* e) { return e != nullptr ? e->dim : 0; }
@@ -1927,8 +2151,8 @@ int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
         const size_t column = static_cast<size_t>(e->speed ? speed[j] : order_book[j]);
         if (column < d) state_host[i * d + column] = exact_join_host(rows[i * d + column], lo[i * r + j]);
       }
-    for (size_t i = 0; i < n; ++i) state_host[i * d + 2] = e->time;  // the clock is kept in double on the host (TE:216); every lane shares it
   }
+  for (size_t i = 0; i < n; ++i) state_host[i * d + 2] = e->time;  // the clock is kept in double on the host (TE:216) in either tier; every lane shares it
   return MBT_OK;
 }
 
@@ -1945,6 +2169,7 @@ int mbt_env_set_action_host(mbt_env* e, const float* action_host) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  e->action_in_stage = false;  // these are the newest actions now
   return MBT_OK;
 }
 

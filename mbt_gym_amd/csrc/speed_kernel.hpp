@@ -121,7 +121,7 @@ __device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s,
   if (V::NORM && P.norm_act) v = (static_cast<double>(a_raw) + 1.0) * P.act_grad[0] + P.act_lo[0];  // TE:124
   double impact, y_new = s.y;
   switch (P.impact_kind) {
-    case kImpactTempPower: impact = X.temp_coef * numpy_power(v, X.impact_exponent); break;  // IMP:55-56
+    case kImpactTempPower: impact = X.temp_coef * (V::POWERS ? numpy_power(v, X.impact_exponent) : numpy_power_1_or_2(v, X.impact_exponent)); break;  // IMP:55-56
     case kImpactTempPerm:
       impact = X.temp_coef * v + s.y;                         // IMP:90-91
       y_new = s.y + X.perm_coef * v * X.impact_dt;            // IMP:87-88
@@ -141,7 +141,9 @@ __device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s,
   const double mid_new = midprice_step_exact(s.mid, z, 0.0, 0.0, X);
   SpeedResultExact r;
   r.next = SpeedExact{c_clip, q_clip, mid_new, y_new};
-  r.reward = static_cast<float>(reward_exact(s.cash, s.q, s.mid, c_clip, q_clip, mid_new, q_init, v, is_terminal, t_now, t_next, P));
+  // (POWERS = false: the host knows every exponent is 1 or 2 and the reward is not the exponential utility - the same operations
+  // without pow() / exp() in the instruction stream, which is what kept this kernel at 143 registers and 3 waves per SIMD)
+  r.reward = static_cast<float>(reward_exact<V::POWERS ? kRewardGeneral : kRewardQuadratic>(s.cash, s.q, s.mid, c_clip, q_clip, mid_new, q_init, v, is_terminal, t_now, t_next, P));
   r.events = (q_clip != q_new ? 64u : 0u) | (c_clip != cash_new ? 128u : 0u);
   return r;
 }
@@ -231,8 +233,17 @@ __device__ __forceinline__ void wave_lds_fence() {
 // working set is cache-resident (2^20 lanes: 7.94 us for the dword loads, 7.50 us staged, traffic alone), worse beyond
 // (2^24 lanes: 134.9 vs 144.3 us the other way round).  The host picks the instantiation by size (mbt_env.hip:
 // tune_for_size).  STREAM: beyond the Infinity Cache the direct loads carry the non-temporal bit, as in step_kernel.
+// precise_state: the quad is advanced as kSpeedPreciseGroups groups of lanes (loads, arithmetic, stores of one group before
+// the loads of the next): the double-precision step on top of sixteen loaded vectors needed 140-147 registers - three waves
+// per SIMD, and the counters said that is what bounds it (waves stalled on memory 60 % of the time, profiles/r03_experiments.txt).
+#ifndef MBT_SPEED_PRECISE_GROUPS
+#define MBT_SPEED_PRECISE_GROUPS 1
+#endif
+#ifndef MBT_SPEED_PRECISE_WAVES
+#define MBT_SPEED_PRECISE_WAVES 1
+#endif
 template <class V, bool STAGED = false, bool STREAM = false>
-__global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuffers B, const StepParams P) {
+__global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES : 1) void speed_step_kernel(const StepBuffers B, const StepParams P) {
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
   const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
@@ -252,8 +263,13 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
                                // be re-used as a temporary by the generator, behind a wait for the load that wrote it)
   ld4_t span_a[4], span_b[4];  // kStaged: the wave's four spans of 64 rows, 80 float4 each
   ldi4_t lo4[4];               // precise_state: the int32 remainders of [cash, inventory, midprice, y] (one 16-byte row per lane, updated in place)
+  constexpr int kGroups = V::PRECISE ? MBT_SPEED_PRECISE_GROUPS : 1, kPerGroup = 4 / kGroups;
+  float r_sum = 0.0f;
+  uint32_t n_clipped = 0;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
+  for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+  for (int l = g * kPerGroup; l < (g + 1) * kPerGroup; ++l) {  // buffers are padded to whole tiles: no load is out of bounds
     const uint32_t lane = lane0 + l * kBlockThreads;
     if (V::PRECISE) {
       const ldi4_t* src = reinterpret_cast<const ldi4_t*>(B.resid) + lane;
@@ -273,19 +289,17 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     if (V::INJECT) z[l] = B.z[lane];
     qi[l] = P.q_init_scalar;
   }
-  if (!V::INJECT) {
+  if (!V::INJECT && g == 0) {
     const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
 #pragma unroll
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
   }
   if (B.q_init != nullptr) {  // (per-lane initial inventories: after the generator - a pointer test between the loads would put a wait there)
 #pragma unroll
-    for (int l = 0; l < 4; ++l) qi[l] = B.q_init[lane0 + l * kBlockThreads];
+    for (int l = g * kPerGroup; l < (g + 1) * kPerGroup; ++l) qi[l] = B.q_init[lane0 + l * kBlockThreads];
   }
-  float r_sum = 0.0f;
-  uint32_t n_clipped = 0;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
+  for (int l = g * kPerGroup; l < (g + 1) * kPerGroup; ++l) {
     const uint32_t lane = lane0 + l * kBlockThreads;
     float* lds_row = staged_rows + (threadIdx.x + l * kBlockThreads) * 5;
     if (!V::INJECT) {
@@ -340,15 +354,22 @@ __global__ __launch_bounds__(kBlockThreads) void speed_step_kernel(const StepBuf
     if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
     if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
     const bool real = lane < P.n;
+    if (B.host_obs != nullptr && real) {  // small-batch host API: what env.step() returns, straight into host memory (step_kernel.hpp: signal_host)
+      B.host_reward[lane] = r.reward;
+      if (V::PRECISE) store_speed_exact<V, false>(nullptr, nullptr, B.host_obs, lane, exact_next, P.t_next_f64, P);
+      else store_speed_row<V, false>(B.host_obs, lane, r.next, P.t_next, V::NORM && P.norm_obs != 0, P);
+    }
     r_sum += real ? r.reward : 0.0f;
     n_clipped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && r.events != 0u));
   }
+  }  // groups
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
     const uint32_t wave_id = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave_id], static_cast<double>(total));
     if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave_id & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
+  signal_host(B);
 }
 
 // Fused rollout for the speed family: fixed speed, or an open-loop schedule tabulated over time steps (e.g. the

@@ -55,10 +55,11 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 // Compile-time shape of one kernel instantiation: what changes the memory layout or the amount of noise is a
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
+enum : int { kHostFill = 1, kHostArrival = 2, kHostReward = 4 };
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
           bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false, int USER_STATE_ = 0,
-          bool USER_DRAWS_ = false>
+          bool USER_DRAWS_ = false, int HOST_ = 0>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -94,6 +95,18 @@ struct Variant {
   static constexpr bool USER_DRAWS = USER_DRAWS_;
   static_assert(USER_STATE_ >= 0 && USER_STATE_ <= 2, "at most two user state columns");
   static_assert(!(USER_STATE_ != 0 && (ARR_ == kArrHawkes || EXO_)), "user state columns take the place of the Hawkes intensities / exogenous depths");
+  // HOST-CALLBACK plugins (mbt_env_create_jit, no device expression): a subclass of the reference's plugin contract that only
+  // has NumPy code (FILL:22-34 `_get_fill_probabilities`, ARR:27-29 `get_arrivals`, RW:10-13 `calculate`) keeps running on the
+  // HOST, between launches; the kernel takes what the host computed for this step instead of evaluating a model -
+  //   kHostFill     the (N, 2) fill probabilities of the step's depths (StepBuffers::host_fill_p): fill <=> u < p, in double
+  //   kHostArrival  the (N, 2) arrival indicators get_arrivals() returned (StepBuffers::host_arrivals)
+  //   kHostReward   the reward is calculate()'d on the host from the float64 states: the kernel reports 0 and the host's
+  //                 values are filed afterwards (host_reward_kernel)
+  // and everything else of the step (masking, cash / inventory, clip, midprice, Hawkes intensities, normalisation) stays here.
+  static constexpr int HOST = HOST_;
+  static constexpr bool HOST_FILL = (HOST_ & 1) != 0, HOST_ARRIVAL = (HOST_ & 2) != 0, HOST_REWARD = (HOST_ & 4) != 0;
+  static_assert(!(HOST_FILL && (USER_FILL_ || EXO_)) && !(HOST_ARRIVAL && (USER_ARRIVAL_ || ARR_ == kArrHawkes)) && !(HOST_REWARD && USER_REWARD_),
+                "a plugin is either a built-in, a device expression or a host callback");
   static constexpr int EXTRA = (ARR_ == kArrHawkes) ? 2 : USER_STATE_;  // columns between the midprice and the exogenous depths
   static constexpr int EXO_COL = 4 + EXTRA;
   static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
@@ -221,6 +234,19 @@ struct StepBuffers {
   double* wave_sums;       // one slot per wave: running sum of rewards since reset
   unsigned long long* clip_count;  // kClipSlots counters, indexed by workgroup: a step in which every lane clips must not
                                    // serialise 8192 atomics on one address (17 -> 144 us at 2^21 lanes before the split)
+  // Small batches over the host API (mbt_env_step_host, the reference's own regime of N ~ 1000): the step kernel ITSELF
+  // mirrors what the API returns - observation rows (n, D) and rewards (n), no pad rows - into pinned, device-mapped host
+  // memory (posted PCIe writes) and the last workgroup to finish raises a flag there that the host spins on: one launch and
+  // no interrupt per env.step() (round 3: a second launch for the export and a hipStreamSynchronize).  All nullptr otherwise.
+  float* host_obs;
+  float* host_reward;
+  uint32_t* done_counter;  // device memory: workgroups of this launch that have finished (reset by the last one)
+  uint32_t* host_flag;     // device-mapped host memory: receives flag_value once every workgroup's mirror stores are visible
+  uint32_t flag_value;
+  uint32_t reserved_pad;
+  // host-callback plugins (Variant::HOST): what the host computed for this step
+  const double* host_fill_p;   // (n_pad, 2) fill probabilities of this step's depths
+  const float* host_arrivals;  // (n_pad, 2) arrivals as 0.0f / 1.0f
 };
 
 // ---- structure of the arithmetic --------------------------------------------------------------------------------
@@ -260,7 +286,7 @@ __device__ __forceinline__ LaneDraw make_draw(const LaneNoise& nz, const StepPar
   d.uf_bid = nz.uf_bid;
   d.uf_ask = nz.uf_ask;
   d.lo_bid = d.hi_bid = d.lo_ask = d.hi_ask = 0.0f;
-  if (!V::EXO && !V::USER_FILL && V::DYN != kDynTouch) {
+  if (!V::EXO && !V::USER_FILL && !V::HOST_FILL && V::DYN != kDynTouch) {
     fill_thresholds(nz.uf_bid, P, d.lo_bid, d.hi_bid);
     fill_thresholds(nz.uf_ask, P, d.lo_ask, d.hi_ask);
   }
@@ -436,25 +462,35 @@ __device__ __forceinline__ double midprice_step_exact(double s, double z, double
   }
 }
 
+// `q ** p` where the HOST already knows that p is 1 or 2 (every reference configuration: mbt_env.hip: reward_weight /
+// speed_powers pick the instantiation): numpy's two fast paths without pow()'s ~300 inlined instructions and its registers
+__device__ __forceinline__ double numpy_power_1_or_2(double q, double p) { return p == 2.0 ? q * q : q; }
+
 // RewardFunction.calculate in double, in the reference's order (RW:23-33, RW:96-109, RW:128-138, RW:57-70, RW:156-163).
 // dt is the difference of the two TIME columns (RW:99, RW:131), i.e. of the accumulated float64 clock, not step_size.
+// TIER (the float32 kernels' reward tiers): kRewardPnl - the mark-to-market change alone; kRewardQuadratic - the penalised rewards
+// with inventory exponents of 1 or 2 and no exponential utility (no pow, no exp in the instruction stream); kRewardGeneral -
+// everything.  The operations and their order are the SAME in every tier: which one runs changes no bit of the result.
+template <int TIER = kRewardGeneral>
 __device__ __forceinline__ double reward_exact(double cash, double q, double mid, double cash_new, double q_new, double mid_new, double q_init,
                                                double speed, bool is_terminal, double t_now, double t_next, const StepParams& P) {
   const PreciseParams& X = P.X;
   const double wealth_new = cash_new + q_new * mid_new;
   const double pnl = wealth_new - (cash + q * mid);
+  if (TIER == kRewardPnl) return X.reward_scale * pnl;
+  const auto power = [](double base, double p) { return TIER == kRewardQuadratic ? numpy_power_1_or_2(base, p) : numpy_power(base, p); };
   double reward = pnl;
-  if (P.reward_kind == kRewExpUtility) {
+  if (TIER == kRewardGeneral && P.reward_kind == kRewExpUtility) {
     reward = is_terminal ? -exp(-X.risk_aversion * wealth_new) : 0.0;
   } else if (P.reward_kind != kRewPnl) {
     const double dt = t_next - t_now;
-    const double qp = numpy_power(q_new, X.exponent);
+    const double qp = power(q_new, X.exponent);
     if (P.reward_kind == kRewRunning) {
       reward = (pnl - dt * X.phi * qp) - X.alpha * (is_terminal ? 1.0 : 0.0) * qp;
     } else if (P.reward_kind == kRewCjMm) {
-      reward = (pnl - dt * X.phi * qp) - X.alpha * ((qp - numpy_power(q, X.exponent)) + dt / X.episode_length * numpy_power(q_init, X.exponent));
+      reward = (pnl - dt * X.phi * qp) - X.alpha * ((qp - power(q, X.exponent)) + dt / X.episode_length * power(q_init, X.exponent));
     } else {  // CjOe: the terminal term MULTIPLIES by the episode length (RW:67)
-      reward = (pnl - dt * X.phi * qp) - dt * X.alpha * (X.exponent * speed * numpy_power(q, X.exponent - 1.0) + numpy_power(q_init, X.exponent) * X.episode_length);
+      reward = (pnl - dt * X.phi * qp) - dt * X.alpha * (X.exponent * speed * power(q, X.exponent - 1.0) + power(q_init, X.exponent) * X.episode_length);
     }
   }
   return X.reward_scale * reward;  // TE:128-129 (1.0 when rewards are not normalised: exact)
@@ -474,6 +510,12 @@ __device__ __forceinline__ uint32_t event_byte(const LaneResult& r) {
          (r.mo_sell ? 32u : 0u) | (r.clipped_q ? 64u : 0u) | (r.clipped_c ? 128u : 0u);
 }
 
+// what a host-callback plugin computed for this lane and step (Variant::HOST; zero otherwise)
+struct HostStep {
+  float arr_bid = 0.f, arr_ask = 0.f;  // ArrivalModel.get_arrivals() of the user's class (ARR:27-29), as 0 / 1
+  double p_bid = 0.0, p_ask = 0.0;     // FillProbabilityModel._get_fill_probabilities(depths) of the user's class (FILL:22-34)
+};
+
 // The Bernoulli decisions of one lane-step - arrivals, fills after the max-inventory mask, market-order flags - which are
 // the same (bit-exact against the float64 reference) in every tier; the tiers differ in how they carry the state.
 struct Decisions {
@@ -487,7 +529,8 @@ struct Decisions {
 // float32 state, the exact tier the reference's float64 value).
 template <class V>
 __device__ __forceinline__ Decisions decide(const float q, const float4 act, const LaneDraw& dr, const double lam_bid, const double lam_ask,
-                                            const double t_now, const bool norm_act, const StepParams& P, const UserProcessState& ups) {
+                                            const double t_now, const bool norm_act, const StepParams& P, const UserProcessState& ups,
+                                            const HostStep& hs = HostStep{}) {
   Decisions D;
   // -- arrivals (ARR:54-56 / ARR:121-123), strict '<'
   float arr_bid = dr.arr_bid, arr_ask = dr.arr_ask;
@@ -501,6 +544,10 @@ __device__ __forceinline__ Decisions decide(const float q, const float4 act, con
     arr_bid = static_cast<double>(dr.arr_bid) < mbt_user_arrival_probability(t_now, 0, P.arr_dt_f64, ups, P.user_arrival_p) ? 1.0f : 0.0f;
     arr_ask = static_cast<double>(dr.arr_ask) < mbt_user_arrival_probability(t_now, 1, P.arr_dt_f64, ups, P.user_arrival_p) ? 1.0f : 0.0f;
 #endif
+  }
+  if (V::HOST_ARRIVAL) {  // the user's get_arrivals() ran on the host (its own generator, ARR:27-29): these ARE the arrivals
+    arr_bid = hs.arr_bid;
+    arr_ask = hs.arr_ask;
   }
   D.arr_bid = arr_bid;
   D.arr_ask = arr_ask;
@@ -519,7 +566,10 @@ __device__ __forceinline__ Decisions decide(const float q, const float4 act, con
     D.off_bid = depth_of(act.x, 0, norm_act, P);
     D.off_ask = depth_of(act.y, 1, norm_act, P);
     bool fb = false, fa = false;
-    if (V::USER_FILL) {
+    if (V::HOST_FILL) {  // FILL:33-34 with the probabilities the user's _get_fill_probabilities returned for these depths
+      fb = static_cast<double>(dr.uf_bid) < hs.p_bid;
+      fa = static_cast<double>(dr.uf_ask) < hs.p_ask;
+    } else if (V::USER_FILL) {
 #ifdef MBT_JIT_USER_CODE
       // the user's _get_fill_probabilities (FILL:22-34), evaluated in double on the de-normalised depth: u < p(depth)
       const double depth_b = norm_act ? (static_cast<double>(act.x) + 1.0) * P.act_grad[0] + P.act_lo[0] : static_cast<double>(act.x);
@@ -564,13 +614,14 @@ __device__ __forceinline__ Decisions decide(const float q, const float4 act, con
 template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
-                                                const StepParams& P, const float z = 0.f, const double t_now = 0.0, const float2 zu = make_float2(0.f, 0.f)) {
+                                                const StepParams& P, const float z = 0.f, const double t_now = 0.0, const float2 zu = make_float2(0.f, 0.f),
+                                                const HostStep& hs = HostStep{}) {
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
   r.lo = make_int4(0, 0, 0, 0);
   const bool norm_act = V::NORM && P.norm_act;
   const UserProcessState ups{V::USER_STATE > 0 ? static_cast<double>(lam.x) : 0.0, V::USER_STATE > 1 ? static_cast<double>(lam.y) : 0.0, zu.x, zu.y};
-  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P, ups);
+  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P, ups, hs);
   const float arr_bid = D.arr_bid, arr_ask = D.arr_ask, n_bid = D.n_bid, n_ask = D.n_ask;
   r.arr_bid = arr_bid != 0.0f;
   r.arr_ask = arr_ask != 0.0f;
@@ -624,7 +675,9 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   // -- reward: the mark-to-market change (c'+q'S') - (c+qS) of RW:27-33 from the step's increments, then the reward
   //    function's own terms
   const float pnl = __builtin_fmaf(dq_clip, mid, __builtin_fmaf(q_clip, d_mid, gain)) + dc_clip;
-  if (V::REWARD == kRewardPnl) {
+  if (V::HOST_REWARD) {
+    r.reward = 0.0f;  // calculate() runs on the host (host_reward_kernel files its values)
+  } else if (V::REWARD == kRewardPnl) {
     r.reward = pnl * P.reward_scale;
   } else if (V::REWARD == kRewardQuadratic) {
     // RunningInventoryPenalty (RW:128-138) and CjMmCriterion (RW:96-109) with exponent 2, branch-free: the host
@@ -660,14 +713,15 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
 template <class V>
 __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const float2 lam, const int4 lo, const float4 act, const LaneDraw& dr,
                                                       const float q_init, const bool is_terminal, const StepParams& P, const float z,
-                                                      const double t_now, const double t_next, const float2 zu = make_float2(0.f, 0.f)) {
+                                                      const double t_now, const double t_next, const float2 zu = make_float2(0.f, 0.f),
+                                                      const HostStep& hs = HostStep{}) {
   const PreciseParams& X = P.X;
   const double cash = exact_join(core.x, lo.x), mid = exact_join(core.w, lo.y), q = core.y;  // (order-book inventories are integers)
   const double lam_bid = V::EXTRA > 0 ? exact_join(lam.x, lo.z) : 0.0, lam_ask = V::EXTRA > 1 ? exact_join(lam.y, lo.w) : 0.0;  // (or the user state columns)
   LaneResult r;
   const bool norm_act = V::NORM && P.norm_act;
   const UserProcessState ups{V::USER_STATE > 0 ? lam_bid : 0.0, V::USER_STATE > 1 ? lam_ask : 0.0, zu.x, zu.y};
-  const Decisions D = decide<V>(core.y, act, dr, lam_bid, lam_ask, t_now, norm_act, P, ups);
+  const Decisions D = decide<V>(core.y, act, dr, lam_bid, lam_ask, t_now, norm_act, P, ups, hs);
   r.arr_bid = D.arr_bid != 0.0f;
   r.arr_ask = D.arr_ask != 0.0f;
   r.fill_bid = D.fill_bid;
@@ -705,6 +759,8 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
 #else
     mid_new = mid;
 #endif
+  } else if (V::BROWNIAN) {
+    mid_new = (mid + X.mu_dt) + X.sigma_sqrt_dt * static_cast<double>(z);  // MID:60-65, = midprice_step_exact's kMidBrownian row
   } else {
     mid_new = midprice_step_exact(mid, z, n_bid, n_ask, X);
   }
@@ -720,7 +776,9 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
 #endif
   }
   // reward
-  if (V::USER_REWARD) {
+  if (V::HOST_REWARD) {
+    r.reward = 0.0f;  // calculate() runs on the host, on these very float64 states (mbt_env_get_state_f64_host)
+  } else if (V::USER_REWARD) {
 #ifdef MBT_JIT_USER_CODE
     UserRewardArgs u;  // RewardFunction.calculate(current_state, action, next_state, is_terminal_step) (RW:10-13) on the float64 states
     u.cash = cash; u.q = q; u.t = t_now; u.mid = mid;
@@ -733,7 +791,7 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
     r.reward = 0.0f;
 #endif
   } else {
-    r.reward = static_cast<float>(reward_exact(cash, q, mid, c_clip, q_clip, mid_new, q_init, 0.0, is_terminal, t_now, t_next, P));
+    r.reward = static_cast<float>(reward_exact<V::REWARD>(cash, q, mid, c_clip, q_clip, mid_new, q_init, 0.0, is_terminal, t_now, t_next, P));
   }
   float c_hi, m_hi, lb_hi = 0.0f, la_hi = 0.0f;
   r.lo = make_int4(0, 0, 0, 0);
@@ -789,6 +847,7 @@ struct LaneLoads {
   float2 zu;    // injected noise of user processes (z1, z2)
   float qi;     // per-lane initial inventory (CjMm)
   int4 lo;      // precise_state: the int32 remainders of [cash, midprice, bid intensity, ask intensity] (exact_join)
+  HostStep hs;  // host-callback plugins: what the host computed for this lane
 };
 
 typedef float ld4_t __attribute__((ext_vector_type(4)));
@@ -840,11 +899,23 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
   L.qi = P.q_init_scalar;
   L.lo = make_int4(0, 0, 0, 0);
   if (V::RES == 4) {
-    const ldi4_t v = *reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
+    const ldi4_t* src = reinterpret_cast<const ldi4_t*>(B.resid + static_cast<size_t>(lane) * 4);
+    const ldi4_t v = NT ? __builtin_nontemporal_load(src) : *src;
     L.lo = make_int4(v.x, v.y, v.z, v.w);
   } else if (V::RES == 2) {
-    const ldi2_t v = *reinterpret_cast<const ldi2_t*>(B.resid + static_cast<size_t>(lane) * 2);
+    const ldi2_t* src = reinterpret_cast<const ldi2_t*>(B.resid + static_cast<size_t>(lane) * 2);
+    const ldi2_t v = NT ? __builtin_nontemporal_load(src) : *src;
     L.lo = make_int4(v.x, v.y, 0, 0);
+  }
+  if (V::HOST_FILL) {
+    const double* p = B.host_fill_p + static_cast<size_t>(lane) * 2;
+    L.hs.p_bid = p[0];
+    L.hs.p_ask = p[1];
+  }
+  if (V::HOST_ARRIVAL) {
+    const float2 a = reinterpret_cast<const float2*>(B.host_arrivals)[lane];
+    L.hs.arr_bid = a.x;
+    L.hs.arr_ask = a.y;
   }
   return L;
 }
@@ -959,8 +1030,8 @@ __device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int
 template <class V>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f, const float2 zu = make_float2(0.f, 0.f)) {
-  const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu)
-                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu);
+  const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu, L.hs)
+                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu, L.hs);
   if (V::PRECISE) store_lo(B.resid, lane, r.lo, V::RES);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
@@ -985,8 +1056,31 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   }
   if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));
   if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
+  if (B.host_obs != nullptr && lane < P.n) {  // small-batch host API: the row and the reward as env.step() returns them, straight into host memory
+    B.host_reward[lane] = r.reward;
+    if (V::PRECISE) store_row_exact<V, false>(B.host_obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
+    else store_row<V, false>(B.host_obs, lane, r.core, r.lam, V::NORM, P);
+  }
   clipped = r.clipped_q | r.clipped_c;
   return r.reward;
+}
+
+// Small-batch host API: tell the host that this launch's mirror (StepBuffers::host_obs / host_reward) is complete, without a
+// second launch and without an interrupt.  Every thread makes its stores to host memory visible (system-scope fence), the
+// workgroup meets, one thread counts the workgroup in; the last workgroup of the launch re-arms the counter and writes the
+// launch's sequence number where the host is spinning.  (Measured, tools/microbench/mb_sync.hip: hipStreamSynchronize costs
+// ~12.5 us around one kernel, a flag written by a follow-up one-thread kernel 8.5; this needs neither.)
+__device__ __forceinline__ void signal_host(const StepBuffers& B) {
+  if (B.host_flag == nullptr) return;  // (a kernel argument: uniform over the launch, so the barrier below is reached by all or none)
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t arrived = __hip_atomic_fetch_add(B.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (arrived == gridDim.x) {
+      __hip_atomic_store(B.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(B.host_flag, B.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // STREAM: the state / action loads carry the non-temporal bit.  Chosen by the host (mbt_env.hip: tune_for_size) when one
@@ -1051,6 +1145,7 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
     if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
   }
+  signal_host(B);
 }
 
 // (the body is a device function so that the run-time compiled kernels of mbt_env_create_jit - plain extern "C" entry
@@ -1323,16 +1418,43 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
 
-// Small batches over the host API: observation rows and rewards written straight into pinned, device-mapped host
-// memory (posted PCIe writes) by one launch, instead of two pageable-memory DMA copies (~25 us each at any size).
-// The same launch files the staged actions in the library's device action buffer, which is what a later
-// step_device() without an action pointer reads.
-__global__ void export_step_kernel(const float* obs, const float* reward, float* host_obs, float* host_reward, uint32_t n_obs, uint32_t n,
-                                   const float* staged_action, float* action, uint32_t n_act) {
+// Holds the environment's stream until the host writes `value` to a word of device-mapped host memory - so that a burst of
+// launches can be ENQUEUED behind it and then run back to back whatever the host's cost per launch is (a tracer's, say:
+// mbt_env_set_launch_gate).  Gives up by itself after `timeout_ticks` of the 100 MHz wall clock: a host that died cannot
+// leave the device spinning.
+__global__ void gate_kernel(const uint32_t* flag, uint32_t value, uint64_t timeout_ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != value) {
+    if (wall_clock64() - t0 > timeout_ticks) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+
+// ---- host-callback plugins (Variant::HOST): the device side of what surrounds the user's NumPy code ---------------------
+// The depths the user's _get_fill_probabilities(depths) is asked about (TE:104 + MD `_limit_depths`): the first two action
+// columns, de-normalised in double exactly as decide<V>() de-normalises them (TE:124) - float64 (n, 2), for the host.
+__global__ void host_depths_kernel(const float* action, int act_dim, uint32_t n, const StepParams P, double* depths) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (host_obs != nullptr && i < n_obs) host_obs[i] = obs[i];
-  if (host_reward != nullptr && i < n) host_reward[i] = reward[i];
-  if (i < n_act) action[i] = staged_action[i];
+  if (i >= n) return;
+  for (int side = 0; side < 2; ++side) {
+    const double a = action[static_cast<size_t>(i) * act_dim + side];
+    depths[static_cast<size_t>(i) * 2 + side] = P.norm_act ? (a + 1.0) * P.act_grad[side] + P.act_lo[side] : a;
+  }
+}
+
+// The rewards the user's calculate() returned for the step that just ran (float64, host-computed from the float64 states):
+// scaled (TE:128-129), rounded once to float32 like every reward this library hands out, filed where the step kernel would
+// have filed its own - the reward buffer, the per-lane returns, the running sums behind the episode statistics.
+__global__ void host_reward_kernel(const double* rewards, double scale, uint32_t n, float* reward, float* lane_returns, double* wave_sums,
+                                   uint32_t n_waves) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float r = i < n ? static_cast<float>(scale * rewards[i]) : 0.0f;
+  if (i < n) {
+    reward[i] = r;
+    if (lane_returns != nullptr) lane_returns[i] += r;
+  }
+  const float total = wave_sum(r);
+  if ((threadIdx.x & 63u) == 0u) unsafeAtomicAdd(&wave_sums[(i >> 6) % n_waves], static_cast<double>(total));
 }
 
 // un-normalised state rows -> normalised observation rows (after set_state)

@@ -22,6 +22,7 @@ Differences from the reference, all deliberate:
 """
 import ctypes as C
 import os
+import warnings
 from collections import OrderedDict
 from typing import Callable, Tuple, Union
 
@@ -32,8 +33,9 @@ from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics, ModelDynamics
 from mbt_gym_amd.gym.index_names import INVENTORY_INDEX, TIME_INDEX
 from mbt_gym_amd.rewards.RewardFunctions import PnL, RewardFunction
 from mbt_gym_amd.spaces import Box
-from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
-from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+from mbt_gym_amd.stochastic_processes.StochasticProcessModel import StochasticProcessModel
+from mbt_gym_amd.stochastic_processes.arrival_models import ArrivalModel, PoissonArrivalModel
+from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction, FillProbabilityModel
 from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
 
 try:  # pragma: no cover - gym is not installed in the build image
@@ -48,6 +50,26 @@ PROCESS_ORDER = ("midprice_model", "arrival_model", "fill_probability_model", "p
 
 class UnsupportedOnDevice(NotImplementedError):
     """The requested plugin combination has no HIP implementation (and there is no CPU path to fall back to)."""
+
+
+class HostCallbackWarning(UserWarning):
+    """A plugin subclass that only has NumPy code is consulted on the host every step: it works, slowly."""
+
+
+def host_callback_role(part):
+    """'fill' / 'arrival' / 'reward' for a subclass of the reference's plugin contract that has NO device form - only the
+    NumPy method the reference asks for (FILL:22-34 `_get_fill_probabilities` / `get_fills`, ARR:27-29 `get_arrivals`,
+    RW:10-13 `calculate`) - and None for everything else (built-ins and device expressions name a `device_kind`)."""
+    if getattr(part, "device_kind", None) is not None:
+        return None
+    if isinstance(part, FillProbabilityModel) and (
+            callable(getattr(part, "_get_fill_probabilities", None)) or type(part).get_fills is not FillProbabilityModel.get_fills):
+        return "fill"
+    if isinstance(part, ArrivalModel) and type(part).get_arrivals is not ArrivalModel.get_arrivals:
+        return "arrival"
+    if isinstance(part, RewardFunction) and type(part).calculate is not RewardFunction.calculate:
+        return "reward"
+    return None
 
 
 class TradingEnvironment(_EnvBase):
@@ -111,6 +133,11 @@ class TradingEnvironment(_EnvBase):
         self.device = device
         self.trajectory_offset = trajectory_offset
         self.noise = noise
+        self._host_plugins = self._find_host_plugins()
+        if self._host_plugins.get("reward") is not None and not precise_state:
+            # calculate() is handed the two state matrices: only the float64 tier hands it the reference's (a reward formed
+            # from float32-rounded cash and midprice levels is off by the rounding of the LEVELS, ~1e-4)
+            precise_state = True
         self.precise_state = precise_state
         self.allow_stiff_hawkes = allow_stiff_hawkes
         # Seeding protocol of the reference: `if seed:` - seed=0 or None leaves the processes unseeded (TE:70);
@@ -147,9 +174,15 @@ class TradingEnvironment(_EnvBase):
                 self.model_dynamics.fill_probability_model, ExponentialFillFunction
             ), "Arrival model must be Poisson and fill probability model must be exponential to scale rewards"
             self.reward_scaling = 1 / self._get_inventory_neutral_rewards()
+        self._step_context = None
+        self._host_state64 = None
         self._handle = self._create_handle(num_trajectories, self.reward_scaling)
         self._events_on = False
         self._last_events = None
+        # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills
+        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival"))
+        if self._host_needs_events:
+            _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
         # environment generator when initial inventories are random; keep the stream aligned
         self._reset_device()
@@ -164,15 +197,21 @@ class TradingEnvironment(_EnvBase):
         # processes a dynamics class does not use are simply absent (None), as in the reference
         parts = [p for p in (md, md.midprice_model, md.arrival_model, md.fill_probability_model, md.price_impact_model,
                              self.reward_function) if p is not None]
+        host_parts = {id(part): role for role, part in self._host_plugins.items()}
         for part in parts:
-            if getattr(part, "device_kind", None) is None:
+            if getattr(part, "device_kind", None) is None and id(part) not in host_parts:
                 raise UnsupportedOnDevice(
-                    f"{type(part).__name__} has no HIP implementation (see DESIGN.md for the supported plugin classes).  "
+                    f"{type(part).__name__} has no HIP implementation and none of the host-callable methods of the plugin contract "
+                    "(_get_fill_probabilities / get_arrivals / calculate): see DESIGN.md for the supported plugin classes.  "
                     "There is no CPU fallback."
                 )
         fields = dict(arrival_kind=_native.ARR_NONE, fill_kind=_native.FILL_NONE, impact_kind=_native.IMPACT_NONE)
         for part in parts:
             fields.update(part.device_params())
+        # NumPy-only subclasses keep running on the host, between launches: the kernel is told to take their results
+        for role, kind in (("fill", dict(fill_kind=_native.FILL_HOST)), ("arrival", dict(arrival_kind=_native.ARR_HOST)), ("reward", dict(reward_kind=_native.REW_HOST))):
+            if role in self._host_plugins:
+                fields.update(kind)
         for key in ("midprice_step_size", "arrival_step_size", "impact_step_size"):
             if fields.get(key) is None:
                 fields[key] = 0.0  # 0 = the environment's terminal_time / n_steps
@@ -290,14 +329,31 @@ class TradingEnvironment(_EnvBase):
         """Compile the user-defined plugins' device expressions without creating anything (needs no GPU); raises
         NativeError with the compiler's diagnostics if they do not compile."""
         code = self._user_code()
+        if code is None and self._host_plugins:
+            code = _native.MbtUserCode()  # host-callback plugins: one run-time instantiation, no expressions
         if code is not None:
             cfg = self._device_config(self.num_trajectories, self.reward_scaling)
             _native.check(_native.load_library().mbt_jit_check(C.byref(cfg), C.byref(code)))
 
     def close(self):
+        """Frees the device state AND the page-locked host memory this environment pooled for its outputs (a buffer a caller
+        still holds an array over is freed with that array)."""
         if getattr(self, "_handle", None) is not None:
             _native.load_library().mbt_env_destroy(self._handle)
             self._handle = None
+        self.release_host_buffers()
+
+    def release_host_buffers(self):
+        """Gives the pinned output buffers of step() / reset() / rollout() back now (they are re-created on demand).  Without
+        this they are returned when idle: a pool keeps two buffers per array in use and frees any further one that nobody
+        referenced for 30 s; recorded-rollout pools keep none."""
+        pools = self.__dict__.pop("_pools", None)
+        if pools is not None:
+            for key in ("obs", "rewards", "dones"):
+                pools[key].release()
+        self._step_context = None
+        for pool in self.__dict__.pop("_trajectory_pools", None) or ():
+            pool.release()
 
     def __del__(self):
         try:
@@ -324,31 +380,135 @@ class TradingEnvironment(_EnvBase):
         """Re-initialise every lane (TE:96-101) and return the (N, D) float32 observation."""
         obs = self._host_buffers()["obs"].acquire()[0]
         self._reset_device(obs)
+        if self._host_plugins:
+            self._reset_host_plugins()
         return obs
 
     def step(self, action: np.ndarray):
         """One environment step for all lanes: ONE kernel launch.  Returns (obs, rewards, dones, infos) with the
         reference's shapes (TE:103-110): (N, D) float32, (N,) float32, (N,) bool, list of N dicts.
 
-        The three arrays live in pinned host memory that the step's DMA copies write directly and that is RE-USED - but only
-        once the caller has let go of an array (`_native.OutputPool`): like the reference's, an array you keep keeps its
-        values.  The action may be any array-like of shape (N, A); handing over `env.action_buffer` (pinned) after writing
-        the action into it saves the one pass that stages other arrays into pinned memory."""
-        n = self.num_trajectories
-        pools = self._host_buffers()
+        The three arrays live in pinned host memory that the step writes directly and that is RE-USED - but only once the
+        caller has let go of an array (`_native.OutputPool`): like the reference's, an array you keep keeps its values.  The
+        pool sees Python references (arrays, views, tensors made from them); a consumer that keeps only a raw ADDRESS of an
+        output (`obs.ctypes.data`, a cffi pointer) and drops the array must keep the array instead, or set
+        MBT_FRESH_OUTPUTS=1 (fresh arrays every step, as the reference returns them; the only mode where reference counts are
+        not exact, i.e. outside standard GIL CPython).  The action may be any array-like of shape (N, A); handing over
+        `env.action_buffer` (pinned) after writing the action into it saves the one pass that stages other arrays."""
+        if self._host_plugins:
+            return self._step_with_host_plugins(action)
+        ctx = self._step_context
+        if ctx is None:
+            ctx = self._make_step_context()
+        pools, step_host, handle, done, done_ref = ctx
         act = self._stage_action(action, pools)
+        obs, obs_ptr = pools["obs"].acquire_with_pointer()
+        rewards, rew_ptr = pools["rewards"].acquire_with_pointer()
+        code = step_host(handle, act.ctypes.data, obs_ptr or obs.ctypes.data, rew_ptr or rewards.ctypes.data, done_ref)
+        if code < 0:
+            _native.check(code)
+        if self._events_on:
+            self._fetch_events()
+        dones = pools["dones"].acquire_with_pointer()[0]
+        dones.fill(done.value != 0)
+        return obs, rewards, dones, self._infos()
+
+    def _make_step_context(self):
+        """What every step() needs, looked up once: the pools, the bound C function, the handle and the done flag."""
+        done = C.c_int32(0)
+        ctx = self._step_context = (self._host_buffers(), _native.load_library().mbt_env_step_host, self._handle, done, C.byref(done))
+        return ctx
+
+    def _fetch_events(self):
+        ev = np.empty((self.num_trajectories,), dtype=np.uint8)
+        _native.check(_native.load_library().mbt_env_get_events_host(self._handle, ev.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._last_events = ev
+
+    # -- host-callback plugins: subclasses of the reference's plugin contract that only have NumPy code ----------------------
+    def _find_host_plugins(self):
+        """{role: object} for the plugin objects whose class has no device form (see `host_callback_role`)."""
+        md = self.model_dynamics
+        found = {}
+        for part in (md.arrival_model, md.fill_probability_model, self.reward_function):
+            role = host_callback_role(part) if part is not None else None
+            if role is None:
+                continue
+            if role in ("fill", "arrival") and part.state_dim != 0:
+                raise UnsupportedOnDevice(
+                    f"{type(part).__name__} only has host (NumPy) code AND owns {part.state_dim} state column(s): the host-callback route serves "
+                    "stateless models (a stateful user process states its update as a device expression: DeviceExpressionArrivalModel)")
+            found[role] = part
+        if found:
+            warnings.warn(
+                "host-callback plugins: " + ", ".join(f"{type(p).__name__} ({r})" for r, p in found.items()) + " only have NumPy code, which "
+                "runs on the host between kernel launches every step (one or two extra host round trips per step; no fused rollout).  "
+                "State the formula as a device expression (DeviceExpressionFillModel / ...ArrivalModel / ...Reward) for the fast path.",
+                HostCallbackWarning, stacklevel=3)
+        return found
+
+    def _reset_host_plugins(self):
+        for role in ("arrival", "fill"):
+            if role in self._host_plugins:
+                self._host_plugins[role].reset()  # TE:97-98
+        self._host_state64 = None
+        if "reward" in self._host_plugins:
+            self._host_state64 = self.state64
+            self._host_plugins["reward"].reset(self._host_state64.copy())  # TE:100
+
+    def _step_with_host_plugins(self, action):
+        """TE:103-110 with the user's NumPy methods where the reference calls them and the fused kernel for everything else:
+        depths (device, float64) -> _get_fill_probabilities / get_fills (host) -> probabilities (device); get_arrivals (host)
+        -> arrivals (device); ONE step launch; float64 states (device) -> calculate (host) -> rewards (device)."""
+        lib, handle, n, plugins = _native.load_library(), self._handle, self.num_trajectories, self._host_plugins
+        dptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        pools = self._host_buffers()
+        act = np.ascontiguousarray(action, dtype=np.float32)
+        if act.shape != (n, self.action_dim):
+            raise ValueError(f"expected shape {(n, self.action_dim)}, got {act.shape}")
+        fill, arrival, reward = plugins.get("fill"), plugins.get("arrival"), plugins.get("reward")
+        if fill is not None:
+            depths = np.empty((n, 2), dtype=np.float64)
+            _native.check(lib.mbt_env_host_depths(handle, _native.fptr(act), dptr(depths)))
+            if type(fill).get_fills is not FillProbabilityModel.get_fills:  # the subclass draws its own fills (FILL:28-34 overridden):
+                p = np.asarray(fill.get_fills(depths), dtype=np.float64)    # 1.0 / 0.0 - `u < 1` holds for every u in [0, 1), `u < 0` never
+            else:
+                p = np.asarray(fill._get_fill_probabilities(depths), dtype=np.float64)  # FILL:34: compared with the lane's uniform on the device
+            p = np.ascontiguousarray(np.broadcast_to(p, (n, 2)))
+            _native.check(lib.mbt_env_set_host_fill_probabilities(handle, dptr(p)))
+        if arrival is not None:
+            arrived = np.ascontiguousarray(np.broadcast_to(np.asarray(arrival.get_arrivals()), (n, 2)), dtype=np.float32)  # ARR:27-29
+            _native.check(lib.mbt_env_set_host_arrivals(handle, _native.fptr(arrived)))
         obs = pools["obs"].acquire()[0]
         rewards = pools["rewards"].acquire()[0]
         done = C.c_int32(0)
-        lib = _native.load_library()
-        _native.check(lib.mbt_env_step_host(self._handle, _native.fptr(act), _native.fptr(obs), _native.fptr(rewards), C.byref(done)))
-        if self._events_on:
-            ev = np.empty((n,), dtype=np.uint8)
-            _native.check(lib.mbt_env_get_events_host(self._handle, ev.ctypes.data_as(C.POINTER(C.c_uint8))))
-            self._last_events = ev
+        _native.check(lib.mbt_env_step_host(handle, act.ctypes.data, obs.ctypes.data, rewards.ctypes.data, C.byref(done)))
+        if self._events_on or self._host_needs_events:
+            self._fetch_events()
+        following = self.state64  # float64 (N, D): with precise_state the reference's own values; the TIME column is the float64 clock
+        raw_action = self.normalise_action(np.asarray(action, dtype=np.float64), inverse=True)  # TE:104: what the plugins are handed
+        # StochasticProcessModel.update of the user's processes, in registry order (TE:206-211), with the step's arrivals and
+        # (masked) fills and the state matrix - which is where a stateless plugin written against the reference's API learns e.g.
+        # the time.  (The matrix is the one AFTER the step: the reference's shows the columns of processes LATER in the registry
+        # still un-advanced at that point - there are none for a stateless model next to built-in ones.)
+        for role in ("arrival", "fill"):
+            if role in plugins:
+                plugins[role].update(self.last_arrivals, self.last_fills.astype(np.float64), raw_action, following)
+        if reward is not None:
+            current = self._host_state64
+            if current is None:
+                raise _native.NativeError(-4, "step() before reset()")
+            r = np.asarray(reward.calculate(current, raw_action, following, bool(done.value)), dtype=np.float64)  # TE:108
+            r = np.ascontiguousarray(np.broadcast_to(r, (n,)))
+            _native.check(lib.mbt_env_set_host_rewards(handle, dptr(r), _native.fptr(rewards)))
+            self._host_state64 = following
         dones = pools["dones"].acquire()[0]
         dones.fill(bool(done.value))
         return obs, rewards, dones, self._infos()
+
+    def set_launch_gate(self, burst: int):
+        """`step_many_device` enqueues its launches in bursts of `burst` behind a gate kernel (0 = off): for runs under a
+        tracer, whose per-launch host cost would otherwise let the queue run dry (include/mbt_env.h: mbt_env_set_launch_gate)."""
+        _native.check(_native.load_library().mbt_env_set_launch_gate(self._handle, int(burst)))
 
     # -- host buffers of step() / reset() ---------------------------------------------------------------------------------
     def _host_buffers(self):
@@ -356,8 +516,9 @@ class TradingEnvironment(_EnvBase):
         if pools is None or pools["n"] != self.num_trajectories:
             n = self.num_trajectories
             pools = {"n": n, "obs": _native.OutputPool((n, self.observation_dim)), "rewards": _native.OutputPool((n,)),
-                     "dones": _native.OutputPool((n,), dtype=np.bool_), "action": None}
+                     "dones": _native.OutputPool((n,), dtype=np.bool_), "action": None, "action_shape": (n, self.action_dim)}
             self._pools = pools
+            self._step_context = None
         return pools
 
     @property
@@ -376,6 +537,10 @@ class TradingEnvironment(_EnvBase):
         return pools["action_array"]
 
     def _stage_action(self, action, pools):
+        if type(action) is np.ndarray and action.dtype == np.float32 and action.size <= (1 << 15) and action.flags.c_contiguous:
+            if action.shape != pools["action_shape"]:
+                raise ValueError(f"expected shape {pools['action_shape']}, got {action.shape}")
+            return action  # small batches: the library copies the caller's array into its own staging (mapped memory) as it is
         staged = self.action_buffer
         if action is staged:
             return staged
@@ -383,7 +548,7 @@ class TradingEnvironment(_EnvBase):
         if a.shape != staged.shape:
             raise ValueError(f"expected shape {staged.shape}, got {a.shape}")
         if a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size * 4 <= (1 << 17):
-            return a  # small batches: the library's own staging (mapped memory) reads the caller's array directly
+            return a
         np.copyto(staged, a, casting="unsafe")  # one pass: conversion to float32 and the move into pinned memory
         return staged
 
@@ -557,7 +722,7 @@ class TradingEnvironment(_EnvBase):
         _native.check(_native.load_library().mbt_env_set_noise_host(self._handle, _native.fptr(ua), _native.fptr(uf), _native.fptr(zz)))
 
     def record_events(self, enabled: bool = True):
-        _native.check(_native.load_library().mbt_env_record_events(self._handle, int(enabled)))
+        _native.check(_native.load_library().mbt_env_record_events(self._handle, int(enabled or getattr(self, "_host_needs_events", False))))
         self._events_on = bool(enabled)
 
     @property
@@ -708,6 +873,7 @@ class TradingEnvironment(_EnvBase):
             self._num_trajectories = num_trajectories
             return
         self.close()
+        self._step_context = None
         self._num_trajectories = num_trajectories
         self.model_dynamics.num_trajectories = num_trajectories
         for proc in self.stochastic_processes.values():

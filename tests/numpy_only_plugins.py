@@ -1,0 +1,93 @@
+"""Plugin subclasses as a user of the REFERENCE writes them: NumPy only, against the reference's plugin contract
+(`FillProbabilityModel._get_fill_probabilities` FILL:22-34, `ArrivalModel.get_arrivals` ARR:27-29, `RewardFunction.calculate`
+RW:10-13), with no device expression and no knowledge of this package.
+
+ONE source for both sides of the parity tests: `define(...)` is handed the base classes of whichever package the classes are
+to live in - the reference's (`tools/refgen/make_golden.py`, build container only: the fixtures `user_fill_and_reward`,
+`user_fill_hawkes_market_normalised`, `user_seasonal_arrivals` are the REAL reference running these classes) or
+mbt_gym_amd's (tests/test_gpu_host_callbacks.py: the same classes, unmodified, in `env.step()` through the host-callback
+route of include/mbt_env.h).  Nothing here imports either package."""
+import types
+
+import numpy as np
+
+
+def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names):
+    """The three classes, bound to the given plugin base classes and state-column indices."""
+    CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX = (
+        index_names.CASH_INDEX, index_names.INVENTORY_INDEX, index_names.TIME_INDEX, index_names.ASSET_PRICE_INDEX)
+
+    class UserPowerLawFill(FillProbabilityModel):
+        """p(depth) = 1 / (1 + (scale depth)^power): a heavier tail than the exponential fill function."""
+
+        def __init__(self, scale, power, step_size, num_trajectories, seed=None):
+            self.scale, self.power = scale, power
+            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
+                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
+
+        def _get_fill_probabilities(self, depths):
+            return 1.0 / (1.0 + (self.scale * depths) ** self.power)
+
+        @property
+        def max_depth(self):
+            return 99.0 ** (1.0 / self.power) / self.scale
+
+        def update(self, arrivals, fills, actions, state=None):
+            pass
+
+    class UserExponentialInventoryCost(RewardFunction):
+        """PnL - dt phi (exp(eta |q'|) - 1) - alpha [terminal] q'^2: an inventory cost that grows exponentially."""
+
+        def __init__(self, phi, eta, alpha):
+            self.phi, self.eta, self.alpha = phi, eta, alpha
+
+        def calculate(self, current_state, action, next_state, is_terminal_step=False):
+            value = lambda s: s[:, CASH_INDEX] + s[:, INVENTORY_INDEX] * s[:, ASSET_PRICE_INDEX]  # noqa: E731
+            dt = next_state[:, TIME_INDEX] - current_state[:, TIME_INDEX]
+            q = next_state[:, INVENTORY_INDEX]
+            return value(next_state) - value(current_state) - dt * self.phi * (np.exp(self.eta * np.abs(q)) - 1.0) - self.alpha * int(is_terminal_step) * q**2
+
+        def reset(self, initial_state):
+            pass
+
+    class UserSeasonalArrivals(ArrivalModel):
+        """A time-of-day intensity profile.  Stateless; the reference hands the state matrix to update() (TE:206-211), which is
+        where a plugin written against its API learns the time."""
+
+        def __init__(self, base, amplitude, period, step_size, num_trajectories, seed=None):
+            self.base, self.amplitude, self.period, self.time = np.array(base, dtype=float), amplitude, period, 0.0
+            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
+                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
+
+        def reset(self):
+            super().reset()
+            self.time = 0.0
+
+        def update(self, arrivals, fills, actions, state=None):
+            self.time = state[0, TIME_INDEX]
+
+        def get_arrivals(self):
+            unif = self.rng.uniform(size=(self.num_trajectories, 2))
+            return unif < self.base * (1.0 + self.amplitude * np.cos(2 * np.pi * self.time / self.period)) * self.step_size
+
+    return types.SimpleNamespace(UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
+                                 UserSeasonalArrivals=UserSeasonalArrivals)
+
+
+class Replay:
+    """Stands in for a numpy Generator inside one process (what tools/refgen/make_golden.py gives the reference's processes):
+    `uniform` / `normal` hand out the pre-drawn, float32-representable arrays of a fixture, step by step."""
+
+    def __init__(self, uniforms=None, normals=None):
+        self.uniforms, self.normals, self.ku, self.kn = uniforms, normals, 0, 0
+
+    def uniform(self, size=None):
+        out = self.uniforms[self.ku].astype(np.float64)
+        assert out.shape == tuple(size)
+        self.ku += 1
+        return out
+
+    def normal(self, size=None):
+        out = self.normals[self.kn].astype(np.float64).reshape(size)
+        self.kn += 1
+        return out

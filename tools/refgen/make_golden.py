@@ -613,34 +613,16 @@ def user_plugin_cases(only=None):
     from mbt_gym.rewards.RewardFunctions import RewardFunction
     from mbt_gym.stochastic_processes.fill_probability_models import FillProbabilityModel
 
-    class UserPowerLawFill(FillProbabilityModel):
-        def __init__(self, scale, power, step_size, num_trajectories, seed=None):
-            self.scale, self.power = scale, power
-            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
-                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
+    # The NumPy-only classes live in tests/numpy_only_plugins.py - ONE source, bound here to the REFERENCE's base classes and in
+    # tests/test_gpu_host_callbacks.py to mbt_gym_amd's: the same user code on both sides of the parity test.
+    import mbt_gym.gym.index_names as reference_index_names
+    from mbt_gym.stochastic_processes.arrival_models import ArrivalModel
 
-        def _get_fill_probabilities(self, depths):
-            return 1.0 / (1.0 + (self.scale * depths) ** self.power)
+    sys.path.insert(0, REPO)
+    from tests.numpy_only_plugins import define as define_numpy_only_plugins
 
-        @property
-        def max_depth(self):
-            return 99.0 ** (1.0 / self.power) / self.scale
-
-        def update(self, arrivals, fills, actions, state=None):
-            pass
-
-    class UserExponentialInventoryCost(RewardFunction):
-        def __init__(self, phi, eta, alpha):
-            self.phi, self.eta, self.alpha = phi, eta, alpha
-
-        def calculate(self, current_state, action, next_state, is_terminal_step=False):
-            value = lambda s: s[:, CASH_INDEX] + s[:, INVENTORY_INDEX] * s[:, ASSET_PRICE_INDEX]  # noqa: E731
-            dt = next_state[:, TIME_INDEX] - current_state[:, TIME_INDEX]
-            q = next_state[:, INVENTORY_INDEX]
-            return value(next_state) - value(current_state) - dt * self.phi * (np.exp(self.eta * np.abs(q)) - 1.0) - self.alpha * int(is_terminal_step) * q**2
-
-        def reset(self, initial_state):
-            pass
+    user = define_numpy_only_plugins(FillProbabilityModel, ArrivalModel, RewardFunction, reference_index_names)
+    UserPowerLawFill, UserExponentialInventoryCost, UserSeasonalArrivals = user.UserPowerLawFill, user.UserExponentialInventoryCost, user.UserSeasonalArrivals
 
     common = dict(normalise_action_space=False, normalise_observation_space=False)
     scale, power = 1.25, 1.5
@@ -685,25 +667,6 @@ def user_plugin_cases(only=None):
 
     # X. a user-defined, stateless ArrivalModel: a time-of-day intensity profile.  The reference hands the state matrix to
     #    update() (TE:206-211), which is where a plugin written against its API learns the time
-    from mbt_gym.stochastic_processes.arrival_models import ArrivalModel
-
-    class UserSeasonalArrivals(ArrivalModel):
-        def __init__(self, base, amplitude, period, step_size, num_trajectories, seed=None):
-            self.base, self.amplitude, self.period, self.time = np.array(base, dtype=float), amplitude, period, 0.0
-            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=step_size, terminal_time=0.0,
-                             initial_state=np.array([[]]), num_trajectories=num_trajectories, seed=seed)
-
-        def reset(self):
-            super().reset()
-            self.time = 0.0
-
-        def update(self, arrivals, fills, actions, state=None):
-            self.time = state[0, TIME_INDEX]
-
-        def get_arrivals(self):
-            unif = self.rng.uniform(size=(self.num_trajectories, 2))
-            return unif < self.base * (1.0 + self.amplitude * np.cos(2 * np.pi * self.time / self.period)) * self.step_size
-
     n, ns = 32, 100
     run_case(
         "user_seasonal_arrivals",
