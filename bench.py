@@ -155,7 +155,9 @@ def build_env(n, offset, device, workload="cfg1", precise=False):
 # (profiles/r03_bench_kernel_trace_hist*.txt).  When a tracer is attached the launches are therefore enqueued in bursts behind
 # a gate kernel (include/mbt_env.h: mbt_env_set_launch_gate) and run back to back, as they do untraced; the line says so.
 TRACED = "ROCP_TOOL_LIBRARIES" in os.environ  # what rocprofv3 sets for the process it launches
-TRACED_LAUNCH_GATE = int(os.environ.get("MBT_BENCH_GATE", "1024" if TRACED else "0") or 0)  # MBT_BENCH_GATE=0: never
+# (bursts of 256: under the tracer the host blocks in a launch once ~550-1000 dispatches are outstanding - a burst of 1024 never
+# reached its gate_open and every gate ran into its time-out, profiles/r04_experiments.txt)
+TRACED_LAUNCH_GATE = int(os.environ.get("MBT_BENCH_GATE", "256" if TRACED else "0") or 0)  # MBT_BENCH_GATE=0: never
 
 
 def timed_steps(env, lib, k, sync_all):

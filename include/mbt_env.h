@@ -343,7 +343,7 @@ int mbt_env_step_many_device(mbt_env* env, uint32_t k, const float* action_devic
  * of a burst then run back to back however long the HOST needs per launch.  For runs under a tracer (rocprofv3 raises the
  * host's cost per launch to ~11 us, above a 7 us kernel: the queue runs dry and kernels that start on an idle chip take
  * 0.5-1.8 us longer than in the untraced run being profiled); not for production - the device idles while a burst is
- * queued.  The gate kernel gives up by itself after 5 s.  burst <= 4096; 0 = off (default). */
+ * queued.  The gate kernel gives up by itself after 1 s.  burst <= 4096; 0 = off (default). */
 int mbt_env_set_launch_gate(mbt_env* env, uint32_t burst);
 
 /* ---- fused rollout: many steps in one launch with an on-device closed-form policy ---------------

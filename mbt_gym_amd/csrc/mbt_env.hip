@@ -133,6 +133,20 @@ constexpr uint32_t kHostFastPathLanes = 32768;
 
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 
+// Which instantiation of a production-noise step kernel: default-policy loads | non-temporal loads (launches beyond the
+// Infinity Cache, tune_for_size) | the small-batch host-API kernel that mirrors its outputs into host memory and raises a
+// completion flag (mbt_env_step_host; step_kernel.hpp: signal_host).  Injected-noise kernels (parity mode) exist in the
+// first form only: asked for a mirror they answer nullptr and the host path takes its two-launch fallback.
+enum LoadMode : int { kPlain = 0, kStream = 1, kMirror = 2 };
+template <class V>
+StepKernel pick_mode(int mode) {
+  return mode == kStream ? mbt::step_kernel<V, true, false> : mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
+}
+template <class V_INJECT>
+StepKernel pick_injected(int mode) {
+  return mode == kMirror ? nullptr : mbt::step_kernel<V_INJECT>;
+}
+
 // Limit-order-book family: arrivals {Poisson, Hawkes} x dynamics {limit, limit+market, touch} x {Brownian, other
 // midprice} x reward weight {PnL, quadratic inventory penalties, general} x normalised x noise = 144 step kernels and
 // 72 rollout kernels; WHICH other midprice and reward are runtime parameters inside them.
@@ -141,49 +155,54 @@ int reward_weight(const mbt_config& c) {
   const bool quadratic = (c.reward_kind == MBT_REW_RUNNING_PENALTY || c.reward_kind == MBT_REW_CJ_MM) && c.inventory_exponent == 2.0;
   return quadratic ? mbt::kRewardQuadratic : mbt::kRewardGeneral;
 }
-// `stream` = the non-temporal-load instantiation (production noise only; see step_kernel and tune_for_size)
 template <int ARR, int DYN, bool BM, int REW, bool NORM>
-StepKernel pick_noise(bool inject, bool stream) {
-  if (inject) return mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, true>>;
-  return stream ? mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, false>, true> : mbt::step_kernel<mbt::Variant<ARR, DYN, BM, REW, NORM, false>, false>;
+StepKernel pick_noise(bool inject, int mode) {
+  if (inject) return pick_injected<mbt::Variant<ARR, DYN, BM, REW, NORM, true>>(mode);
+  return pick_mode<mbt::Variant<ARR, DYN, BM, REW, NORM, false>>(mode);
 }
 template <int ARR, int DYN, bool BM, int REW>
-StepKernel pick_flags(bool norm, bool inject, bool stream) {
-  return norm ? pick_noise<ARR, DYN, BM, REW, true>(inject, stream) : pick_noise<ARR, DYN, BM, REW, false>(inject, stream);
+StepKernel pick_flags(bool norm, bool inject, int mode) {
+  return norm ? pick_noise<ARR, DYN, BM, REW, true>(inject, mode) : pick_noise<ARR, DYN, BM, REW, false>(inject, mode);
 }
 template <int ARR, int DYN, bool BM>
-StepKernel pick_rew(int rew, bool norm, bool inject, bool stream) {
+StepKernel pick_rew(int rew, bool norm, bool inject, int mode) {
   switch (rew) {
-    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject, stream);
-    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject, stream);
-    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject, stream);
+    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject, mode);
+    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject, mode);
+    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject, mode);
   }
 }
 template <int ARR, int DYN>
-StepKernel pick_pen(bool bm, int rew, bool norm, bool inject, bool stream) {
-  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject, stream) : pick_rew<ARR, DYN, false>(rew, norm, inject, stream);
+StepKernel pick_pen(bool bm, int rew, bool norm, bool inject, int mode) {
+  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject, mode) : pick_rew<ARR, DYN, false>(rew, norm, inject, mode);
 }
 template <int ARR>
-StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, bool stream) {
+StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, int mode) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject, stream);
-    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject, stream);
-    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, stream);
+    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject, mode);
+    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject, mode);
+    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, mode);
   }
 }
-// `staged` = the instantiation that loads 20-byte rows through LDS (cache-resident sizes, only with an impact state);
-// `stream` = non-temporal direct loads (sizes beyond the Infinity Cache); see speed_step_kernel
+// Speed family.  kPlain: rows of 20 bytes LOADED through LDS (`staged`: cache-resident sizes, only with an impact state);
+// kStream: non-temporal direct loads (sizes beyond the Infinity Cache); kMirror: the small-batch host-API kernel (staged
+// like kPlain); see speed_step_kernel.
 // POW: the instantiation that can raise to arbitrary powers (speed_powers below); every reference configuration runs without
+template <class V, class V_INJECT, bool STATE>
+StepKernel pick_speed_mode(bool inject, int mode) {
+  if (inject) return mode == kMirror ? nullptr : mbt::speed_step_kernel<V_INJECT>;
+  if (mode == kStream) return mbt::speed_step_kernel<V, false, true>;
+  if (mode == kMirror) return mbt::speed_step_kernel<V, STATE, false, true>;
+  return mbt::speed_step_kernel<V, STATE>;
+}
 template <bool STATE, bool POW>
-StepKernel pick_speed_pow(bool norm, bool inject, bool stream) {
-  if (inject) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, false, POW>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, true, false, POW>>;
-  if (stream) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>, false, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>, false, true>;
-  if (STATE) return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>, true> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>, true>;
-  return norm ? mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>> : mbt::speed_step_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>>;
+StepKernel pick_speed_pow(bool norm, bool inject, int mode) {
+  return norm ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, false, POW>, mbt::SpeedVariant<STATE, true, true, false, POW>, STATE>(inject, mode)
+              : pick_speed_mode<mbt::SpeedVariant<STATE, false, false, false, POW>, mbt::SpeedVariant<STATE, false, true, false, POW>, STATE>(inject, mode);
 }
 template <bool STATE>
-StepKernel pick_speed(bool powers, bool norm, bool inject, bool stream) {
-  return powers ? pick_speed_pow<STATE, true>(norm, inject, stream) : pick_speed_pow<STATE, false>(norm, inject, stream);
+StepKernel pick_speed(bool powers, bool norm, bool inject, int mode) {
+  return powers ? pick_speed_pow<STATE, true>(norm, inject, mode) : pick_speed_pow<STATE, false>(norm, inject, mode);
 }
 bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
 // does this speed-dynamics configuration raise anything to a power other than 1 (impact, IMP:55) or 2 (inventory penalty,
@@ -195,88 +214,81 @@ bool speed_powers(const mbt_config& c) {
 
 
 // ExogenousMmFillProbabilityModel: the general tier only (runtime midprice coefficients, every reward, runtime
-// normalisation flags), 8 step + 4 rollout kernels.
+// normalisation flags), 8 step (+ 4 mirror) + 4 rollout kernels.
 bool exogenous_fill(const mbt_config& c) {
   return c.fill_kind == MBT_FILL_EXOGENOUS_MM && (c.dynamics_kind == MBT_DYN_LIMIT || c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET);
 }
 template <int ARR, int DYN>
-StepKernel pick_exogenous(bool inject) {
-  return inject ? mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, true>>
-                : mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>>;
+StepKernel pick_exogenous(bool inject, int mode) {
+  if (inject) return pick_injected<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, true>>(mode);
+  using V = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>;
+  return mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
 }
 
 // precise_state: the general tier again (every midprice model, every reward, runtime normalisation flags) on the
 // reference's float64 state: {Poisson-type, Hawkes} x {limit, limit + market, touch} + the exogenous-depth fill model on
 // {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 6 + 2 for speed dynamics (the float32 kernel with a precise branch).
 // Round 4: like the float32 tier, the contract tier has SPECIALISED instantiations for what the BASELINE configurations run -
-// Brownian midprice x {plain PnL, the penalised rewards with exponent 2} x raw spaces (no pow / exp / normalisation code in the
-// instruction stream: reward_exact<TIER>) - and a STREAM (non-temporal loads) instantiation of every production-noise kernel for
-// launches beyond the Infinity Cache; same operations in the same order, so which one runs changes no bit.
+// {Brownian, other built-in midprice} x {plain PnL, the penalised rewards with exponent 2} x raw spaces (no pow / exp /
+// normalisation code in the instruction stream: reward_exact<TIER>) - and STREAM / MIRROR instantiations of every
+// production-noise kernel; same operations in the same order, so which one runs changes no bit.
 template <int ARR, int DYN, bool EXO>
-StepKernel pick_precise(bool inject, bool stream) {
-  using V = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>;
-  if (inject) return mbt::step_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>;
-  return stream ? mbt::step_kernel<V, true> : mbt::step_kernel<V, false>;
+StepKernel pick_precise(bool inject, int mode) {
+  if (inject) return pick_injected<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>(mode);
+  return pick_mode<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>(mode);
 }
 template <int ARR, int DYN, int REW>
-StepKernel pick_precise_special(bool brownian, bool stream) {
+StepKernel pick_precise_special(bool brownian, int mode) {
   using B = mbt::Variant<ARR, DYN, true, REW, false, false, false, true>;   // Brownian midprice (BASELINE configs 1, 2, 4)
   using G = mbt::Variant<ARR, DYN, false, REW, false, false, false, true>;  // any other built-in midprice (config 3: OU)
-  if (brownian) return stream ? mbt::step_kernel<B, true> : mbt::step_kernel<B, false>;
-  return stream ? mbt::step_kernel<G, true> : mbt::step_kernel<G, false>;
+  return brownian ? pick_mode<B>(mode) : pick_mode<G>(mode);
 }
 template <int ARR, int DYN>
-StepKernel pick_precise_tier(int special_reward, bool brownian, bool inject, bool stream) {
-  if (special_reward == mbt::kRewardPnl) return pick_precise_special<ARR, DYN, mbt::kRewardPnl>(brownian, stream);
-  if (special_reward == mbt::kRewardQuadratic) return pick_precise_special<ARR, DYN, mbt::kRewardQuadratic>(brownian, stream);
-  return pick_precise<ARR, DYN, false>(inject, stream);
+StepKernel pick_precise_tier(int special_reward, bool brownian, bool inject, int mode) {
+  if (special_reward == mbt::kRewardPnl) return pick_precise_special<ARR, DYN, mbt::kRewardPnl>(brownian, mode);
+  if (special_reward == mbt::kRewardQuadratic) return pick_precise_special<ARR, DYN, mbt::kRewardQuadratic>(brownian, mode);
+  return pick_precise<ARR, DYN, false>(inject, mode);
 }
 // special_reward: kRewardPnl / kRewardQuadratic when the specialised instantiation applies, kRewardGeneral otherwise
 template <int ARR>
-StepKernel pick_precise_dyn(int dyn, bool exo, int special_reward, bool brownian, bool inject, bool stream) {
+StepKernel pick_precise_dyn(int dyn, bool exo, int special_reward, bool brownian, bool inject, int mode) {
   switch (dyn) {
-    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject, stream) : pick_precise_tier<ARR, mbt::kDynLimit>(special_reward, brownian, inject, stream);
-    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject, stream) : pick_precise_tier<ARR, mbt::kDynLimitAndMarket>(special_reward, brownian, inject, stream);
-    default: return pick_precise_tier<ARR, mbt::kDynTouch>(special_reward, brownian, inject, stream);
+    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject, mode) : pick_precise_tier<ARR, mbt::kDynLimit>(special_reward, brownian, inject, mode);
+    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject, mode) : pick_precise_tier<ARR, mbt::kDynLimitAndMarket>(special_reward, brownian, inject, mode);
+    default: return pick_precise_tier<ARR, mbt::kDynTouch>(special_reward, brownian, inject, mode);
   }
 }
-// (the precise_state tier of the speed family is the same kernel: `staged` / `stream` as above; POW as for the float32 tier)
-template <bool STATE, bool POW>
-StepKernel pick_speed_precise_pow(bool inject, bool stream) {
-  using V = mbt::SpeedVariant<STATE, true, false, true, POW>;
-  if (inject) return mbt::speed_step_kernel<mbt::SpeedVariant<STATE, true, true, true, POW>>;
-  if (stream) return mbt::speed_step_kernel<V, false, true>;
-  return STATE ? mbt::speed_step_kernel<V, true> : mbt::speed_step_kernel<V>;
-}
+// (the precise_state tier of the speed family is the same kernel; POW as for the float32 tier)
 template <bool STATE>
-StepKernel pick_speed_precise(bool powers, bool inject, bool stream) {
-  return powers ? pick_speed_precise_pow<STATE, true>(inject, stream) : pick_speed_precise_pow<STATE, false>(inject, stream);
+StepKernel pick_speed_precise(bool powers, bool inject, int mode) {
+  return powers ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true>, mbt::SpeedVariant<STATE, true, true, true, true>, STATE>(inject, mode)
+                : pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, false>, mbt::SpeedVariant<STATE, true, true, true, false>, STATE>(inject, mode);
 }
 
-StepKernel pick_kernel(const mbt_config& c, bool stream) {
+StepKernel pick_kernel(const mbt_config& c, int mode) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
-    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(speed_powers(c), inject, stream) : pick_speed_precise<false>(speed_powers(c), inject, stream);
-    return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, stream) : pick_speed<false>(speed_powers(c), norm, inject, stream);
+    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(speed_powers(c), inject, mode) : pick_speed_precise<false>(speed_powers(c), inject, mode);
+    return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, mode) : pick_speed<false>(speed_powers(c), norm, inject, mode);
   }
   if (c.precise_state) {
     const int tier = reward_weight(c);
     const bool special = !inject && !norm && !exogenous_fill(c) && tier != mbt::kRewardGeneral;
     const int special_reward = special ? tier : mbt::kRewardGeneral;
     const bool brownian = c.midprice_kind == MBT_MID_BROWNIAN;
-    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, stream)
-                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, stream);
+    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, mode)
+                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, mode);
   }
   if (exogenous_fill(c)) {
     const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
-    if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject);
-    return market ? pick_exogenous<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(inject) : pick_exogenous<mbt::kArrPoisson, mbt::kDynLimit>(inject);
+    if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject, mode) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject, mode);
+    return market ? pick_exogenous<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(inject, mode) : pick_exogenous<mbt::kArrPoisson, mbt::kDynLimit>(inject, mode);
   }
   const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
   const int rew = reward_weight(c);
-  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject, stream)
-                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject, stream);
+  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject, mode)
+                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject, mode);
 }
 
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
@@ -380,9 +392,10 @@ struct mbt_env {
   bool was_reset = false, noise_ready = false, q_init_per_lane = false;
   bool record_events = false, track_returns = false;
   StepKernel kernel = nullptr;
+  StepKernel kernel_mirror = nullptr;  // the small-batch host-API instantiation (nullptr: none - the two-launch fallback serves the host path)
   RolloutKernel rollout = nullptr;
   mbt::StepParams params;
-  hipFunction_t jit_step = nullptr, jit_rollout = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
+  hipFunction_t jit_step = nullptr, jit_rollout = nullptr, jit_step_mirror = nullptr;  // run-time compiled kernels of mbt_env_create_jit (owned by the module cache)
   double user_fill_p[8] = {}, user_reward_p[8] = {}, user_arrival_p[8] = {}, user_mid_p[8] = {}, user_state_p[8] = {};  // parameters of the user's device expressions
   int user_state_columns = 0;      // state columns owned by user processes (mbt_user_code.state_columns), after the midprice
   bool user_draws = false;         // ... that read the two extra normals z1, z2
@@ -578,7 +591,9 @@ void fill_static_params(mbt_env* e) {
 // MBT_STEP_DYNAMIC_LDS = bytes override the choice (measurement knobs).
 void tune_for_size(mbt_env* e) {
   const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + 2u * e->res);
-  const bool hbm_resident = bytes_per_launch > (size_t(320) << 20);
+  // (round 4: rows that are NOT 16 bytes wide lose with non-temporal loads far beyond 320 MB - Hawkes + OU at 2^22 lanes: 252 MB
+  // float32 43.5 vs 36.6 us, 386 MB precise_state 69.5 vs 56.5 us - and win only around 1 GB, 2^24 lanes: 165.8 vs 177.2 us)
+  const bool hbm_resident = bytes_per_launch > (size_t(e->dim == 4 ? 320 : 640) << 20);
   e->stream_loads = hbm_resident;
   e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;  // AS 2^24: 115.7 -> 114.2 us; Hawkes (D = 6) loses with it
   // Inside the cache the same cap pays for ONE kernel: the lightest one (Brownian midprice, Poisson arrivals, limit orders,
@@ -696,9 +711,9 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   B.clip_count = e->clip_count;
   if (e->jit_step != nullptr) {
     void* args[] = {&B, &P};
-    HIP_TRY(hipModuleLaunchKernel(e->jit_step, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, e->step_dynamic_lds, e->stream, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(mirror ? e->jit_step_mirror : e->jit_step, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, e->step_dynamic_lds, e->stream, args, nullptr));
   } else {
-    hipLaunchKernelGGL(e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P);
+    hipLaunchKernelGGL(mirror ? e->kernel_mirror : e->kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P);
     HIP_TRY(hipGetLastError());
   }
   e->time = t_next;
@@ -841,9 +856,9 @@ int prepare_learned_policy(mbt_env* e, const mbt_policy* policy, mbt::LearnedPol
 int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj, float* rew_traj,
                    uint32_t* steps_done, int32_t* done) {
   if (!e->was_reset) return fail(MBT_ERR_STATE, "rollout() before reset()");
+  if (e->host_mask != 0) return fail(MBT_ERR_INVALID, "host-callback plugins (NumPy-only subclasses) are consulted between launches: this environment runs step by step, not as a fused rollout");
   if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "rollouts draw Philox noise; this environment is in injected-noise mode");
   if (policy == nullptr) return fail(MBT_ERR_INVALID, "null policy");
-  if (e->host_mask != 0) return fail(MBT_ERR_INVALID, "host-callback plugins (NumPy-only subclasses) are consulted between launches: this environment runs step by step, not as a fused rollout");
   if (policy->kind == MBT_POLICY_ACTION_BUFFER) {
     const int rc_file = file_staged_action(e);
     if (rc_file != MBT_OK) return rc_file;
@@ -929,6 +944,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
       hipLaunchKernelGGL(mbt::policy_kernel, dim3(policy_blocks(e)), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
                          e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
       HIP_TRY(hipGetLastError());
+      e->action_in_stage = false;
       if (act_traj != nullptr) HIP_TRY(hipMemcpyAsync(act_traj + k * row_act, e->action, row_act * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
       const int rc = launch_step(e, nullptr, &ended);
       if (rc != MBT_OK) return rc;
@@ -1168,7 +1184,7 @@ int jit_compile(const std::string& source, std::vector<char>& code) {
 
 struct JitKernels {
   hipModule_t module = nullptr;
-  hipFunction_t step = nullptr, rollout = nullptr;
+  hipFunction_t step = nullptr, rollout = nullptr, step_mirror = nullptr;
 };
 
 // One module per distinct (device, generated source): environments that share plugins share the compiled code.  Modules
@@ -1191,6 +1207,10 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
   HIP_TRY(hipModuleLoadData(&k.module, code.data()));
   HIP_TRY(hipModuleGetFunction(&k.step, k.module, "mbt_user_step"));
   if (with_rollout) HIP_TRY(hipModuleGetFunction(&k.rollout, k.module, "mbt_user_rollout"));
+  if (hipModuleGetFunction(&k.step_mirror, k.module, "mbt_user_step_mirror") != hipSuccess) {  // (injected-noise units have none)
+    (void)hipGetLastError();
+    k.step_mirror = nullptr;
+  }
   cache.emplace(key, k);
   out = k;
   return MBT_OK;
@@ -1241,6 +1261,8 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
          ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
+  if (!inject)  // the small-batch host-API instantiation (step_kernel.hpp: signal_host)
+    src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step_mirror(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false, true>(B, P); }\n";
   if (!inject && host_mask == 0)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
            "mbt::rollout_body<V>(B, P, R); }\n";
@@ -1503,9 +1525,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     }
     e->jit_step = kernels.step;
     e->jit_rollout = kernels.rollout;
+    e->jit_step_mirror = kernels.step_mirror;
     e->stream_loads = false;  // one instantiation is compiled: default-policy loads
   } else {
-    e->kernel = pick_kernel(*cfg, e->stream_loads);
+    e->kernel = pick_kernel(*cfg, e->stream_loads ? kStream : kPlain);
+    e->kernel_mirror = pick_kernel(*cfg, kMirror);
     e->rollout = pick_rollout_kernel(*cfg);
   }
   fill_static_params(e);
@@ -1725,19 +1749,28 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
     const size_t n_obs = size_t(e->n) * e->dim;
     std::memcpy(e->h_stage + e->stage_action, action_host, size_t(e->n) * e->act_dim * sizeof(float));
     e->action_in_stage = false;  // (set below: launch_step must not file the PREVIOUS stage contents first)
-    int rc = launch_step(e, e->d_stage + e->stage_action, done, /*mirror=*/true);
+    const bool mirror = e->jit_step != nullptr ? e->jit_step_mirror != nullptr : e->kernel_mirror != nullptr;
+    int rc = launch_step(e, e->d_stage + e->stage_action, done, mirror);
     if (rc != MBT_OK) return rc;
     e->action_in_stage = true;
-    const uint32_t* flag = reinterpret_cast<const uint32_t*>(e->h_stage + e->stage_flag);
-    const uint32_t want = e->flag_seq;
-    const auto t0 = std::chrono::steady_clock::now();
-    uint32_t spins = 0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
-      if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-        // not a latency path any more (a clock ramp, a page migration - or a kernel that died): let the runtime wait and report
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(MBT_ERR_HIP, "the step kernel finished without raising its completion flag");
-        break;
+    if (!mirror) {  // (injected-noise kernels have no mirror instantiation: a second launch exports, the stream is waited for)
+      const uint32_t threads = 256, blocks = static_cast<uint32_t>((n_obs + threads - 1) / threads);
+      hipLaunchKernelGGL(mbt::export_step_kernel, dim3(blocks), dim3(threads), 0, e->stream, current_obs(e), e->reward, e->d_stage + e->stage_obs,
+                         e->d_stage + e->stage_reward, static_cast<uint32_t>(n_obs), e->n);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+      const uint32_t* flag = reinterpret_cast<const uint32_t*>(e->h_stage + e->stage_flag);
+      const uint32_t want = e->flag_seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      uint32_t spins = 0;
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+          // not a latency path any more (a clock ramp, a page migration - or a kernel that died): let the runtime wait and report
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(MBT_ERR_HIP, "the step kernel finished without raising its completion flag");
+          break;
+        }
       }
     }
     if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
@@ -1798,7 +1831,7 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
   while (steps < k) {
     if (e->gate_chunk != 0 && !e->gate_closed) {  // a new burst: everything up to gate_open() is enqueued behind this kernel
       e->gate_seq += 1;
-      hipLaunchKernelGGL(mbt::gate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_gate, e->gate_seq, 500000000ull /* 5 s of the 100 MHz clock */);
+      hipLaunchKernelGGL(mbt::gate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_gate, e->gate_seq, 100000000ull /* 1 s of the 100 MHz clock */);
       HIP_TRY(hipGetLastError());
       e->gate_closed = true;
       in_burst = 0;
@@ -1992,6 +2025,7 @@ int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   hipLaunchKernelGGL(mbt::policy_kernel, dim3(policy_blocks(e)), dim3(mbt::kBlockThreads), 0, e->stream, current_obs(e), e->action, e->dim, e->act_dim, LP,
                      e->params.pair_offset, e->philox_step, e->params.key0, e->params.key1);
   HIP_TRY(hipGetLastError());
+  e->action_in_stage = false;  // the policy's actions are the newest now
   return MBT_OK;
 }
 

@@ -237,12 +237,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // the loads of the next): the double-precision step on top of sixteen loaded vectors needed 140-147 registers - three waves
 // per SIMD, and the counters said that is what bounds it (waves stalled on memory 60 % of the time, profiles/r03_experiments.txt).
 #ifndef MBT_SPEED_PRECISE_GROUPS
-#define MBT_SPEED_PRECISE_GROUPS 1
+#define MBT_SPEED_PRECISE_GROUPS 4
 #endif
 #ifndef MBT_SPEED_PRECISE_WAVES
 #define MBT_SPEED_PRECISE_WAVES 1
 #endif
-template <class V, bool STAGED = false, bool STREAM = false>
+template <class V, bool STAGED = false, bool STREAM = false, bool MIRROR = false>
 __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES : 1) void speed_step_kernel(const StepBuffers B, const StepParams P) {
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES
     if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(r.events);
     if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
     const bool real = lane < P.n;
-    if (B.host_obs != nullptr && real) {  // small-batch host API: what env.step() returns, straight into host memory (step_kernel.hpp: signal_host)
+    if (MIRROR && real) {  // small-batch host API: what env.step() returns, straight into host memory (step_kernel.hpp: signal_host)
       B.host_reward[lane] = r.reward;
       if (V::PRECISE) store_speed_exact<V, false>(nullptr, nullptr, B.host_obs, lane, exact_next, P.t_next_f64, P);
       else store_speed_row<V, false>(B.host_obs, lane, r.next, P.t_next, V::NORM && P.norm_obs != 0, P);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES
     unsafeAtomicAdd(&B.wave_sums[wave_id], static_cast<double>(total));
     if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave_id & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
-  signal_host(B);
+  if (MIRROR) signal_host(B);
 }
 
 // Fused rollout for the speed family: fixed speed, or an open-loop schedule tabulated over time steps (e.g. the

@@ -1027,7 +1027,8 @@ __device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int
 }
 
 // Arithmetic and stores of one lane; returns its reward (0 for a pad lane) and counts a clip.
-template <class V>
+// MIRROR: the instantiation for small batches over the host API (see step_body) also writes what env.step() returns into host memory.
+template <class V, bool MIRROR = false>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f, const float2 zu = make_float2(0.f, 0.f)) {
   const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu, L.hs)
@@ -1056,7 +1057,7 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   }
   if (B.events != nullptr) B.events[lane] = static_cast<uint8_t>(event_byte(r));
   if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
-  if (B.host_obs != nullptr && lane < P.n) {  // small-batch host API: the row and the reward as env.step() returns them, straight into host memory
+  if (MIRROR && lane < P.n) {  // small-batch host API: the row and the reward as env.step() returns them, straight into host memory
     B.host_reward[lane] = r.reward;
     if (V::PRECISE) store_row_exact<V, false>(B.host_obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
     else store_row<V, false>(B.host_obs, lane, r.core, r.lam, V::NORM, P);
@@ -1070,8 +1071,10 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
 // workgroup meets, one thread counts the workgroup in; the last workgroup of the launch re-arms the counter and writes the
 // launch's sequence number where the host is spinning.  (Measured, tools/microbench/mb_sync.hip: hipStreamSynchronize costs
 // ~12.5 us around one kernel, a flag written by a follow-up one-thread kernel 8.5; this needs neither.)
+// A SEPARATE instantiation (step_body's MIRROR), not a run-time branch in every kernel: measured as a wave-uniform branch on a
+// kernel argument, the mirror + this epilogue cost the benchmark kernel 0.8 us of its 6.65 (2^20 lanes, five workgroups per
+// CU; 0.7 us for its precise_state twin, 0.1-0.3 for the heavier kernels: profiles/r04_experiments.txt) - code that never ran.
 __device__ __forceinline__ void signal_host(const StepBuffers& B) {
-  if (B.host_flag == nullptr) return;  // (a kernel argument: uniform over the launch, so the barrier below is reached by all or none)
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1089,8 +1092,11 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
 // and a LOSS where the working set does fit (2^20..2^22 lanes), hence two instantiations rather than one policy.  (A
 // run-time branch around the two load sequences does not survive the optimiser: it merges the branches' loads and drops
 // the hint.)
-template <class V, bool STREAM = false>
+// MIRROR: small batches over the host API (mbt_env_step_host, N <= 32768): the kernel also mirrors its outputs into
+// device-mapped host memory and raises a completion flag there (signal_host) - ONE launch per env.step(), no interrupt.
+template <class V, bool STREAM = false, bool MIRROR = false>
 __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {
+  static_assert(!(STREAM && MIRROR), "streaming loads are for launches beyond the Infinity Cache, the mirror for small batches");
   const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
   LaneLoads L0 = load_lane<V, STREAM>(B, P, lane0), L1 = load_lane<V, STREAM>(B, P, lane1);  // issue every load ...
@@ -1115,8 +1121,8 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
   // in LDS instead (12 / 16 KB) and writes them out as contiguous whole-line float4 - through the L2.
   __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM > 4 ? kTileLanes * V::DIM : 4];
   bool clipped0, clipped1;
-  float r0 = finish_lane<V>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM, nz0.z, zu0);
-  float r1 = finish_lane<V>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM, nz1.z, zu1);
+  float r0 = finish_lane<V, MIRROR>(B, P, lane0, L0, d0, clipped0, staged_rows + threadIdx.x * V::DIM, nz0.z, zu0);
+  float r1 = finish_lane<V, MIRROR>(B, P, lane1, L1, d1, clipped1, staged_rows + (threadIdx.x + kBlockThreads) * V::DIM, nz1.z, zu1);
   if (V::DIM > 4) {
     __syncthreads();
     constexpr int kTileVectors = kTileLanes * V::DIM / 4;  // float4 per tile: 3 (D = 6) or 4 (D = 8) per thread; 2.5 for D = 5
@@ -1145,14 +1151,14 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
     if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
   }
-  signal_host(B);
+  if (MIRROR) signal_host(B);
 }
 
 // (the body is a device function so that the run-time compiled kernels of mbt_env_create_jit - plain extern "C" entry
 // points around one instantiation - share it with the ahead-of-time instantiations)
-template <class V, bool STREAM = false>
+template <class V, bool STREAM = false, bool MIRROR = false>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
-  step_body<V, STREAM>(B, P);
+  step_body<V, STREAM, MIRROR>(B, P);
 }
 
 // ---- fused rollout -----------------------------------------------------------------------
@@ -1418,13 +1424,22 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
   if (lane_returns != nullptr) lane_returns[i] = 0.0f;
 }
 
+// Small batches over the host API for kernels WITHOUT a mirror instantiation (injected-noise mode): observation rows and rewards
+// copied into pinned, device-mapped host memory by a second launch (instead of two DMA copies, ~25 us each at any size).
+__global__ void export_step_kernel(const float* obs, const float* reward, float* host_obs, float* host_reward, uint32_t n_obs, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (host_obs != nullptr && i < n_obs) host_obs[i] = obs[i];
+  if (host_reward != nullptr && i < n) host_reward[i] = reward[i];
+}
+
 // Holds the environment's stream until the host writes `value` to a word of device-mapped host memory - so that a burst of
 // launches can be ENQUEUED behind it and then run back to back whatever the host's cost per launch is (a tracer's, say:
 // mbt_env_set_launch_gate).  Gives up by itself after `timeout_ticks` of the 100 MHz wall clock: a host that died cannot
 // leave the device spinning.
 __global__ void gate_kernel(const uint32_t* flag, uint32_t value, uint64_t timeout_ticks) {
   const uint64_t t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != value) {
+  // (the host counts bursts up and may already have opened LATER gates when this kernel gets to run: at-or-past, not equal)
+  while (static_cast<int32_t>(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
     if (wall_clock64() - t0 > timeout_ticks) break;
     __builtin_amdgcn_s_sleep(64);
   }

@@ -70,7 +70,7 @@ class StableBaselinesTradingEnvironment(_VecEnvBase):
 
     def step_wait(self):
         obs, rewards, dones, infos = self.env.step(self.actions)
-        if not dones.min():
+        if not dones[0]:  # (the clock is shared - TE:218-220 fills `dones` with ONE flag - so lane 0 speaks for `dones.min()`, SBE:30)
             return obs, rewards, dones, infos
         # episode over in every lane (the clock is shared): hand out the terminal observation, then auto-reset (SBE:28-37)
         if self.store_terminal_observation_info:
@@ -78,8 +78,8 @@ class StableBaselinesTradingEnvironment(_VecEnvBase):
                 infos = TerminalObservationInfos(obs)
             else:
                 infos = list(infos) if isinstance(infos, list) else [infos]
-                for lane in range(len(infos)):
-                    infos[lane]["terminal_observation"] = obs[lane, :]
+                for info, row in zip(infos, obs):
+                    info["terminal_observation"] = row
         return self.env.reset(), rewards, dones, infos
 
     def seed(self, seed: Optional[int] = None):

@@ -181,7 +181,7 @@ class TradingEnvironment(_EnvBase):
         self._last_events = None
         # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills
         self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival"))
-        if self._host_needs_events:
+        if self._host_needs_events and self._handle is not None:
             _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
         # environment generator when initial inventories are random; keep the stream aligned

@@ -42,29 +42,70 @@ def test_device_expressions_compile_without_a_gpu(no_device):
     all_three.check_device_expressions()  # a user arrival model, fill model and reward in one kernel
 
 
-def test_a_plugin_class_without_a_device_form_is_refused(no_device):
-    """A subclass of the plugin base classes that only has NumPy code (what the reference accepts) cannot run: there is no
-    CPU fallback.  It is refused at construction with a message that names the device routes."""
-    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment, UnsupportedOnDevice
-    from mbt_gym_amd.rewards.RewardFunctions import DeviceExpressionReward, RewardFunction
-    from mbt_gym_amd.stochastic_processes.fill_probability_models import DeviceExpressionFillModel
+def test_numpy_only_plugin_classes_take_the_host_callback_route(no_device):
+    """A subclass of the plugin base classes that only has NumPy code - what a user of the reference writes (FILL:22-34, ARR:27-29,
+    RW:10-13) - is accepted: its method keeps running on the host between launches and the kernel takes its results (MBT_FILL_HOST /
+    MBT_ARR_HOST / MBT_REW_HOST).  The run-time instantiation compiles without a GPU.  What has neither a device form nor a
+    host-callable method of the contract is still refused, and so is a NumPy-only process that owns state columns."""
+    import warnings
 
-    class NumpyOnlyReward(RewardFunction):
-        def calculate(self, current_state, action, next_state, is_terminal_step=False):
-            return np.zeros(len(current_state))
+    import mbt_gym_amd.gym.index_names as index_names
+    from mbt_gym_amd import _native
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import HostCallbackWarning, TradingEnvironment, UnsupportedOnDevice, host_callback_role
+    from mbt_gym_amd.rewards.RewardFunctions import DeviceExpressionReward, PnL, RewardFunction
+    from mbt_gym_amd.stochastic_processes.arrival_models import ArrivalModel, PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import DeviceExpressionFillModel, ExponentialFillFunction, FillProbabilityModel
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+    from tests.numpy_only_plugins import define
 
-        def reset(self, initial_state):
-            pass
+    user = define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names)
+    n, ns = 8, 20
+    fill, arrivals, reward = user.UserPowerLawFill(1.25, 1.5, 1 / ns, n), user.UserSeasonalArrivals([40.0, 30.0], 0.8, 0.5, 1 / ns, n), user.UserExponentialInventoryCost(0.05, 0.3, 0.02)
+    assert [host_callback_role(p) for p in (fill, arrivals, reward, PnL(), ExponentialFillFunction(), PoissonArrivalModel())] == ["fill", "arrival", "reward", None, None, None]
 
-    env = make_env(_cfg(8, fill="exponential", reward="pnl"))
-    env.reward_function = NumpyOnlyReward()
-    with pytest.raises(UnsupportedOnDevice):
-        env._device_config(8, 1.0)
+    def build(**kw):
+        md = LimitOrderModelDynamics(midprice_model=BrownianMotionMidpriceModel(step_size=1 / ns, num_trajectories=n), arrival_model=kw.pop("arrival", arrivals),
+                                     fill_probability_model=kw.pop("fill", fill), num_trajectories=n)
+        return TradingEnvironment(n_steps=ns, model_dynamics=md, reward_function=kw.pop("reward", reward), num_trajectories=n, normalise_action_space=False,
+                                  normalise_observation_space=False, **kw)
+
+    with pytest.warns(HostCallbackWarning, match="UserPowerLawFill"):
+        env = build()
+    cfg = env._device_config(n, 1.0)
+    assert (cfg.fill_kind, cfg.arrival_kind, cfg.reward_kind) == (_native.FILL_HOST, _native.ARR_HOST, _native.REW_HOST)
+    assert cfg.precise_state == 1 and env.precise_state  # calculate() is handed float64 states: the float64 tier is implied
+    assert env.action_space.high[0] == pytest.approx(99.0 ** (1 / 1.5) / 1.25, rel=1e-6)  # the user's max_depth bounds the action (MD:118-121)
+    env.check_device_expressions()  # one run-time instantiation (Variant::HOST = fill | arrival | reward), compiled by hiprtc without a GPU
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", HostCallbackWarning)
+        only_fill = build(arrival=PoissonArrivalModel(step_size=1 / ns, num_trajectories=n), reward=PnL())
+    assert not only_fill.precise_state and only_fill._device_config(n, 1.0).reward_kind == _native.REW_PNL
+    only_fill.check_device_expressions()
+
+    class StatefulNumpyArrivals(ArrivalModel):  # NumPy-only AND two state columns: refused, with the device route named
+        def __init__(self):
+            super().__init__(np.zeros((1, 2)), np.ones((1, 2)), 1 / ns, 1.0, np.full((1, 2), 0.5), n, None)
+
+        def get_arrivals(self):
+            return np.zeros((n, 2), dtype=bool)
+
+    with pytest.raises(UnsupportedOnDevice, match="stateless"):
+        build(arrival=StatefulNumpyArrivals())
+
+    class NothingToRun(FillProbabilityModel):  # neither a device form nor _get_fill_probabilities / get_fills
+        def __init__(self):
+            super().__init__(np.array([[]]), np.array([[]]), 1 / ns, 0.0, np.array([[]]), n, None)
+
+        max_depth = 3.0
+
+    nothing = build(fill=NothingToRun(), arrival=PoissonArrivalModel(step_size=1 / ns, num_trajectories=n), reward=PnL())
+    with pytest.raises(UnsupportedOnDevice, match="no HIP implementation"):
+        nothing._device_config(n, 1.0)  # (what the constructor does when it creates the device handle)
     with pytest.raises(TypeError, match="device_expression"):
         type("NoExpression", (DeviceExpressionReward,), {})()
     with pytest.raises(TypeError, match="device_expression"):
         type("NoExpression", (DeviceExpressionFillModel,), {})()
-    assert TradingEnvironment is not None
 
 
 @pytest.mark.gpu
