@@ -84,8 +84,25 @@ double exact_join_host(float hi, int32_t lo) { return static_cast<double>(hi) + 
 // Pinned host memory handed to callers (mbt_host_alloc): a host pointer inside one of these blocks is DMA-able as it is, so
 // the "*_host" entry points copy straight into / out of it; any other host pointer is pageable as far as the library knows
 // (a foreign pinned allocation is recognised through hipPointerGetAttributes) and goes through a pinned bounce buffer.
+struct PinnedBlock {
+  size_t bytes = 0;
+  uintptr_t device_base = 0;  // the same block as the DEVICE addresses it (mapped, coherent): 0 if it could not be mapped
+};
 std::mutex g_pinned_mutex;
-std::map<uintptr_t, size_t> g_pinned_blocks;  // base address -> bytes
+std::map<uintptr_t, PinnedBlock> g_pinned_blocks;  // base address -> block
+
+// The device's address of [p, p + bytes) if that range lies inside one block of mbt_host_alloc (nullptr otherwise): memory the
+// small-batch step kernel may write its outputs into DIRECTLY (mbt_env_step_host: no staging copy on the way out).
+void* device_alias(const void* p, size_t bytes) {
+  if (p == nullptr) return nullptr;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  std::lock_guard<std::mutex> guard(g_pinned_mutex);
+  auto it = g_pinned_blocks.upper_bound(a);
+  if (it == g_pinned_blocks.begin()) return nullptr;
+  --it;
+  if (a < it->first || a + bytes > it->first + it->second.bytes || it->second.device_base == 0) return nullptr;
+  return reinterpret_cast<void*>(it->second.device_base + (a - it->first));
+}
 
 bool is_pinned_host(const void* p, size_t bytes) {
   if (p == nullptr) return false;
@@ -95,7 +112,7 @@ bool is_pinned_host(const void* p, size_t bytes) {
     auto it = g_pinned_blocks.upper_bound(a);
     if (it != g_pinned_blocks.begin()) {
       --it;
-      if (a >= it->first && a + bytes <= it->first + it->second) return true;
+      if (a >= it->first && a + bytes <= it->first + it->second.bytes) return true;
     }
   }
   // foreign memory: pinned only if the runtime knows BOTH ends of [p, p + bytes) as host memory (a registration may cover
@@ -657,8 +674,9 @@ int file_staged_action(mbt_env* e) {
   return MBT_OK;
 }
 
-// mirror: the launch also writes what env.step() returns into the stage and raises its flag (small-batch host API)
-int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror = false) {
+// mirror: the launch also writes what env.step() returns into host memory - the stage, or the caller's own arrays when they
+// are device-mapped (mirror_obs / mirror_reward) - and raises its flag (small-batch host API)
+int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror = false, float* mirror_obs = nullptr, float* mirror_reward = nullptr) {
   if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
   if (action_dev == nullptr && e->action_in_stage) {
     const int rc_file = file_staged_action(e);
@@ -691,8 +709,8 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   B.host_fill_p = e->host_fill_p;
   B.host_arrivals = e->host_arrivals;
   if (mirror) {
-    B.host_obs = e->d_stage + e->stage_obs;
-    B.host_reward = e->d_stage + e->stage_reward;
+    B.host_obs = mirror_obs != nullptr ? mirror_obs : e->d_stage + e->stage_obs;
+    B.host_reward = mirror_reward != nullptr ? mirror_reward : e->d_stage + e->stage_reward;
     B.done_counter = e->done_counter;
     B.host_flag = reinterpret_cast<uint32_t*>(e->d_stage + e->stage_flag);
     B.flag_value = ++e->flag_seq;
@@ -1750,7 +1768,11 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
     std::memcpy(e->h_stage + e->stage_action, action_host, size_t(e->n) * e->act_dim * sizeof(float));
     e->action_in_stage = false;  // (set below: launch_step must not file the PREVIOUS stage contents first)
     const bool mirror = e->jit_step != nullptr ? e->jit_step_mirror != nullptr : e->kernel_mirror != nullptr;
-    int rc = launch_step(e, e->d_stage + e->stage_action, done, mirror);
+    // the caller's arrays are blocks of mbt_host_alloc (the Python layer's output pools are): the kernel writes them directly
+    float* direct_obs = mirror ? static_cast<float*>(device_alias(obs_host, n_obs * sizeof(float))) : nullptr;
+    float* direct_rew = mirror ? static_cast<float*>(device_alias(reward_host, size_t(e->n) * sizeof(float))) : nullptr;
+    if (direct_obs == nullptr || direct_rew == nullptr || reinterpret_cast<uintptr_t>(direct_obs) % 16 != 0) direct_obs = direct_rew = nullptr;  // (rows leave as 16-byte vectors)
+    int rc = launch_step(e, e->d_stage + e->stage_action, done, mirror, direct_obs, direct_rew);
     if (rc != MBT_OK) return rc;
     e->action_in_stage = true;
     if (!mirror) {  // (injected-noise kernels have no mirror instantiation: a second launch exports, the stream is waited for)
@@ -1773,6 +1795,7 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
         }
       }
     }
+    if (direct_obs != nullptr) return MBT_OK;  // already where the caller wants them
     if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
     if (reward_host != nullptr) std::memcpy(reward_host, e->h_stage + e->stage_reward, size_t(e->n) * sizeof(float));
     return MBT_OK;
@@ -2139,13 +2162,23 @@ int mbt_env_get_state_host(mbt_env* e, float* state_host) {
 void* mbt_host_alloc(size_t bytes) {
   if (bytes == 0) return nullptr;
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+  // (mapped + coherent: besides being DMA-able the block can be written by a kernel and read by the host while the kernel's
+  // stream is live - what lets the small-batch step kernel put observations and rewards straight into the caller's arrays)
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     (void)hipGetLastError();
-    fail(MBT_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes);
-    return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      fail(MBT_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes);
+      return nullptr;
+    }
   }
+  PinnedBlock block;
+  block.bytes = bytes;
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) == hipSuccess) block.device_base = reinterpret_cast<uintptr_t>(dev);
+  else (void)hipGetLastError();
   std::lock_guard<std::mutex> guard(g_pinned_mutex);
-  g_pinned_blocks[reinterpret_cast<uintptr_t>(p)] = bytes;
+  g_pinned_blocks[reinterpret_cast<uintptr_t>(p)] = block;
   return p;
 }
 

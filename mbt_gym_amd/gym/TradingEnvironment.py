@@ -411,7 +411,7 @@ class TradingEnvironment(_EnvBase):
             self._fetch_events()
         dones = pools["dones"].acquire_with_pointer()[0]
         dones.fill(done.value != 0)
-        return obs, rewards, dones, self._infos()
+        return obs, rewards, dones, (self._empty_infos or self._infos())
 
     def _make_step_context(self):
         """What every step() needs, looked up once: the pools, the bound C function, the handle and the done flag."""

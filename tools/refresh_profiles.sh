@@ -45,9 +45,9 @@ profile bench --lanes 1048576
 profile hbm_resident --lanes 16777216 --steps 600 --warmup 100
 cp "$OUT/${TAG}_bench_pmc_summary.json" "$OUT/${TAG}_pmc_summary.json"   # the name bench.py's roofline.traffic reads
 
-# per-dispatch durations and gaps with --kernel-trace alone (launches stay back to back) and with --stats (the host becomes the bottleneck)
-bash tools/dbg/kernel_trace_hist.sh > /dev/null 2>&1; cp gpurun_out/dbg/kernel_trace_hist.txt "$OUT/${TAG}_bench_kernel_trace_hist.txt"
-MBT_KT_STATS=--stats bash tools/dbg/kernel_trace_hist.sh > /dev/null 2>&1; cp gpurun_out/dbg/kernel_trace_hist.txt "$OUT/${TAG}_bench_kernel_trace_hist_with_stats.txt"; stamp "kernel trace histograms"
+# per-dispatch durations and gaps under the tracer: gated launches (what the summary above is made of) and ungated ones (the host becomes the bottleneck)
+MBT_KT_STATS=--stats MBT_KT_ARGS=--no-configs bash tools/dbg/kernel_trace_hist.sh > /dev/null 2>&1; cp gpurun_out/dbg/kernel_trace_hist.txt "$OUT/${TAG}_bench_kernel_trace_hist_gated.txt"
+MBT_BENCH_GATE=0 MBT_KT_STATS=--stats MBT_KT_ARGS=--no-configs bash tools/dbg/kernel_trace_hist.sh > /dev/null 2>&1; cp gpurun_out/dbg/kernel_trace_hist.txt "$OUT/${TAG}_bench_kernel_trace_hist_ungated.txt"; stamp "kernel trace histograms"
 python tests/perf/parity_report.py > "$OUT/${TAG}_parity_report.txt" 2> /dev/null; stamp "parity report"
 MBT_BENCH_STEPS=1000 python tests/perf/bench_configs.py > "$OUT/${TAG}_step_kernel_all_configs.json" 2> /dev/null; stamp "all configs"
 python tests/perf/bench_regimes.py > "$OUT/${TAG}_regimes.json" 2> /dev/null; stamp "regimes"
