@@ -151,9 +151,20 @@ typedef struct mbt_config {
   /* Numerics tier.
    * 0 (default): float32 state, the 44 B / env-step kernels.  Decisions (arrivals, fills, inventory) are bit-exact against
    *   the float64 reference on the same draws - except that Hawkes intensities are float32 STATE, so a draw within the
-   *   float32 error of lambda dt can decide differently (3e-9 per draw) - and rewards are within 1e-5 + 1e-6 |r| on
-   *   lane-steps where the clip of TE:283-289 does not fire, within 1.2e-4 where it does (the reward then carries the level
-   *   of the float32 cash / midprice); real-valued inventory (speed dynamics) accumulates float32 rounding.
+   *   float32 error of lambda dt, |u - lambda dt| <= (2e-5 + 3e-7 lambda) dt, can decide differently (probability
+   *   2 (2e-5 + 3e-7 lambda) dt per draw and side: ~1e-6 per lane-step at lambda ~ 40, dt ~ 1/40).  Rewards, with U = 2^-24
+   *   (one float32 rounding) and S_err, c_err = |float32 state - reference state| of midprice and cash BEFORE the step:
+   *       |r - r_ref| <= 1e-5 + 1e-6 max(|r|, |q' dS|)                       (the contract + float32's own output rounding)
+   *                    + |q'| L (S_err + 2 U |S|)                            (L = 0 for Brownian / jump / constant midprices - the
+   *                                                                           increment does not read the state; theta for OU;
+   *                                                                           |dS / S| for GBM)
+   *                    + [the clip of TE:283-289 fired] (4 (S_err + 2 U |S|) + c_err + 4 U |cash|)
+   *   i.e. 1e-5-class wherever no float32 state LEVEL enters the reward, and exactly the state error marked to market where
+   *   one does (a clip; a state-proportional increment).  The state columns themselves drift like a sum of independent
+   *   roundings: <= 6 sqrt(k / 6) ulp32(|x|max) after k steps (six sigma), cash additionally by what it inherits from the
+   *   midprice through - dq S.  tests/float32_tier_bounds.py is this formula, tests/test_gpu_random_configs.py asserts it.
+   *   Real-valued inventory (speed dynamics) is float32 state too: its error shows times the price move, and times the
+   *   price where the clip fires.
    * 1: the reference's float64 state, EXACTLY - every real-valued column (cash, midprice, Hawkes intensities, the inventory
    *   and impact state of speed dynamics) is its float32 rounding in the state row plus an int32 remainder in a side
    *   buffer (mbt_exact_split: the same 8 bytes as a float32 pair, all 53 bits) - stepped in double in the reference's own
