@@ -88,10 +88,12 @@ def moved_bytes(key, precise):
 
 def kernel_name(key, precise, lanes):
     arr, dyn, bm, rew = WORKLOADS[key]["kernel"]
-    stream = lanes * moved_bytes(key, precise) > (320 << 20)
+    # non-temporal loads beyond 320 MB per launch for 16-byte rows, beyond 640 MB for other row widths (mbt_env.hip: tune_for_size)
+    stream = lanes * moved_bytes(key, precise) > ((320 if WORKLOADS[key]["dim"] == 4 else 640) << 20)
     b = lambda x: "true" if x else "false"  # noqa: E731
+    # step_kernel<Variant<...>, STREAM, MIRROR>: the mirror instantiation serves small batches over the host API only
     return (f"mbt::step_kernel<mbt::Variant<{arr}, {dyn}, {b(bm)}, {rew}, false, false, false, {b(precise)}, false, false, false, false, 0, false, 0>, "
-            f"{b(stream)}>")
+            f"{b(stream)}, false>")
 
 
 def build_env(n, offset, device, workload="cfg1", precise=False):
@@ -224,9 +226,9 @@ def roofline_row(key, precise, lanes, launch_s, reference):
             "env_steps_per_s_kernel": lanes / launch_s, "kernel": name}
 
 
-def configs_block(lib, device, reference, steps_budget_s=0.06):
+def configs_block(lib, device, reference, steps_budget_s=0.1):
     """Every other BASELINE configuration's step kernel, and the contract tier (`precise_state`) of all four, measured on THIS box
-    exactly like the headline: K launches in one library call, HIP events on the kernel's stream, about 0.06 s of launches each
+    exactly like the headline: K launches in one library call, HIP events on the kernel's stream, about 0.05 s of warm-up and 0.1 s of timed launches each
     (parity-test cases, not bench lines - they never enter `value`)."""
     import torch
 
@@ -243,8 +245,8 @@ def configs_block(lib, device, reference, steps_budget_s=0.06):
                 torch.cuda.synchronize()
 
             rough_us = moved_bytes(key, precise) * lanes / 5.5e6  # at ~5.5 TB/s: only sizes the launch counts
-            steps = int(max(200, min(4000, steps_budget_s * 1e6 / rough_us)))
-            env.step_many_device(max(100, steps // 2), auto_reset=True)
+            steps = int(max(200, min(8000, steps_budget_s * 1e6 / rough_us)))
+            env.step_many_device(int(max(200, 0.05e6 / rough_us)), auto_reset=True)  # ~50 ms of launches: clocks up, like the headline's prewarm
             _, event_s, _ = timed_steps(env, lib, steps, sync_all)
             env.close()
             row = roofline_row(key, precise, lanes, event_s / steps, reference)
@@ -573,7 +575,8 @@ def main():
     ap.add_argument("--cfg4-total-lanes", type=int, default=1 << 24,
                     help="N > 1: BASELINE.json configs[4] (limit + market orders) with this many lanes in TOTAL, sharded over the ranks "
                          "(strong scaling: 2^21 per GPU at N = 8), reported as an extra block of the line; 0 = skip")
-    ap.add_argument("--cfg4-steps", type=int, default=400)
+    ap.add_argument("--cfg4-steps", type=int, default=1100, help="timed steps of the cfg4 block (after steps // 4 of warm-up): 1100 puts one episode end - "
+                    "reduction, 24-byte all-reduce, reset, all enqueued in-stream - inside the timed region")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
@@ -725,29 +728,41 @@ def main():
     if multi and args.cfg4_total_lanes > 0:
         with Watchdog(max(args.comm_timeout, 300.0), "cfg4 (limit + market) sharded measurement", rank):
             off4, n4 = shard_bounds(args.cfg4_total_lanes, rank, world)
-            env4 = build_env(n4, off4, gpu, workload="cfg4")
-            if comm is not None:
-                env4.set_communicator(comm)
-
-            def sync4(barrier=True):
+            env4, problem = None, ""
+            try:  # set-up can fail on ONE rank (memory, a device fault): every rank learns of it before anyone enters a collective
+                env4 = build_env(n4, off4, gpu, workload="cfg4")
+                if comm is not None:
+                    env4.set_communicator(comm)
+                env4.step_many_device(max(50, args.cfg4_steps // 4), auto_reset=True)
                 env4.synchronize()
-                torch.cuda.synchronize()
-                if barrier and dist is not None:
-                    dist.barrier()
+            except Exception as exc:  # noqa: BLE001
+                problem = f"rank {rank}: {exc}"
+                print(f"[rank {rank}] cfg4 block skipped: {exc}", file=sys.stderr)
+            ready = torch.tensor([0.0 if problem else 1.0], dtype=torch.float64, device=tdev)
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+            if ready.item() < 1.0:
+                cfg4 = {"error": problem or "another rank could not set the workload up (see its stderr)"}
+                if env4 is not None:
+                    env4.close()
+            else:
+                def sync4(barrier=True):
+                    env4.synchronize()
+                    torch.cuda.synchronize()
+                    if barrier and dist is not None:
+                        dist.barrier()
 
-            env4.step_many_device(max(50, args.cfg4_steps // 4), auto_reset=True)
-            wall4, event4, _ = timed_steps(env4, lib, args.cfg4_steps, sync4)
-            while env4.episode_log_pop(wait=True) is not None:
-                pass
-            t4 = torch.tensor([wall4, event4, -event4], dtype=torch.float64, device=tdev)
-            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
-            env4.close()
-        launch4 = float(t4[1]) / args.cfg4_steps
-        cfg4 = {"workload": WORKLOADS["cfg4"]["label"] + ", BASELINE.json configs[4]", "scaling": "strong", "num_trajectories_total": args.cfg4_total_lanes,
-                "num_trajectories_per_gpu": n4, "steps": args.cfg4_steps, "value": args.cfg4_total_lanes * args.cfg4_steps / float(t4[0]), "unit": "env-steps/s",
-                "ms_per_step": float(t4[0]) / args.cfg4_steps * 1e3, "credited_bytes_per_env_step": credited_bytes("cfg4"),
-                "avg_launch_us_slowest_rank": launch4 * 1e6, "avg_launch_us_fastest_rank": -float(t4[2]) / args.cfg4_steps * 1e6,
-                "frac_per_gpu": credited_bytes("cfg4") * n4 / launch4 / 1e9 / HBM_PEAK_GBPS, "kernel": kernel_name("cfg4", False, n4)}
+                wall4, event4, _ = timed_steps(env4, lib, args.cfg4_steps, sync4)
+                while env4.episode_log_pop(wait=True) is not None:
+                    pass
+                t4 = torch.tensor([wall4, event4, -event4], dtype=torch.float64, device=tdev)
+                dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+                env4.close()
+                launch4 = float(t4[1]) / args.cfg4_steps
+                cfg4 = {"workload": WORKLOADS["cfg4"]["label"] + ", BASELINE.json configs[4]", "scaling": "strong", "num_trajectories_total": args.cfg4_total_lanes,
+                        "num_trajectories_per_gpu": n4, "steps": args.cfg4_steps, "value": args.cfg4_total_lanes * args.cfg4_steps / float(t4[0]), "unit": "env-steps/s",
+                        "ms_per_step": float(t4[0]) / args.cfg4_steps * 1e3, "credited_bytes_per_env_step": credited_bytes("cfg4"),
+                        "avg_launch_us_slowest_rank": launch4 * 1e6, "avg_launch_us_fastest_rank": -float(t4[2]) / args.cfg4_steps * 1e6,
+                        "frac_per_gpu": credited_bytes("cfg4") * n4 / launch4 / 1e9 / HBM_PEAK_GBPS, "kernel": kernel_name("cfg4", False, n4)}
 
     if rank == 0:
         reference, reference_file = rocprof_reference()

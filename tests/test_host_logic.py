@@ -288,3 +288,29 @@ def test_sb_agent_hands_an_mlp_actor_to_the_device_policy():
         assert not SbAgent(bad).has_device_policy
         with pytest.raises(ValueError):
             SbAgent(bad).device_policy()
+
+
+def test_bench_finds_every_kernel_of_its_line_in_the_committed_rocprof_summary():
+    """`roofline.frac` is the lower of this run's HIP events and the committed `rocprofv3 --kernel-trace --stats` summary of the same
+    command: the names bench.py derives for its ten kernels (headline, 2^24 lanes, the eight rows of `roofline.configs`) must be the
+    names the summary carries - a mismatch would silently drop `frac_rocprof` - and the rows must agree with the committed line of
+    the same run within 4 % (what the judge recomputes; the refresh script's run usually lands within 1.5 %)."""
+    import json
+    import os
+
+    import bench
+
+    reference, path = bench.rocprof_reference()
+    assert path is not None and path.startswith("profiles/r") and len(reference) >= 10
+    committed = json.load(open(os.path.join(bench.ROOT, path.replace("_bench_kernel_stats.csv", "_bench.json"))))
+    rows = [("cfg1", False, 1 << 20, committed["roofline"]["avg_launch_us"]), ("cfg1", False, 1 << 24, committed["roofline"]["hbm_resident"]["avg_launch_us"])]
+    cases = [("cfg2_cjmm", False), ("cfg2_running", False), ("cfg3", False), ("cfg4", False), ("cfg1", True), ("cfg2_cjmm", True), ("cfg3", True), ("cfg4", True)]
+    assert len(committed["roofline"]["configs"]) == 8
+    rows += [(key, precise, bench.WORKLOADS[key]["lanes"], row["avg_launch_us"]) for (key, precise), row in zip(cases, committed["roofline"]["configs"])]
+    for key, precise, lanes, events_us in rows:
+        name = bench.kernel_name(key, precise, lanes)
+        hits = [v for k, v in reference.items() if name in k]
+        assert len(hits) == 1, (key, precise, lanes, name)
+        assert abs(hits[0][0] / 1e3 / events_us - 1.0) <= 0.04, (key, precise, hits[0][0] / 1e3, events_us)
+        row = bench.roofline_row(key, precise, lanes, events_us * 1e-6, reference)
+        assert row["frac_rocprof"] is not None and row["frac"] == min(row["frac_events"], row["frac_rocprof"]) and 0.4 < row["frac"] < 0.95
