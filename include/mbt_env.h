@@ -335,7 +335,7 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
  *      RW:96-109, RW:128-138, TE:112-129) --------------------------------------------------------- */
 /* action: (N, A) float32 row-major, A = 2 (limit) or 4 (limit + market).  Outputs: obs (N, D), reward (N),
  * done (scalar; lane-invariant, TE:218-220).  Any output pointer may be NULL.
- * Batches of up to 32768 lanes (the reference's own regime is N ~ 1000) take ONE launch and no interrupt: the step kernel
+ * Batches of up to 65536 lanes (the reference's own regime is N ~ 1000) take ONE launch and no interrupt: the step kernel
  * reads the actions from, and mirrors observation rows and rewards into, pinned device-mapped host memory and raises a
  * completion flag there that this call spins on. */
 int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);

@@ -144,9 +144,11 @@ struct PinnedMemo {
 };
 
 // up to this many lanes the host API stages through device-mapped pinned memory (mbt_env_step_host); measured per step,
-// DMA path vs mapped staging: 52 vs 33 us at 8192 lanes, 85 vs 70 at 32768, 138 vs 131 at 65536, 149 vs 228 at 131072.
+// DMA path vs mapped staging: 52 vs 33 us at 8192 lanes, 85 vs 70 at 32768, 138 vs 131 at 65536, 149 vs 228 at 131072 (round 3: a second
+// launch exported the outputs).  Round 4, the one-launch mirror: 74.5 (DMA) vs 69.5 us at 65536 lanes with a pinned action, 84.2 vs 69.9
+// with a pageable one, 108.6 vs 95.5 through the SB3 adapter (profiles/r04_experiments.txt 7): the threshold moved to 65536.
 // MBT_HOST_FAST_PATH_LANES overrides it (measurement knob).
-constexpr uint32_t kHostFastPathLanes = 32768;
+constexpr uint32_t kHostFastPathLanes = 65536;
 
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 

@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
 // and a LOSS where the working set does fit (2^20..2^22 lanes), hence two instantiations rather than one policy.  (A
 // run-time branch around the two load sequences does not survive the optimiser: it merges the branches' loads and drops
 // the hint.)
-// MIRROR: small batches over the host API (mbt_env_step_host, N <= 32768): the kernel also mirrors its outputs into
+// MIRROR: small batches over the host API (mbt_env_step_host, N <= 65536): the kernel also mirrors its outputs into
 // device-mapped host memory and raises a completion flag there (signal_host) - ONE launch per env.step(), no interrupt.
 template <class V, bool STREAM = false, bool MIRROR = false>
 __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {

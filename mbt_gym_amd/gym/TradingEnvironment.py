@@ -537,10 +537,10 @@ class TradingEnvironment(_EnvBase):
         return pools["action_array"]
 
     def _stage_action(self, action, pools):
-        if type(action) is np.ndarray and action.dtype == np.float32 and action.size <= (1 << 15) and action.flags.c_contiguous:
+        if type(action) is np.ndarray and action.dtype == np.float32 and action.size <= (1 << 18) and action.flags.c_contiguous:
             if action.shape != pools["action_shape"]:
                 raise ValueError(f"expected shape {pools['action_shape']}, got {action.shape}")
-            return action  # small batches: the library copies the caller's array into its own staging (mapped memory) as it is
+            return action  # batches the library stages itself (up to 65536 lanes: one copy into its mapped stage): the caller's array as it is
         staged = self.action_buffer
         if action is staged:
             return staged

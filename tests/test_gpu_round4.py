@@ -45,7 +45,7 @@ def _action(rng, cfg, n):
 
 
 @pytest.mark.parametrize("kw", VARIANTS)
-@pytest.mark.parametrize("n", [1000, 37])
+@pytest.mark.parametrize("n", [1000, 37, 40000])
 def test_small_batch_step_mirrors_exactly_what_the_device_holds(n, kw):
     """env.step() of a small batch is ONE launch: the kernel itself writes observation rows and rewards into host memory and
     raises a flag.  What comes back is what the device buffers hold (the DMA path's answer), in every tier and layout - and it is
