@@ -404,6 +404,11 @@ typedef struct mbt_policy {
   int32_t table_q_offset;
   int32_t reserved1;
 } mbt_policy;
+/* mbt_env_rollout_host keeps its HBM staging (up to 8 GiB per recorded array: a 2^20-lane, 200-step recording is 5.9 GB, and
+ * allocating and freeing it every episode cost as much as copying it out) and mbt_env_step_host its pinned bounce buffer until
+ * mbt_env_destroy.  A long-lived environment that recorded once and will not again gives them back with this call (they are
+ * re-created on demand). */
+int mbt_env_release_staging(mbt_env* env);
 /* Device variant: trajectory pointers are device memory sized for the PADDED lane count mbt_env_padded_lanes(). */
 int mbt_env_rollout_device(mbt_env* env, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,
                            float* rew_traj, uint32_t* steps_done, int32_t* done);

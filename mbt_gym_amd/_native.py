@@ -210,6 +210,7 @@ SIGNATURES = {
     "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "mbt_env_rollout_host": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, _F, _F, _F, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "mbt_env_release_staging": (C.c_int, [_ENV]),
     "mbt_env_policy_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy)]),
     "mbt_env_padded_lanes": (C.c_uint64, [_ENV]),
     "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),

@@ -2118,6 +2118,21 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
   return rc;
 }
 
+int mbt_env_release_staging(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int j = 0; j < 3; ++j) {
+    if (e->traj_stage[j] != nullptr) (void)hipFree(e->traj_stage[j]);
+    e->traj_stage[j] = nullptr;
+    e->traj_stage_floats[j] = 0;
+  }
+  if (e->h_bounce != nullptr) (void)hipHostFree(e->h_bounce);
+  e->h_bounce = nullptr;
+  e->bounce_floats = 0;
+  return MBT_OK;
+}
+
 int mbt_env_set_user_noise_host(mbt_env* e, const float* z_user) {
   if (e == nullptr || z_user == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");

@@ -354,6 +354,8 @@ class TradingEnvironment(_EnvBase):
         self._step_context = None
         for pool in self.__dict__.pop("_trajectory_pools", None) or ():
             pool.release()
+        if getattr(self, "_handle", None) is not None:  # ... and what the LIBRARY kept for recorded rollouts: up to 8 GiB of HBM staging per array
+            _native.check(_native.load_library().mbt_env_release_staging(self._handle))
 
     def __del__(self):
         try:

@@ -241,3 +241,27 @@ def test_one_process_two_devices_is_bit_equal_to_one_device():
         np.testing.assert_array_equal(r_m, r_s)
     np.testing.assert_array_equal(multi.state, single.state)
     single.close(), multi.close()
+
+
+def test_released_buffers_come_back_on_demand():
+    """pinned output pools and the library's HBM staging of recorded rollouts are returned by close() - and by
+    release_host_buffers() on a live environment, after which everything is re-created on demand and nothing changes in what
+    the environment computes."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+
+    cfg = _cfg(3000, n_steps=30)
+    a, b = make_env(cfg), make_env(cfg)
+    agent_a, agent_b = FixedActionAgent(np.array([0.5, 0.6], np.float32), a), FixedActionAgent(np.array([0.5, 0.6], np.float32), b)
+    a.reset(), b.reset()
+    first_a, first_b = a.rollout(agent_a), b.rollout(agent_b)
+    kept = first_a[0]  # an array the caller still holds must survive the release with its values
+    a.release_host_buffers()
+    assert "_pools" not in a.__dict__ and "_trajectory_pools" not in a.__dict__
+    np.testing.assert_array_equal(kept, first_b[0])
+    a.reset(), b.reset()
+    for x, y in zip(a.rollout(agent_a)[:3], b.rollout(agent_b)[:3]):
+        np.testing.assert_array_equal(x, y)
+    obs_a = a.reset()
+    np.testing.assert_array_equal(obs_a, b.reset())
+    a.close(), b.close()
+    assert "_pools" not in a.__dict__
