@@ -292,7 +292,8 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
  *      _get_fill_probabilities(depths) and hands the (N, 2) float64 result to mbt_env_set_host_fill_probabilities: a fill is
  *      u < p with u the lane's uniform (Philox, or injected), compared in double (FILL:33-34).
  *   2. MBT_ARR_HOST:  the caller's get_arrivals() (which draws from the caller's own generator, ARR:55) -> (N, 2) 0.0f / 1.0f
- *      -> mbt_env_set_host_arrivals.  Stateless models only (no state columns).
+ *      -> mbt_env_set_host_arrivals.  A model that owns state columns keeps them on the host and files them after its update():
+ *      mbt_env_set_host_state_columns.
  *   3. mbt_env_step_* as usual (refused with MBT_ERR_STATE if an input of this step is missing).
  *   4. MBT_REW_HOST:  the step reports rewards of 0; the caller reads the float64 states (mbt_env_get_state_f64_host - before
  *      and after the step; with precise_state they ARE the reference's float64 states), evaluates calculate() and files the
@@ -304,6 +305,13 @@ int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_h
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
 int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
 int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
+/* A host-callback arrival model that OWNS state (SP:8-53: one or two columns, declared through mbt_user_code.state_columns /
+ * state_initial / state_owner = 1 with NULL update expressions, mbt_env_create_jit): the kernel carries its columns through
+ * the step unchanged; after the caller's update(arrivals, fills, action, state) ran, the new (N, d) float64 values are filed
+ * with this call - their float32 rounding into the state row (TE:206-211: the reference copies process.current_state into the
+ * state matrix), the int32 remainders too under precise_state, the normalised observation row if there is one.  Follow it
+ * with mbt_env_get_obs_host for the observation env.step() returns. */
+int mbt_env_set_host_state_columns(mbt_env* env, const double* columns_host);
 
 /* Every launch and copy of an environment is ordered on ONE stream: its own (created non-blocking, so it does not
  * synchronise with the null stream) until this call hands it another hipStream_t, e.g. torch's current stream.

@@ -456,6 +456,7 @@ struct mbt_env {
   float* host_arrivals = nullptr;    // (n_pad, 2) device
   double* host_scratch = nullptr;    // (n_pad, 2) device: depths out / rewards in
   bool host_fill_ready = false, host_arrivals_ready = false, host_reward_pending = false;
+  int host_state_first = 0, host_state_count = 0;  // the state columns a host-callback arrival model owns (the LAST user columns: registry order, TE:303-318)
 };
 
 namespace {
@@ -1276,8 +1277,9 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   src += "__device__ double mbt_user_state_next(int which, double S, double t, double dt_mid, double dt_arr, double z, double arr_bid, double arr_ask, double fills_bid, "
          "double fills_ask, const UserProcessState& u_, const double* p) {\n  (void)which; (void)S; (void)t; (void)dt_mid; (void)dt_arr; (void)z; (void)arr_bid; (void)arr_ask; "
          "(void)fills_bid; (void)fills_ask; (void)p;\n" + process_symbols + state_decl +
-         "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? u.state_update[0] : "0.0") + "); }\n"
-         "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? u.state_update[1] : "0.0") + "); }\n}\n}  // namespace mbt\n";
+         // (a column the HOST advances - a host-callback arrival model's own state - passes through the kernel unchanged: "x0" / "x1")
+         "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? (u.state_update[0] != nullptr && u.state_update[0][0] != 0 ? u.state_update[0] : "x0") : "0.0") + "); }\n"
+         "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? (u.state_update[1] != nullptr && u.state_update[1][0] != 0 ? u.state_update[1] : "x1") : "0.0") + "); }\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
          ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
@@ -1440,11 +1442,13 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (any_host && cfg->fill_kind == MBT_FILL_EXOGENOUS_MM && host_fill) return fail(MBT_ERR_INVALID, "a fill model is either built in or a host callback");
     if (code->state_columns < 0 || code->state_columns > 2) return fail(MBT_ERR_INVALID, "user processes own at most two state columns (got %d)", code->state_columns);
     if (code->state_columns > 0) {
-      if (!(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_ARR_USER)");
+      if (!(user_mid || user_arrival || host_arrival)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_ARR_USER / MBT_ARR_HOST)");
       if (cfg->arrival_kind == MBT_ARR_HAWKES || exogenous_fill(*cfg))
         return fail(MBT_ERR_INVALID, "user state columns take the place of the Hawkes intensities / exogenous depths: Poisson-type or user arrivals, exponential or user fills");
-      for (int j = 0; j < code->state_columns; ++j)
-        if (code->state_update[j] == nullptr || code->state_update[j][0] == 0) return fail(MBT_ERR_INVALID, "user state column %d has no update expression", j);
+      for (int j = 0; j < code->state_columns; ++j) {
+        const bool host_owned = host_arrival && code->state_owner[j] == 1;  // advanced by the caller's update() on the host (mbt_env_set_host_state_columns)
+        if (!host_owned && (code->state_update[j] == nullptr || code->state_update[j][0] == 0)) return fail(MBT_ERR_INVALID, "user state column %d has no update expression", j);
+      }
     }
     if (code->extra_normals && !(user_mid || user_arrival)) return fail(MBT_ERR_INVALID, "extra normals are drawn for user-defined midprice / arrival models");
   }
@@ -1508,6 +1512,12 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->speed = speed;
   e->user_state_columns = needs_jit ? code->state_columns : 0;
   e->user_draws = needs_jit && code->extra_normals != 0;
+  if (needs_jit && host_arrival)
+    for (int j = 0; j < code->state_columns; ++j)
+      if (code->state_owner[j] == 1) {
+        if (e->host_state_count == 0) e->host_state_first = 4 + j;
+        e->host_state_count += 1;
+      }
   for (int j = 0; j < 2; ++j) e->user_state_initial[j] = needs_jit ? code->state_initial[j] : 0.0;
   e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0) + e->user_state_columns;
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
@@ -2009,6 +2019,20 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
   HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->host_arrivals_ready = true;
+  return MBT_OK;
+}
+
+int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
+  if (e == nullptr || columns_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!(e->host_mask & mbt::kHostArrival) || e->host_state_count == 0)
+    return fail(MBT_ERR_STATE, "this environment has no host-callback arrival model that owns state columns");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int d = e->host_state_count;
+  HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(mbt::host_columns_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->host_scratch, e->n, d, e->dim, e->host_state_first,
+                     e->state[e->cur], e->resid, e->res, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
 }
 

@@ -282,13 +282,19 @@ class TradingEnvironment(_EnvBase):
         arrival_code = arrival.device_code() if getattr(arrival, "device_kind", None) == _native.ARR_USER else None
         mid = self.model_dynamics.midprice_model
         mid_code = mid.device_code() if getattr(mid, "device_kind", None) == _native.MID_USER else None
-        if fill_code is None and reward_code is None and arrival_code is None and mid_code is None:
+        if fill_code is None and reward_code is None and arrival_code is None and mid_code is None and not (
+                self._host_plugins.get("arrival") is not None and self._host_plugins["arrival"].state_dim > 0):
             return None
         # State columns owned by user processes, in the registry order of TE:303-318 (the midprice's second factor, then the
         # arrival model's columns).  Each process writes its expressions in terms of ITS OWN columns x0 (, x1); the kernel
         # numbers the columns globally, so the arrival model's are shifted behind a midprice factor.
         mid_state = mid.device_state() if mid_code is not None and hasattr(mid, "device_state") else None
         arr_state = arrival.device_state() if arrival_code is not None and hasattr(arrival, "device_state") else None
+        host_arrival = self._host_plugins.get("arrival")
+        if host_arrival is not None and host_arrival.state_dim > 0:
+            # a NumPy-only arrival model that owns columns: no update expressions - the kernel carries the columns through, the
+            # model's own update() advances them on the host and the result is filed after the step (mbt_env_set_host_state_columns)
+            arr_state = ([""] * host_arrival.state_dim, {}, [float(v) for v in np.asarray(host_arrival.initial_state, dtype=np.float64)[0]], False)
         state = None
         if mid_state is not None or arr_state is not None:
             updates, params, initial, extra, owners = [], {}, [], False, []
@@ -304,7 +310,7 @@ class TradingEnvironment(_EnvBase):
                 if shift + len(arr_state[0]) > 2:
                     raise UnsupportedOnDevice("user processes own at most two state columns between them (a second midprice factor and a one-column arrival model, or a two-column arrival model)")
                 rename = (lambda e: re.sub(r"\bx0\b", "x1", e)) if shift else (lambda e: e)
-                if shift and any(re.search(r"\bx1\b", e) for e in list(arr_state[0]) + [arrival_code[0]]):
+                if shift and any(re.search(r"\bx1\b", e) for e in list(arr_state[0]) + ([arrival_code[0]] if arrival_code is not None else [])):
                     raise UnsupportedOnDevice("with a two-factor midprice the arrival model owns ONE column (x0)")
                 updates += [rename(e) for e in arr_state[0]]
                 clash = {k for k in arr_state[1] if k in params and params[k] != arr_state[1][k]}
@@ -314,7 +320,8 @@ class TradingEnvironment(_EnvBase):
                 initial += arr_state[2]
                 extra |= arr_state[3]
                 owners += [1] * len(arr_state[0])
-                arrival_code = (rename(arrival_code[0]), arrival_code[1])
+                if arrival_code is not None:
+                    arrival_code = (rename(arrival_code[0]), arrival_code[1])
             if mid_code is not None and mid_state is None and arr_state is not None:
                 pass  # (a one-column user midprice beside a stateful arrival model reads no state)
             state = (updates, params, initial, extra, owners)
@@ -435,11 +442,13 @@ class TradingEnvironment(_EnvBase):
             role = host_callback_role(part) if part is not None else None
             if role is None:
                 continue
-            if role in ("fill", "arrival") and part.state_dim != 0:
+            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2):
                 raise UnsupportedOnDevice(
                     f"{type(part).__name__} only has host (NumPy) code AND owns {part.state_dim} state column(s): the host-callback route serves "
-                    "stateless models (a stateful user process states its update as a device expression: DeviceExpressionArrivalModel)")
+                    "stateless fill models and arrival models with at most two columns of their own (otherwise: a device expression, DeviceExpressionArrivalModel)")
             found[role] = part
+            if role in ("fill", "arrival"):
+                part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
         if found:
             warnings.warn(
                 "host-callback plugins: " + ", ".join(f"{type(p).__name__} ({r})" for r, p in found.items()) + " only have NumPy code, which "
@@ -495,6 +504,16 @@ class TradingEnvironment(_EnvBase):
         for role in ("arrival", "fill"):
             if role in plugins:
                 plugins[role].update(self.last_arrivals, self.last_fills.astype(np.float64), raw_action, following)
+        if arrival is not None and arrival.state_dim > 0:
+            # TE:209-211: the model's columns of the state matrix <- process.current_state, which ITS update() just advanced (float64, on
+            # the host); the device files them - float32 rounding into the row, the remainder too under precise_state - and the
+            # observation this step returns shows them, like the reference's
+            lo, hi = self.stochastic_process_indices["arrival_model"]
+            columns = np.ascontiguousarray(np.broadcast_to(np.asarray(arrival.current_state, dtype=np.float64), (n, hi - lo)))
+            _native.check(lib.mbt_env_set_host_state_columns(handle, dptr(columns)))
+            _native.check(lib.mbt_env_get_obs_host(handle, _native.fptr(obs)))
+            following = following.copy()
+            following[:, lo:hi] = columns if self.precise_state else columns.astype(np.float32)
         if reward is not None:
             current = self._host_state64
             if current is None:

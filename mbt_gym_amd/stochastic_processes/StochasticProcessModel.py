@@ -52,6 +52,7 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
         self._env = None  # set by TradingEnvironment: (env, first column, last column)
         self._columns = None
         self._host_state = None  # stand-alone use: the (N, d) float64 state between update() calls
+        self._host_callback = False  # a NumPy-only subclass inside an environment: ITS update() advances its state, on the host
 
     # ---- descriptor side --------------------------------------------------------------------------------
     def device_params(self) -> dict:
@@ -73,7 +74,9 @@ class StochasticProcessModel(metaclass=abc.ABCMeta):
 
     @property
     def _stand_alone(self) -> bool:
-        return self._env is None  # not handed to a TradingEnvironment: driven by the caller
+        # not handed to a TradingEnvironment: driven by the caller - or handed to one as a host-callback plugin (a NumPy-only
+        # subclass): its own methods keep its state on the host, the environment copies it into the state matrix (TE:206-211)
+        return self._env is None or self._host_callback
 
     @property
     def current_state(self) -> np.ndarray:

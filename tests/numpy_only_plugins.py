@@ -4,7 +4,7 @@ RW:10-13), with no device expression and no knowledge of this package.
 
 ONE source for both sides of the parity tests: `define(...)` is handed the base classes of whichever package the classes are
 to live in - the reference's (`tools/refgen/make_golden.py`, build container only: the fixtures `user_fill_and_reward`,
-`user_fill_hawkes_market_normalised`, `user_seasonal_arrivals` are the REAL reference running these classes) or
+`user_fill_hawkes_market_normalised`, `user_seasonal_arrivals`, `user_cross_hawkes` are the REAL reference running these classes) or
 mbt_gym_amd's (tests/test_gpu_host_callbacks.py: the same classes, unmodified, in `env.step()` through the host-callback
 route of include/mbt_env.h).  Nothing here imports either package."""
 import types
@@ -13,7 +13,7 @@ import numpy as np
 
 
 def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names):
-    """The three classes, bound to the given plugin base classes and state-column indices."""
+    """The classes, bound to the given plugin base classes and state-column indices."""
     CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX = (
         index_names.CASH_INDEX, index_names.INVENTORY_INDEX, index_names.TIME_INDEX, index_names.ASSET_PRICE_INDEX)
 
@@ -70,8 +70,25 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names):
             unif = self.rng.uniform(size=(self.num_trajectories, 2))
             return unif < self.base * (1.0 + self.amplitude * np.cos(2 * np.pi * self.time / self.period)) * self.step_size
 
+    class UserCrossExcitingHawkes(ArrivalModel):
+        """An arrival model WITH STATE (SP:8-53: a subclass carries its own (N, d) current_state): two intensities like the
+        reference's Hawkes model (ARR:86-126) in which an arrival on one side also excites the other."""
+
+        def __init__(self, baseline, speed, jump, cross, step_size, terminal_time, num_trajectories, seed=None):
+            self.baseline, self.speed, self.jump, self.cross = np.array(baseline, dtype=float).reshape(1, 2), speed, jump, cross
+            super().__init__(min_value=np.zeros((1, 2)), max_value=self.baseline * 10, step_size=step_size, terminal_time=terminal_time,
+                             initial_state=self.baseline, num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            lam = self.current_state
+            self.current_state = lam + self.speed * (self.baseline - lam) * self.step_size + self.jump * arrivals + self.cross * arrivals[:, ::-1]
+
+        def get_arrivals(self):
+            unif = self.rng.uniform(size=(self.num_trajectories, 2))
+            return unif < self.current_state * self.step_size
+
     return types.SimpleNamespace(UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
-                                 UserSeasonalArrivals=UserSeasonalArrivals)
+                                 UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes)
 
 
 class Replay:

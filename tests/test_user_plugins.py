@@ -46,7 +46,7 @@ def test_numpy_only_plugin_classes_take_the_host_callback_route(no_device):
     """A subclass of the plugin base classes that only has NumPy code - what a user of the reference writes (FILL:22-34, ARR:27-29,
     RW:10-13) - is accepted: its method keeps running on the host between launches and the kernel takes its results (MBT_FILL_HOST /
     MBT_ARR_HOST / MBT_REW_HOST).  The run-time instantiation compiles without a GPU.  What has neither a device form nor a
-    host-callable method of the contract is still refused, and so is a NumPy-only process that owns state columns."""
+    host-callable method of the contract is still refused, and so is a NumPy-only arrival model with more than two columns of its own."""
     import warnings
 
     import mbt_gym_amd.gym.index_names as index_names
@@ -83,15 +83,28 @@ def test_numpy_only_plugin_classes_take_the_host_callback_route(no_device):
     assert not only_fill.precise_state and only_fill._device_config(n, 1.0).reward_kind == _native.REW_PNL
     only_fill.check_device_expressions()
 
-    class StatefulNumpyArrivals(ArrivalModel):  # NumPy-only AND two state columns: refused, with the device route named
-        def __init__(self):
-            super().__init__(np.zeros((1, 2)), np.ones((1, 2)), 1 / ns, 1.0, np.full((1, 2), 0.5), n, None)
+    class StatefulNumpyArrivals(ArrivalModel):  # NumPy-only AND two state columns of its own: accepted - ITS update() advances them on the host
+        def __init__(self, columns=2):
+            super().__init__(np.zeros((1, columns)), np.ones((1, columns)), 1 / ns, 1.0, np.full((1, columns), 0.5), n, None)
 
         def get_arrivals(self):
             return np.zeros((n, 2), dtype=bool)
 
-    with pytest.raises(UnsupportedOnDevice, match="stateless"):
-        build(arrival=StatefulNumpyArrivals())
+        def update(self, arrivals, fills, action, state=None):
+            self.current_state = self.current_state * 0.5
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", HostCallbackWarning)
+        stateful = build(arrival=StatefulNumpyArrivals(), reward=PnL())
+    code = stateful._user_code()
+    assert code.state_columns == 2 and list(code.state_owner) == [1, 1] and list(code.state_initial) == [0.5, 0.5] and not code.state_update[0]
+    assert stateful.observation_dim == 6 and stateful._device_config(n, 1.0).arrival_kind == _native.ARR_HOST
+    stateful.check_device_expressions()  # the kernel carries the two columns through; mbt_env_set_host_state_columns files the host's values
+    model = stateful.model_dynamics.arrival_model
+    model.update(None, None, None)
+    np.testing.assert_array_equal(model.current_state, np.full((n, 2), 0.25))  # its own state, on the host, although it is attached
+    with pytest.raises(UnsupportedOnDevice, match="at most two columns"):
+        build(arrival=StatefulNumpyArrivals(columns=3), reward=PnL())
 
     class NothingToRun(FillProbabilityModel):  # neither a device form nor _get_fill_probabilities / get_fills
         def __init__(self):

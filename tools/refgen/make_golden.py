@@ -717,19 +717,7 @@ def user_plugin_cases(only=None):
 
     # Z1. a user-defined ArrivalModel WITH STATE (SP:8-53: a subclass carries its own (N, d) current_state): two intensities
     #     like the reference's Hawkes model (ARR:86-126) in which an arrival on one side also excites the other
-    class UserCrossExcitingHawkes(ArrivalModel):
-        def __init__(self, baseline, speed, jump, cross, step_size, terminal_time, num_trajectories, seed=None):
-            self.baseline, self.speed, self.jump, self.cross = np.array(baseline, dtype=float).reshape(1, 2), speed, jump, cross
-            super().__init__(min_value=np.zeros((1, 2)), max_value=self.baseline * 10, step_size=step_size, terminal_time=terminal_time,
-                             initial_state=self.baseline, num_trajectories=num_trajectories, seed=seed)
-
-        def update(self, arrivals, fills, actions, state=None):
-            lam = self.current_state
-            self.current_state = lam + self.speed * (self.baseline - lam) * self.step_size + self.jump * arrivals + self.cross * arrivals[:, ::-1]
-
-        def get_arrivals(self):
-            unif = self.rng.uniform(size=(self.num_trajectories, 2))
-            return unif < self.current_state * self.step_size
+    UserCrossExcitingHawkes = user.UserCrossExcitingHawkes  # (tests/numpy_only_plugins.py: the same source the host-callback tests bind to mbt_gym_amd)
 
     n, ns = 32, 90
     run_case(
