@@ -56,7 +56,9 @@ enum {
    * e.g. CEV-free local-volatility mixtures, drifting OU, GBM with trade impact.  The built-in kinds are the rows
    * (1,0,theta=0) BM, (1,0,theta) OU [drift forced to 0], (0,1) GBM, +jump_size for the jump variants, (0,0) constant. */
   MBT_MID_LINEAR_SDE = 6,
-  MBT_MID_USER = 7 /* a user-defined one-column MidpriceModel subclass (SP:8-53) with an arbitrary increment: mbt_env_create_jit only */
+  MBT_MID_USER = 7 /* a user-defined one-column MidpriceModel subclass (SP:8-53) with an arbitrary increment: mbt_env_create_jit only */,
+  MBT_MID_HOST = 8 /* a MidpriceModel subclass that only has HOST code: update() runs in the caller AFTER the launch, see "host-callback
+                    * plugins" (needs MBT_REW_HOST: the reward of a step holds the midprice the caller is about to compute) */
 };
 enum {
   MBT_ARR_POISSON = 0 /* ARR:32-56 */, MBT_ARR_HAWKES = 1 /* ARR:86-126 */, MBT_ARR_POISSON_NONLINEAR = 2 /* ARR:59-83 */,
@@ -300,17 +302,25 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
  *      (N) float64 result with mbt_env_set_host_rewards: multiplied by cfg.reward_scale (TE:128-129), rounded once to float32,
  *      written to the reward buffer, added to the episode-return sums; reward_out (N float32, may be NULL) receives what
  *      env.step() returns.  The next step is refused until this happened.
+ *   5. MBT_MID_HOST:  the kernel holds the midprice column(s) still; after the launch the caller's update(arrivals, fills, action,
+ *      state) advances them on the host (MID: the reference calls it first of the processes, TE:206-211) and files them with
+ *      mbt_env_set_host_state_columns - BEFORE step 4, whose `next_state` shows them: the reward function (built-in classes
+ *      included: mbt_reward_calculate_host evaluates them on the float64 matrices) is then a host callback by construction, which
+ *      is why MBT_MID_HOST is only accepted together with MBT_REW_HOST.  Order-book dynamics.
  * Fused rollouts are not available for such an environment (MBT_ERR_INVALID): the host is consulted every step. */
 int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_host);
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
 int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
 int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
-/* A host-callback arrival model that OWNS state (SP:8-53: one or two columns, declared through mbt_user_code.state_columns /
- * state_initial / state_owner = 1 with NULL update expressions, mbt_env_create_jit): the kernel carries its columns through
- * the step unchanged; after the caller's update(arrivals, fills, action, state) ran, the new (N, d) float64 values are filed
+/* The state columns host-callback processes OWN (SP:8-53), ONE contiguous block in registry order (TE:303-318): with
+ * MBT_MID_HOST the midprice column 3 and the midprice model's further columns (declared through mbt_user_code.state_columns /
+ * state_initial / state_owner = 0 with NULL update expressions), then the columns of a host-callback arrival model that owns
+ * state (state_owner = 1, NULL update expressions; mbt_env_create_jit) - d columns in all.  The kernel carries them through the
+ * step unchanged; after the caller's update(arrivals, fills, action, state) calls ran, the new (N, d) float64 values are filed
  * with this call - their float32 rounding into the state row (TE:206-211: the reference copies process.current_state into the
- * state matrix), the int32 remainders too under precise_state, the normalised observation row if there is one.  Follow it
- * with mbt_env_get_obs_host for the observation env.step() returns. */
+ * state matrix), the int32 remainders too under precise_state, the normalised observation row if there is one.  Also valid
+ * right after a reset (a process whose reset() sets per-lane initial values).  Follow it with mbt_env_get_obs_host for the
+ * observation env.step() / env.reset() returns. */
 int mbt_env_set_host_state_columns(mbt_env* env, const double* columns_host);
 
 /* Every launch and copy of an environment is ordered on ONE stream: its own (created non-blocking, so it does not

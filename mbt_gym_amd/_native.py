@@ -13,7 +13,7 @@ import numpy as np
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
 ABI_VERSION = 6
 
-MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER = 0, 1, 2, 3, 4, 5, 6, 7
+MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER, MID_HOST = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER, ARR_HOST = 0, 1, 2, 3, 4, 5
 FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER, FILL_HOST = 0, 1, 2, 3, 4
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3

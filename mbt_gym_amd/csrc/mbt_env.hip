@@ -456,7 +456,8 @@ struct mbt_env {
   float* host_arrivals = nullptr;    // (n_pad, 2) device
   double* host_scratch = nullptr;    // (n_pad, 2) device: depths out / rewards in
   bool host_fill_ready = false, host_arrivals_ready = false, host_reward_pending = false;
-  int host_state_first = 0, host_state_count = 0;  // the state columns a host-callback arrival model owns (the LAST user columns: registry order, TE:303-318)
+  int host_state_first = 0, host_state_count = 0;  // the state columns host-callback processes own: one block in registry order (TE:303-318)
+  bool host_mid = false;             // MBT_MID_HOST: cfg.midprice_kind reads MBT_MID_CONSTANT, the caller moves the midprice between launches
 };
 
 namespace {
@@ -1412,6 +1413,20 @@ int mbt_device_name(int device, char* buf, size_t buf_len) {
   return MBT_OK;
 }
 
+// MBT_MID_HOST as the kernels see it: a midprice that stands still during the launch (the caller's update() moves it between
+// launches, mbt_env_set_host_state_columns).  Returns whether the configuration names one; `reason` is set when it cannot run.
+static bool lower_host_midprice(const mbt_config& in, mbt_config& out, const char** reason) {
+  out = in;
+  *reason = nullptr;
+  if (in.midprice_kind != MBT_MID_HOST) return false;
+  if (in.reward_kind != MBT_REW_HOST)
+    *reason = "MBT_MID_HOST: the midprice moves after the launch, so the step's reward is formed by the caller - reward_kind must be MBT_REW_HOST";
+  else if (in.dynamics_kind == MBT_DYN_SPEED)
+    *reason = "host-callback midprice models run on the order-book kernels";
+  out.midprice_kind = MBT_MID_CONSTANT;
+  return true;
+}
+
 static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
   if (cfg == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   *out = nullptr;
@@ -1419,6 +1434,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   // and nothing of *code, may be read before the versions are known to agree
   if (cfg->abi_version != MBT_ABI_VERSION)
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
+  mbt_config lowered;
+  const char* refused = nullptr;
+  const bool host_mid = lower_host_midprice(*cfg, lowered, &refused);
+  if (refused != nullptr) return fail(MBT_ERR_INVALID, "%s", refused);
+  cfg = &lowered;
   const bool user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
@@ -1442,11 +1462,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (any_host && cfg->fill_kind == MBT_FILL_EXOGENOUS_MM && host_fill) return fail(MBT_ERR_INVALID, "a fill model is either built in or a host callback");
     if (code->state_columns < 0 || code->state_columns > 2) return fail(MBT_ERR_INVALID, "user processes own at most two state columns (got %d)", code->state_columns);
     if (code->state_columns > 0) {
-      if (!(user_mid || user_arrival || host_arrival)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_ARR_USER / MBT_ARR_HOST)");
+      if (!(user_mid || user_arrival || host_arrival || host_mid)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_MID_HOST / MBT_ARR_USER / MBT_ARR_HOST)");
       if (cfg->arrival_kind == MBT_ARR_HAWKES || exogenous_fill(*cfg))
         return fail(MBT_ERR_INVALID, "user state columns take the place of the Hawkes intensities / exogenous depths: Poisson-type or user arrivals, exponential or user fills");
       for (int j = 0; j < code->state_columns; ++j) {
-        const bool host_owned = host_arrival && code->state_owner[j] == 1;  // advanced by the caller's update() on the host (mbt_env_set_host_state_columns)
+        const bool host_owned = (host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0);  // advanced by the caller's update() on the host (mbt_env_set_host_state_columns)
         if (!host_owned && (code->state_update[j] == nullptr || code->state_update[j][0] == 0)) return fail(MBT_ERR_INVALID, "user state column %d has no update expression", j);
       }
     }
@@ -1512,12 +1532,16 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->speed = speed;
   e->user_state_columns = needs_jit ? code->state_columns : 0;
   e->user_draws = needs_jit && code->extra_normals != 0;
-  if (needs_jit && host_arrival)
+  // the columns host-callback processes own: one contiguous block in registry order (midprice column 3, the midprice model's
+  // further columns, then a host arrival model's)
+  if (host_mid) e->host_state_first = 3, e->host_state_count = 1;
+  if (needs_jit)
     for (int j = 0; j < code->state_columns; ++j)
-      if (code->state_owner[j] == 1) {
+      if ((host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0)) {
         if (e->host_state_count == 0) e->host_state_first = 4 + j;
         e->host_state_count += 1;
       }
+  e->host_mid = host_mid;
   for (int j = 0; j < 2; ++j) e->user_state_initial[j] = needs_jit ? code->state_initial[j] : 0.0;
   e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0) + e->user_state_columns;
   e->act_dim = speed ? 1 : (cfg->dynamics_kind == MBT_DYN_LIMIT_AND_MARKET ? 4 : 2);
@@ -1609,7 +1633,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (e->host_mask != 0) {
     if (host_fill) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));
     if (host_arrival) ENV_TRY(dev_alloc(&e->host_arrivals, np * 2, e->stream));
-    ENV_TRY(dev_alloc(&e->host_scratch, np * 2, e->stream));
+    ENV_TRY(dev_alloc(&e->host_scratch, np * 4, e->stream));  // (N) rewards or (N, d <= 3) state columns, float64
   }
   if (hipHostMalloc(reinterpret_cast<void**>(&e->log_host), 3 * mbt_env::kLogSlots * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     mbt_env_destroy(e);
@@ -1663,6 +1687,12 @@ const char* mbt_jit_log(void) { return g_jit_log.c_str(); }
 
 int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   if (cfg == nullptr || code == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (cfg->abi_version != MBT_ABI_VERSION) return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
+  mbt_config lowered;
+  const char* refused = nullptr;
+  (void)lower_host_midprice(*cfg, lowered, &refused);
+  if (refused != nullptr) return fail(MBT_ERR_INVALID, "%s", refused);
+  cfg = &lowered;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER, user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
   const bool any_host = cfg->fill_kind == MBT_FILL_HOST || cfg->arrival_kind == MBT_ARR_HOST || cfg->reward_kind == MBT_REW_HOST;
@@ -2024,8 +2054,8 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
 
 int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   if (e == nullptr || columns_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
-  if (!(e->host_mask & mbt::kHostArrival) || e->host_state_count == 0)
-    return fail(MBT_ERR_STATE, "this environment has no host-callback arrival model that owns state columns");
+  if (e->host_state_count == 0)
+    return fail(MBT_ERR_STATE, "this environment has no host-callback process that owns state columns (MBT_MID_HOST, or MBT_ARR_HOST with state)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int d = e->host_state_count;
   HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));

@@ -1457,7 +1457,7 @@ __global__ void host_depths_kernel(const float* action, int act_dim, uint32_t n,
   }
 }
 
-// The state columns a host-callback arrival model OWNS (SP:8-53), after its update() ran on the host: float64 (n, d) values into
+// The state columns host-callback processes OWN (SP:8-53; MBT_MID_HOST: from the midprice column on), after their update() ran on the host: float64 (n, d) values into
 // the state row (their float32 rounding; with precise_state the int32 remainder too, so state64 hands the user's own values
 // back) and into the normalised observation row, the way TE:206-211 copies process.current_state into the state matrix.
 __global__ void host_columns_kernel(const double* columns, uint32_t n, int d, int dim, int first, float* state, int32_t* resid, int res, float* obs,
@@ -1467,10 +1467,10 @@ __global__ void host_columns_kernel(const double* columns, uint32_t n, int d, in
   for (int j = 0; j < d; ++j) {
     const double x = columns[static_cast<size_t>(i) * d + j];
     float hi = static_cast<float>(x);
-    if (resid != nullptr && res == 4) {
+    if (resid != nullptr && (first - 2) + j < res) {
       int32_t lo;
       exact_split(x, hi, lo);
-      resid[static_cast<size_t>(i) * 4 + (first - 2) + j] = lo;  // remainder columns: [cash, midprice, x0, x1] - state column 4 + k <-> remainder 2 + k
+      resid[static_cast<size_t>(i) * res + (first - 2) + j] = lo;  // remainder columns: [cash, midprice (, x0, x1)] - state column 3 + k <-> remainder 1 + k
     }
     state[static_cast<size_t>(i) * dim + first + j] = hi;
     if (obs != nullptr) obs[static_cast<size_t>(i) * dim + first + j] = !P.norm_obs ? hi : (resid != nullptr ? normalise_column_exact(x, first + j, P) : normalise_column(hi, first + j, P));

@@ -37,6 +37,7 @@ from mbt_gym_amd.stochastic_processes.StochasticProcessModel import StochasticPr
 from mbt_gym_amd.stochastic_processes.arrival_models import ArrivalModel, PoissonArrivalModel
 from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction, FillProbabilityModel
 from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+from mbt_gym_amd.stochastic_processes.price_impact_models import PriceImpactModel
 
 try:  # pragma: no cover - gym is not installed in the build image
     import gym as _gym
@@ -57,11 +58,15 @@ class HostCallbackWarning(UserWarning):
 
 
 def host_callback_role(part):
-    """'fill' / 'arrival' / 'reward' for a subclass of the reference's plugin contract that has NO device form - only the
-    NumPy method the reference asks for (FILL:22-34 `_get_fill_probabilities` / `get_fills`, ARR:27-29 `get_arrivals`,
-    RW:10-13 `calculate`) - and None for everything else (built-ins and device expressions name a `device_kind`)."""
+    """'fill' / 'arrival' / 'reward' / 'midprice' for a subclass of the reference's plugin contract that has NO device form -
+    only the NumPy method the reference asks for (FILL:22-34 `_get_fill_probabilities` / `get_fills`, ARR:27-29 `get_arrivals`,
+    RW:10-13 `calculate`, SP:33-35 `update` of a MidpriceModel) - and None for everything else (built-ins and device expressions
+    name a `device_kind`)."""
     if getattr(part, "device_kind", None) is not None:
         return None
+    if (isinstance(part, StochasticProcessModel) and not isinstance(part, (FillProbabilityModel, ArrivalModel, PriceImpactModel))
+            and type(part).update is not StochasticProcessModel.update):
+        return "midprice"  # MidpriceModel IS StochasticProcessModel (MID:9): a subclass that brings its own update()
     if isinstance(part, FillProbabilityModel) and (
             callable(getattr(part, "_get_fill_probabilities", None)) or type(part).get_fills is not FillProbabilityModel.get_fills):
         return "fill"
@@ -134,9 +139,10 @@ class TradingEnvironment(_EnvBase):
         self.trajectory_offset = trajectory_offset
         self.noise = noise
         self._host_plugins = self._find_host_plugins()
-        if self._host_plugins.get("reward") is not None and not precise_state:
+        if (self._host_plugins.get("reward") is not None or "midprice" in self._host_plugins) and not precise_state:
             # calculate() is handed the two state matrices: only the float64 tier hands it the reference's (a reward formed
-            # from float32-rounded cash and midprice levels is off by the rounding of the LEVELS, ~1e-4)
+            # from float32-rounded cash and midprice levels is off by the rounding of the LEVELS, ~1e-4).  A host midprice
+            # implies a host-formed reward: the step's reward holds the midprice its update() computes AFTER the launch
             precise_state = True
         self.precise_state = precise_state
         self.allow_stiff_hawkes = allow_stiff_hawkes
@@ -180,7 +186,7 @@ class TradingEnvironment(_EnvBase):
         self._events_on = False
         self._last_events = None
         # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills
-        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival"))
+        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival", "midprice"))
         if self._host_needs_events and self._handle is not None:
             _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
@@ -209,9 +215,12 @@ class TradingEnvironment(_EnvBase):
         for part in parts:
             fields.update(part.device_params())
         # NumPy-only subclasses keep running on the host, between launches: the kernel is told to take their results
-        for role, kind in (("fill", dict(fill_kind=_native.FILL_HOST)), ("arrival", dict(arrival_kind=_native.ARR_HOST)), ("reward", dict(reward_kind=_native.REW_HOST))):
+        for role, kind in (("fill", dict(fill_kind=_native.FILL_HOST)), ("arrival", dict(arrival_kind=_native.ARR_HOST)), ("reward", dict(reward_kind=_native.REW_HOST)),
+                           ("midprice", dict(midprice_kind=_native.MID_HOST, reward_kind=_native.REW_HOST))):
             if role in self._host_plugins:
                 fields.update(kind)
+        if "midprice" in self._host_plugins:
+            fields["initial_price"] = float(np.asarray(md.midprice_model.initial_state, dtype=np.float64)[0, 0])
         for key in ("midprice_step_size", "arrival_step_size", "impact_step_size"):
             if fields.get(key) is None:
                 fields[key] = 0.0  # 0 = the environment's terminal_time / n_steps
@@ -282,14 +291,20 @@ class TradingEnvironment(_EnvBase):
         arrival_code = arrival.device_code() if getattr(arrival, "device_kind", None) == _native.ARR_USER else None
         mid = self.model_dynamics.midprice_model
         mid_code = mid.device_code() if getattr(mid, "device_kind", None) == _native.MID_USER else None
+        host_mid = self._host_plugins.get("midprice")
         if fill_code is None and reward_code is None and arrival_code is None and mid_code is None and not (
-                self._host_plugins.get("arrival") is not None and self._host_plugins["arrival"].state_dim > 0):
+                self._host_plugins.get("arrival") is not None and self._host_plugins["arrival"].state_dim > 0) and not (
+                host_mid is not None and host_mid.state_dim > 1):
             return None
         # State columns owned by user processes, in the registry order of TE:303-318 (the midprice's second factor, then the
         # arrival model's columns).  Each process writes its expressions in terms of ITS OWN columns x0 (, x1); the kernel
         # numbers the columns globally, so the arrival model's are shifted behind a midprice factor.
         mid_state = mid.device_state() if mid_code is not None and hasattr(mid, "device_state") else None
         arr_state = arrival.device_state() if arrival_code is not None and hasattr(arrival, "device_state") else None
+        if host_mid is not None and host_mid.state_dim > 1:
+            # a NumPy-only midprice model with further columns (a second factor): carried through by the kernel like the midprice
+            # column itself, advanced by the model's own update() on the host
+            mid_state = ([""] * (host_mid.state_dim - 1), {}, [float(v) for v in np.asarray(host_mid.initial_state, dtype=np.float64)[0, 1:]], False)
         host_arrival = self._host_plugins.get("arrival")
         if host_arrival is not None and host_arrival.state_dim > 0:
             # a NumPy-only arrival model that owns columns: no update expressions - the kernel carries the columns through, the
@@ -390,7 +405,7 @@ class TradingEnvironment(_EnvBase):
         obs = self._host_buffers()["obs"].acquire()[0]
         self._reset_device(obs)
         if self._host_plugins:
-            self._reset_host_plugins()
+            self._reset_host_plugins(obs)
         return obs
 
     def step(self, action: np.ndarray):
@@ -438,17 +453,30 @@ class TradingEnvironment(_EnvBase):
         """{role: object} for the plugin objects whose class has no device form (see `host_callback_role`)."""
         md = self.model_dynamics
         found = {}
-        for part in (md.arrival_model, md.fill_probability_model, self.reward_function):
+        for slot, part in (("midprice", md.midprice_model), ("arrival", md.arrival_model), ("fill", md.fill_probability_model), ("reward", self.reward_function)):
             role = host_callback_role(part) if part is not None else None
             if role is None:
                 continue
-            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2):
+            if role != slot:
+                raise UnsupportedOnDevice(f"{type(part).__name__} is a {role} model by its class, handed over as the {slot} model")
+            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2) or (role == "midprice" and not 1 <= part.state_dim <= 3):
                 raise UnsupportedOnDevice(
                     f"{type(part).__name__} only has host (NumPy) code AND owns {part.state_dim} state column(s): the host-callback route serves "
-                    "stateless fill models and arrival models with at most two columns of their own (otherwise: a device expression, DeviceExpressionArrivalModel)")
+                    "stateless fill models, arrival models with at most two columns of their own and midprice models with at most two beside the "
+                    "price (otherwise: a device expression, DeviceExpressionArrivalModel / DeviceExpressionMidpriceModel)")
             found[role] = part
-            if role in ("fill", "arrival"):
+            if role in ("fill", "arrival", "midprice"):
                 part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
+        if "midprice" in found:
+            if md.price_impact_model is not None:
+                raise UnsupportedOnDevice(f"{type(found['midprice']).__name__} only has host (NumPy) code: the host-callback route for midprice models serves order-book dynamics")
+            if host_callback_role(self.reward_function) is None and getattr(self.reward_function, "device_kind", None) == _native.REW_USER:
+                raise UnsupportedOnDevice(
+                    f"{type(found['midprice']).__name__} moves the midprice on the host AFTER the launch, so the step's reward is formed on the host too "
+                    f"(calculate() on the float64 states): {type(self.reward_function).__name__} exists as a device expression only")
+            owned = (found["midprice"].state_dim - 1) + (found["arrival"].state_dim if "arrival" in found else 0)
+            if owned > 2:
+                raise UnsupportedOnDevice(f"host-callback processes own {owned} state columns beside the midprice: at most two")
         if found:
             warnings.warn(
                 "host-callback plugins: " + ", ".join(f"{type(p).__name__} ({r})" for r, p in found.items()) + " only have NumPy code, which "
@@ -457,19 +485,46 @@ class TradingEnvironment(_EnvBase):
                 HostCallbackWarning, stacklevel=3)
         return found
 
-    def _reset_host_plugins(self):
-        for role in ("arrival", "fill"):
+    def _host_owned_columns(self):
+        """(first, last, blocks): the ONE contiguous block of state columns host-callback processes own, in registry order
+        (midprice columns, then a stateful arrival model's), as mbt_env_set_host_state_columns takes it."""
+        blocks = []
+        for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model")):
+            part = self._host_plugins.get(role)
+            if part is not None and part.state_dim > 0:
+                blocks.append((part, *self.stochastic_process_indices[name]))
+        return (blocks[0][1], blocks[-1][2], blocks) if blocks else (0, 0, blocks)
+
+    def _file_host_columns(self, obs):
+        """TE:209-211: the host processes' columns of the state matrix <- process.current_state (float64, on the host): the device
+        files them - float32 rounding into the row, the remainder too under precise_state - and `obs` is read again."""
+        lo, hi, blocks = self._host_owned_columns()
+        if not blocks:
+            return None
+        n, lib = self.num_trajectories, _native.load_library()
+        columns = np.empty((n, hi - lo), dtype=np.float64)
+        for part, first, last in blocks:
+            columns[:, first - lo:last - lo] = np.broadcast_to(np.asarray(part.current_state, dtype=np.float64), (n, last - first))
+        _native.check(lib.mbt_env_set_host_state_columns(self._handle, columns.ctypes.data_as(C.POINTER(C.c_double))))
+        if obs is not None:
+            _native.check(lib.mbt_env_get_obs_host(self._handle, _native.fptr(obs)))
+        return lo, hi, columns
+
+    def _reset_host_plugins(self, obs=None):
+        for role in ("midprice", "arrival", "fill"):
             if role in self._host_plugins:
                 self._host_plugins[role].reset()  # TE:97-98
-        self._host_state64 = None
-        if "reward" in self._host_plugins:
-            self._host_state64 = self.state64
-            self._host_plugins["reward"].reset(self._host_state64.copy())  # TE:100
+        if "midprice" in self._host_plugins:  # (an arrival model's initial columns are the configuration's; a midprice's reset() may set any)
+            self._file_host_columns(obs)
+        self._host_state64 = self.state64  # what the next step's update() / calculate() calls are handed as the state before it
+        if "reward" in self._host_plugins or "midprice" in self._host_plugins:
+            self.reward_function.reset(self._host_state64.copy())  # TE:100
 
     def _step_with_host_plugins(self, action):
         """TE:103-110 with the user's NumPy methods where the reference calls them and the fused kernel for everything else:
         depths (device, float64) -> _get_fill_probabilities / get_fills (host) -> probabilities (device); get_arrivals (host)
-        -> arrivals (device); ONE step launch; float64 states (device) -> calculate (host) -> rewards (device)."""
+        -> arrivals (device); ONE step launch; update() of the user's processes in registry order (host) -> the columns they own
+        (device); float64 states (device) -> calculate (host) -> rewards (device)."""
         lib, handle, n, plugins = _native.load_library(), self._handle, self.num_trajectories, self._host_plugins
         dptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
         pools = self._host_buffers()
@@ -497,31 +552,35 @@ class TradingEnvironment(_EnvBase):
             self._fetch_events()
         following = self.state64  # float64 (N, D): with precise_state the reference's own values; the TIME column is the float64 clock
         raw_action = self.normalise_action(np.asarray(action, dtype=np.float64), inverse=True)  # TE:104: what the plugins are handed
+        current = self._host_state64
+        if current is None:
+            raise _native.NativeError(-4, "step() before reset()")
         # StochasticProcessModel.update of the user's processes, in registry order (TE:206-211), with the step's arrivals and
-        # (masked) fills and the state matrix - which is where a stateless plugin written against the reference's API learns e.g.
-        # the time.  (The matrix is the one AFTER the step: the reference's shows the columns of processes LATER in the registry
-        # still un-advanced at that point - there are none for a stateless model next to built-in ones.)
-        for role in ("arrival", "fill"):
-            if role in plugins:
-                plugins[role].update(self.last_arrivals, self.last_fills.astype(np.float64), raw_action, following)
-        if arrival is not None and arrival.state_dim > 0:
-            # TE:209-211: the model's columns of the state matrix <- process.current_state, which ITS update() just advanced (float64, on
-            # the host); the device files them - float32 rounding into the row, the remainder too under precise_state - and the
-            # observation this step returns shows them, like the reference's
-            lo, hi = self.stochastic_process_indices["arrival_model"]
-            columns = np.ascontiguousarray(np.broadcast_to(np.asarray(arrival.current_state, dtype=np.float64), (n, hi - lo)))
-            _native.check(lib.mbt_env_set_host_state_columns(handle, dptr(columns)))
-            _native.check(lib.mbt_env_get_obs_host(handle, _native.fptr(obs)))
+        # (masked) fills and the state matrix AS THE REFERENCE'S STANDS AT THAT POINT: cash, inventory and time already advanced
+        # (TE:213-216), the columns of the processes earlier in the registry advanced, the process's own and later ones not yet.
+        matrix = current.copy()
+        matrix[:, :3] = following[:, :3]
+        host_parts = {id(part) for part in plugins.values()}
+        moved = False
+        for name, process in self.stochastic_processes.items():
+            lo, hi = self.stochastic_process_indices[name]
+            if id(process) in host_parts:
+                process.update(self.last_arrivals, self.last_fills.astype(np.float64), raw_action, matrix)
+                if hi > lo:
+                    matrix[:, lo:hi] = process.current_state  # TE:209-211
+                    moved = True
+            else:
+                matrix[:, lo:hi] = following[:, lo:hi]
+        if moved:
+            lo, hi, columns = self._file_host_columns(obs)
             following = following.copy()
-            following[:, lo:hi] = columns if self.precise_state else columns.astype(np.float32)
-        if reward is not None:
-            current = self._host_state64
-            if current is None:
-                raise _native.NativeError(-4, "step() before reset()")
-            r = np.asarray(reward.calculate(current, raw_action, following, bool(done.value)), dtype=np.float64)  # TE:108
+            following[:, lo:hi] = columns if self.precise_state else columns.astype(np.float32)  # what the device holds
+        if reward is not None or "midprice" in plugins:
+            # TE:108 - a built-in class evaluates it on the device, on these float64 matrices (mbt_reward_calculate_host)
+            r = np.asarray(self.reward_function.calculate(current, raw_action, following, bool(done.value)), dtype=np.float64)
             r = np.ascontiguousarray(np.broadcast_to(r, (n,)))
             _native.check(lib.mbt_env_set_host_rewards(handle, dptr(r), _native.fptr(rewards)))
-            self._host_state64 = following
+        self._host_state64 = following
         dones = pools["dones"].acquire()[0]
         dones.fill(bool(done.value))
         return obs, rewards, dones, self._infos()

@@ -1,10 +1,11 @@
 """Plugin subclasses as a user of the REFERENCE writes them: NumPy only, against the reference's plugin contract
 (`FillProbabilityModel._get_fill_probabilities` FILL:22-34, `ArrivalModel.get_arrivals` ARR:27-29, `RewardFunction.calculate`
-RW:10-13), with no device expression and no knowledge of this package.
+RW:10-13, `MidpriceModel.update` SP:33-35), with no device expression and no knowledge of this package.
 
 ONE source for both sides of the parity tests: `define(...)` is handed the base classes of whichever package the classes are
 to live in - the reference's (`tools/refgen/make_golden.py`, build container only: the fixtures `user_fill_and_reward`,
-`user_fill_hawkes_market_normalised`, `user_seasonal_arrivals`, `user_cross_hawkes` are the REAL reference running these classes) or
+`user_fill_hawkes_market_normalised`, `user_seasonal_arrivals`, `user_cross_hawkes`, `user_cev_midprice`, `user_two_factor_midprice(_normalised)`
+are the REAL reference running these classes) or
 mbt_gym_amd's (tests/test_gpu_host_callbacks.py: the same classes, unmodified, in `env.step()` through the host-callback
 route of include/mbt_env.h).  Nothing here imports either package."""
 import types
@@ -12,8 +13,9 @@ import types
 import numpy as np
 
 
-def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names):
+def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, MidpriceModel=None):
     """The classes, bound to the given plugin base classes and state-column indices."""
+    MidpriceModel = MidpriceModel or ArrivalModel.__mro__[1]  # (MidpriceModel IS StochasticProcessModel, MID:9)
     CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX = (
         index_names.CASH_INDEX, index_names.INVENTORY_INDEX, index_names.TIME_INDEX, index_names.ASSET_PRICE_INDEX)
 
@@ -87,8 +89,40 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names):
             unif = self.rng.uniform(size=(self.num_trajectories, 2))
             return unif < self.current_state * self.step_size
 
+    class UserCevMidprice(MidpriceModel):
+        """dS = mu S dt + sigma S^gamma sqrt(dt) Z: constant elasticity of variance, written for any number of trajectories (the
+        reference's own CEV class broadcasts (N,) noise against an (N, 1) state and cannot be used for N > 1, MID:401-409)."""
+
+        def __init__(self, drift, volatility, gamma, initial_price, lo, hi, terminal_time, step_size, num_trajectories, seed=None):
+            self.drift, self.volatility, self.gamma = drift, volatility, gamma
+            super().__init__(min_value=np.array([[lo]]), max_value=np.array([[hi]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[initial_price]]), num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            s = self.current_state
+            z = self.rng.normal(size=(self.num_trajectories, 1))
+            self.current_state = s + self.drift * s * self.step_size + self.volatility * s**self.gamma * np.sqrt(self.step_size) * z
+
+    class UserShortTermAlphaMidprice(MidpriceModel):
+        """A midprice WITH A SECOND STATE COLUMN: dS = alpha dt + sigma sqrt(dt) Z1, and a short-term alpha that mean-reverts, diffuses
+        and jumps on the market's order flow, d alpha = -kappa alpha dt + xi sqrt(dt) Z2 + eps (sell arrivals - buy arrivals)."""
+
+        def __init__(self, volatility, kappa, xi, eps, initial_price, lo, hi, alpha_lo, alpha_hi, terminal_time, step_size, num_trajectories, seed=None):
+            self.volatility, self.kappa, self.xi, self.eps = volatility, kappa, xi, eps
+            super().__init__(min_value=np.array([[lo, alpha_lo]]), max_value=np.array([[hi, alpha_hi]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[initial_price, 0.0]]), num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            s, a = self.current_state[:, 0:1], self.current_state[:, 1:2]
+            z = self.rng.normal(size=(self.num_trajectories, 2))
+            dt = self.step_size
+            s_new = s + a * dt + self.volatility * np.sqrt(dt) * z[:, 0:1]
+            a_new = a - self.kappa * a * dt + self.xi * np.sqrt(dt) * z[:, 1:2] + self.eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
+            self.current_state = np.append(s_new, a_new, axis=1)
+
     return types.SimpleNamespace(UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
-                                 UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes)
+                                 UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes,
+                                 UserCevMidprice=UserCevMidprice, UserShortTermAlphaMidprice=UserShortTermAlphaMidprice)
 
 
 class Replay:

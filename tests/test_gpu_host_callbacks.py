@@ -85,7 +85,35 @@ def _cross_hawkes(g, **kw):  # case "user_cross_hawkes": an arrival model that O
     return env
 
 
-CASES = {"user_fill_and_reward": _fill_and_reward, "user_fill_hawkes_market_normalised": _fill_hawkes_market, "user_seasonal_arrivals": _seasonal_arrivals,
+def _cev_midprice(g, **kw):  # case "user_cev_midprice": a MidpriceModel subclass whose update() is NumPy (a non-linear increment)
+    n, ns = 32, 80
+    mid = USER.UserCevMidprice(0.05, 0.6, 0.75, 50.0, 20.0, 80.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n)
+    md = LimitOrderModelDynamics(
+        midprice_model=mid, arrival_model=PoissonArrivalModel(intensity=np.array([50.0, 50.0]), step_size=1 / ns, num_trajectories=n),
+        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=1 / ns, num_trajectories=n), num_trajectories=n)
+    env = TradingEnvironment(terminal_time=1.0, n_steps=ns, seed=65, initial_inventory=2, max_inventory=8, num_trajectories=n,
+                             reward_function=RunningInventoryPenalty(0.01, 0.02), model_dynamics=md, noise="injected", **RAW, **kw)
+    mid.rng = Replay(normals=g["z"])  # the user's update() draws from ITS generator (SP:27)
+    return env
+
+
+def _two_factor_midprice(g, normalised=False, **kw):  # cases "user_two_factor_midprice(_normalised)": a midprice model that owns TWO columns
+    n, ns = 32, 80
+    mid = USER.UserShortTermAlphaMidprice(1.2, 8.0, 3.0, 0.75, 100.0, 90.0, 110.0, -10.0, 10.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n)
+    md = LimitOrderModelDynamics(
+        midprice_model=mid, arrival_model=PoissonArrivalModel(intensity=np.array([45.0, 60.0]), step_size=1 / ns, num_trajectories=n),
+        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=1 / ns, num_trajectories=n), num_trajectories=n)
+    env = TradingEnvironment(terminal_time=1.0, n_steps=ns, seed=67, initial_inventory=1, max_inventory=5, num_trajectories=n,
+                             reward_function=RunningInventoryPenalty(0.01, 0.05), model_dynamics=md, noise="injected",
+                             normalise_action_space=normalised, normalise_observation_space=normalised, **kw)
+    # update() draws rng.normal(size=(N, 2)) in one call: column 0 is the fixture's `z`, column 1 `z_user[..., 0]` (tools/refgen/make_golden.py: user_normals)
+    mid.rng = Replay(normals=np.stack([g["z"], g["z_user"][:, :, 0]], axis=-1))
+    return env
+
+
+CASES = {"user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
+         "user_two_factor_midprice_normalised": lambda g, **kw: _two_factor_midprice(g, normalised=True, **kw),
+         "user_fill_and_reward": _fill_and_reward, "user_fill_hawkes_market_normalised": _fill_hawkes_market, "user_seasonal_arrivals": _seasonal_arrivals,
          "user_cross_hawkes": _cross_hawkes}
 
 
@@ -95,7 +123,8 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
     cfg, g = load_case(name)
     env = _quiet(lambda: CASES[name](g, precise_state=precise))
     exact = env.precise_state  # implied by a host-computed reward
-    assert exact == (precise or name == "user_fill_and_reward")
+    host_midprice = "midprice" in name
+    assert exact == (precise or name == "user_fill_and_reward" or host_midprice)  # host-formed rewards imply the float64 tier
     env.record_events(True)
     obs = env.reset()
     n, normalised = cfg.num_trajectories, cfg.normalise_observation_space
@@ -103,8 +132,10 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
         np.testing.assert_array_equal(obs, g["obs0"].astype(np.float32))
     q_of = (lambda o: np.rint((o[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)) if normalised else (lambda o: o[:, 1].astype(np.float64))
     for k in range(g["actions"].shape[0]):
-        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])  # (a host midprice draws its normals itself, from the replayed generator: z is not read)
         obs, rew, dones, infos = env.step(g["actions"][k])
+        if host_midprice and not normalised:  # the model's own columns, advanced by ITS update() on the host in float64: the reference's values
+            np.testing.assert_array_equal(env.state64[:, 3:], g["obs"][k][:, 3:], err_msg=f"{name} step {k}: float64 midprice columns")
         np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"{name} step {k}: arrivals")
         np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"{name} step {k}: fills")
         np.testing.assert_array_equal(q_of(obs), q_of(g["obs"][k]), err_msg=f"{name} step {k}: inventory")

@@ -687,16 +687,7 @@ def user_plugin_cases(only=None):
     #    own CEV class broadcasts (N,) noise against an (N, 1) state and cannot be used for N > 1, MID:401-409)
     from mbt_gym.stochastic_processes.midprice_models import MidpriceModel
 
-    class UserCevMidprice(MidpriceModel):
-        def __init__(self, drift, volatility, gamma, initial_price, lo, hi, terminal_time, step_size, num_trajectories, seed=None):
-            self.drift, self.volatility, self.gamma = drift, volatility, gamma
-            super().__init__(min_value=np.array([[lo]]), max_value=np.array([[hi]]), step_size=step_size, terminal_time=terminal_time,
-                             initial_state=np.array([[initial_price]]), num_trajectories=num_trajectories, seed=seed)
-
-        def update(self, arrivals, fills, actions, state=None):
-            s = self.current_state
-            z = self.rng.normal(size=(self.num_trajectories, 1))
-            self.current_state = s + self.drift * s * self.step_size + self.volatility * s**self.gamma * np.sqrt(self.step_size) * z
+    UserCevMidprice = user.UserCevMidprice  # (tests/numpy_only_plugins.py: the same source the host-callback tests bind to mbt_gym_amd)
 
     n, ns = 32, 80
     run_case(
@@ -737,19 +728,7 @@ def user_plugin_cases(only=None):
 
     # Z2. a user-defined TWO-COLUMN MidpriceModel: price + a mean-reverting short-term alpha that order flow pushes (what the
     #     reference's ShortTermOuAlphaMidpriceModel, MID:149-190, describes and cannot run for N > 1); two normals per step
-    class UserShortTermAlphaMidprice(MidpriceModel):
-        def __init__(self, volatility, kappa, xi, eps, initial_price, lo, hi, alpha_lo, alpha_hi, terminal_time, step_size, num_trajectories, seed=None):
-            self.volatility, self.kappa, self.xi, self.eps = volatility, kappa, xi, eps
-            super().__init__(min_value=np.array([[lo, alpha_lo]]), max_value=np.array([[hi, alpha_hi]]), step_size=step_size, terminal_time=terminal_time,
-                             initial_state=np.array([[initial_price, 0.0]]), num_trajectories=num_trajectories, seed=seed)
-
-        def update(self, arrivals, fills, actions, state=None):
-            s, a = self.current_state[:, 0:1], self.current_state[:, 1:2]
-            z = self.rng.normal(size=(self.num_trajectories, 2))
-            dt = self.step_size
-            s_new = s + a * dt + self.volatility * np.sqrt(dt) * z[:, 0:1]
-            a_new = a - self.kappa * a * dt + self.xi * np.sqrt(dt) * z[:, 1:2] + self.eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
-            self.current_state = np.append(s_new, a_new, axis=1)
+    UserShortTermAlphaMidprice = user.UserShortTermAlphaMidprice  # (tests/numpy_only_plugins.py)
 
     n, ns = 32, 80
     alpha = dict(volatility=1.2, alpha_kappa=8.0, alpha_xi=3.0, alpha_eps=0.75, initial_price=100.0, midprice_lo=90.0, midprice_hi=110.0, alpha_lo=-10.0, alpha_hi=10.0)
