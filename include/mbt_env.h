@@ -80,7 +80,7 @@ enum {
   MBT_REW_PNL = 0 /* RW:20-36 */, MBT_REW_RUNNING_PENALTY = 1 /* RW:116-143 */, MBT_REW_CJ_MM = 2 /* RW:77-113 */,
   MBT_REW_EXP_UTILITY = 3 /* RW:149-163 */, MBT_REW_CJ_OE = 4 /* RW:39-74, speed dynamics */,
   MBT_REW_USER = 5 /* a user-defined RewardFunction subclass (RW:8-17): mbt_env_create_jit only */,
-  MBT_REW_HOST = 6 /* a RewardFunction subclass that only has HOST code: calculate() runs in the caller (order-book dynamics) */
+  MBT_REW_HOST = 6 /* a RewardFunction subclass that only has HOST code: calculate() runs in the caller (every dynamics kind) */
 };
 enum {
   MBT_IMPACT_NONE = -1, MBT_IMPACT_TEMPORARY_POWER = 0 /* IMP:34-61 */, MBT_IMPACT_TEMPORARY_AND_PERMANENT = 1 /* IMP:64-96 */,
@@ -301,12 +301,14 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
  *      and after the step; with precise_state they ARE the reference's float64 states), evaluates calculate() and files the
  *      (N) float64 result with mbt_env_set_host_rewards: multiplied by cfg.reward_scale (TE:128-129), rounded once to float32,
  *      written to the reward buffer, added to the episode-return sums; reward_out (N float32, may be NULL) receives what
- *      env.step() returns.  The next step is refused until this happened.
+ *      env.step() returns.  The next step is refused until this happened.  (Trading-with-speed dynamics: the speed kernels are
+ *      built ahead of time and have no host-reward form - the step files the mark-to-market change and this call REPLACES it,
+ *      in the reward buffer and in the return sums.)
  *   5. MBT_MID_HOST:  the kernel holds the midprice column(s) still; after the launch the caller's update(arrivals, fills, action,
  *      state) advances them on the host (MID: the reference calls it first of the processes, TE:206-211) and files them with
  *      mbt_env_set_host_state_columns - BEFORE step 4, whose `next_state` shows them: the reward function (built-in classes
  *      included: mbt_reward_calculate_host evaluates them on the float64 matrices) is then a host callback by construction, which
- *      is why MBT_MID_HOST is only accepted together with MBT_REW_HOST.  Order-book dynamics.
+ *      is why MBT_MID_HOST is only accepted together with MBT_REW_HOST.  With trading-with-speed dynamics: the price column alone.
  * Fused rollouts are not available for such an environment (MBT_ERR_INVALID): the host is consulted every step. */
 int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_host);
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);

@@ -457,6 +457,7 @@ struct mbt_env {
   double* host_scratch = nullptr;    // (n_pad, 2) device: depths out / rewards in
   bool host_fill_ready = false, host_arrivals_ready = false, host_reward_pending = false;
   int host_state_first = 0, host_state_count = 0;  // the state columns host-callback processes own: one block in registry order (TE:303-318)
+  bool host_reward_replaces = false; // MBT_REW_HOST on the speed kernels: the kernel filed its PnL, mbt_env_set_host_rewards takes it back out
   bool host_mid = false;             // MBT_MID_HOST: cfg.midprice_kind reads MBT_MID_CONSTANT, the caller moves the midprice between launches
 };
 
@@ -1413,18 +1414,30 @@ int mbt_device_name(int device, char* buf, size_t buf_len) {
   return MBT_OK;
 }
 
-// MBT_MID_HOST as the kernels see it: a midprice that stands still during the launch (the caller's update() moves it between
-// launches, mbt_env_set_host_state_columns).  Returns whether the configuration names one; `reason` is set when it cannot run.
-static bool lower_host_midprice(const mbt_config& in, mbt_config& out, const char** reason) {
+// The host-callback kinds the kernels never see, lowered to what the kernels run:
+//   MBT_MID_HOST -> a midprice that stands still during the launch (the caller's update() moves it between launches,
+//                   mbt_env_set_host_state_columns);
+//   MBT_REW_HOST with SPEED dynamics -> the kernel's PnL (the speed kernels are built ahead of time, without a host variant):
+//                   mbt_env_set_host_rewards then REPLACES what the kernel filed - reward buffer and return sums.
+// `reason` is set when the configuration cannot run.
+struct HostLowering {
+  bool midprice = false, speed_reward = false;
+};
+static HostLowering lower_host_kinds(const mbt_config& in, mbt_config& out, const char** reason) {
+  HostLowering h;
   out = in;
   *reason = nullptr;
-  if (in.midprice_kind != MBT_MID_HOST) return false;
-  if (in.reward_kind != MBT_REW_HOST)
-    *reason = "MBT_MID_HOST: the midprice moves after the launch, so the step's reward is formed by the caller - reward_kind must be MBT_REW_HOST";
-  else if (in.dynamics_kind == MBT_DYN_SPEED)
-    *reason = "host-callback midprice models run on the order-book kernels";
-  out.midprice_kind = MBT_MID_CONSTANT;
-  return true;
+  if (in.midprice_kind == MBT_MID_HOST) {
+    if (in.reward_kind != MBT_REW_HOST)
+      *reason = "MBT_MID_HOST: the midprice moves after the launch, so the step's reward is formed by the caller - reward_kind must be MBT_REW_HOST";
+    out.midprice_kind = MBT_MID_CONSTANT;
+    h.midprice = true;
+  }
+  if (in.dynamics_kind == MBT_DYN_SPEED && in.reward_kind == MBT_REW_HOST) {
+    out.reward_kind = MBT_REW_PNL;
+    h.speed_reward = true;
+  }
+  return h;
 }
 
 static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out) {
@@ -1436,9 +1449,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
   mbt_config lowered;
   const char* refused = nullptr;
-  const bool host_mid = lower_host_midprice(*cfg, lowered, &refused);
+  const HostLowering host_lowered = lower_host_kinds(*cfg, lowered, &refused);
   if (refused != nullptr) return fail(MBT_ERR_INVALID, "%s", refused);
   cfg = &lowered;
+  const bool host_mid = host_lowered.midprice;
   const bool user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
@@ -1558,7 +1572,8 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
-  e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | (host_reward ? mbt::kHostReward : 0);
+  e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | ((host_reward || host_lowered.speed_reward) ? mbt::kHostReward : 0);
+  e->host_reward_replaces = host_lowered.speed_reward;
   e->res = !cfg->precise_state ? 0 : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
   tune_for_size(e);
   if (needs_jit) {
@@ -1690,13 +1705,16 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   if (cfg->abi_version != MBT_ABI_VERSION) return fail(MBT_ERR_ABI, "mbt_config.abi_version %u != library %u", cfg->abi_version, MBT_ABI_VERSION);
   mbt_config lowered;
   const char* refused = nullptr;
-  (void)lower_host_midprice(*cfg, lowered, &refused);
+  const HostLowering host_lowered = lower_host_kinds(*cfg, lowered, &refused);
   if (refused != nullptr) return fail(MBT_ERR_INVALID, "%s", refused);
   cfg = &lowered;
   const bool user_fill = cfg->fill_kind == MBT_FILL_USER, user_reward = cfg->reward_kind == MBT_REW_USER, user_arrival = cfg->arrival_kind == MBT_ARR_USER;
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
   const bool any_host = cfg->fill_kind == MBT_FILL_HOST || cfg->arrival_kind == MBT_ARR_HOST || cfg->reward_kind == MBT_REW_HOST;
-  if (!user_fill && !user_reward && !user_arrival && !user_mid && !any_host) return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
+  if (!user_fill && !user_reward && !user_arrival && !user_mid && !any_host) {
+    if (host_lowered.speed_reward) return MBT_OK;  // host-formed rewards on the ahead-of-time speed kernels: nothing to compile
+    return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
+  }
   if (user_mid && (code->midprice_increment == nullptr || code->midprice_increment[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression");
   if (user_fill && (code->fill_probability == nullptr || code->fill_probability[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_FILL_USER without a fill_probability expression");
   if (user_reward && (code->reward == nullptr || code->reward[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_REW_USER without a reward expression");
@@ -2060,7 +2078,7 @@ int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   const int d = e->host_state_count;
   HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(mbt::host_columns_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->host_scratch, e->n, d, e->dim, e->host_state_first,
-                     e->state[e->cur], e->resid, e->res, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
+                     e->state[e->cur], e->resid, e->res, e->speed ? 1 : 0, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
@@ -2074,7 +2092,7 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
   HIP_TRY(hipMemcpyAsync(e->host_scratch, rewards_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
   const uint32_t blocks = (e->n + 255u) / 256u;
   hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
-                     e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves);
+                     e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves, e->host_reward_replaces ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (reward_out_host != nullptr) HIP_TRY(hipMemcpyAsync(reward_out_host, e->reward, size_t(e->n) * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));

@@ -1460,17 +1460,20 @@ __global__ void host_depths_kernel(const float* action, int act_dim, uint32_t n,
 // The state columns host-callback processes OWN (SP:8-53; MBT_MID_HOST: from the midprice column on), after their update() ran on the host: float64 (n, d) values into
 // the state row (their float32 rounding; with precise_state the int32 remainder too, so state64 hands the user's own values
 // back) and into the normalised observation row, the way TE:206-211 copies process.current_state into the state matrix.
-__global__ void host_columns_kernel(const double* columns, uint32_t n, int d, int dim, int first, float* state, int32_t* resid, int res, float* obs,
-                                    const StepParams P) {
+__global__ void host_columns_kernel(const double* columns, uint32_t n, int d, int dim, int first, float* state, int32_t* resid, int res, int speed,
+                                    float* obs, const StepParams P) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int j = 0; j < d; ++j) {
     const double x = columns[static_cast<size_t>(i) * d + j];
     float hi = static_cast<float>(x);
-    if (resid != nullptr && (first - 2) + j < res) {
+    // remainder columns: order book [cash, midprice (, x0, x1)] - state column 3 + k <-> remainder 1 + k; speed dynamics [cash,
+    // inventory, midprice, impact state] - state column 3 + k <-> remainder 2 + k
+    const int slot = (first - (speed ? 1 : 2)) + j;
+    if (resid != nullptr && slot < res) {
       int32_t lo;
       exact_split(x, hi, lo);
-      resid[static_cast<size_t>(i) * res + (first - 2) + j] = lo;  // remainder columns: [cash, midprice (, x0, x1)] - state column 3 + k <-> remainder 1 + k
+      resid[static_cast<size_t>(i) * res + slot] = lo;
     }
     state[static_cast<size_t>(i) * dim + first + j] = hi;
     if (obs != nullptr) obs[static_cast<size_t>(i) * dim + first + j] = !P.norm_obs ? hi : (resid != nullptr ? normalise_column_exact(x, first + j, P) : normalise_column(hi, first + j, P));
@@ -1480,15 +1483,18 @@ __global__ void host_columns_kernel(const double* columns, uint32_t n, int d, in
 // The rewards the user's calculate() returned for the step that just ran (float64, host-computed from the float64 states):
 // scaled (TE:128-129), rounded once to float32 like every reward this library hands out, filed where the step kernel would
 // have filed its own - the reward buffer, the per-lane returns, the running sums behind the episode statistics.
+// `replace`: the step kernel has no host-reward form (speed dynamics) and filed its own reward already - the difference goes in.
 __global__ void host_reward_kernel(const double* rewards, double scale, uint32_t n, float* reward, float* lane_returns, double* wave_sums,
-                                   uint32_t n_waves) {
+                                   uint32_t n_waves, int replace) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const float r = i < n ? static_cast<float>(scale * rewards[i]) : 0.0f;
+  float add = r;
   if (i < n) {
+    if (replace) add = r - reward[i];
     reward[i] = r;
-    if (lane_returns != nullptr) lane_returns[i] += r;
+    if (lane_returns != nullptr) lane_returns[i] += add;
   }
-  const float total = wave_sum(r);
+  const float total = wave_sum(add);
   if ((threadIdx.x & 63u) == 0u) unsafeAtomicAdd(&wave_sums[(i >> 6) % n_waves], static_cast<double>(total));
 }
 

@@ -186,7 +186,7 @@ class TradingEnvironment(_EnvBase):
         self._events_on = False
         self._last_events = None
         # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills
-        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival", "midprice"))
+        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival", "midprice")) and self.model_dynamics.arrival_model is not None
         if self._host_needs_events and self._handle is not None:
             _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
@@ -468,8 +468,9 @@ class TradingEnvironment(_EnvBase):
             if role in ("fill", "arrival", "midprice"):
                 part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
         if "midprice" in found:
-            if md.price_impact_model is not None:
-                raise UnsupportedOnDevice(f"{type(found['midprice']).__name__} only has host (NumPy) code: the host-callback route for midprice models serves order-book dynamics")
+            if md.price_impact_model is not None and found["midprice"].state_dim > 1:
+                raise UnsupportedOnDevice(f"{type(found['midprice']).__name__} only has host (NumPy) code and owns {found['midprice'].state_dim} columns: "
+                                          "with trading-with-speed dynamics a host-callback midprice model is the price column alone")
             if host_callback_role(self.reward_function) is None and getattr(self.reward_function, "device_kind", None) == _native.REW_USER:
                 raise UnsupportedOnDevice(
                     f"{type(found['midprice']).__name__} moves the midprice on the host AFTER the launch, so the step's reward is formed on the host too "
@@ -562,10 +563,12 @@ class TradingEnvironment(_EnvBase):
         matrix[:, :3] = following[:, :3]
         host_parts = {id(part) for part in plugins.values()}
         moved = False
+        # (trading-with-speed dynamics have no order flow: the reference hands update() None, None - MD:273-275, TE:199-204)
+        arrivals, fills = (self.last_arrivals, self.last_fills.astype(np.float64)) if self._host_needs_events else (None, None)
         for name, process in self.stochastic_processes.items():
             lo, hi = self.stochastic_process_indices[name]
             if id(process) in host_parts:
-                process.update(self.last_arrivals, self.last_fills.astype(np.float64), raw_action, matrix)
+                process.update(arrivals, fills, raw_action, matrix)
                 if hi > lo:
                     matrix[:, lo:hi] = process.current_state  # TE:209-211
                     moved = True

@@ -36,6 +36,13 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
     ExogenousMmFillProbabilityModel, ExponentialFillFunction = fill_m.ExogenousMmFillProbabilityModel, fill_m.ExponentialFillFunction
 
     n, dt, T = cfg.num_trajectories, cfg.step_size, cfg.terminal_time
+    # trading-with-speed dynamics run on kernels built ahead of time: a user's plugin takes the host-callback route there, as the
+    # NumPy class it is (tests/numpy_only_plugins.py, bound to `package`'s base classes) - not a device expression
+    numpy_only = None
+    if cfg.dynamics == "speed" and (cfg.midprice == "user_cev" or cfg.reward == "user_exp_inventory_cost"):
+        from tests.numpy_only_plugins import define
+
+        numpy_only = define(fill_m.FillProbabilityModel, arr_m.ArrivalModel, rw.RewardFunction, importlib.import_module(package + ".gym.index_names"))
     mid_dt = cfg.midprice_step_size or dt
     arr_dt = cfg.arrival_step_size or dt
     common = dict(terminal_time=T, step_size=mid_dt, num_trajectories=n)
@@ -54,7 +61,8 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
             drift=cfg.drift, volatility=cfg.volatility, scale_constant=cfg.mid_coef_add, scale_proportional=cfg.mid_coef_mul,
             mean_reversion_level=cfg.ou_level, mean_reversion_speed=cfg.ou_speed, jump_size=cfg.jump_size, initial_price=cfg.initial_price,
             min_value=cfg.midprice_lo, max_value=cfg.midprice_hi, **common),
-        "user_cev": lambda: __import__("tests.user_plugins", fromlist=["x"]).CevMidprice(
+        "user_cev": lambda: numpy_only.UserCevMidprice(cfg.drift, cfg.volatility, cfg.cev_gamma, cfg.initial_price, cfg.midprice_lo, cfg.midprice_hi, **common)
+        if numpy_only is not None else __import__("tests.user_plugins", fromlist=["x"]).CevMidprice(
             drift=cfg.drift, volatility=cfg.volatility, gamma=cfg.cev_gamma, initial_price=cfg.initial_price, min_value=cfg.midprice_lo,
             max_value=cfg.midprice_hi, **common),
         "user_alpha": lambda: __import__("tests.user_plugins", fromlist=["x"]).ShortTermAlphaMidprice(
@@ -106,7 +114,8 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
         "cjmm": lambda: rw.CjMmCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
         "cjoe": lambda: rw.CjOeCriterion(cfg.phi, cfg.alpha, cfg.inventory_exponent, terminal_time=T),
         "exp_utility": lambda: rw.ExponentialUtility(cfg.risk_aversion),
-        "user_exp_inventory_cost": lambda: __import__("tests.user_plugins", fromlist=["x"]).ExponentialInventoryCost(cfg.phi, cfg.eta, cfg.alpha),
+        "user_exp_inventory_cost": lambda: numpy_only.UserExponentialInventoryCost(cfg.phi, cfg.eta, cfg.alpha)
+        if numpy_only is not None else __import__("tests.user_plugins", fromlist=["x"]).ExponentialInventoryCost(cfg.phi, cfg.eta, cfg.alpha),
     }[cfg.reward]()
     kwargs = dict(
         terminal_time=T, n_steps=cfg.n_steps, reward_function=rew, model_dynamics=md, initial_cash=cfg.initial_cash,

@@ -111,7 +111,20 @@ def _two_factor_midprice(g, normalised=False, **kw):  # cases "user_two_factor_m
     return env
 
 
-CASES = {"user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
+def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed": NumPy-only plugins on the trading-with-speed kernels, built by the
+    def build(g, **kw):  # shared factory exactly as the generic fixture tests build them (tests/env_factory.py picks the NumPy classes there)
+        from tests.env_factory import make_env
+
+        env = make_env(load_case(name)[0], noise="injected", **kw)
+        if name == "user_cev_midprice_speed":
+            env.model_dynamics.midprice_model.rng = Replay(normals=g["z"])
+        return env
+
+    return build
+
+
+CASES = {"user_reward_speed": _speed("user_reward_speed"), "user_cev_midprice_speed": _speed("user_cev_midprice_speed"),
+         "user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
          "user_two_factor_midprice_normalised": lambda g, **kw: _two_factor_midprice(g, normalised=True, **kw),
          "user_fill_and_reward": _fill_and_reward, "user_fill_hawkes_market_normalised": _fill_hawkes_market, "user_seasonal_arrivals": _seasonal_arrivals,
          "user_cross_hawkes": _cross_hawkes}
@@ -124,7 +137,8 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
     env = _quiet(lambda: CASES[name](g, precise_state=precise))
     exact = env.precise_state  # implied by a host-computed reward
     host_midprice = "midprice" in name
-    assert exact == (precise or name == "user_fill_and_reward" or host_midprice)  # host-formed rewards imply the float64 tier
+    speed = name.endswith("_speed")
+    assert exact == (precise or name == "user_fill_and_reward" or host_midprice or speed)  # host-formed rewards imply the float64 tier
     env.record_events(True)
     obs = env.reset()
     n, normalised = cfg.num_trajectories, cfg.normalise_observation_space
@@ -132,8 +146,14 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
         np.testing.assert_array_equal(obs, g["obs0"].astype(np.float32))
     q_of = (lambda o: np.rint((o[:, 1].astype(np.float64) + 1) * cfg.max_inventory - cfg.max_inventory)) if normalised else (lambda o: o[:, 1].astype(np.float64))
     for k in range(g["actions"].shape[0]):
-        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])  # (a host midprice draws its normals itself, from the replayed generator: z is not read)
+        env.set_noise(None if speed else g["u_arr"][k], None if speed else g["u_fill"][k], g["z"][k])  # (a host midprice draws its normals itself, from the replayed generator: z is not read)
         obs, rew, dones, infos = env.step(g["actions"][k])
+        if speed:  # no order flow (MD:273-275): inventory is real-valued state, the reference's to the bit in this tier
+            np.testing.assert_array_equal(env.state64, g["obs"][k], err_msg=f"{name} step {k}: float64 state")
+            np.testing.assert_array_equal(rew, g["rewards"][k].astype(np.float32), err_msg=f"{name} step {k}: rewards")
+            np.testing.assert_array_equal(obs, g["obs"][k].astype(np.float32), err_msg=f"{name} step {k}: observation")
+            assert bool(dones[0]) == bool(g["done"][k])
+            continue
         if host_midprice and not normalised:  # the model's own columns, advanced by ITS update() on the host in float64: the reference's values
             np.testing.assert_array_equal(env.state64[:, 3:], g["obs"][k][:, 3:], err_msg=f"{name} step {k}: float64 midprice columns")
         np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"{name} step {k}: arrivals")
@@ -172,19 +192,23 @@ def test_host_callback_plugins_say_so_and_have_no_fused_rollout():
     env.close()
 
 
-def test_host_computed_rewards_feed_the_episode_statistics():
-    """What the host files with mbt_env_set_host_rewards is what the device-side accounting sees: reward buffer, return sums."""
-    cfg, g = load_case("user_fill_and_reward")
-    env = _quiet(lambda: CASES["user_fill_and_reward"](g))
+@pytest.mark.parametrize("name", ["user_fill_and_reward", "user_reward_speed"])
+def test_host_computed_rewards_feed_the_episode_statistics(name):
+    """What the host files with mbt_env_set_host_rewards is what the device-side accounting sees: reward buffer, return sums - also
+    on the speed kernels, which file their own reward first and have it REPLACED (include/mbt_env.h, MBT_REW_HOST)."""
+    import torch
+
+    cfg, g = load_case(name)
+    env = _quiet(lambda: CASES[name](g))
     env.reset()
     total = np.zeros(cfg.num_trajectories, np.float64)
+    speed = name.endswith("_speed")
     for k in range(10):
-        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        env.set_noise(None if speed else g["u_arr"][k], None if speed else g["u_fill"][k], g["z"][k])
         _, rew, _, _ = env.step(g["actions"][k])
         total += rew
-        import torch
-
         np.testing.assert_array_equal(torch.as_tensor(env.reward_device, device="cuda").cpu().numpy(), rew)
+        np.testing.assert_array_equal(rew, g["rewards"][k].astype(np.float32))
     assert env.episode_return_sums()[0] == pytest.approx(total.sum(), rel=1e-6)
     env.close()
 

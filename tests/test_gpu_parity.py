@@ -26,7 +26,7 @@ import pytest
 
 from oracle.mbt_oracle import InjectedNoise, OracleEnv
 from tests.env_factory import make_env
-from tests.golden_io import CASES, load_case, step_size_changes
+from tests.golden_io import KERNEL_NOISE_CASES as CASES, load_case, step_size_changes
 
 pytestmark = pytest.mark.gpu
 

@@ -766,9 +766,45 @@ def user_plugin_cases(only=None):
              max_inventory=4, seed=63, **common),
         poisson_thr=40.0 / ns, action_kind="touch")
 
+    # X1 / X2 (round 4). NumPy-only plugins with TRADING-WITH-SPEED dynamics (MD:243-275): a user reward next to a stateful impact
+    #     model, with the inventory limit in reach; a user midprice under the Cartea-Jaimungal execution criterion (RW:39-74)
+    n, ns = 32, 100
+    run_case(
+        "user_reward_speed",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=71, initial_inventory=10, max_inventory=10, num_trajectories=n,
+            reward_function=UserExponentialInventoryCost(0.02, 0.15, 0.01),
+            model_dynamics=TradinghWithSpeedModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(drift=0.02, volatility=1.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                price_impact_model=TemporaryAndPermanentPriceImpact(temporary_impact_coefficient=0.02, permanent_impact_coefficient=0.015, n_steps=ns, terminal_time=1.0, num_trajectories=n),
+                num_trajectories=n),
+            **common),
+        ns, n, 1, 71,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.02, volatility=1.0, initial_price=100.0, arrival="none", dynamics="speed",
+             midprice_step_size=1 / ns, impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, impact_step_size=1.0 / ns,
+             reward="user_exp_inventory_cost", phi=0.02, eta=0.15, alpha=0.01, initial_inventory=10, max_inventory=10, seed=71, **common),
+        action_kind="speed")
+    run_case(
+        "user_cev_midprice_speed",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=72, initial_inventory=10, max_inventory=1000, num_trajectories=n,
+            reward_function=CjOeCriterion(per_step_inventory_aversion=0.01, terminal_inventory_aversion=0.05, terminal_time=1.0),
+            model_dynamics=TradinghWithSpeedModelDynamics(
+                midprice_model=UserCevMidprice(0.05, 0.6, 0.75, 50.0, 20.0, 80.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                price_impact_model=TemporaryPowerPriceImpact(temporary_impact_coefficient=0.03, temporary_impact_exponent=1.0, num_trajectories=n),
+                num_trajectories=n),
+            **common),
+        ns, n, 1, 72,
+        dict(n_steps=ns, terminal_time=1.0, midprice="user_cev", drift=0.05, volatility=0.6, cev_gamma=0.75, initial_price=50.0, midprice_lo=20.0,
+             midprice_hi=80.0, arrival="none", dynamics="speed", midprice_step_size=1 / ns, impact="temp_power", temporary_impact=0.03, impact_exponent=1.0,
+             reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10, max_inventory=1000, seed=72, **common),
+        action_kind="speed")
+
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-round4":  # NumPy-only plugins with speed dynamics (leaves the other fixtures' bytes untouched)
+        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
         user_plugin_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
         exogenous_fill_cases()
