@@ -84,7 +84,11 @@ enum {
 };
 enum {
   MBT_IMPACT_NONE = -1, MBT_IMPACT_TEMPORARY_POWER = 0 /* IMP:34-61 */, MBT_IMPACT_TEMPORARY_AND_PERMANENT = 1 /* IMP:64-96 */,
-  MBT_IMPACT_TEMPORARY_AND_TRANSIENT = 2 /* IMP:99-139 */, MBT_IMPACT_TRANSIENT = 3 /* IMP:142-179 */
+  MBT_IMPACT_TEMPORARY_AND_TRANSIENT = 2 /* IMP:99-139 */, MBT_IMPACT_TRANSIENT = 3 /* IMP:142-179 */,
+  /* a PriceImpactModel subclass (IMP:9-31) that only has HOST code: get_impact(action) runs in the caller before every step
+   * (mbt_env_set_host_impacts), see "host-callback plugins"; _STATE: the model owns the state column y (initial value
+   * initial_transient_impact), advanced by its own update() on the host (mbt_env_set_host_state_columns).  precise_state only. */
+  MBT_IMPACT_HOST = 4, MBT_IMPACT_HOST_STATE = 5
 };
 enum {
   MBT_NOISE_PHILOX = 0,   /* counter-based Philox4x32-10 drawn inside the kernel (production) */
@@ -309,15 +313,20 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code);
  *      mbt_env_set_host_state_columns - BEFORE step 4, whose `next_state` shows them: the reward function (built-in classes
  *      included: mbt_reward_calculate_host evaluates them on the float64 matrices) is then a host callback by construction, which
  *      is why MBT_MID_HOST is only accepted together with MBT_REW_HOST.  With trading-with-speed dynamics: the price column alone.
+ *   6. MBT_IMPACT_HOST / MBT_IMPACT_HOST_STATE (trading-with-speed dynamics, precise_state): the caller's get_impact(action) on the
+ *      de-normalised action (MD:263; float64 (N)) -> mbt_env_set_host_impacts before the step: execution price = midprice + that
+ *      value.  A model that owns the impact-state column keeps it on the host and files it after its update() like the others.
  * Fused rollouts are not available for such an environment (MBT_ERR_INVALID): the host is consulted every step. */
 int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_host);
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
 int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
 int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
+int mbt_env_set_host_impacts(mbt_env* env, const double* impacts_host);
 /* The state columns host-callback processes OWN (SP:8-53), ONE contiguous block in registry order (TE:303-318): with
  * MBT_MID_HOST the midprice column 3 and the midprice model's further columns (declared through mbt_user_code.state_columns /
  * state_initial / state_owner = 0 with NULL update expressions), then the columns of a host-callback arrival model that owns
- * state (state_owner = 1, NULL update expressions; mbt_env_create_jit) - d columns in all.  The kernel carries them through the
+ * state (state_owner = 1, NULL update expressions; mbt_env_create_jit) or, with speed dynamics, the impact-state column of
+ * MBT_IMPACT_HOST_STATE - d columns in all.  The kernel carries them through the
  * step unchanged; after the caller's update(arrivals, fills, action, state) calls ran, the new (N, d) float64 values are filed
  * with this call - their float32 rounding into the state row (TE:206-211: the reference copies process.current_state into the
  * state matrix), the int32 remainders too under precise_state, the normalised observation row if there is one.  Also valid

@@ -18,7 +18,7 @@ ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER, ARR_HOST = 0
 FILL_EXPONENTIAL, FILL_NONE, FILL_EXOGENOUS_MM, FILL_USER, FILL_HOST = 0, 1, 2, 3, 4
 DYN_LIMIT, DYN_LIMIT_AND_MARKET, DYN_AT_THE_TOUCH, DYN_SPEED = 0, 1, 2, 3
 REW_PNL, REW_RUNNING_PENALTY, REW_CJ_MM, REW_EXP_UTILITY, REW_CJ_OE, REW_USER, REW_HOST = 0, 1, 2, 3, 4, 5, 6
-IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT = -1, 0, 1, 2, 3
+IMPACT_NONE, IMPACT_TEMPORARY_POWER, IMPACT_TEMPORARY_AND_PERMANENT, IMPACT_TEMPORARY_AND_TRANSIENT, IMPACT_TRANSIENT, IMPACT_HOST, IMPACT_HOST_STATE = -1, 0, 1, 2, 3, 4, 5
 NOISE_PHILOX, NOISE_INJECTED = 0, 1
 
 
@@ -205,6 +205,7 @@ SIGNATURES = {
     "mbt_env_host_depths": (C.c_int, [_ENV, _F, C.POINTER(C.c_double)]),
     "mbt_env_set_host_fill_probabilities": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_set_host_arrivals": (C.c_int, [_ENV, _F]),
+    "mbt_env_set_host_impacts": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_set_host_rewards": (C.c_int, [_ENV, C.POINTER(C.c_double), _F]),
     "mbt_env_set_host_state_columns": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_step_many_device": (C.c_int, [_ENV, C.c_uint32, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -223,7 +223,8 @@ template <bool STATE>
 StepKernel pick_speed(bool powers, bool norm, bool inject, int mode) {
   return powers ? pick_speed_pow<STATE, true>(norm, inject, mode) : pick_speed_pow<STATE, false>(norm, inject, mode);
 }
-bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT; }
+bool host_impact(const mbt_config& c) { return c.impact_kind == MBT_IMPACT_HOST || c.impact_kind == MBT_IMPACT_HOST_STATE; }
+bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT && c.impact_kind != MBT_IMPACT_HOST; }
 // does this speed-dynamics configuration raise anything to a power other than 1 (impact, IMP:55) or 2 (inventory penalty,
 // RW:59-68), or use the exponential utility?  (No reference configuration does; the kernels without are a quarter the code.)
 bool speed_powers(const mbt_config& c) {
@@ -284,10 +285,17 @@ StepKernel pick_speed_precise(bool powers, bool inject, int mode) {
                 : pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, false>, mbt::SpeedVariant<STATE, true, true, true, false>, STATE>(inject, mode);
 }
 
+// (a host-callback price impact model: the precise_state kernels with SpeedVariant::HOST_IMPACT, general reward form)
+template <bool STATE>
+StepKernel pick_speed_host_impact(bool inject, int mode) {
+  return pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true, true>, mbt::SpeedVariant<STATE, true, true, true, true, true>, STATE>(inject, mode);
+}
+
 StepKernel pick_kernel(const mbt_config& c, int mode) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
   if (c.dynamics_kind == MBT_DYN_SPEED) {
+    if (host_impact(c)) return impact_has_state(c) ? pick_speed_host_impact<true>(inject, mode) : pick_speed_host_impact<false>(inject, mode);
     if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(speed_powers(c), inject, mode) : pick_speed_precise<false>(speed_powers(c), inject, mode);
     return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, mode) : pick_speed<false>(speed_powers(c), norm, inject, mode);
   }
@@ -689,6 +697,8 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   }
   if ((e->host_mask & mbt::kHostFill) && !e->host_fill_ready)
     return fail(MBT_ERR_STATE, "host-callback fill model: mbt_env_set_host_fill_probabilities must precede every step()");
+  if ((e->host_mask & mbt::kHostImpact) && !e->host_fill_ready)
+    return fail(MBT_ERR_STATE, "host-callback price impact model: mbt_env_set_host_impacts must precede every step()");
   if ((e->host_mask & mbt::kHostArrival) && !e->host_arrivals_ready)
     return fail(MBT_ERR_STATE, "host-callback arrival model: mbt_env_set_host_arrivals must precede every step()");
   if (e->host_reward_pending)
@@ -1500,8 +1510,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (speed) {
     if (cfg->arrival_kind != MBT_ARR_NONE || cfg->fill_kind != MBT_FILL_NONE)
       return fail(MBT_ERR_INVALID, "speed dynamics take no arrival or fill model (MD:273-275)");
-    if (cfg->impact_kind < MBT_IMPACT_TEMPORARY_POWER || cfg->impact_kind > MBT_IMPACT_TRANSIENT)
+    if (cfg->impact_kind < MBT_IMPACT_TEMPORARY_POWER || cfg->impact_kind > MBT_IMPACT_HOST_STATE)
       return fail(MBT_ERR_INVALID, "speed dynamics need a price impact model (impact kind %d)", cfg->impact_kind);
+    if (host_impact(*cfg) && !cfg->precise_state)
+      return fail(MBT_ERR_INVALID, "MBT_IMPACT_HOST: the caller's get_impact() returns float64 values - set precise_state");
     if (cfg->midprice_kind == MBT_MID_BROWNIAN_JUMP || cfg->midprice_kind == MBT_MID_OU_JUMP ||
         (cfg->midprice_kind == MBT_MID_LINEAR_SDE && cfg->jump_size != 0.0))
       return fail(MBT_ERR_INVALID, "jump midprice models move on the agent's fills; speed dynamics have none");
@@ -1555,6 +1567,10 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
         if (e->host_state_count == 0) e->host_state_first = 4 + j;
         e->host_state_count += 1;
       }
+  if (cfg->impact_kind == MBT_IMPACT_HOST_STATE) {  // the impact-state column, behind the midprice column of speed rows
+    if (e->host_state_count == 0) e->host_state_first = 4;
+    e->host_state_count += 1;
+  }
   e->host_mid = host_mid;
   for (int j = 0; j < 2; ++j) e->user_state_initial[j] = needs_jit ? code->state_initial[j] : 0.0;
   e->dim = speed ? (impact_has_state(*cfg) ? 5 : 4) : 4 + (cfg->arrival_kind == MBT_ARR_HAWKES ? 2 : 0) + (exogenous_fill(*cfg) ? 2 : 0) + e->user_state_columns;
@@ -1572,7 +1588,8 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->arr_dt = cfg->arrival_step_size > 0.0 ? cfg->arrival_step_size : e->dt;
   e->imp_dt = cfg->impact_step_size > 0.0 ? cfg->impact_step_size : e->dt;
   e->seed = cfg->seed;
-  e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | ((host_reward || host_lowered.speed_reward) ? mbt::kHostReward : 0);
+  e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | ((host_reward || host_lowered.speed_reward) ? mbt::kHostReward : 0) |
+                 (host_impact(*cfg) ? mbt::kHostImpact : 0);
   e->host_reward_replaces = host_lowered.speed_reward;
   e->res = !cfg->precise_state ? 0 : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
   tune_for_size(e);
@@ -1646,7 +1663,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   ENV_TRY(dev_alloc(&e->log_dev, 3 * mbt_env::kLogSlots, e->stream));
   ENV_TRY(dev_alloc(&e->done_counter, 1, e->stream));
   if (e->host_mask != 0) {
-    if (host_fill) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));
+    if (host_fill || host_impact(*cfg)) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));  // (N, 2) fill probabilities / (N) price impacts
     if (host_arrival) ENV_TRY(dev_alloc(&e->host_arrivals, np * 2, e->stream));
     ENV_TRY(dev_alloc(&e->host_scratch, np * 4, e->stream));  // (N) rewards or (N, d <= 3) state columns, float64
   }
@@ -1712,7 +1729,7 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
   const bool user_mid = cfg->midprice_kind == MBT_MID_USER;
   const bool any_host = cfg->fill_kind == MBT_FILL_HOST || cfg->arrival_kind == MBT_ARR_HOST || cfg->reward_kind == MBT_REW_HOST;
   if (!user_fill && !user_reward && !user_arrival && !user_mid && !any_host) {
-    if (host_lowered.speed_reward) return MBT_OK;  // host-formed rewards on the ahead-of-time speed kernels: nothing to compile
+    if (host_lowered.speed_reward || host_lowered.midprice || host_impact(*cfg)) return MBT_OK;  // host callbacks on the ahead-of-time speed kernels: nothing to compile
     return fail(MBT_ERR_INVALID, "no plugin kind of the configuration names a user-defined plugin");
   }
   if (user_mid && (code->midprice_increment == nullptr || code->midprice_increment[0] == 0)) return fail(MBT_ERR_INVALID, "MBT_MID_USER without a midprice_increment expression");
@@ -2056,6 +2073,16 @@ int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  e->host_fill_ready = true;
+  return MBT_OK;
+}
+
+int mbt_env_set_host_impacts(mbt_env* e, const double* impacts_host) {
+  if (e == nullptr || impacts_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!(e->host_mask & mbt::kHostImpact)) return fail(MBT_ERR_STATE, "the price impact model of this environment is not a host callback (MBT_IMPACT_HOST)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->host_fill_p, impacts_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the caller's array may go away
   e->host_fill_ready = true;
   return MBT_OK;
 }

@@ -23,9 +23,14 @@
 
 namespace mbt {
 
-template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false, bool POWERS_ = true>
+template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false, bool POWERS_ = true, bool HOST_IMPACT_ = false>
 struct SpeedVariant {
   static constexpr bool HAS_IMPACT_STATE = HAS_IMPACT_STATE_, NORM = NORM_, INJECT = INJECT_;
+  // HOST_IMPACT: a PriceImpactModel subclass that only has HOST code (MBT_IMPACT_HOST / MBT_IMPACT_HOST_STATE): the (N) float64
+  // impacts its get_impact(action) returned for this step are read from StepBuffers::host_fill_p, its state column (if it owns
+  // one) passes through unchanged - ITS update() advances it on the host (mbt_env_set_host_state_columns).  precise_state only.
+  static constexpr bool HOST_IMPACT = HOST_IMPACT_;
+  static_assert(!HOST_IMPACT_ || PRECISE_, "host-computed price impacts are float64 values: the precise_state tier");
   // POWERS: the instantiation can raise to arbitrary powers (a temporary impact with exponent != 1, IMP:55; an inventory
   // penalty with exponent != 2, RW:59-68; exponential utility).  Every reference configuration has exponent 1 / 2: the host
   // picks the instantiation WITHOUT them then (mbt_env.hip: pick_speed) - four inlined powf bodies made the kernel 3300
@@ -115,12 +120,14 @@ struct SpeedResultExact {
 
 template <class V>
 __device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s, float a_raw, float z, float q_init, bool is_terminal,
-                                                             double t_now, double t_next, const StepParams& P) {
+                                                             double t_now, double t_next, const StepParams& P, double host_impact = 0.0) {
   const PreciseParams& X = P.X;
   double v = a_raw;
   if (V::NORM && P.norm_act) v = (static_cast<double>(a_raw) + 1.0) * P.act_grad[0] + P.act_lo[0];  // TE:124
   double impact, y_new = s.y;
-  switch (P.impact_kind) {
+  if (V::HOST_IMPACT) {
+    impact = host_impact;  // price_impact_model.get_impact(action) (MD:263), evaluated by the caller's own class on the host
+  } else switch (P.impact_kind) {
     case kImpactTempPower: impact = X.temp_coef * (V::POWERS ? numpy_power(v, X.impact_exponent) : numpy_power_1_or_2(v, X.impact_exponent)); break;  // IMP:55-56
     case kImpactTempPerm:
       impact = X.temp_coef * v + s.y;                         // IMP:90-91
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES
     SpeedExact exact_next = {0.0, 0.0, 0.0, 0.0};
     if (V::PRECISE) {  // the reference's float64 arithmetic on the exactly held state (speed_lane_exact); the row keeps the float32 roundings
       const SpeedExact e = {exact_join(s[l].cash, lo4[l].x), exact_join(s[l].q, lo4[l].y), exact_join(s[l].mid, lo4[l].z), V::DIM == 5 ? exact_join(s[l].y, lo4[l].w) : 0.0};
-      const SpeedResultExact rx = speed_lane_exact<V>(e, act[l], z[l], qi[l], P.is_terminal != 0, P.t_now, P.t_next_f64, P);
+      const SpeedResultExact rx = speed_lane_exact<V>(e, act[l], z[l], qi[l], P.is_terminal != 0, P.t_now, P.t_next_f64, P,
+                                                      V::HOST_IMPACT ? B.host_fill_p[lane] : 0.0);
       exact_next = rx.next;
       int32_t lo_c, lo_q, lo_m, lo_y = 0;
       exact_split(rx.next.cash, r.next.cash, lo_c);

@@ -55,7 +55,7 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 // Compile-time shape of one kernel instantiation: what changes the memory layout or the amount of noise is a
 // template parameter; the midprice and reward kinds are wave-uniform runtime switches (a few scalar branches).
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
-enum : int { kHostFill = 1, kHostArrival = 2, kHostReward = 4 };
+enum : int { kHostFill = 1, kHostArrival = 2, kHostReward = 4, kHostImpact = 8 /* speed kernels: SpeedVariant::HOST_IMPACT; host library only */ };
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
           bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false, int USER_STATE_ = 0,
@@ -245,7 +245,7 @@ struct StepBuffers {
   uint32_t flag_value;
   uint32_t reserved_pad;
   // host-callback plugins (Variant::HOST): what the host computed for this step
-  const double* host_fill_p;   // (n_pad, 2) fill probabilities of this step's depths
+  const double* host_fill_p;   // (n_pad, 2) fill probabilities of this step's depths; speed dynamics with a host-callback impact model: (n_pad) price impacts
   const float* host_arrivals;  // (n_pad, 2) arrivals as 0.0f / 1.0f
 };
 

@@ -74,6 +74,8 @@ def host_callback_role(part):
         return "arrival"
     if isinstance(part, RewardFunction) and type(part).calculate is not RewardFunction.calculate:
         return "reward"
+    if isinstance(part, PriceImpactModel) and type(part).get_impact is not PriceImpactModel.get_impact:
+        return "impact"  # IMP:25-27
     return None
 
 
@@ -139,10 +141,11 @@ class TradingEnvironment(_EnvBase):
         self.trajectory_offset = trajectory_offset
         self.noise = noise
         self._host_plugins = self._find_host_plugins()
-        if (self._host_plugins.get("reward") is not None or "midprice" in self._host_plugins) and not precise_state:
+        if (self._host_plugins.get("reward") is not None or "midprice" in self._host_plugins or "impact" in self._host_plugins) and not precise_state:
             # calculate() is handed the two state matrices: only the float64 tier hands it the reference's (a reward formed
             # from float32-rounded cash and midprice levels is off by the rounding of the LEVELS, ~1e-4).  A host midprice
-            # implies a host-formed reward: the step's reward holds the midprice its update() computes AFTER the launch
+            # implies a host-formed reward: the step's reward holds the midprice its update() computes AFTER the launch; a host
+            # price impact model hands the kernel float64 impacts
             precise_state = True
         self.precise_state = precise_state
         self.allow_stiff_hawkes = allow_stiff_hawkes
@@ -221,6 +224,11 @@ class TradingEnvironment(_EnvBase):
                 fields.update(kind)
         if "midprice" in self._host_plugins:
             fields["initial_price"] = float(np.asarray(md.midprice_model.initial_state, dtype=np.float64)[0, 0])
+        if "impact" in self._host_plugins:
+            impact = self._host_plugins["impact"]
+            fields["impact_kind"] = _native.IMPACT_HOST_STATE if impact.state_dim else _native.IMPACT_HOST
+            if impact.state_dim:
+                fields["initial_transient_impact"] = float(np.asarray(impact.initial_state, dtype=np.float64)[0, 0])
         for key in ("midprice_step_size", "arrival_step_size", "impact_step_size"):
             if fields.get(key) is None:
                 fields[key] = 0.0  # 0 = the environment's terminal_time / n_steps
@@ -453,19 +461,21 @@ class TradingEnvironment(_EnvBase):
         """{role: object} for the plugin objects whose class has no device form (see `host_callback_role`)."""
         md = self.model_dynamics
         found = {}
-        for slot, part in (("midprice", md.midprice_model), ("arrival", md.arrival_model), ("fill", md.fill_probability_model), ("reward", self.reward_function)):
+        for slot, part in (("midprice", md.midprice_model), ("arrival", md.arrival_model), ("fill", md.fill_probability_model), ("impact", md.price_impact_model),
+                           ("reward", self.reward_function)):
             role = host_callback_role(part) if part is not None else None
             if role is None:
                 continue
             if role != slot:
                 raise UnsupportedOnDevice(f"{type(part).__name__} is a {role} model by its class, handed over as the {slot} model")
-            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2) or (role == "midprice" and not 1 <= part.state_dim <= 3):
+            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2) or (role == "midprice" and not 1 <= part.state_dim <= 3) or (
+                    role == "impact" and part.state_dim > 1):
                 raise UnsupportedOnDevice(
                     f"{type(part).__name__} only has host (NumPy) code AND owns {part.state_dim} state column(s): the host-callback route serves "
-                    "stateless fill models, arrival models with at most two columns of their own and midprice models with at most two beside the "
-                    "price (otherwise: a device expression, DeviceExpressionArrivalModel / DeviceExpressionMidpriceModel)")
+                    "stateless fill models, arrival models with at most two columns of their own, midprice models with at most two beside the "
+                    "price and price impact models with at most one (otherwise: a device expression, DeviceExpressionArrivalModel / DeviceExpressionMidpriceModel)")
             found[role] = part
-            if role in ("fill", "arrival", "midprice"):
+            if role in ("fill", "arrival", "midprice", "impact"):
                 part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
         if "midprice" in found:
             if md.price_impact_model is not None and found["midprice"].state_dim > 1:
@@ -482,7 +492,8 @@ class TradingEnvironment(_EnvBase):
             warnings.warn(
                 "host-callback plugins: " + ", ".join(f"{type(p).__name__} ({r})" for r, p in found.items()) + " only have NumPy code, which "
                 "runs on the host between kernel launches every step (one or two extra host round trips per step; no fused rollout).  "
-                "State the formula as a device expression (DeviceExpressionFillModel / ...ArrivalModel / ...Reward) for the fast path.",
+                "State the formula as a device expression (DeviceExpressionFillModel / ...ArrivalModel / ...MidpriceModel / ...Reward; order-book "
+                "dynamics) for the fast path.",
                 HostCallbackWarning, stacklevel=3)
         return found
 
@@ -490,7 +501,7 @@ class TradingEnvironment(_EnvBase):
         """(first, last, blocks): the ONE contiguous block of state columns host-callback processes own, in registry order
         (midprice columns, then a stateful arrival model's), as mbt_env_set_host_state_columns takes it."""
         blocks = []
-        for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model")):
+        for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model"), ("impact", "price_impact_model")):
             part = self._host_plugins.get(role)
             if part is not None and part.state_dim > 0:
                 blocks.append((part, *self.stochastic_process_indices[name]))
@@ -512,10 +523,10 @@ class TradingEnvironment(_EnvBase):
         return lo, hi, columns
 
     def _reset_host_plugins(self, obs=None):
-        for role in ("midprice", "arrival", "fill"):
+        for role in ("midprice", "arrival", "fill", "impact"):
             if role in self._host_plugins:
                 self._host_plugins[role].reset()  # TE:97-98
-        if "midprice" in self._host_plugins:  # (an arrival model's initial columns are the configuration's; a midprice's reset() may set any)
+        if "midprice" in self._host_plugins or "impact" in self._host_plugins:  # (an arrival model's initial columns are the configuration's; these reset()s may set any)
             self._file_host_columns(obs)
         self._host_state64 = self.state64  # what the next step's update() / calculate() calls are handed as the state before it
         if "reward" in self._host_plugins or "midprice" in self._host_plugins:
@@ -545,6 +556,10 @@ class TradingEnvironment(_EnvBase):
         if arrival is not None:
             arrived = np.ascontiguousarray(np.broadcast_to(np.asarray(arrival.get_arrivals()), (n, 2)), dtype=np.float32)  # ARR:27-29
             _native.check(lib.mbt_env_set_host_arrivals(handle, _native.fptr(arrived)))
+        if "impact" in plugins:  # MD:263: price_impact_model.get_impact(action) on the de-normalised action (as the kernel de-normalises it: from float32)
+            speeds = self.normalise_action(act.astype(np.float64), inverse=True)
+            impacts = np.ascontiguousarray(np.broadcast_to(np.asarray(plugins["impact"].get_impact(speeds), dtype=np.float64).reshape(-1, 1), (n, 1))[:, 0])
+            _native.check(lib.mbt_env_set_host_impacts(handle, dptr(impacts)))
         obs = pools["obs"].acquire()[0]
         rewards = pools["rewards"].acquire()[0]
         done = C.c_int32(0)

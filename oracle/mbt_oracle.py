@@ -108,7 +108,8 @@ class OracleConfig:
     market_half_spread: float = 0.5  # MD:189
     max_depth: Optional[float] = None  # MD:103 / FILL:60-62
     # price impact (speed dynamics): "temp_power" (IMP:34-61), "temp_perm" (IMP:64-96), "temp_transient" (IMP:99-139),
-    # "transient" (IMP:142-179)
+    # "transient" (IMP:142-179); "user_sqrt": a USER-DEFINED PriceImpactModel subclass (plugin contract IMP:9-31) -
+    # impact = temporary_impact * sign(v) sqrt(|v|) + y with y <- y - resilience y dt + kernel_coefficient v dt (tests/numpy_only_plugins.py)
     impact: str = "none"
     temporary_impact: float = 0.01
     impact_exponent: float = 1.0  # IMP:38
@@ -150,7 +151,7 @@ class OracleConfig:
 
     @property
     def impact_has_state(self) -> bool:
-        return self.impact in ("temp_perm", "temp_transient", "transient")
+        return self.impact in ("temp_perm", "temp_transient", "transient", "user_sqrt")
 
     @property
     def arrival_columns(self) -> int:
@@ -252,7 +253,7 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
         lo += [float(v) for v in cfg.exo_depth_lo]
         hi += [float(v) for v in cfg.exo_depth_hi]
     if cfg.impact_has_state:  # IMP:77-78, IMP:117-118, IMP:158-159
-        coef = cfg.permanent_impact if cfg.impact == "temp_perm" else cfg.transient_impact
+        coef = cfg.permanent_impact if cfg.impact == "temp_perm" else cfg.kernel_coefficient if cfg.impact == "user_sqrt" else cfg.transient_impact
         lo.append(-cfg.max_speed * cfg.terminal_time * coef)
         hi.append(cfg.max_speed * cfg.terminal_time * coef)
     return np.float32(np.array(lo)), np.float32(np.array(hi))
@@ -419,6 +420,8 @@ class OracleEnv:
                 price_impact = cfg.temporary_impact * action + y  # IMP:90-91
             elif cfg.impact == "temp_transient":
                 price_impact = cfg.temporary_impact * action + cfg.transient_impact * y  # IMP:134-135
+            elif cfg.impact == "user_sqrt":  # the user's get_impact()
+                price_impact = cfg.temporary_impact * np.sign(action) * np.sqrt(np.abs(action)) + y
             else:
                 price_impact = cfg.transient_impact * y  # IMP:174-175
             execution_price = mid + price_impact

@@ -39,10 +39,11 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
     # trading-with-speed dynamics run on kernels built ahead of time: a user's plugin takes the host-callback route there, as the
     # NumPy class it is (tests/numpy_only_plugins.py, bound to `package`'s base classes) - not a device expression
     numpy_only = None
-    if cfg.dynamics == "speed" and (cfg.midprice == "user_cev" or cfg.reward == "user_exp_inventory_cost"):
+    if cfg.dynamics == "speed" and (cfg.midprice == "user_cev" or cfg.reward == "user_exp_inventory_cost" or cfg.impact == "user_sqrt"):
         from tests.numpy_only_plugins import define
 
-        numpy_only = define(fill_m.FillProbabilityModel, arr_m.ArrivalModel, rw.RewardFunction, importlib.import_module(package + ".gym.index_names"))
+        numpy_only = define(fill_m.FillProbabilityModel, arr_m.ArrivalModel, rw.RewardFunction, importlib.import_module(package + ".gym.index_names"),
+                            PriceImpactModel=imp_m.PriceImpactModel)
     mid_dt = cfg.midprice_step_size or dt
     arr_dt = cfg.arrival_step_size or dt
     common = dict(terminal_time=T, step_size=mid_dt, num_trajectories=n)
@@ -106,6 +107,8 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
                                                                              cfg.kernel_coefficient, n_steps=imp_steps, terminal_time=T, num_trajectories=n),
             "transient": lambda: imp_m.TransientPriceImpact(cfg.transient_impact, cfg.resilience, cfg.initial_transient_impact, cfg.kernel_coefficient,
                                                             n_steps=imp_steps, terminal_time=T, num_trajectories=n),
+            "user_sqrt": lambda: numpy_only.UserSquareRootImpact(cfg.temporary_impact, cfg.resilience, cfg.kernel_coefficient, cfg.max_speed,
+                                                                 step_size=cfg.impact_step_size or dt, terminal_time=T, num_trajectories=n),
         }[cfg.impact]()
         md = dyn.TradinghWithSpeedModelDynamics(midprice_model=mid, price_impact_model=impact, num_trajectories=n)
     rew = {

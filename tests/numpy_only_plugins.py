@@ -1,6 +1,7 @@
 """Plugin subclasses as a user of the REFERENCE writes them: NumPy only, against the reference's plugin contract
 (`FillProbabilityModel._get_fill_probabilities` FILL:22-34, `ArrivalModel.get_arrivals` ARR:27-29, `RewardFunction.calculate`
-RW:10-13, `MidpriceModel.update` SP:33-35), with no device expression and no knowledge of this package.
+RW:10-13, `MidpriceModel.update` SP:33-35, `PriceImpactModel.get_impact` IMP:25-27), with no device expression and no knowledge of
+this package.
 
 ONE source for both sides of the parity tests: `define(...)` is handed the base classes of whichever package the classes are
 to live in - the reference's (`tools/refgen/make_golden.py`, build container only: the fixtures `user_fill_and_reward`,
@@ -13,9 +14,10 @@ import types
 import numpy as np
 
 
-def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, MidpriceModel=None):
+def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, MidpriceModel=None, PriceImpactModel=None):
     """The classes, bound to the given plugin base classes and state-column indices."""
     MidpriceModel = MidpriceModel or ArrivalModel.__mro__[1]  # (MidpriceModel IS StochasticProcessModel, MID:9)
+    PriceImpactModel = PriceImpactModel or MidpriceModel
     CASH_INDEX, INVENTORY_INDEX, TIME_INDEX, ASSET_PRICE_INDEX = (
         index_names.CASH_INDEX, index_names.INVENTORY_INDEX, index_names.TIME_INDEX, index_names.ASSET_PRICE_INDEX)
 
@@ -120,7 +122,28 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, Midp
             a_new = a - self.kappa * a * dt + self.xi * np.sqrt(dt) * z[:, 1:2] + self.eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
             self.current_state = np.append(s_new, a_new, axis=1)
 
-    return types.SimpleNamespace(UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
+    class UserSquareRootImpact(PriceImpactModel):
+        """The square-root law of market impact on top of a transient component that decays (IMP:9-31 asks for get_impact and
+        max_speed): impact = c sign(v) sqrt(|v|) + y;  y <- y - rho y dt + k v dt.  The model OWNS the state column y."""
+
+        def __init__(self, coefficient, resilience, kernel, max_speed, step_size, terminal_time, num_trajectories, seed=None):
+            self.coefficient, self.resilience, self.kernel, self._max_speed = coefficient, resilience, kernel, max_speed
+            bound = max_speed * terminal_time * kernel
+            super().__init__(min_value=np.array([[-bound]]), max_value=np.array([[bound]]), step_size=step_size, terminal_time=terminal_time,
+                             initial_state=np.array([[0.0]]), num_trajectories=num_trajectories, seed=seed)
+
+        def get_impact(self, action):
+            return self.coefficient * np.sign(action) * np.sqrt(np.abs(action)) + self.current_state
+
+        def update(self, arrivals, fills, actions, state=None):
+            y = self.current_state
+            self.current_state = y - self.resilience * y * self.step_size + self.kernel * actions * self.step_size
+
+        @property
+        def max_speed(self):
+            return self._max_speed
+
+    return types.SimpleNamespace(UserSquareRootImpact=UserSquareRootImpact, UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
                                  UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes,
                                  UserCevMidprice=UserCevMidprice, UserShortTermAlphaMidprice=UserShortTermAlphaMidprice)
 

@@ -111,7 +111,7 @@ def _two_factor_midprice(g, normalised=False, **kw):  # cases "user_two_factor_m
     return env
 
 
-def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed": NumPy-only plugins on the trading-with-speed kernels, built by the
+def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed", "user_impact_speed": NumPy-only plugins on the trading-with-speed kernels, built by the
     def build(g, **kw):  # shared factory exactly as the generic fixture tests build them (tests/env_factory.py picks the NumPy classes there)
         from tests.env_factory import make_env
 
@@ -124,6 +124,7 @@ def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed": NumPy
 
 
 CASES = {"user_reward_speed": _speed("user_reward_speed"), "user_cev_midprice_speed": _speed("user_cev_midprice_speed"),
+         "user_impact_speed": _speed("user_impact_speed"),
          "user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
          "user_two_factor_midprice_normalised": lambda g, **kw: _two_factor_midprice(g, normalised=True, **kw),
          "user_fill_and_reward": _fill_and_reward, "user_fill_hawkes_market_normalised": _fill_hawkes_market, "user_seasonal_arrivals": _seasonal_arrivals,

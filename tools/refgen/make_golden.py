@@ -621,7 +621,9 @@ def user_plugin_cases(only=None):
     sys.path.insert(0, REPO)
     from tests.numpy_only_plugins import define as define_numpy_only_plugins
 
-    user = define_numpy_only_plugins(FillProbabilityModel, ArrivalModel, RewardFunction, reference_index_names)
+    from mbt_gym.stochastic_processes.price_impact_models import PriceImpactModel
+
+    user = define_numpy_only_plugins(FillProbabilityModel, ArrivalModel, RewardFunction, reference_index_names, PriceImpactModel=PriceImpactModel)
     UserPowerLawFill, UserExponentialInventoryCost, UserSeasonalArrivals = user.UserPowerLawFill, user.UserExponentialInventoryCost, user.UserSeasonalArrivals
 
     common = dict(normalise_action_space=False, normalise_observation_space=False)
@@ -800,10 +802,28 @@ def user_plugin_cases(only=None):
              reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10, max_inventory=1000, seed=72, **common),
         action_kind="speed")
 
+    # X3 (round 4). a user-defined PriceImpactModel (IMP:9-31) that owns the impact-state column: the square-root law on top of a
+    #     decaying transient component, under the running inventory penalty; the inventory limit in reach
+    run_case(
+        "user_impact_speed",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=73, initial_inventory=10, max_inventory=10, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.1),
+            model_dynamics=TradinghWithSpeedModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(drift=0.02, volatility=1.0, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                price_impact_model=user.UserSquareRootImpact(0.05, 2.0, 0.3, 10.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+                num_trajectories=n),
+            **common),
+        ns, n, 1, 73,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.02, volatility=1.0, initial_price=100.0, arrival="none", dynamics="speed",
+             midprice_step_size=1 / ns, impact="user_sqrt", temporary_impact=0.05, resilience=2.0, kernel_coefficient=0.3, initial_transient_impact=0.0,
+             impact_step_size=1.0 / ns, reward="running", phi=0.01, alpha=0.1, initial_inventory=10, max_inventory=10, seed=73, **common),
+        action_kind="speed")
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--only-round4":  # NumPy-only plugins with speed dynamics (leaves the other fixtures' bytes untouched)
-        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed"))
+        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed", "user_impact_speed"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
         user_plugin_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
