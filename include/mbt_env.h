@@ -278,7 +278,7 @@ typedef struct mbt_user_code {
   const char* state_param_names;
   double state_params[8];
   double state_initial[2];
-  int32_t state_owner[2];  /* 0 = the midprice model's column (dt = its step size), 1 = the arrival model's */
+  int32_t state_owner[2];  /* 0 = the midprice model's column (dt = its step size), 1 = the arrival model's, 2 = a host-callback fill model's (MBT_FILL_HOST: no update expression) */
 } mbt_user_code;
 int mbt_env_create_jit(const mbt_config* cfg, const mbt_user_code* code, mbt_env** out);
 const char* mbt_jit_log(void);    /* thread local; "" when the last compilation had nothing to say */
@@ -325,7 +325,7 @@ int mbt_env_set_host_impacts(mbt_env* env, const double* impacts_host);
 /* The state columns host-callback processes OWN (SP:8-53), ONE contiguous block in registry order (TE:303-318): with
  * MBT_MID_HOST the midprice column 3 and the midprice model's further columns (declared through mbt_user_code.state_columns /
  * state_initial / state_owner = 0 with NULL update expressions), then the columns of a host-callback arrival model that owns
- * state (state_owner = 1, NULL update expressions; mbt_env_create_jit) or, with speed dynamics, the impact-state column of
+ * state (state_owner = 1, NULL update expressions; mbt_env_create_jit), then a host-callback fill model's (state_owner = 2) or, with speed dynamics, the impact-state column of
  * MBT_IMPACT_HOST_STATE - d columns in all.  The kernel carries them through the
  * step unchanged; after the caller's update(arrivals, fills, action, state) calls ran, the new (N, d) float64 values are filed
  * with this call - their float32 rounding into the state row (TE:206-211: the reference copies process.current_state into the

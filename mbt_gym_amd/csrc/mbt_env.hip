@@ -1486,11 +1486,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     if (any_host && cfg->fill_kind == MBT_FILL_EXOGENOUS_MM && host_fill) return fail(MBT_ERR_INVALID, "a fill model is either built in or a host callback");
     if (code->state_columns < 0 || code->state_columns > 2) return fail(MBT_ERR_INVALID, "user processes own at most two state columns (got %d)", code->state_columns);
     if (code->state_columns > 0) {
-      if (!(user_mid || user_arrival || host_arrival || host_mid)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice or arrival model (MBT_MID_USER / MBT_MID_HOST / MBT_ARR_USER / MBT_ARR_HOST)");
+      if (!(user_mid || user_arrival || host_arrival || host_mid || host_fill)) return fail(MBT_ERR_INVALID, "user state columns belong to a user-defined midprice, arrival or host-callback fill model (MBT_MID_USER / MBT_MID_HOST / MBT_ARR_USER / MBT_ARR_HOST / MBT_FILL_HOST)");
       if (cfg->arrival_kind == MBT_ARR_HAWKES || exogenous_fill(*cfg))
         return fail(MBT_ERR_INVALID, "user state columns take the place of the Hawkes intensities / exogenous depths: Poisson-type or user arrivals, exponential or user fills");
       for (int j = 0; j < code->state_columns; ++j) {
-        const bool host_owned = (host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0);  // advanced by the caller's update() on the host (mbt_env_set_host_state_columns)
+        const bool host_owned = (host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0) || (host_fill && code->state_owner[j] == 2);  // advanced by the caller's update() on the host (mbt_env_set_host_state_columns)
         if (!host_owned && (code->state_update[j] == nullptr || code->state_update[j][0] == 0)) return fail(MBT_ERR_INVALID, "user state column %d has no update expression", j);
       }
     }
@@ -1563,7 +1563,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   if (host_mid) e->host_state_first = 3, e->host_state_count = 1;
   if (needs_jit)
     for (int j = 0; j < code->state_columns; ++j)
-      if ((host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0)) {
+      if ((host_arrival && code->state_owner[j] == 1) || (host_mid && code->state_owner[j] == 0) || (host_fill && code->state_owner[j] == 2)) {
         if (e->host_state_count == 0) e->host_state_first = 4 + j;
         e->host_state_count += 1;
       }

@@ -299,10 +299,10 @@ class TradingEnvironment(_EnvBase):
         arrival_code = arrival.device_code() if getattr(arrival, "device_kind", None) == _native.ARR_USER else None
         mid = self.model_dynamics.midprice_model
         mid_code = mid.device_code() if getattr(mid, "device_kind", None) == _native.MID_USER else None
-        host_mid = self._host_plugins.get("midprice")
+        host_mid, host_fill = self._host_plugins.get("midprice"), self._host_plugins.get("fill")
         if fill_code is None and reward_code is None and arrival_code is None and mid_code is None and not (
                 self._host_plugins.get("arrival") is not None and self._host_plugins["arrival"].state_dim > 0) and not (
-                host_mid is not None and host_mid.state_dim > 1):
+                host_mid is not None and host_mid.state_dim > 1) and not (host_fill is not None and host_fill.state_dim > 0):
             return None
         # State columns owned by user processes, in the registry order of TE:303-318 (the midprice's second factor, then the
         # arrival model's columns).  Each process writes its expressions in terms of ITS OWN columns x0 (, x1); the kernel
@@ -318,8 +318,11 @@ class TradingEnvironment(_EnvBase):
             # a NumPy-only arrival model that owns columns: no update expressions - the kernel carries the columns through, the
             # model's own update() advances them on the host and the result is filed after the step (mbt_env_set_host_state_columns)
             arr_state = ([""] * host_arrival.state_dim, {}, [float(v) for v in np.asarray(host_arrival.initial_state, dtype=np.float64)[0]], False)
+        fill_state = None
+        if host_fill is not None and host_fill.state_dim > 0:  # a NumPy-only fill model that owns columns: the same arrangement, behind the arrival model's
+            fill_state = ([""] * host_fill.state_dim, [float(v) for v in np.asarray(host_fill.initial_state, dtype=np.float64)[0]])
         state = None
-        if mid_state is not None or arr_state is not None:
+        if mid_state is not None or arr_state is not None or fill_state is not None:
             updates, params, initial, extra, owners = [], {}, [], False, []
             shift = 0
             if mid_state is not None:
@@ -345,8 +348,12 @@ class TradingEnvironment(_EnvBase):
                 owners += [1] * len(arr_state[0])
                 if arrival_code is not None:
                     arrival_code = (rename(arrival_code[0]), arrival_code[1])
-            if mid_code is not None and mid_state is None and arr_state is not None:
-                pass  # (a one-column user midprice beside a stateful arrival model reads no state)
+            if fill_state is not None:
+                if len(updates) + len(fill_state[0]) > 2:
+                    raise UnsupportedOnDevice("user processes own at most two state columns between them (midprice factor, arrival model, fill model)")
+                updates += fill_state[0]
+                initial += fill_state[1]
+                owners += [2] * len(fill_state[0])
             state = (updates, params, initial, extra, owners)
         extra_normals = bool(getattr(mid, "uses_extra_normals", False) and mid_code is not None) or bool(getattr(arrival, "uses_extra_normals", False) and arrival_code is not None)
         if state is None and extra_normals:
@@ -468,11 +475,11 @@ class TradingEnvironment(_EnvBase):
                 continue
             if role != slot:
                 raise UnsupportedOnDevice(f"{type(part).__name__} is a {role} model by its class, handed over as the {slot} model")
-            if (role == "fill" and part.state_dim != 0) or (role == "arrival" and part.state_dim > 2) or (role == "midprice" and not 1 <= part.state_dim <= 3) or (
+            if (role == "fill" and part.state_dim > 2) or (role == "arrival" and part.state_dim > 2) or (role == "midprice" and not 1 <= part.state_dim <= 3) or (
                     role == "impact" and part.state_dim > 1):
                 raise UnsupportedOnDevice(
                     f"{type(part).__name__} only has host (NumPy) code AND owns {part.state_dim} state column(s): the host-callback route serves "
-                    "stateless fill models, arrival models with at most two columns of their own, midprice models with at most two beside the "
+                    "fill and arrival models with at most two columns of their own, midprice models with at most two beside the "
                     "price and price impact models with at most one (otherwise: a device expression, DeviceExpressionArrivalModel / DeviceExpressionMidpriceModel)")
             found[role] = part
             if role in ("fill", "arrival", "midprice", "impact"):
@@ -485,9 +492,14 @@ class TradingEnvironment(_EnvBase):
                 raise UnsupportedOnDevice(
                     f"{type(found['midprice']).__name__} moves the midprice on the host AFTER the launch, so the step's reward is formed on the host too "
                     f"(calculate() on the float64 states): {type(self.reward_function).__name__} exists as a device expression only")
-            owned = (found["midprice"].state_dim - 1) + (found["arrival"].state_dim if "arrival" in found else 0)
-            if owned > 2:
-                raise UnsupportedOnDevice(f"host-callback processes own {owned} state columns beside the midprice: at most two")
+        owned = sum(part.state_dim - (role == "midprice") for role, part in found.items() if role in ("midprice", "arrival", "fill"))
+        if owned > 2:
+            raise UnsupportedOnDevice(f"host-callback processes own {owned} state columns beside the midprice: at most two")
+        if found:  # what they own is filed as ONE block of columns (mbt_env_set_host_state_columns)
+            spans = [self.stochastic_process_indices[name] for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model"),
+                     ("fill", "fill_probability_model"), ("impact", "price_impact_model")) if role in found and found[role].state_dim > 0]
+            if any(nxt[0] != prev[1] for prev, nxt in zip(spans, spans[1:])):
+                raise UnsupportedOnDevice("the state columns of the host-callback processes are not adjacent (a device-resident process owns columns between them)")
         if found:
             warnings.warn(
                 "host-callback plugins: " + ", ".join(f"{type(p).__name__} ({r})" for r, p in found.items()) + " only have NumPy code, which "
@@ -501,7 +513,7 @@ class TradingEnvironment(_EnvBase):
         """(first, last, blocks): the ONE contiguous block of state columns host-callback processes own, in registry order
         (midprice columns, then a stateful arrival model's), as mbt_env_set_host_state_columns takes it."""
         blocks = []
-        for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model"), ("impact", "price_impact_model")):
+        for role, name in (("midprice", "midprice_model"), ("arrival", "arrival_model"), ("fill", "fill_probability_model"), ("impact", "price_impact_model")):
             part = self._host_plugins.get(role)
             if part is not None and part.state_dim > 0:
                 blocks.append((part, *self.stochastic_process_indices[name]))

@@ -95,9 +95,16 @@ class OracleConfig:
     # "user_power_law": a USER-DEFINED FillProbabilityModel subclass (plugin contract FILL:9-39; the reference's own
     # PowerFillFunction, FILL:96-123, is not per-trajectory): p(depth) = 1 / (1 + (fill_scale depth)^fill_power),
     # max_depth = 99^(1/fill_power) / fill_scale (where p = 1 %)
+    # "user_adaptive": a USER-DEFINED FillProbabilityModel subclass WITH STATE (one column of its own, SP:8-53): p(depth) =
+    # exp(-kappa depth) with a decay rate the agent's own fills push up and that relaxes to its level, kappa <- kappa +
+    # fill_kappa_speed (fill_exponent - kappa) dt + fill_kappa_jump (trades on either side) (tests/numpy_only_plugins.py)
     fill: str = "exponential"
     fill_scale: float = 1.0
     fill_power: float = 1.5
+    fill_kappa_speed: float = 0.0
+    fill_kappa_jump: float = 0.0
+    fill_kappa_lo: float = 0.0
+    fill_kappa_hi: float = 0.0
     fill_exponent: float = 1.5
     base_fill_probability: float = 1.0  # FILL:132
     exo_depth: Sequence[float] = (0.0, 0.0)  # initial states of the (bid, ask) best-depth processes (FILL:148-154)
@@ -163,7 +170,8 @@ class OracleConfig:
 
     @property
     def state_dim(self) -> int:
-        return (3 + self.midprice_columns + self.arrival_columns + (2 if self.has_exogenous_fill else 0) + (1 if self.impact_has_state else 0))  # TE:311-318
+        return (3 + self.midprice_columns + self.arrival_columns + (2 if self.has_exogenous_fill else 0) + (1 if self.fill == "user_adaptive" else 0)
+                + (1 if self.impact_has_state else 0))  # TE:311-318
 
     @property
     def arrival_column(self) -> int:
@@ -221,6 +229,8 @@ def resolved_max_depth(cfg: OracleConfig) -> float:
         return cfg.max_depth
     if cfg.fill == "user_power_law":
         return float(99.0 ** (1.0 / cfg.fill_power) / cfg.fill_scale)
+    if cfg.fill == "user_adaptive":  # the user's max_depth: where the fill probability AT THE LEVEL is 1 %
+        return float(-np.log(0.01) / cfg.fill_exponent)
     if cfg.has_exogenous_fill:
         return float(-np.log(0.01) / cfg.fill_exponent + np.max(np.asarray(cfg.exo_depth_hi, dtype=np.float64)[0]))
     return float(-np.log(0.01) / cfg.fill_exponent)
@@ -252,6 +262,9 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
     if cfg.has_exogenous_fill:  # FILL:146-147
         lo += [float(v) for v in cfg.exo_depth_lo]
         hi += [float(v) for v in cfg.exo_depth_hi]
+    if cfg.fill == "user_adaptive":  # the user's min_value / max_value (SP:11-12)
+        lo.append(float(cfg.fill_kappa_lo))
+        hi.append(float(cfg.fill_kappa_hi))
     if cfg.impact_has_state:  # IMP:77-78, IMP:117-118, IMP:158-159
         coef = cfg.permanent_impact if cfg.impact == "temp_perm" else cfg.kernel_coefficient if cfg.impact == "user_sqrt" else cfg.transient_impact
         lo.append(-cfg.max_speed * cfg.terminal_time * coef)
@@ -364,6 +377,8 @@ class OracleEnv:
             cols.append(np.repeat(np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2), n, axis=0))
         if cfg.has_exogenous_fill:  # FILL:148-154
             cols.append(np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0))
+        if cfg.fill == "user_adaptive":  # the user's initial_state (SP:30-31)
+            cols.append(np.repeat(np.array([[cfg.fill_exponent]], dtype=np.float64), n, axis=0))
         if cfg.impact_has_state:  # IMP:81 (0) / IMP:121, IMP:162 (initial transient impact)
             y0 = 0 if cfg.impact == "temp_perm" else cfg.initial_transient_impact
             cols.append(np.repeat(np.array([[y0]]), n, axis=0))
@@ -450,6 +465,8 @@ class OracleEnv:
                 fills = u_fill < prob
             elif cfg.fill == "user_power_law":  # the user's _get_fill_probabilities behind FILL:28-34
                 fills = u_fill < 1.0 / (1.0 + (cfg.fill_scale * depths) ** cfg.fill_power)
+            elif cfg.fill == "user_adaptive":  # the user's _get_fill_probabilities on ITS OWN column, as the step found it
+                fills = u_fill < np.exp(-st[:, cfg.exo_column:cfg.exo_column + 1] * depths)
             else:
                 fills = u_fill < np.exp(-cfg.fill_exponent * depths)
             # no bid fill at +max inventory, no ask fill at -max inventory, pre-update q (TE:323-327)
@@ -525,6 +542,10 @@ class OracleEnv:
             base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
             adt = cfg.arrival_step_size or dt
             st[:, ac:ac + 2] = lam + cfg.hawkes_speed * (base - lam) * adt + cfg.hawkes_jump * arrivals + cfg.hawkes_cross * arrivals[:, ::-1]
+        if cfg.fill == "user_adaptive":  # the user's update(arrivals, fills, ...): the (masked) fills of the step (TE:199-211)
+            fc = cfg.exo_column
+            k = prev[:, fc:fc + 1]
+            st[:, fc] = (k + cfg.fill_kappa_speed * (cfg.fill_exponent - k) * dt + cfg.fill_kappa_jump * np.sum(arrivals * fills, axis=1, keepdims=True))[:, 0]
         if cfg.impact_has_state:
             y = prev[:, -1].reshape(-1, 1)
             h = cfg.impact_step_size or dt

@@ -122,6 +122,26 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, Midp
             a_new = a - self.kappa * a * dt + self.xi * np.sqrt(dt) * z[:, 1:2] + self.eps * (arrivals[:, 1:2] * 1.0 - arrivals[:, 0:1] * 1.0)
             self.current_state = np.append(s_new, a_new, axis=1)
 
+    class UserAdaptiveFill(FillProbabilityModel):
+        """A fill model WITH STATE (SP:8-53): p(depth) = exp(-kappa depth) with a decay rate kappa of its own - the agent's fills thin
+        the book out behind them (kappa jumps) and it relaxes to its level: kappa <- kappa + speed (level - kappa) dt + jump trades."""
+
+        def __init__(self, level, speed, jump, lo, hi, step_size, num_trajectories, seed=None):
+            self.level, self.speed, self.jump = level, speed, jump
+            super().__init__(min_value=np.array([[lo]]), max_value=np.array([[hi]]), step_size=step_size, terminal_time=0.0,
+                             initial_state=np.array([[level]]), num_trajectories=num_trajectories, seed=seed)
+
+        def _get_fill_probabilities(self, depths):
+            return np.exp(-self.current_state * depths)
+
+        @property
+        def max_depth(self):
+            return -np.log(0.01) / self.level
+
+        def update(self, arrivals, fills, actions, state=None):
+            k = self.current_state
+            self.current_state = k + self.speed * (self.level - k) * self.step_size + self.jump * np.sum(arrivals * fills, axis=1, keepdims=True)
+
     class UserSquareRootImpact(PriceImpactModel):
         """The square-root law of market impact on top of a transient component that decays (IMP:9-31 asks for get_impact and
         max_speed): impact = c sign(v) sqrt(|v|) + y;  y <- y - rho y dt + k v dt.  The model OWNS the state column y."""
@@ -143,7 +163,7 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, Midp
         def max_speed(self):
             return self._max_speed
 
-    return types.SimpleNamespace(UserSquareRootImpact=UserSquareRootImpact, UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
+    return types.SimpleNamespace(UserSquareRootImpact=UserSquareRootImpact, UserAdaptiveFill=UserAdaptiveFill, UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
                                  UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes,
                                  UserCevMidprice=UserCevMidprice, UserShortTermAlphaMidprice=UserShortTermAlphaMidprice)
 

@@ -124,7 +124,7 @@ def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed", "user
 
 
 CASES = {"user_reward_speed": _speed("user_reward_speed"), "user_cev_midprice_speed": _speed("user_cev_midprice_speed"),
-         "user_impact_speed": _speed("user_impact_speed"),
+         "user_impact_speed": _speed("user_impact_speed"), "user_adaptive_fill": _speed("user_adaptive_fill"),
          "user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
          "user_two_factor_midprice_normalised": lambda g, **kw: _two_factor_midprice(g, normalised=True, **kw),
          "user_fill_and_reward": _fill_and_reward, "user_fill_hawkes_market_normalised": _fill_hawkes_market, "user_seasonal_arrivals": _seasonal_arrivals,

@@ -820,10 +820,28 @@ def user_plugin_cases(only=None):
              impact_step_size=1.0 / ns, reward="running", phi=0.01, alpha=0.1, initial_inventory=10, max_inventory=10, seed=73, **common),
         action_kind="speed")
 
+    # X4 (round 4). a user-defined FillProbabilityModel WITH STATE (SP:8-53): the decay rate of the fill probability is a column of its own
+    n, ns = 32, 80
+    run_case(
+        "user_adaptive_fill",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=74, initial_inventory=(-2, 3), max_inventory=5, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.05),
+            model_dynamics=LimitOrderModelDynamics(
+                midprice_model=BrownianMotionMidpriceModel(volatility=1.5, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                arrival_model=PoissonArrivalModel(intensity=np.array([50.0, 40.0]), step_size=1 / ns, num_trajectories=n),
+                fill_probability_model=user.UserAdaptiveFill(1.5, 4.0, 0.5, 0.5, 8.0, step_size=1 / ns, num_trajectories=n), num_trajectories=n),
+            **common),
+        ns, n, 2, 74,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", volatility=1.5, initial_price=100.0, arrival="poisson", intensity=[50.0, 40.0], fill="user_adaptive",
+             fill_exponent=1.5, fill_kappa_speed=4.0, fill_kappa_jump=0.5, fill_kappa_lo=0.5, fill_kappa_hi=8.0, dynamics="limit", reward="running", phi=0.01,
+             alpha=0.05, initial_inventory=[-2, 3], max_inventory=5, seed=74, **common),
+        poisson_thr=40.0 / ns, fill_prob=lambda d: np.exp(-1.5 * d))
+
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--only-round4":  # NumPy-only plugins with speed dynamics (leaves the other fixtures' bytes untouched)
-        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed", "user_impact_speed"))
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-round4":  # NumPy-only plugins of round 4 (leaves the other fixtures' bytes untouched)
+        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed", "user_impact_speed", "user_adaptive_fill"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
         user_plugin_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
