@@ -556,6 +556,8 @@ class TradingEnvironment(_EnvBase):
         if act.shape != (n, self.action_dim):
             raise ValueError(f"expected shape {(n, self.action_dim)}, got {act.shape}")
         fill, arrival, reward = plugins.get("fill"), plugins.get("arrival"), plugins.get("reward")
+        if self._host_state64 is None:  # a step right after the constructor or the batch-size setter (TE:74: the state exists from there on)
+            self._host_state64 = self.state64
         if fill is not None:
             depths = np.empty((n, 2), dtype=np.float64)
             _native.check(lib.mbt_env_host_depths(handle, _native.fptr(act), dptr(depths)))
@@ -581,8 +583,6 @@ class TradingEnvironment(_EnvBase):
         following = self.state64  # float64 (N, D): with precise_state the reference's own values; the TIME column is the float64 clock
         raw_action = self.normalise_action(np.asarray(action, dtype=np.float64), inverse=True)  # TE:104: what the plugins are handed
         current = self._host_state64
-        if current is None:
-            raise _native.NativeError(-4, "step() before reset()")
         # StochasticProcessModel.update of the user's processes, in registry order (TE:206-211), with the step's arrivals and
         # (masked) fills and the state matrix AS THE REFERENCE'S STANDS AT THAT POINT: cash, inventory and time already advanced
         # (TE:213-216), the columns of the processes earlier in the registry advanced, the process's own and later ones not yet.
@@ -991,6 +991,9 @@ class TradingEnvironment(_EnvBase):
         self._empty_infos = None
         self._handle = self._create_handle(num_trajectories, self.reward_scaling)
         self._last_events, self._events_on = None, False
+        self._host_state64 = None  # (host-callback plugins: the state before the next step is read from the new rows)
+        if self._host_needs_events:
+            _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         self._reset_device()
 
     @property

@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 
 from oracle.mbt_oracle import InjectedNoise, OracleEnv  # noqa: E402
 from tests.env_factory import make_env  # noqa: E402
-from tests.golden_io import CASES, load_case, step_size_changes  # noqa: E402
+from tests.golden_io import KERNEL_NOISE_CASES as CASES, load_case, step_size_changes  # noqa: E402  (the fixture whose midprice draws on the host: tests/test_gpu_host_callbacks.py)
 
 
 def run(name, **env_kw):

@@ -177,6 +177,29 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
     env.close()
 
 
+def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
+    """TE:74 materialises the state in the constructor and TE:173-178 re-allocates it: a host-callback environment steps from both
+    without a reset() in between (the state before the step is read from the device), and keeps recording the events its plugins'
+    update() is handed."""
+    cfg, g = load_case("user_cross_hawkes")
+    env = _quiet(lambda: CASES["user_cross_hawkes"](g))
+    arrivals = env.model_dynamics.arrival_model
+    before = arrivals.current_state.copy()
+    for k in range(3):  # no reset(): the constructor's state
+        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        obs, rew, _, _ = env.step(g["actions"][k])
+        assert arrivals.current_state.shape == (cfg.num_trajectories, 2) and env.last_arrivals.shape == (cfg.num_trajectories, 2)
+        np.testing.assert_array_equal(obs[:, 4:6], arrivals.current_state.astype(np.float32))  # its update() ran and its columns were filed
+    assert not np.array_equal(before, arrivals.current_state)
+    env.num_trajectories = 64  # TE:173-178
+    assert env.model_dynamics.arrival_model.current_state.shape == (64, 2)
+    env.set_noise(np.full((64, 2), 0.9, np.float32), np.full((64, 2), 0.9, np.float32), np.zeros(64, np.float32))
+    obs, rew, dones, infos = env.step(np.full((64, 2), 0.5, np.float32))
+    assert obs.shape == (64, 6) and rew.shape == (64,) and len(infos) == 64 and env.last_arrivals.shape == (64, 2)
+    np.testing.assert_array_equal(env.last_arrivals, False)  # u = 0.9 against lambda dt ~ 0.2
+    env.close(), ref.close()
+
+
 def test_host_callback_plugins_say_so_and_have_no_fused_rollout():
     cfg, g = load_case("user_fill_and_reward")
     with pytest.warns(HostCallbackWarning, match="UserPowerLawFill"):
