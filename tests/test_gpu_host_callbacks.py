@@ -201,6 +201,25 @@ def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
     env.close(), ref.close()
 
 
+def test_the_bring_your_own_numpy_plugins_example_runs(capsys, monkeypatch):
+    """examples/bring_your_own_numpy_plugins.py: three NumPy-only classes (fill model, reward, price impact model) in env.step();
+    selling ten units at constant speed under the square-root law costs 10 c sqrt(10) on average."""
+    import importlib.util
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bring_your_own_numpy_plugins.py")
+    spec = importlib.util.spec_from_file_location("bring_your_own_numpy_plugins", path)
+    example = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(example)
+    monkeypatch.setattr(sys, "argv", [path, "4096"])
+    _quiet(example.main)
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert lines[0].startswith("market making") and lines[1].startswith("optimal execution")
+    cost = float(lines[1].split("mean episode return")[1].split(",")[0])
+    assert cost == pytest.approx(-10 * 0.05 * np.sqrt(10), abs=0.5)  # (Monte-Carlo error of the Brownian part: ~0.1 at 4096 lanes)
+
+
 def test_host_callback_plugins_say_so_and_have_no_fused_rollout():
     cfg, g = load_case("user_fill_and_reward")
     with pytest.warns(HostCallbackWarning, match="UserPowerLawFill"):
