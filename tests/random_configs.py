@@ -87,3 +87,32 @@ def random_speed_actions(rng, cfg, steps):
     if cfg.normalise_action_space:
         return rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)).astype(np.float32)
     return (rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)) * hi).astype(np.float32)
+
+
+NUMPY_ONLY_KINDS = ("reward_speed", "midprice_speed", "impact_speed", "adaptive_fill")
+
+
+def random_numpy_only_config(rng, n, kind):
+    """A random market around one of the NumPy-only user classes of tests/numpy_only_plugins.py (tests/env_factory.py builds it from
+    the class itself, on either package): a user reward / midprice / price impact model with trading-with-speed dynamics, or the
+    fill model that owns a state column with order-book dynamics."""
+    if kind == "adaptive_fill":
+        cfg = random_config(rng, n)
+        cfg.dynamics = str(rng.choice(["limit", "limit_and_market"]))
+        cfg.arrival = str(rng.choice(["poisson", "poisson_nonlinear"]))  # (two more columns of a Hawkes model + this one: beyond the device's rows)
+        cfg.fill, cfg.fill_kappa_speed, cfg.fill_kappa_jump, cfg.fill_kappa_lo, cfg.fill_kappa_hi = "user_adaptive", float(rng.uniform(0.0, 8.0)), float(rng.uniform(0.0, 1.0)), 0.1, 20.0
+        cfg.normalise_action_space = cfg.normalise_observation_space = bool(rng.integers(0, 2))
+        return cfg
+    cfg = random_speed_config(rng, n)
+    if kind == "reward_speed":
+        cfg.reward, cfg.eta = "user_exp_inventory_cost", float(rng.uniform(0.02, 0.25))
+    elif kind == "midprice_speed":
+        cfg.midprice, cfg.initial_price, cfg.cev_gamma = "user_cev", float(rng.choice([50.0, 100.0])), float(rng.uniform(0.5, 1.0))
+        cfg.volatility, cfg.midprice_lo, cfg.midprice_hi = float(rng.uniform(0.05, 0.3)), 0.4 * cfg.initial_price, 1.6 * cfg.initial_price
+    else:
+        cfg.impact, cfg.initial_transient_impact = "user_sqrt", 0.0
+    return cfg
+
+
+def random_numpy_only_actions(rng, cfg, steps):
+    return random_speed_actions(rng, cfg, steps) if cfg.dynamics == "speed" else random_actions(rng, cfg, steps)

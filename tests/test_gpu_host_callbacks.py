@@ -201,6 +201,49 @@ def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
     env.close(), ref.close()
 
 
+@pytest.mark.parametrize("kind", ["reward_speed", "midprice_speed", "impact_speed", "adaptive_fill"])
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("MBT_FUZZ_SCALE", "1")) * 4))
+def test_numpy_only_user_classes_on_random_markets_equal_the_oracle(case, kind):
+    """The host-callback route over random markets (tests/random_configs.py: random_numpy_only_config), in the float64 tier, against
+    the oracle - whose restatement of these user classes is pinned to the REFERENCE running the classes themselves on the same
+    distribution of markets (tests/test_oracle_vs_reference_live.py).  State, observations, rewards: array-equal."""
+    from oracle.mbt_oracle import InjectedNoise, OracleEnv
+    from tests.env_factory import make_env
+    from tests.random_configs import NUMPY_ONLY_KINDS, random_numpy_only_actions, random_numpy_only_config
+
+    rng = np.random.default_rng(int(__import__("os").environ.get("MBT_FUZZ_SEED", "0")) + 29000 + 100 * NUMPY_ONLY_KINDS.index(kind) + case)
+    n = int(rng.choice([5, 64, 700]))
+    cfg = random_numpy_only_config(rng, n, kind)
+    if cfg.dynamics == "speed" and cfg.impact == "temp_power" and cfg.impact_exponent != 1.0:
+        cfg.impact_exponent = 1.0  # (pow of device libm against NumPy's: an ulp of float64 - the bit-for-bit claim is for exponents 1 and 2)
+    steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+    actions = random_numpy_only_actions(rng, cfg, steps)
+    u_arr = (rng.integers(0, 1 << 24, size=(steps, n, 2)) / float(1 << 24)).astype(np.float32)
+    u_fill = (rng.integers(0, 1 << 24, size=(steps, n, 2)) / float(1 << 24)).astype(np.float32)
+    z = rng.normal(size=(steps, n)).astype(np.float32)
+    env = _quiet(lambda: make_env(cfg, noise="injected", precise_state=True))
+    if kind == "midprice_speed":
+        env.model_dynamics.midprice_model.rng = Replay(normals=z)
+    oracle = OracleEnv(cfg, InjectedNoise(u_arr, u_fill, z))
+    obs, o_obs = env.reset(), oracle.reset()
+    np.testing.assert_array_equal(obs, o_obs.astype(np.float32), err_msg=f"{kind} case {case}: reset")
+    speed = cfg.dynamics == "speed"
+    tag = f"{kind} case {case} ({cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n})"
+    for k in range(steps):
+        env.set_noise(None if speed else u_arr[k], None if speed else u_fill[k], z[k])
+        obs, rew, dones, _ = env.step(actions[k])
+        o_obs, o_rew, o_done = oracle.step(actions[k].astype(np.float64))
+        if cfg.reward == "exp_utility":  # exp of device libm against NumPy's (tests/test_gpu_precise.py: REWARD_VIA_LIBM)
+            np.testing.assert_allclose(rew, np.broadcast_to(o_rew, (n,)), rtol=2.0 ** -23, atol=1e-12, err_msg=f"{tag} step {k}: reward")
+        else:
+            np.testing.assert_array_equal(rew, np.broadcast_to(o_rew, (n,)).astype(np.float32), err_msg=f"{tag} step {k}: reward")
+        np.testing.assert_array_equal(obs, o_obs.astype(np.float32), err_msg=f"{tag} step {k}: observation")
+        if not cfg.normalise_observation_space:
+            np.testing.assert_array_equal(env.state64, o_obs, err_msg=f"{tag} step {k}: float64 state")
+        assert bool(dones[0]) == bool(o_done[0])
+    env.close()
+
+
 def test_the_bring_your_own_numpy_plugins_example_runs(capsys, monkeypatch):
     """examples/bring_your_own_numpy_plugins.py: three NumPy-only classes (fill model, reward, price impact model) in env.step();
     selling ten units at constant speed under the square-root law costs 10 c sqrt(10) on average."""

@@ -21,7 +21,8 @@ import pytest
 
 from oracle.mbt_oracle import InjectedNoise, OracleEnv
 from tests.env_factory import make_env
-from tests.random_configs import random_actions, random_config, random_speed_actions, random_speed_config
+from tests.random_configs import (NUMPY_ONLY_KINDS, random_actions, random_config, random_numpy_only_actions, random_numpy_only_config, random_speed_actions,
+                                  random_speed_config)
 
 REFERENCE = "/root/reference"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -116,6 +117,21 @@ def test_oracle_equals_the_reference_on_a_random_optimal_execution_configuration
     u_arr, u_fill, z = _noise(rng, cfg.n_steps, n)
     tag = f"live speed case {case}: {cfg.midprice}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
     _compare(cfg, actions, u_arr, u_fill, z, tag)
+
+
+@pytest.mark.parametrize("kind", NUMPY_ONLY_KINDS)
+@pytest.mark.parametrize("case", range(max(3, CASES // 8)))
+def test_oracle_restates_the_numpy_only_user_classes_on_random_markets(case, kind):
+    """tests/numpy_only_plugins.py bound to the REFERENCE's base classes and run by the reference, against the oracle's restatement of
+    those classes (oracle/mbt_oracle.py: "user_exp_inventory_cost", "user_cev", "user_sqrt", "user_adaptive") - the pin the GPU tests of
+    the host-callback route lean on, spread from one fixture per class over random markets."""
+    rng = np.random.default_rng(SEED + 27000 + 100 * NUMPY_ONLY_KINDS.index(kind) + case)
+    n = int(rng.choice([1, 5, 64]))
+    cfg = random_numpy_only_config(rng, n, kind)
+    steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
+    actions = random_numpy_only_actions(rng, cfg, steps)
+    u_arr, u_fill, z = _noise(rng, steps, n)
+    _compare(cfg, actions, u_arr, u_fill, z, f"live {kind} case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.impact}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}")
 
 
 # ---- the closed-form agents (callers of the path; host code on both sides) -------------------------------------------
