@@ -224,6 +224,7 @@ class TradingEnvironment(_EnvBase):
                 fields.update(kind)
         if "midprice" in self._host_plugins:
             fields["initial_price"] = float(np.asarray(md.midprice_model.initial_state, dtype=np.float64)[0, 0])
+            fields["midprice_step_size"] = md.midprice_model.step_size  # MD:265: speed dynamics trade `speed x the MIDPRICE model's step size`
         if "impact" in self._host_plugins:
             impact = self._host_plugins["impact"]
             fields["impact_kind"] = _native.IMPACT_HOST_STATE if impact.state_dim else _native.IMPACT_HOST

@@ -198,7 +198,7 @@ def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
     obs, rew, dones, infos = env.step(np.full((64, 2), 0.5, np.float32))
     assert obs.shape == (64, 6) and rew.shape == (64,) and len(infos) == 64 and env.last_arrivals.shape == (64, 2)
     np.testing.assert_array_equal(obs[:, 4:6], arrivals.current_state.astype(np.float32))
-    env.close(), ref.close()
+    env.close()
 
 
 @pytest.mark.parametrize("kind", ["reward_speed", "midprice_speed", "impact_speed", "adaptive_fill"])

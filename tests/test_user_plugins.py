@@ -123,6 +123,7 @@ def test_numpy_only_plugin_classes_take_the_host_callback_route(no_device):
     env = with_midprice(cev)
     cfg = env._device_config(n, 1.0)
     assert (cfg.midprice_kind, cfg.reward_kind, cfg.initial_price, cfg.precise_state) == (_native.MID_HOST, _native.REW_HOST, 50.0, 1)
+    assert cfg.midprice_step_size == 1 / ns  # the model's OWN step size (SP:21): what speed dynamics trade per step (MD:265)
     assert env._user_code() is None and env._host_owned_columns()[:2] == (3, 4)
     env.check_device_expressions()
     two = with_midprice(user.UserShortTermAlphaMidprice(1.2, 8.0, 3.0, 0.75, 100.0, 90.0, 110.0, -10.0, 10.0, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
