@@ -81,7 +81,14 @@ class OracleConfig:
     #   p_side(t) = intensity_side (1 + seasonal_amplitude cos(2 pi t / seasonal_period)) dt, t = the time before the step
     # "user_cross_hawkes": a USER-DEFINED ArrivalModel WITH STATE (two intensities, like ARR:86-126) in which an arrival on one
     #   side also excites the other: lambda <- lambda + hawkes_speed (base - lambda) dt + hawkes_jump arrivals + hawkes_cross arrivals[::-1]
+    # "user_state_reading": a USER-DEFINED ArrivalModel WITH STATE whose update() reads the state matrix it is handed (TE:206-211): two
+    # intensities relaxing (hawkes_speed) to intensity * (1 + arrival_tilt * NEW time) + arrival_sensitivity * (NEW midprice -
+    # arrival_reference_price) * (-1, +1), thinned by arrival_crowding * |NEW inventory|, floored at 0 (tests/numpy_only_plugins.py)
     arrival: str = "poisson"
+    arrival_tilt: float = 0.0
+    arrival_sensitivity: float = 0.0
+    arrival_crowding: float = 0.0
+    arrival_reference_price: float = 0.0
     hawkes_cross: float = 0.0
     seasonal_amplitude: float = 0.0
     seasonal_period: float = 1.0
@@ -162,7 +169,7 @@ class OracleConfig:
 
     @property
     def arrival_columns(self) -> int:
-        return 2 if self.arrival in ("hawkes", "user_cross_hawkes") else 0
+        return 2 if self.arrival in ("hawkes", "user_cross_hawkes", "user_state_reading") else 0
 
     @property
     def midprice_columns(self) -> int:
@@ -255,7 +262,7 @@ def observation_bounds(cfg: OracleConfig) -> Tuple[np.ndarray, np.ndarray]:
     if cfg.midprice == "user_alpha":  # the second column of the user's midprice model
         lo.append(float(cfg.alpha_lo))
         hi.append(float(cfg.alpha_hi))
-    if cfg.arrival in ("hawkes", "user_cross_hawkes"):
+    if cfg.arrival in ("hawkes", "user_cross_hawkes", "user_state_reading"):
         base = np.asarray(cfg.intensity, dtype=np.float64).reshape(-1)
         lo += [0.0, 0.0]  # ARR:100
         hi += list(base * 10)  # ARR:101, ARR:125-126
@@ -373,7 +380,7 @@ class OracleEnv:
         cols = [np.repeat(np.array([[cfg.initial_price]], dtype=np.float64), n, axis=0)]
         if cfg.midprice == "user_alpha":
             cols.append(np.repeat(np.array([[cfg.alpha_initial]], dtype=np.float64), n, axis=0))
-        if cfg.arrival in ("hawkes", "user_cross_hawkes"):
+        if cfg.arrival in ("hawkes", "user_cross_hawkes", "user_state_reading"):
             cols.append(np.repeat(np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2), n, axis=0))
         if cfg.has_exogenous_fill:  # FILL:148-154
             cols.append(np.repeat(np.asarray(cfg.exo_depth, dtype=np.float64).reshape(1, 2), n, axis=0))
@@ -542,6 +549,14 @@ class OracleEnv:
             base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
             adt = cfg.arrival_step_size or dt
             st[:, ac:ac + 2] = lam + cfg.hawkes_speed * (base - lam) * adt + cfg.hawkes_jump * arrivals + cfg.hawkes_cross * arrivals[:, ::-1]
+        if cfg.arrival == "user_state_reading":  # the user's update() on the matrix AS IT STANDS HERE: agent columns, time and midprice advanced
+            ac = cfg.arrival_column
+            lam = prev[:, ac:ac + 2]
+            base = np.asarray(cfg.intensity, dtype=np.float64).reshape(1, 2)
+            adt = cfg.arrival_step_size or dt
+            t_new, price_new, q_new = st[0, TIME], st[:, PRICE:PRICE + 1], st[:, INVENTORY:INVENTORY + 1]
+            target = base * (1.0 + cfg.arrival_tilt * t_new) + cfg.arrival_sensitivity * (price_new - cfg.arrival_reference_price) * np.array([[-1.0, 1.0]])
+            st[:, ac:ac + 2] = np.maximum(lam + cfg.hawkes_speed * (target - lam) * adt - cfg.arrival_crowding * np.abs(q_new) * lam * adt, 0.0)
         if cfg.fill == "user_adaptive":  # the user's update(arrivals, fills, ...): the (masked) fills of the step (TE:199-211)
             fc = cfg.exo_column
             k = prev[:, fc:fc + 1]

@@ -40,7 +40,7 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
     # NumPy class it is (tests/numpy_only_plugins.py, bound to `package`'s base classes) - not a device expression; so does a fill
     # model WITH STATE (device expressions state stateless fill models)
     numpy_only = None
-    if (cfg.dynamics == "speed" and (cfg.midprice == "user_cev" or cfg.reward == "user_exp_inventory_cost" or cfg.impact == "user_sqrt")) or cfg.fill == "user_adaptive":
+    if (cfg.dynamics == "speed" and (cfg.midprice == "user_cev" or cfg.reward == "user_exp_inventory_cost" or cfg.impact == "user_sqrt")) or cfg.fill == "user_adaptive" or cfg.arrival == "user_state_reading":
         from tests.numpy_only_plugins import define
 
         numpy_only = define(fill_m.FillProbabilityModel, arr_m.ArrivalModel, rw.RewardFunction, importlib.import_module(package + ".gym.index_names"),
@@ -79,6 +79,8 @@ def make_env(cfg, noise="philox", package="mbt_gym_amd", **overrides):
         "none": lambda: None,
         "user_seasonal": lambda: __import__("tests.user_plugins", fromlist=["x"]).SeasonalArrivals(
             base=cfg.intensity, amplitude=cfg.seasonal_amplitude, period=cfg.seasonal_period, step_size=arr_dt, num_trajectories=n),
+        "user_state_reading": lambda: numpy_only.UserStateReadingArrivals(cfg.intensity, cfg.hawkes_speed, cfg.arrival_tilt, cfg.arrival_sensitivity, cfg.arrival_crowding,
+                                                                          cfg.arrival_reference_price, step_size=arr_dt, terminal_time=T, num_trajectories=n),
         "user_cross_hawkes": lambda: __import__("tests.user_plugins", fromlist=["x"]).CrossExcitingHawkes(
             baseline=cfg.intensity, speed=cfg.hawkes_speed, jump=cfg.hawkes_jump, cross=cfg.hawkes_cross, step_size=arr_dt, terminal_time=T, num_trajectories=n),
     }[cfg.arrival]()

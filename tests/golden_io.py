@@ -11,10 +11,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # environment trajectories; `agents_*.npz` (tools/refgen/make_agent_golden.py) hold agent outputs and are loaded by their own tests
 CASES = sorted(name for name in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
                if not name.startswith("agents_"))
-# fixtures whose midprice model is a NumPy-only class that draws from ITS OWN generator in update() (host-callback route with
-# trading-with-speed dynamics): the generic per-fixture GPU tests inject noise into the kernels and cannot feed that generator -
+# fixtures with a NumPy-only class that draws from ITS OWN generator (a midprice model's update() with trading-with-speed dynamics,
+# an arrival model's get_arrivals()): the generic per-fixture GPU tests inject noise into the kernels and cannot feed that generator -
 # tests/test_gpu_host_callbacks.py replays it
-DRAWS_ON_THE_HOST = ("user_cev_midprice_speed",)
+DRAWS_ON_THE_HOST = ("user_cev_midprice_speed", "user_state_reading_arrivals")
 KERNEL_NOISE_CASES = [name for name in CASES if name not in DRAWS_ON_THE_HOST]
 
 

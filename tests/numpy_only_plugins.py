@@ -91,6 +91,28 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, Midp
             unif = self.rng.uniform(size=(self.num_trajectories, 2))
             return unif < self.current_state * self.step_size
 
+    class UserStateReadingArrivals(ArrivalModel):
+        """An arrival model whose update() READS THE STATE MATRIX it is handed (TE:206-211).  At that point of the reference's step cash,
+        inventory and time have advanced (TE:213-216), the midprice - first in the registry - has too, the model's own columns have
+        not.  Two intensities that relax to a baseline tilted by the NEW time, lean against the NEW price's distance from a
+        reference price (sellers arrive as it rises) and thin out as the agent's NEW inventory grows."""
+
+        def __init__(self, baseline, speed, tilt, sensitivity, crowding, reference_price, step_size, terminal_time, num_trajectories, seed=None):
+            self.baseline, self.speed, self.tilt = np.array(baseline, dtype=float).reshape(1, 2), speed, tilt
+            self.sensitivity, self.crowding, self.reference_price = sensitivity, crowding, reference_price
+            super().__init__(min_value=np.zeros((1, 2)), max_value=self.baseline * 10, step_size=step_size, terminal_time=terminal_time,
+                             initial_state=self.baseline, num_trajectories=num_trajectories, seed=seed)
+
+        def update(self, arrivals, fills, actions, state=None):
+            lam = self.current_state
+            t, price, q = state[0, TIME_INDEX], state[:, ASSET_PRICE_INDEX:ASSET_PRICE_INDEX + 1], state[:, INVENTORY_INDEX:INVENTORY_INDEX + 1]
+            target = self.baseline * (1.0 + self.tilt * t) + self.sensitivity * (price - self.reference_price) * np.array([[-1.0, 1.0]])
+            self.current_state = np.maximum(lam + self.speed * (target - lam) * self.step_size - self.crowding * np.abs(q) * lam * self.step_size, 0.0)
+
+        def get_arrivals(self):
+            unif = self.rng.uniform(size=(self.num_trajectories, 2))
+            return unif < self.current_state * self.step_size
+
     class UserCevMidprice(MidpriceModel):
         """dS = mu S dt + sigma S^gamma sqrt(dt) Z: constant elasticity of variance, written for any number of trajectories (the
         reference's own CEV class broadcasts (N,) noise against an (N, 1) state and cannot be used for N > 1, MID:401-409)."""
@@ -163,7 +185,7 @@ def define(FillProbabilityModel, ArrivalModel, RewardFunction, index_names, Midp
         def max_speed(self):
             return self._max_speed
 
-    return types.SimpleNamespace(UserSquareRootImpact=UserSquareRootImpact, UserAdaptiveFill=UserAdaptiveFill, UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
+    return types.SimpleNamespace(UserStateReadingArrivals=UserStateReadingArrivals, UserSquareRootImpact=UserSquareRootImpact, UserAdaptiveFill=UserAdaptiveFill, UserPowerLawFill=UserPowerLawFill, UserExponentialInventoryCost=UserExponentialInventoryCost,
                                  UserSeasonalArrivals=UserSeasonalArrivals, UserCrossExcitingHawkes=UserCrossExcitingHawkes,
                                  UserCevMidprice=UserCevMidprice, UserShortTermAlphaMidprice=UserShortTermAlphaMidprice)
 

@@ -123,7 +123,15 @@ def _speed(name):  # cases "user_reward_speed", "user_cev_midprice_speed", "user
     return build
 
 
-CASES = {"user_reward_speed": _speed("user_reward_speed"), "user_cev_midprice_speed": _speed("user_cev_midprice_speed"),
+def _state_reading_arrivals(g, **kw):  # case "user_state_reading_arrivals": update() reads the NEW time, midprice and inventory off the matrix it is handed
+    from tests.env_factory import make_env
+
+    env = make_env(load_case("user_state_reading_arrivals")[0], noise="injected", **kw)
+    env.model_dynamics.arrival_model.rng = Replay(uniforms=g["u_arr"])
+    return env
+
+
+CASES = {"user_state_reading_arrivals": _state_reading_arrivals, "user_reward_speed": _speed("user_reward_speed"), "user_cev_midprice_speed": _speed("user_cev_midprice_speed"),
          "user_impact_speed": _speed("user_impact_speed"), "user_adaptive_fill": _speed("user_adaptive_fill"),
          "user_cev_midprice": _cev_midprice, "user_two_factor_midprice": _two_factor_midprice,
          "user_two_factor_midprice_normalised": lambda g, **kw: _two_factor_midprice(g, normalised=True, **kw),
@@ -160,7 +168,7 @@ def test_numpy_only_subclasses_run_in_step_and_match_the_reference(name, precise
         np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"{name} step {k}: arrivals")
         np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"{name} step {k}: fills")
         np.testing.assert_array_equal(q_of(obs), q_of(g["obs"][k]), err_msg=f"{name} step {k}: inventory")
-        if name == "user_cross_hawkes":  # the model's own columns, advanced by ITS update() on the host in float64: the reference's values, rounded once
+        if name == "user_cross_hawkes" or (exact and name == "user_state_reading_arrivals"):  # the model's own columns, advanced by ITS update() on the host in float64: the reference's values, rounded once
             np.testing.assert_array_equal(obs[:, 4:6], g["obs"][k][:, 4:6].astype(np.float32), err_msg=f"{name} step {k}: the arrival model's state columns")
             if exact:
                 np.testing.assert_array_equal(env.state64[:, 4:6], g["obs"][k][:, 4:6], err_msg=f"{name} step {k}: float64 state columns")

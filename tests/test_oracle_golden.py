@@ -25,7 +25,7 @@ def test_fixture_set_is_complete():
         "speed_temp_perm_cjoe", "speed_power_running", "speed_temp_transient_pnl", "speed_transient_pnl",
         "step_size_change_hawkes", "step_size_change_speed", "user_linear_sde_midprice",
         "user_fill_and_reward", "user_fill_hawkes_market_normalised", "user_reward_touch", "user_seasonal_arrivals", "user_cev_midprice",
-        "user_cross_hawkes", "user_two_factor_midprice", "user_two_factor_midprice_normalised", "user_reward_speed", "user_cev_midprice_speed", "user_impact_speed", "user_adaptive_fill",
+        "user_cross_hawkes", "user_two_factor_midprice", "user_two_factor_midprice_normalised", "user_reward_speed", "user_cev_midprice_speed", "user_impact_speed", "user_adaptive_fill", "user_state_reading_arrivals",
     }
 
 

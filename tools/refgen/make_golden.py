@@ -838,10 +838,28 @@ def user_plugin_cases(only=None):
              alpha=0.05, initial_inventory=[-2, 3], max_inventory=5, seed=74, **common),
         poisson_thr=40.0 / ns, fill_prob=lambda d: np.exp(-1.5 * d))
 
+    # X5 (round 4). a user-defined ArrivalModel whose update() READS THE STATE MATRIX (TE:206-211): pins WHAT the reference hands a process at
+    #     that point - new cash / inventory / time, the midprice already advanced, the model's own columns not yet
+    n, ns = 32, 90
+    run_case(
+        "user_state_reading_arrivals",
+        lambda: TradingEnvironment(
+            terminal_time=1.0, n_steps=ns, seed=75, initial_inventory=(-2, 3), max_inventory=6, num_trajectories=n,
+            reward_function=RunningInventoryPenalty(0.01, 0.05),
+            model_dynamics=lo_dynamics(
+                n, 1 / ns, 1.0,
+                BrownianMotionMidpriceModel(drift=0.5, volatility=2.5, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+                user.UserStateReadingArrivals([40.0, 30.0], 20.0, 0.6, 3.0, 0.8, 100.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n)),
+            **common),
+        ns, n, 2, 75,
+        dict(n_steps=ns, terminal_time=1.0, midprice="bm", drift=0.5, volatility=2.5, initial_price=100.0, arrival="user_state_reading", intensity=[40.0, 30.0],
+             hawkes_speed=20.0, arrival_tilt=0.6, arrival_sensitivity=3.0, arrival_crowding=0.8, arrival_reference_price=100.0, fill_exponent=1.5, dynamics="limit",
+             reward="running", phi=0.01, alpha=0.05, initial_inventory=[-2, 3], max_inventory=6, seed=75, **common))
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--only-round4":  # NumPy-only plugins of round 4 (leaves the other fixtures' bytes untouched)
-        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed", "user_impact_speed", "user_adaptive_fill"))
+        user_plugin_cases(only=("user_reward_speed", "user_cev_midprice_speed", "user_impact_speed", "user_adaptive_fill", "user_state_reading_arrivals"))
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-user-plugins":
         user_plugin_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "--only-exogenous":  # leave the other fixtures' bytes untouched
