@@ -89,13 +89,20 @@ def random_speed_actions(rng, cfg, steps):
     return (rng.uniform(0.0 if positive else -0.4, 0.4, size=(steps, n, 1)) * hi).astype(np.float32)
 
 
-NUMPY_ONLY_KINDS = ("reward_speed", "midprice_speed", "impact_speed", "adaptive_fill")
+NUMPY_ONLY_KINDS = ("reward_speed", "midprice_speed", "impact_speed", "adaptive_fill", "state_reading_arrivals")
 
 
 def random_numpy_only_config(rng, n, kind):
     """A random market around one of the NumPy-only user classes of tests/numpy_only_plugins.py (tests/env_factory.py builds it from
     the class itself, on either package): a user reward / midprice / price impact model with trading-with-speed dynamics, or the
     fill model that owns a state column with order-book dynamics."""
+    if kind == "state_reading_arrivals":
+        cfg = random_config(rng, n)
+        cfg.dynamics, cfg.fill = str(rng.choice(["limit", "limit_and_market"])), "exponential"
+        cfg.arrival, cfg.hawkes_speed = "user_state_reading", min(float(rng.uniform(5.0, 40.0)), 0.9 / cfg.step_size)
+        cfg.arrival_tilt, cfg.arrival_sensitivity, cfg.arrival_crowding = float(rng.uniform(-0.5, 1.0)), float(rng.uniform(0.0, 4.0)), float(rng.uniform(0.0, 1.0))
+        cfg.arrival_reference_price = cfg.initial_price
+        return cfg
     if kind == "adaptive_fill":
         cfg = random_config(rng, n)
         cfg.dynamics = str(rng.choice(["limit", "limit_and_market"]))

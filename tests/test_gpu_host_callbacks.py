@@ -209,7 +209,7 @@ def test_stepping_right_after_the_constructor_and_after_a_batch_resize():
     env.close()
 
 
-@pytest.mark.parametrize("kind", ["reward_speed", "midprice_speed", "impact_speed", "adaptive_fill"])
+@pytest.mark.parametrize("kind", ["reward_speed", "midprice_speed", "impact_speed", "adaptive_fill", "state_reading_arrivals"])
 @pytest.mark.parametrize("case", range(int(__import__("os").environ.get("MBT_FUZZ_SCALE", "1")) * 4))
 def test_numpy_only_user_classes_on_random_markets_equal_the_oracle(case, kind):
     """The host-callback route over random markets (tests/random_configs.py: random_numpy_only_config), in the float64 tier, against
@@ -232,6 +232,8 @@ def test_numpy_only_user_classes_on_random_markets_equal_the_oracle(case, kind):
     env = _quiet(lambda: make_env(cfg, noise="injected", precise_state=True))
     if kind == "midprice_speed":
         env.model_dynamics.midprice_model.rng = Replay(normals=z)
+    if kind == "state_reading_arrivals":
+        env.model_dynamics.arrival_model.rng = Replay(uniforms=u_arr)
     oracle = OracleEnv(cfg, InjectedNoise(u_arr, u_fill, z))
     obs, o_obs = env.reset(), oracle.reset()
     np.testing.assert_array_equal(obs, o_obs.astype(np.float32), err_msg=f"{kind} case {case}: reset")
