@@ -265,8 +265,10 @@ typedef struct mbt_user_code {
    * arrivals and no exogenous-depth fill model (the columns take the place of the built-in Hawkes intensities).  Each
    * column is advanced by its own expression  state_update[j]  for the NEXT value, of type double, in
    *     S, t, dt (the step size of the process that owns the column, state_owner), x0, x1 (the columns BEFORE the step), z (the lane's midprice normal), z1, z2,
-   *     arr_bid, arr_ask (1.0 where an order arrived), fills_bid, fills_ask (1.0 where the agent's quote was executed)
-   * and the named state parameters - evaluated, like the reference's update() calls, from the state before the step.  The
+   *     arr_bid, arr_ask (1.0 where an order arrived), fills_bid, fills_ask (1.0 where the agent's quote was executed),
+   *     S_next, t_next, q_next, cash_next (what the state matrix the reference hands update() holds at that point, TE:206-211:
+   *     cash / inventory after the agent's update and the clip, the advanced clock, the midprice already advanced)
+   * and the named state parameters - x0, x1, S, t as the step found them, like the process's own state in the reference's update().  The
    * midprice_increment and arrival_probability expressions may read x0, x1 (and z1, z2) too: a two-factor midprice
    * (dS = alpha dt + sigma dW, alpha its own OU process), a Hawkes variant with cross-excitation, a stochastic intensity.
    * extra_normals = 1 draws z1, z2 - two more standard normals per lane and step, a third Philox block per pair of lanes

@@ -1288,7 +1288,8 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   const auto owner_dt = [&](int j) { return std::string(u.state_owner[j] == 1 ? "dt_arr" : "dt_mid"); };  // each column advances with its owner's step size (SP:21)
   src += "__device__ double mbt_user_state_next(int which, double S, double t, double dt_mid, double dt_arr, double z, double arr_bid, double arr_ask, double fills_bid, "
          "double fills_ask, const UserProcessState& u_, const double* p) {\n  (void)which; (void)S; (void)t; (void)dt_mid; (void)dt_arr; (void)z; (void)arr_bid; (void)arr_ask; "
-         "(void)fills_bid; (void)fills_ask; (void)p;\n" + process_symbols + state_decl +
+         "(void)fills_bid; (void)fills_ask; (void)p;\n" + process_symbols +
+         "  const double S_next = u_.S_next, t_next = u_.t_next, q_next = u_.q_next, cash_next = u_.cash_next;\n  (void)S_next; (void)t_next; (void)q_next; (void)cash_next;\n" + state_decl +
          // (a column the HOST advances - a host-callback arrival model's own state - passes through the kernel unchanged: "x0" / "x1")
          "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? (u.state_update[0] != nullptr && u.state_update[0][0] != 0 ? u.state_update[0] : "x0") : "0.0") + "); }\n"
          "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? (u.state_update[1] != nullptr && u.state_update[1][0] != 0 ? u.state_update[1] : "x1") : "0.0") + "); }\n}\n}  // namespace mbt\n";

@@ -196,6 +196,10 @@ struct StepParams {
 // two extra normals of the step (zero when the configuration has none)
 struct UserProcessState {
   double x0, x1, z1, z2;
+  // what the state matrix holds when the reference calls a process's update() (TE:206-211): cash, inventory and time after the
+  // agent's update and the clip (TE:213-216), the midprice already advanced (first in the registry) - `S_next`, `t_next`,
+  // `q_next`, `cash_next` of the state-update expressions; zero (unset) for the arrival / midprice expressions, which run earlier
+  double S_next, t_next, q_next, cash_next;
 };
 
 #ifdef MBT_JIT_USER_CODE
@@ -615,7 +619,7 @@ template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
                                                 const StepParams& P, const float z = 0.f, const double t_now = 0.0, const float2 zu = make_float2(0.f, 0.f),
-                                                const HostStep& hs = HostStep{}) {
+                                                const HostStep& hs = HostStep{}, const double t_next_f64 = 0.0) {  // (t_next_f64: the advanced clock in double, for user state-update expressions)
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
   r.lo = make_int4(0, 0, 0, 0);
@@ -667,8 +671,10 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   if (V::USER_STATE > 0) {
 #ifdef MBT_JIT_USER_CODE
     // the user processes' own update() (SP:8-53), each from the state BEFORE the step, in double; the columns are float32
-    r.lam.x = static_cast<float>(mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, ups, P.user_state_p));
-    if (V::USER_STATE > 1) r.lam.y = static_cast<float>(mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, ups, P.user_state_p));
+    UserProcessState upn = ups;
+    upn.S_next = mid_new, upn.t_next = t_next_f64, upn.q_next = q_clip, upn.cash_next = c_clip;
+    r.lam.x = static_cast<float>(mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, upn, P.user_state_p));
+    if (V::USER_STATE > 1) r.lam.y = static_cast<float>(mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, arr_bid, arr_ask, n_bid, n_ask, upn, P.user_state_p));
 #endif
   }
 
@@ -771,8 +777,10 @@ __device__ __forceinline__ LaneResult lane_step_exact(const float4 core, const f
   }
   if (V::USER_STATE > 0) {
 #ifdef MBT_JIT_USER_CODE
-    lam_bid_new = mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, ups, P.user_state_p);
-    if (V::USER_STATE > 1) lam_ask_new = mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, ups, P.user_state_p);
+    UserProcessState upn = ups;
+    upn.S_next = mid_new, upn.t_next = t_next, upn.q_next = q_clip, upn.cash_next = c_clip;
+    lam_bid_new = mbt_user_state_next(0, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, upn, P.user_state_p);
+    if (V::USER_STATE > 1) lam_ask_new = mbt_user_state_next(1, mid, t_now, P.mid_dt_f64, P.arr_dt_f64, z, D.arr_bid, D.arr_ask, n_bid, n_ask, upn, P.user_state_p);
 #endif
   }
   // reward
@@ -1032,7 +1040,7 @@ template <class V, bool MIRROR = false>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f, const float2 zu = make_float2(0.f, 0.f)) {
   const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu, L.hs)
-                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu, L.hs);
+                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu, L.hs, P.t_next_f64);
   if (V::PRECISE) store_lo(B.resid, lane, r.lo, V::RES);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
@@ -1298,7 +1306,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       // lane values into adjacent registers and SGPR spills from the longer live ranges: 3.48e11 instead of 3.62e11 env-steps/s at
       // 2^20 lanes.  profiles/r03_experiments.txt.  The compiler already packs the two SIDES of a lane where that is free.)
       const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t, zu[l])
-                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l]);
+                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l], HostStep{}, t);
       core[l] = r.core;
       lam[l] = r.lam;
       lo[l] = r.lo;

@@ -62,7 +62,9 @@ class DeviceExpressionArrivalModel(ArrivalModel):
     d = 2): pass `initial_state`, `min_value`, `max_value` of shape (1, d) and set `state_expressions` to d expressions for
     the NEXT value of each column, in `x0`, `x1` (the model's columns before the step), `arr_bid`, `arr_ask` (1.0 where an
     order arrived this step), `fills_bid`, `fills_ask`, `t`, `dt`, `S`, `z` and, with `uses_extra_normals = True`, `z1`, `z2`
-    (two more N(0, 1) draws per lane and step); `device_expression` reads `x0`, `x1` too.  E.g. Hawkes intensities that
+    (two more N(0, 1) draws per lane and step); `S_next`, `t_next`, `q_next`, `cash_next` are what the `state` matrix handed to the
+    reference's `update(arrivals, fills, action, state)` holds at that point (TE:206-211: the agent's columns and the clock
+    advanced, the midprice - earlier in the registry - too); `device_expression` reads `x0`, `x1` too.  E.g. Hawkes intensities that
     also excite each other:
 
         class CrossExcitingHawkes(DeviceExpressionArrivalModel):

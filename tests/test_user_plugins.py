@@ -283,6 +283,81 @@ def test_user_plugin_refusals_and_cache():
             normalise_observation_space=False)
 
 
+def _state_reading_env(g, **kw):
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
+    from mbt_gym_amd.rewards.RewardFunctions import RunningInventoryPenalty
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+    from tests.user_plugins import StateReadingArrivals
+
+    n, ns = 32, 90  # tools/refgen/make_golden.py: case "user_state_reading_arrivals", constructor call for constructor call
+    md = LimitOrderModelDynamics(
+        midprice_model=BrownianMotionMidpriceModel(drift=0.5, volatility=2.5, initial_price=100, terminal_time=1.0, step_size=1 / ns, num_trajectories=n),
+        arrival_model=StateReadingArrivals([40.0, 30.0], 20.0, 0.6, 3.0, 0.8, 100.0, step_size=1 / ns, terminal_time=1.0, num_trajectories=n),
+        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=1 / ns, num_trajectories=n), num_trajectories=n)
+    kw = dict(dict(noise="injected", initial_inventory=(-2, 3)), **kw)
+    return TradingEnvironment(terminal_time=1.0, n_steps=ns, seed=75, max_inventory=6, num_trajectories=n, reward_function=RunningInventoryPenalty(0.01, 0.05),
+                              model_dynamics=md, normalise_action_space=False, normalise_observation_space=False, **kw)
+
+
+def test_state_update_expressions_name_the_matrix_the_reference_hands_update(no_device):
+    """`S_next`, `t_next`, `q_next`, `cash_next` in a state-update expression (include/mbt_env.h): compiles without a GPU."""
+    from tests.golden_io import load_case
+
+    env = _state_reading_env(load_case("user_state_reading_arrivals")[1])
+    code = env._user_code()
+    assert code.state_columns == 2 and b"t_next" in code.state_update[0] and b"S_next" in code.state_update[1]
+    env.check_device_expressions()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precise", [False, True])
+def test_a_device_expression_that_reads_the_advanced_state_matches_the_reference(precise):
+    """The reference hands update() the state matrix with cash / inventory / time and the midprice already advanced (TE:206-211); the
+    NumPy class of the fixture reads them off it, the device expression names them `S_next`, `t_next`, `q_next`."""
+    from tests.golden_io import load_case
+
+    cfg, g = load_case("user_state_reading_arrivals")
+    env = _state_reading_env(g, precise_state=precise)
+    env.record_events(True)
+    env.reset()
+    for k in range(g["actions"].shape[0]):
+        env.set_noise(g["u_arr"][k], g["u_fill"][k], g["z"][k])
+        obs, rew, dones, _ = env.step(g["actions"][k])
+        np.testing.assert_array_equal(env.last_arrivals.astype(np.uint8), g["arrivals"][k], err_msg=f"step {k}: arrivals")
+        np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"step {k}: fills")
+        np.testing.assert_array_equal(obs[:, 1], g["obs"][k][:, 1], err_msg=f"step {k}: inventory")
+        if precise:
+            np.testing.assert_allclose(env.state64[:, 4:6], g["obs"][k][:, 4:6], rtol=1e-12, atol=1e-12, err_msg=f"step {k}: intensities")
+            np.testing.assert_array_equal(rew, g["rewards"][k].astype(np.float32), err_msg=f"step {k}: rewards")
+        else:
+            np.testing.assert_allclose(obs[:, 4:6], g["obs"][k][:, 4:6], rtol=2e-6, atol=2e-4, err_msg=f"step {k}: intensities (float32 state)")
+    env.close()
+
+
+@pytest.mark.gpu
+def test_the_fused_rollout_hands_state_update_expressions_the_same_advanced_state_as_the_step_kernel():
+    """`t_next` / `S_next` / `q_next` inside the fused rollout kernel (its own clock, its own registers) and in the step kernel: a
+    rollout under a fixed action is the step loop, bit for bit (production noise)."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+    from tests.golden_io import load_case
+
+    g = load_case("user_state_reading_arrivals")[1]
+    env_a, env_b = _state_reading_env(g, noise="philox", initial_inventory=1), _state_reading_env(g, noise="philox", initial_inventory=1)
+    agent = FixedActionAgent(np.array([0.5, 0.7], np.float32), env_a)
+    env_a.reset(), env_b.reset()
+    obs_r, act_r, rew_r, steps, done = env_a.rollout(agent)
+    assert steps == env_a.n_steps and done
+    action = np.tile(np.array([[0.5, 0.7]], np.float32), (env_b.num_trajectories, 1))
+    for k in range(steps):
+        obs, rew, dones, _ = env_b.step(action)
+        np.testing.assert_array_equal(obs_r[k + 1], obs, err_msg=f"step {k}: observation (incl. the two intensities)")  # (time-major: tests/test_gpu_rollout.py)
+        np.testing.assert_array_equal(rew_r[k], rew, err_msg=f"step {k}: reward")
+    np.testing.assert_array_equal(env_a.state, env_b.state)
+    env_a.close(), env_b.close()
+
+
 @pytest.mark.gpu
 def test_normalise_rewards_calibrates_an_environment_with_a_user_defined_reward():
     """TE:329-343 rolls a copy of the environment out under the fixed action 1 / kappa; with a user-defined reward (or

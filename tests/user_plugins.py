@@ -89,6 +89,26 @@ class CrossExcitingHawkes(DeviceExpressionArrivalModel):
         return {"base_bid": self.baseline[0, 0], "base_ask": self.baseline[0, 1], "beta": self.speed, "eta": self.jump, "cross": self.cross}
 
 
+class StateReadingArrivals(DeviceExpressionArrivalModel):
+    """An arrival model whose update() reads the state matrix it is handed (TE:206-211): the device-expression form of
+    tests/numpy_only_plugins.py: UserStateReadingArrivals (fixture `user_state_reading_arrivals`), operation for operation - the NEW
+    time, midprice and inventory are `t_next`, `S_next`, `q_next`."""
+
+    device_expression = "(side == 0 ? x0 : x1) * dt"
+    state_expressions = ("fmax(x0 + beta * ((base_bid * (1.0 + tilt * t_next) + sens * (S_next - ref) * -1.0) - x0) * dt - crowd * fabs(q_next) * x0 * dt, 0.0)",
+                         "fmax(x1 + beta * ((base_ask * (1.0 + tilt * t_next) + sens * (S_next - ref) * 1.0) - x1) * dt - crowd * fabs(q_next) * x1 * dt, 0.0)")
+
+    def __init__(self, baseline, speed, tilt, sensitivity, crowding, reference_price, step_size, terminal_time, num_trajectories, seed=None):
+        self.baseline, self.speed, self.tilt = np.asarray(baseline, dtype=np.float64).reshape(1, 2), speed, tilt
+        self.sensitivity, self.crowding, self.reference_price = sensitivity, crowding, reference_price
+        super().__init__(step_size=step_size, num_trajectories=num_trajectories, seed=seed, initial_state=self.baseline, min_value=np.zeros((1, 2)),
+                         max_value=self.baseline * 10, terminal_time=terminal_time)
+
+    def device_expression_params(self):
+        return {"base_bid": self.baseline[0, 0], "base_ask": self.baseline[0, 1], "beta": self.speed, "tilt": self.tilt, "sens": self.sensitivity,
+                "ref": self.reference_price, "crowd": self.crowding}
+
+
 class ShortTermAlphaMidprice(DeviceExpressionMidpriceModel):
     """A TWO-COLUMN midprice: the price and a mean-reverting short-term alpha that order flow pushes and the price drifts
     with (what the reference's ShortTermOuAlphaMidpriceModel describes, MID:149-190, per trajectory); two normals per step."""
