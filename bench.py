@@ -76,27 +76,49 @@ WORKLOADS = {
 
 def credited_bytes(key):
     """ALGORITHMIC bytes per env-step, SURVEY.md section 8d: state read + action read + next-state write + reward write in
-    float32 - 44 / 60 / 52 B.  The int32 remainders the precise_state tier also moves (+16 / +32 B) are overhead, not credit."""
+    float32 - 44 / 60 / 52 B.  The int32 remainders a tier also moves (below) are overhead, not credit."""
     w = WORKLOADS[key]
     return 4 * (w["dim"] + w["act"] + w["dim"] + 1)
 
 
-def moved_bytes(key, precise):
-    w = WORKLOADS[key]
-    return credited_bytes(key) + (0 if not precise else 16 * (4 if w["kernel"][0] == 1 else 2))  # remainder columns: read + written
+def remainder_columns(key, precise, lam32=False):
+    """int32 remainder columns per lane (include/mbt_env.h): precise_state holds [cash, midprice (, bid / ask intensity)] exactly, the
+    float32 tier of a Hawkes model its two intensities - unless `hawkes_float32_intensities` (lam32) opts out."""
+    hawkes = WORKLOADS[key]["kernel"][0] == 1
+    if precise:
+        return 4 if hawkes else 2
+    return 2 if hawkes and not lam32 else 0
 
 
-def kernel_name(key, precise, lanes):
+def moved_bytes(key, precise, lam32=False):
+    """Bytes per env-step the kernel actually moves: the credited ones + 8 per remainder column (4 read, 4 written) - 60 / 92 / 68 B in
+    the precise_state tier, 76 B for Hawkes rows with exact intensities.  tests/test_bench_bytes.py ties this to the PMC summaries."""
+    return credited_bytes(key) + 8 * remainder_columns(key, precise, lam32)
+
+
+def tier_label(key, precise, lam32=False):
+    if precise:
+        return "precise_state (the reference's float64 arithmetic)"
+    if WORKLOADS[key]["kernel"][0] == 1:
+        return "float32, float32 intensities (hawkes_float32_intensities: 60 B rows, arrivals not exact)" if lam32 else "float32, exact Hawkes intensities (default: arrivals = the reference's)"
+    return "float32"
+
+
+def kernel_name(key, precise, lanes, lam32=False):
     arr, dyn, bm, rew = WORKLOADS[key]["kernel"]
-    # non-temporal loads beyond 320 MB per launch for 16-byte rows, beyond 640 MB for other row widths (mbt_env.hip: tune_for_size)
-    stream = lanes * moved_bytes(key, precise) > ((320 if WORKLOADS[key]["dim"] == 4 else 640) << 20)
+    # non-temporal loads once the lines a launch touches no longer fit the Infinity Cache: 16-byte rows beyond 300 MB DISTINCT (the state
+    # is updated in place), other row widths beyond 640 MB moved (mbt_env.hip: tune_for_size)
+    w = WORKLOADS[key]
+    distinct = lanes * 4 * (w["dim"] + w["act"] + 1 + remainder_columns(key, precise, lam32))
+    stream = distinct > (300 << 20) if w["dim"] == 4 else lanes * moved_bytes(key, precise, lam32) > (640 << 20)
     b = lambda x: "true" if x else "false"  # noqa: E731
+    exact_lam = arr == 1 and not precise and not lam32  # Variant::EXACT_LAM, the last template argument
     # step_kernel<Variant<...>, STREAM, MIRROR>: the mirror instantiation serves small batches over the host API only
-    return (f"mbt::step_kernel<mbt::Variant<{arr}, {dyn}, {b(bm)}, {rew}, false, false, false, {b(precise)}, false, false, false, false, 0, false, 0>, "
+    return (f"mbt::step_kernel<mbt::Variant<{arr}, {dyn}, {b(bm)}, {rew}, false, false, false, {b(precise)}, false, false, false, false, 0, false, 0, {b(exact_lam)}>, "
             f"{b(stream)}, false>")
 
 
-def build_env(n, offset, device, workload="cfg1", precise=False):
+def build_env(n, offset, device, workload="cfg1", precise=False, lam32=False):
     """One shard of the trajectory axis of a BASELINE workload, through the public plugin API."""
     from mbt_gym_amd.gym.ModelDynamics import LimitAndMarketOrderModelDynamics, LimitOrderModelDynamics
     from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
@@ -122,6 +144,7 @@ def build_env(n, offset, device, workload="cfg1", precise=False):
         terminal_time=1.0, n_steps=N_STEPS, model_dynamics=dynamics, reward_function=reward, initial_inventory=10 if workload == "cfg4" else 0,
         max_inventory=100 if workload.startswith("cfg2") else N_STEPS, seed=SEED + (360 if workload.startswith("cfg2") else 0), num_trajectories=n,
         normalise_action_space=False, normalise_observation_space=False, device=device, trajectory_offset=offset, precise_state=precise,
+        hawkes_float32_intensities=lam32,
     )
     if workload == "cfg4":
         # (bid depth, ask depth, market buy, market sell): the flags ~ Bernoulli(0.01), drawn ON THE DEVICE straight into the
@@ -210,50 +233,53 @@ def rocprof_reference():
     return rows, os.path.relpath(paths[-1], ROOT)
 
 
-def roofline_row(key, precise, lanes, launch_s, reference):
+def roofline_row(key, precise, lanes, launch_s, reference, lam32=False):
     """One kernel against the HBM roofline in CREDITED bytes: `frac_events` from this run's HIP events, `frac_rocprof` from the
     committed rocprofv3 summary (None when it has no row for this kernel), `frac` the lower of the two."""
-    name = kernel_name(key, precise, lanes)
+    name = kernel_name(key, precise, lanes, lam32)
     credited = credited_bytes(key) * lanes
     frac_events = credited / launch_s / 1e9 / HBM_PEAK_GBPS
     hit = next((v for k, v in reference.items() if name in k), None)
     frac_rocprof = None if hit is None else credited / (hit[0] * 1e-9) / 1e9 / HBM_PEAK_GBPS
     frac = frac_events if frac_rocprof is None else min(frac_events, frac_rocprof)
-    return {"config": WORKLOADS[key]["label"], "tier": "precise_state (the reference's float64 arithmetic)" if precise else "float32",
-            "lanes": lanes, "credited_bytes_per_env_step": credited_bytes(key), "moved_bytes_per_env_step": moved_bytes(key, precise),
+    moved = moved_bytes(key, precise, lam32)
+    return {"config": WORKLOADS[key]["label"], "tier": tier_label(key, precise, lam32),
+            "lanes": lanes, "credited_bytes_per_env_step": credited_bytes(key), "moved_bytes_per_env_step": moved,
             "avg_launch_us": launch_s * 1e6, "avg_launch_us_rocprof": None if hit is None else hit[0] / 1e3,
             "frac_events": frac_events, "frac_rocprof": frac_rocprof, "frac": frac, "achieved": frac * HBM_PEAK_GBPS,
+            "moved_GBps": moved * lanes / launch_s / 1e9,  # what the memory system actually carried (not a roofline credit)
             "env_steps_per_s_kernel": lanes / launch_s, "kernel": name}
 
 
 def configs_block(lib, device, reference, steps_budget_s=0.1):
     """Every other BASELINE configuration's step kernel, and the contract tier (`precise_state`) of all four, measured on THIS box
     exactly like the headline: K launches in one library call, HIP events on the kernel's stream, about 0.05 s of warm-up and 0.1 s of timed launches each
-    (parity-test cases, not bench lines - they never enter `value`)."""
+    (parity-test cases, not bench lines - they never enter `value`).  cfg3 (Hawkes) has three rows: the default tier (exact
+    intensities, 76 B moved), the float32-intensity opt-out (60 B, what SURVEY section 8d prices) and precise_state (92 B)."""
     import torch
 
     rows = []
-    cases = [("cfg2_cjmm", False), ("cfg2_running", False), ("cfg3", False), ("cfg4", False),
-             ("cfg1", True), ("cfg2_cjmm", True), ("cfg3", True), ("cfg4", True)]
-    for key, precise in cases:
+    cases = [("cfg2_cjmm", False, False), ("cfg2_running", False, False), ("cfg3", False, False), ("cfg3", False, True), ("cfg4", False, False),
+             ("cfg1", True, False), ("cfg2_cjmm", True, False), ("cfg3", True, False), ("cfg4", True, False)]
+    for key, precise, lam32 in cases:
         lanes = WORKLOADS[key]["lanes"]
         try:
-            env = build_env(lanes, 0, device, workload=key, precise=precise)
+            env = build_env(lanes, 0, device, workload=key, precise=precise, lam32=lam32)
 
             def sync_all(barrier=True, env=env):
                 env.synchronize()
                 torch.cuda.synchronize()
 
-            rough_us = moved_bytes(key, precise) * lanes / 5.5e6  # at ~5.5 TB/s: only sizes the launch counts
+            rough_us = moved_bytes(key, precise, lam32) * lanes / 5.5e6  # at ~5.5 TB/s: only sizes the launch counts
             steps = int(max(200, min(8000, steps_budget_s * 1e6 / rough_us)))
             env.step_many_device(int(max(200, 0.05e6 / rough_us)), auto_reset=True)  # ~50 ms of launches: clocks up, like the headline's prewarm
             _, event_s, _ = timed_steps(env, lib, steps, sync_all)
             env.close()
-            row = roofline_row(key, precise, lanes, event_s / steps, reference)
+            row = roofline_row(key, precise, lanes, event_s / steps, reference, lam32)
             row["steps_timed"] = steps
             rows.append(row)
         except Exception as exc:  # noqa: BLE001 - one configuration failing must not take the line down
-            rows.append({"config": WORKLOADS[key]["label"], "tier": "precise_state" if precise else "float32", "error": str(exc)})
+            rows.append({"config": WORKLOADS[key]["label"], "tier": tier_label(key, precise, lam32), "error": str(exc)})
     return rows
 
 
@@ -385,6 +411,106 @@ def hbm_resident_measurement(lib, device, reference, steps=600, warmup=100):
         "note": "working set 738 MB per launch > 256 MB Infinity Cache: HBM-resident; the achievable copy rate of the chip "
                 "is ~6.3 TB/s (0.79 of the spec peak)",
     }
+
+
+def rollout_counters():
+    """Shader-side counters of the returns-only fused rollout from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN_pmc_rollout.json, tools/pmc_rollout_summary.py: SQ_INSTS_VALU, SQ_WAVES, GRBM_GUI_ACTIVE ... one small group per
+    pass) - counters cannot be read from inside the benchmark process - or None."""
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_rollout.json")) if re.fullmatch(r"r\d+_pmc_rollout\.json", os.path.basename(p)))
+    if not paths:
+        return None
+    out = json.load(open(paths[-1]))
+    out["source"] = os.path.relpath(paths[-1], ROOT)
+    return out
+
+
+def write_floor():
+    """The write-only floors of the recording pattern (28 B per lane and step, time-major, one long-running kernel) from the newest
+    committed tools/microbench/mb_floor output (profiles/rNN_floors.txt): {log2 lanes: best us per step over the store policies}."""
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_floors.txt")) if re.fullmatch(r"r\d+_floors\.txt", os.path.basename(p)))
+    floors, lanes = {}, None
+    for line in (open(paths[-1]) if paths else []):
+        m = re.match(r"record\s+28 B written per lane and step, 2\^(\d+) lanes", line)
+        if m:
+            lanes = int(m.group(1))
+            continue
+        m = re.search(r"median\s+([0-9.]+) \(min\s+([0-9.]+)\) us/step", line)
+        if lanes is not None and m and "written" in line:
+            floors[lanes] = min(floors.get(lanes, 1e30), float(m.group(1)))
+        elif not line.startswith("  "):
+            lanes = None
+    return floors, (os.path.relpath(paths[-1], ROOT) if paths else None)
+
+
+def rollout_block(lib, device):
+    """SURVEY section 8f row 1 / 8d "rollout mode", measured on THIS box with HIP events on the environment's stream: the fused
+    rollout kernel (a whole 1000-step episode of BASELINE configs[1] per launch, the policy evaluated in the kernel).
+    Returns only: ~0 B of HBM traffic per env-step - instruction-issue bound, so NO HBM fraction is quoted; the line gives env-steps/s
+    and the vector-issue fraction the committed counters give for the same launch.  Recorded (generate_trajectory's layout, GT:11-15):
+    28 B written per env-step, against the 8 TB/s line and against the write-only floor of the same store pattern."""
+    import ctypes as C
+
+    import torch
+
+    from mbt_gym_amd import _native
+    from mbt_gym_amd.agents.BaselineAgents import AvellanedaStoikovAgent, FixedSpreadAgent
+
+    def timed(env, agent, episodes, **pointers):
+        env.reset_device()
+        env.rollout_device(agent, **pointers)  # warm (and the first touch of a recording's pages)
+        env.synchronize()
+        _native.check(lib.mbt_env_timer_begin(env._handle))
+        for _ in range(episodes):
+            env.reset_device()
+            steps, done = env.rollout_device(agent, **pointers)
+            assert done and steps == env.n_steps
+        ms = C.c_float(0)
+        _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
+        return ms.value / 1e3 / episodes
+
+    out = {"what": "fused rollout kernel: one launch = one 1000-step episode of BASELINE configs[1], policy evaluated in the kernel (SURVEY 8f row 1)"}
+    counters = rollout_counters()
+    n = LANES_PER_GPU
+    env = build_env(n, 0, device)
+    try:
+        for name, agent in (("avellaneda_stoikov_policy", AvellanedaStoikovAgent(0.1, env)), ("fixed_policy", FixedSpreadAgent(env, half_spread=QUOTE[0]))):
+            t = timed(env, agent, 8)
+            row = {"lanes": n, "env_steps_per_s": n * env.n_steps / t, "us_per_env_step_of_all_lanes": t / env.n_steps * 1e6, "ms_per_episode": t * 1e3,
+                   "hbm_bytes_per_env_step": 0, "bound": "vector instruction issue (no HBM fraction applies)"}
+            hit = (counters or {}).get(name)
+            if hit is not None:
+                row["valu_issue_fraction"] = hit["valu_issue_fraction"]
+                row["valu_instructions_per_wave_and_step"] = hit["valu_instructions_per_wave_and_step"]
+                row["counters"] = counters["source"]
+            out["returns_only_" + name] = row
+    finally:
+        env.close()
+    floors, floors_file = write_floor()
+    for log2n in (18, 20):
+        n = 1 << log2n
+        env = build_env(n, 0, device)
+        try:
+            lanes = env.padded_lanes
+            obs = torch.empty((env.n_steps + 1, lanes, 4), dtype=torch.float32, device=f"cuda:{device}")
+            act = torch.empty((env.n_steps, lanes, 2), dtype=torch.float32, device=f"cuda:{device}")
+            rew = torch.empty((env.n_steps, lanes), dtype=torch.float32, device=f"cuda:{device}")
+            t = timed(env, AvellanedaStoikovAgent(0.1, env), 4, obs_ptr=obs.data_ptr(), act_ptr=act.data_ptr(), rew_ptr=rew.data_ptr())
+            us = t / env.n_steps * 1e6
+            row = {"lanes": n, "env_steps_per_s": n * env.n_steps / t, "us_per_env_step_of_all_lanes": us, "written_bytes_per_env_step": 28,
+                   "write_GBps": 28.0 * n / us * 1e-3, "frac_of_8TBps": 28.0 * n / us * 1e-3 / HBM_PEAK_GBPS, "GB_per_episode": 28e-9 * n * env.n_steps,
+                   "mean_return_of_the_recording": float(rew[:, :n].sum(dim=0).mean())}
+            if log2n in floors:
+                row["write_only_floor_us"] = floors[log2n]
+                row["floor_over_kernel"] = floors[log2n] / us
+                row["floor_source"] = floors_file
+            out[f"recorded_avellaneda_stoikov_2^{log2n}"] = row
+            del obs, act, rew
+        except Exception as exc:  # noqa: BLE001 - a device without room for the recording still reports the rest
+            out[f"recorded_avellaneda_stoikov_2^{log2n}"] = {"error": str(exc)}
+        finally:
+            env.close()
+    return out
 
 
 def spawn_ranks(args):
@@ -578,6 +704,7 @@ def main():
     ap.add_argument("--cfg4-steps", type=int, default=1100, help="timed steps of the cfg4 block (after steps // 4 of warm-up): 1100 puts one episode end - "
                     "reduction, 24-byte all-reduce, reset, all enqueued in-stream - inside the timed region")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the fused-rollout block (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-distributed", action="store_true", help="testing: take the multi-rank code path (process group, C-ABI communicator, collective check) even with one rank")
@@ -718,9 +845,15 @@ def main():
             for _ in range(reps):
                 reduce_once([1.0, 0.0, 1.0])
             per_call = (time.perf_counter() - t0) / reps
+            # every rank must have finished - and all-reduced - the SAME number of episodes (the step counts are functions of the
+            # arguments alone for exactly this reason): the line says what each end of the range saw
+            finished = float(len(warm_episodes) + len(episode_returns))
+            span = torch.tensor([finished, -finished], dtype=torch.float64, device=tdev)
+            dist.all_reduce(span, op=dist.ReduceOp.MAX)
         collective = {"what": "24-byte all-reduce of [sum R, sum R^2, lanes], blocking form (H2D 24 B + all-reduce + D2H 24 B + wait)",
                       "us": per_call * 1e6, "known_answer_ok": correct, "per_episode_share_of_stepping": per_call / (N_STEPS * wall / args.steps),
-                      "episodes_all_reduced_before_the_timed_region": len(warm_episodes)}
+                      "episodes_all_reduced_before_the_timed_region": len(warm_episodes),
+                      "episodes_in_the_log_per_rank": {"min": int(-span[1].item()), "max": int(span[0].item())}}
 
     # BASELINE.json configs[4]: limit + market orders, --cfg4-total-lanes in TOTAL sharded over the ranks (strong scaling), the
     # episode-return all-reduce on the same communicator; timed like the headline (barrier, K launches in one call, max over ranks)
@@ -822,6 +955,11 @@ def main():
                 out["roofline"]["hbm_resident"] = {"error": str(exc)}
         if world == 1 and not args.no_configs:
             out["roofline"]["configs"] = configs_block(lib, gpu, reference)
+        if world == 1 and not args.no_rollout:
+            try:
+                out["rollout"] = rollout_block(lib, gpu)
+            except Exception as exc:  # noqa: BLE001
+                out["rollout"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:

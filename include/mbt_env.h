@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 6u
+#define MBT_ABI_VERSION 7u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -156,9 +156,8 @@ typedef struct mbt_config {
   double mid_coef_add, mid_coef_mul;         /* MBT_MID_LINEAR_SDE only */
   /* Numerics tier.
    * 0 (default): float32 state, the 44 B / env-step kernels.  Decisions (arrivals, fills, inventory) are bit-exact against
-   *   the float64 reference on the same draws - except that Hawkes intensities are float32 STATE, so a draw within the
-   *   float32 error of lambda dt, |u - lambda dt| <= (2e-5 + 3e-7 lambda) dt, can decide differently (probability
-   *   2 (2e-5 + 3e-7 lambda) dt per draw and side: ~1e-6 per lane-step at lambda ~ 40, dt ~ 1/40).  Rewards, with U = 2^-24
+   *   the float64 reference on the same draws - Hawkes arrivals included: the intensities they are decided on are held exactly
+   *   (hawkes_float32_intensities below; 76 B / env-step for Hawkes rows).  Rewards, with U = 2^-24
    *   (one float32 rounding) and S_err, c_err = |float32 state - reference state| of midprice and cash BEFORE the step:
    *       |r - r_ref| <= 1e-5 + 1e-6 max(|r|, |q' dS|)                       (the contract + float32's own output rounding)
    *                    + |q'| L (S_err + 2 U |S|)                            (L = 0 for Brownian / jump / constant midprices - the
@@ -184,6 +183,18 @@ typedef struct mbt_config {
    * hawkes_speed * arrival_step_size < 1; from 1 it oscillates and from 2 it diverges (in the float64 reference as well),
    * and float32 state no longer tracks float64 state.  mbt_env_create rejects such a configuration unless this is 1. */
   int32_t allow_stiff_hawkes;
+  /* ---- ABI 7 ---- */
+  /* Hawkes intensities in the float32 tier (precise_state == 0; ignored otherwise and without a Hawkes arrival model).
+   * 0 (default): the two intensity columns - and only they - are held EXACTLY (float32 rounding in the state row, what the
+   *   observation shows, + an int32 remainder each in a side buffer: mbt_exact_split), the recursion lambda += speed (base -
+   *   lambda) dt + jump arrivals and the threshold lambda dt are evaluated in double in the reference's order (ARR:110-123): the
+   *   arrivals - hence fills and inventories - ARE the float64 reference's on the same draws, like every other decision of this
+   *   tier.  Cash and midprice stay float32 with the increment-form reward.  +16 B per env-step: 76 instead of 60.
+   * 1: float32 intensities, 60 B per env-step - what SURVEY section 8d prices; a draw with |u - lambda dt| <= (2e-5 + 3e-7
+   *   lambda) dt can then decide differently from the reference (probability 2 (2e-5 + 3e-7 lambda) dt per draw and side:
+   *   ~1e-6 per lane-step at lambda ~ 40, dt ~ 1/40), after which that lane's path is another sample of the same process. */
+  int32_t hawkes_float32_intensities;
+  int32_t reserved2;
 } mbt_config;
 
 typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
@@ -462,8 +473,14 @@ int mbt_env_set_noise_host(mbt_env* env, const float* u_arr, const float* u_fill
 int mbt_env_set_user_noise_host(mbt_env* env, const float* z_user);
 
 /* ---- device buffers (zero-copy consumers) ------------------------------------------------------ */
-float* mbt_env_action_ptr(mbt_env* env);   /* (N, A) staging buffer a device policy may write */
-float* mbt_env_obs_ptr(mbt_env* env);      /* (N, D) observation of the last reset/step; D = 4: this IS the state */
+/* (N, A) staging buffer a device policy may write.  After a small-batch mbt_env_step_host the newest actions sit in the
+ * library's host stage; THIS call files them into the buffer first, so a writer must (re-)fetch the pointer after a host step
+ * rather than write through one it fetched before (the library cannot see such a write and would file the stage over it at
+ * the next mbt_env_step_device(NULL)).  Passing an explicit action pointer to step_device / step_many_device is always safe. */
+float* mbt_env_action_ptr(mbt_env* env);
+/* (N, D) observation of the last reset/step; without normalisation this IS the state, which the next step updates IN PLACE: the
+ * rows are valid until the next step / rollout / reset is enqueued on the environment's stream (copy them there to keep them). */
+float* mbt_env_obs_ptr(mbt_env* env);
 float* mbt_env_reward_ptr(mbt_env* env);   /* (N) rewards of the last step */
 int mbt_env_obs_dim(mbt_env* env);
 int mbt_env_action_dim(mbt_env* env);

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER, MID_HOST = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER, ARR_HOST = 0, 1, 2, 3, 4, 5
@@ -53,6 +53,7 @@ class MbtConfig(C.Structure):
         ("exogenous_depth", C.c_double * 2), ("base_fill_probability", C.c_double),
         ("reward_terminal_time", C.c_double), ("mid_coef_add", C.c_double), ("mid_coef_mul", C.c_double),
         ("precise_state", C.c_int32), ("allow_stiff_hawkes", C.c_int32),
+        ("hawkes_float32_intensities", C.c_int32), ("reserved2", C.c_int32),  # ABI 7
     ]
 
 

@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -23,8 +24,7 @@
 #include <string>
 
 #include "../../include/mbt_env.h"
-#include "speed_kernel.hpp"
-#include "step_kernel.hpp"
+#include "kernel_table.hpp"
 
 namespace {
 
@@ -131,14 +131,20 @@ bool is_pinned_host(const void* p, size_t bytes) {
 
 // (per environment: callers pass the same buffers step after step, and for a pageable one the classification above costs
 // driver calls every time - the answer for the last (pointer, size) of each role is remembered)
+// (an address can change KIND under the memo: a block of mbt_host_alloc freed and the same address handed out again by malloc, or the
+// reverse - every mbt_host_alloc / mbt_host_free advances a generation that the memo's answer is tied to)
+std::atomic<uint64_t> g_pinned_generation{0};
 struct PinnedMemo {
   const void* p = nullptr;
   size_t bytes = 0;
+  uint64_t generation = ~uint64_t(0);
   bool pinned = false;
   bool lookup(const void* q, size_t n) {
-    if (q == p && n == bytes) return pinned;
+    const uint64_t now = g_pinned_generation.load(std::memory_order_acquire);
+    if (q == p && n == bytes && generation == now) return pinned;
     p = q;
     bytes = n;
+    generation = now;
     return pinned = is_pinned_host(q, n);
   }
 };
@@ -150,232 +156,51 @@ struct PinnedMemo {
 // MBT_HOST_FAST_PATH_LANES overrides it (measurement knob).
 constexpr uint32_t kHostFastPathLanes = 65536;
 
-using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
+using mbt_table::StepKernel;
+using mbt_table::RolloutKernel;
+using mbt_table::LearnedRolloutKernel;
+using mbt_table::kPlain;
+using mbt_table::kStream;
+using mbt_table::kMirror;
+using mbt_table::exact_intensities;
+using mbt_table::exogenous_fill;
+using mbt_table::host_impact;
+using mbt_table::impact_has_state;
+using mbt_table::reward_weight;
+using mbt_table::speed_powers;
 
-// Which instantiation of a production-noise step kernel: default-policy loads | non-temporal loads (launches beyond the
-// Infinity Cache, tune_for_size) | the small-batch host-API kernel that mirrors its outputs into host memory and raises a
-// completion flag (mbt_env_step_host; step_kernel.hpp: signal_host).  Injected-noise kernels (parity mode) exist in the
-// first form only: asked for a mirror they answer nullptr and the host path takes its two-launch fallback.
-enum LoadMode : int { kPlain = 0, kStream = 1, kMirror = 2 };
-template <class V>
-StepKernel pick_mode(int mode) {
-  return mode == kStream ? mbt::step_kernel<V, true, false> : mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
-}
-template <class V_INJECT>
-StepKernel pick_injected(int mode) {
-  return mode == kMirror ? nullptr : mbt::step_kernel<V_INJECT>;
-}
+// arrivals as the kernel table counts them: 0 Poisson-type | 1 Hawkes, float32 intensities | 2 Hawkes, exact intensities
+int arrival_family(const mbt_config& c) { return c.arrival_kind != MBT_ARR_HAWKES ? 0 : (exact_intensities(c) ? 2 : 1); }
 
-// Limit-order-book family: arrivals {Poisson, Hawkes} x dynamics {limit, limit+market, touch} x {Brownian, other
-// midprice} x reward weight {PnL, quadratic inventory penalties, general} x normalised x noise = 144 step kernels and
-// 72 rollout kernels; WHICH other midprice and reward are runtime parameters inside them.
-int reward_weight(const mbt_config& c) {
-  if (c.reward_kind == MBT_REW_PNL) return mbt::kRewardPnl;
-  const bool quadratic = (c.reward_kind == MBT_REW_RUNNING_PENALTY || c.reward_kind == MBT_REW_CJ_MM) && c.inventory_exponent == 2.0;
-  return quadratic ? mbt::kRewardQuadratic : mbt::kRewardGeneral;
-}
-template <int ARR, int DYN, bool BM, int REW, bool NORM>
-StepKernel pick_noise(bool inject, int mode) {
-  if (inject) return pick_injected<mbt::Variant<ARR, DYN, BM, REW, NORM, true>>(mode);
-  return pick_mode<mbt::Variant<ARR, DYN, BM, REW, NORM, false>>(mode);
-}
-template <int ARR, int DYN, bool BM, int REW>
-StepKernel pick_flags(bool norm, bool inject, int mode) {
-  return norm ? pick_noise<ARR, DYN, BM, REW, true>(inject, mode) : pick_noise<ARR, DYN, BM, REW, false>(inject, mode);
-}
-template <int ARR, int DYN, bool BM>
-StepKernel pick_rew(int rew, bool norm, bool inject, int mode) {
-  switch (rew) {
-    case mbt::kRewardPnl: return pick_flags<ARR, DYN, BM, mbt::kRewardPnl>(norm, inject, mode);
-    case mbt::kRewardQuadratic: return pick_flags<ARR, DYN, BM, mbt::kRewardQuadratic>(norm, inject, mode);
-    default: return pick_flags<ARR, DYN, BM, mbt::kRewardGeneral>(norm, inject, mode);
-  }
-}
-template <int ARR, int DYN>
-StepKernel pick_pen(bool bm, int rew, bool norm, bool inject, int mode) {
-  return bm ? pick_rew<ARR, DYN, true>(rew, norm, inject, mode) : pick_rew<ARR, DYN, false>(rew, norm, inject, mode);
-}
-template <int ARR>
-StepKernel pick_dyn(int dyn, bool bm, int rew, bool norm, bool inject, int mode) {
-  switch (dyn) {
-    case MBT_DYN_LIMIT: return pick_pen<ARR, mbt::kDynLimit>(bm, rew, norm, inject, mode);
-    case MBT_DYN_LIMIT_AND_MARKET: return pick_pen<ARR, mbt::kDynLimitAndMarket>(bm, rew, norm, inject, mode);
-    default: return pick_pen<ARR, mbt::kDynTouch>(bm, rew, norm, inject, mode);
-  }
-}
-// Speed family.  kPlain: rows of 20 bytes LOADED through LDS (`staged`: cache-resident sizes, only with an impact state);
-// kStream: non-temporal direct loads (sizes beyond the Infinity Cache); kMirror: the small-batch host-API kernel (staged
-// like kPlain); see speed_step_kernel.
-// POW: the instantiation that can raise to arbitrary powers (speed_powers below); every reference configuration runs without
-template <class V, class V_INJECT, bool STATE>
-StepKernel pick_speed_mode(bool inject, int mode) {
-  if (inject) return mode == kMirror ? nullptr : mbt::speed_step_kernel<V_INJECT>;
-  if (mode == kStream) return mbt::speed_step_kernel<V, false, true>;
-  if (mode == kMirror) return mbt::speed_step_kernel<V, STATE, false, true>;
-  return mbt::speed_step_kernel<V, STATE>;
-}
-template <bool STATE, bool POW>
-StepKernel pick_speed_pow(bool norm, bool inject, int mode) {
-  return norm ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, false, POW>, mbt::SpeedVariant<STATE, true, true, false, POW>, STATE>(inject, mode)
-              : pick_speed_mode<mbt::SpeedVariant<STATE, false, false, false, POW>, mbt::SpeedVariant<STATE, false, true, false, POW>, STATE>(inject, mode);
-}
-template <bool STATE>
-StepKernel pick_speed(bool powers, bool norm, bool inject, int mode) {
-  return powers ? pick_speed_pow<STATE, true>(norm, inject, mode) : pick_speed_pow<STATE, false>(norm, inject, mode);
-}
-bool host_impact(const mbt_config& c) { return c.impact_kind == MBT_IMPACT_HOST || c.impact_kind == MBT_IMPACT_HOST_STATE; }
-bool impact_has_state(const mbt_config& c) { return c.impact_kind >= MBT_IMPACT_TEMPORARY_AND_PERMANENT && c.impact_kind != MBT_IMPACT_HOST; }
-// does this speed-dynamics configuration raise anything to a power other than 1 (impact, IMP:55) or 2 (inventory penalty,
-// RW:59-68), or use the exponential utility?  (No reference configuration does; the kernels without are a quarter the code.)
-bool speed_powers(const mbt_config& c) {
-  return (c.impact_kind == MBT_IMPACT_TEMPORARY_POWER && c.impact_exponent != 1.0) || (c.reward_kind != MBT_REW_PNL && c.inventory_exponent != 2.0) ||
-         c.reward_kind == MBT_REW_EXP_UTILITY;
-}
-
-
-// ExogenousMmFillProbabilityModel: the general tier only (runtime midprice coefficients, every reward, runtime
-// normalisation flags), 8 step (+ 4 mirror) + 4 rollout kernels.
-bool exogenous_fill(const mbt_config& c) {
-  return c.fill_kind == MBT_FILL_EXOGENOUS_MM && (c.dynamics_kind == MBT_DYN_LIMIT || c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET);
-}
-template <int ARR, int DYN>
-StepKernel pick_exogenous(bool inject, int mode) {
-  if (inject) return pick_injected<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, true>>(mode);
-  using V = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, true>;
-  return mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
-}
-
-// precise_state: the general tier again (every midprice model, every reward, runtime normalisation flags) on the
-// reference's float64 state: {Poisson-type, Hawkes} x {limit, limit + market, touch} + the exogenous-depth fill model on
-// {limit, limit + market}, x noise = 20 step + 10 rollout kernels; 6 + 2 for speed dynamics (the float32 kernel with a precise branch).
-// Round 4: like the float32 tier, the contract tier has SPECIALISED instantiations for what the BASELINE configurations run -
-// {Brownian, other built-in midprice} x {plain PnL, the penalised rewards with exponent 2} x raw spaces (no pow / exp /
-// normalisation code in the instruction stream: reward_exact<TIER>) - and STREAM / MIRROR instantiations of every
-// production-noise kernel; same operations in the same order, so which one runs changes no bit.
-template <int ARR, int DYN, bool EXO>
-StepKernel pick_precise(bool inject, int mode) {
-  if (inject) return pick_injected<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>(mode);
-  return pick_mode<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>(mode);
-}
-template <int ARR, int DYN, int REW>
-StepKernel pick_precise_special(bool brownian, int mode) {
-  using B = mbt::Variant<ARR, DYN, true, REW, false, false, false, true>;   // Brownian midprice (BASELINE configs 1, 2, 4)
-  using G = mbt::Variant<ARR, DYN, false, REW, false, false, false, true>;  // any other built-in midprice (config 3: OU)
-  return brownian ? pick_mode<B>(mode) : pick_mode<G>(mode);
-}
-template <int ARR, int DYN>
-StepKernel pick_precise_tier(int special_reward, bool brownian, bool inject, int mode) {
-  if (special_reward == mbt::kRewardPnl) return pick_precise_special<ARR, DYN, mbt::kRewardPnl>(brownian, mode);
-  if (special_reward == mbt::kRewardQuadratic) return pick_precise_special<ARR, DYN, mbt::kRewardQuadratic>(brownian, mode);
-  return pick_precise<ARR, DYN, false>(inject, mode);
-}
-// special_reward: kRewardPnl / kRewardQuadratic when the specialised instantiation applies, kRewardGeneral otherwise
-template <int ARR>
-StepKernel pick_precise_dyn(int dyn, bool exo, int special_reward, bool brownian, bool inject, int mode) {
-  switch (dyn) {
-    case MBT_DYN_LIMIT: return exo ? pick_precise<ARR, mbt::kDynLimit, true>(inject, mode) : pick_precise_tier<ARR, mbt::kDynLimit>(special_reward, brownian, inject, mode);
-    case MBT_DYN_LIMIT_AND_MARKET: return exo ? pick_precise<ARR, mbt::kDynLimitAndMarket, true>(inject, mode) : pick_precise_tier<ARR, mbt::kDynLimitAndMarket>(special_reward, brownian, inject, mode);
-    default: return pick_precise_tier<ARR, mbt::kDynTouch>(special_reward, brownian, inject, mode);
-  }
-}
-// (the precise_state tier of the speed family is the same kernel; POW as for the float32 tier)
-template <bool STATE>
-StepKernel pick_speed_precise(bool powers, bool inject, int mode) {
-  return powers ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true>, mbt::SpeedVariant<STATE, true, true, true, true>, STATE>(inject, mode)
-                : pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, false>, mbt::SpeedVariant<STATE, true, true, true, false>, STATE>(inject, mode);
-}
-
-// (a host-callback price impact model: the precise_state kernels with SpeedVariant::HOST_IMPACT, general reward form)
-template <bool STATE>
-StepKernel pick_speed_host_impact(bool inject, int mode) {
-  return pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true, true>, mbt::SpeedVariant<STATE, true, true, true, true, true>, STATE>(inject, mode);
-}
-
+// The instantiations themselves live in csrc/kernels_*.hip (kernel_table.hpp); this is the configuration logic in front of them.
 StepKernel pick_kernel(const mbt_config& c, int mode) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   const bool inject = c.noise_mode == MBT_NOISE_INJECTED;
-  if (c.dynamics_kind == MBT_DYN_SPEED) {
-    if (host_impact(c)) return impact_has_state(c) ? pick_speed_host_impact<true>(inject, mode) : pick_speed_host_impact<false>(inject, mode);
-    if (c.precise_state) return impact_has_state(c) ? pick_speed_precise<true>(speed_powers(c), inject, mode) : pick_speed_precise<false>(speed_powers(c), inject, mode);
-    return impact_has_state(c) ? pick_speed<true>(speed_powers(c), norm, inject, mode) : pick_speed<false>(speed_powers(c), norm, inject, mode);
-  }
+  if (c.dynamics_kind == MBT_DYN_SPEED) return mbt_table::pick_step_speed(c, mode);
+  const bool brownian = c.midprice_kind == MBT_MID_BROWNIAN;
+  const int tier = reward_weight(c);
   if (c.precise_state) {
-    const int tier = reward_weight(c);
     const bool special = !inject && !norm && !exogenous_fill(c) && tier != mbt::kRewardGeneral;
-    const int special_reward = special ? tier : mbt::kRewardGeneral;
-    const bool brownian = c.midprice_kind == MBT_MID_BROWNIAN;
-    return c.arrival_kind == MBT_ARR_HAWKES ? pick_precise_dyn<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, mode)
-                                            : pick_precise_dyn<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c), special_reward, brownian, inject, mode);
+    return mbt_table::pick_step_precise(c.arrival_kind == MBT_ARR_HAWKES, c.dynamics_kind, exogenous_fill(c), special ? tier : mbt::kRewardGeneral, brownian, inject, mode);
   }
-  if (exogenous_fill(c)) {
-    const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
-    if (c.arrival_kind == MBT_ARR_HAWKES) return market ? pick_exogenous<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(inject, mode) : pick_exogenous<mbt::kArrHawkes, mbt::kDynLimit>(inject, mode);
-    return market ? pick_exogenous<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(inject, mode) : pick_exogenous<mbt::kArrPoisson, mbt::kDynLimit>(inject, mode);
+  if (exogenous_fill(c)) return mbt_table::pick_step_exogenous(arrival_family(c), c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET, inject, mode);
+  switch (arrival_family(c)) {
+    case 2: return mbt_table::pick_step_hawkes_exact(c.dynamics_kind, brownian, tier, norm, inject, mode);
+    case 1: return mbt_table::pick_step_hawkes(c.dynamics_kind, brownian, tier, norm, inject, mode);
+    default: return mbt_table::pick_step_poisson(c.dynamics_kind, brownian, tier, norm, inject, mode);
   }
-  const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
-  const int rew = reward_weight(c);
-  return c.arrival_kind == MBT_ARR_HAWKES ? pick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm, inject, mode)
-                                          : pick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm, inject, mode);
 }
 
-using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
-template <bool STATE, bool POW>
-RolloutKernel pick_speed_rollout(bool norm) {
-  return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>>;
-}
-
-template <int ARR, int DYN, bool BM>
-RolloutKernel rpick_rew(int rew, bool norm) {
-  switch (rew) {
-    case mbt::kRewardPnl: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardPnl, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardPnl, false, false>>;
-    case mbt::kRewardQuadratic: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardQuadratic, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardQuadratic, false, false>>;
-    default: return norm ? mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardGeneral, true, false>> : mbt::rollout_kernel<mbt::Variant<ARR, DYN, BM, mbt::kRewardGeneral, false, false>>;
-  }
-}
-template <int ARR>
-RolloutKernel rpick_dyn(int dyn, bool bm, int rew, bool norm) {
-  switch (dyn) {
-    case MBT_DYN_LIMIT: return bm ? rpick_rew<ARR, mbt::kDynLimit, true>(rew, norm) : rpick_rew<ARR, mbt::kDynLimit, false>(rew, norm);
-    case MBT_DYN_LIMIT_AND_MARKET: return bm ? rpick_rew<ARR, mbt::kDynLimitAndMarket, true>(rew, norm) : rpick_rew<ARR, mbt::kDynLimitAndMarket, false>(rew, norm);
-    default: return bm ? rpick_rew<ARR, mbt::kDynTouch, true>(rew, norm) : rpick_rew<ARR, mbt::kDynTouch, false>(rew, norm);
-  }
-}
-template <int ARR>
-RolloutKernel rpick_precise(int dyn, bool exo) {
-  switch (dyn) {
-    case MBT_DYN_LIMIT:
-      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true, true>>
-                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
-    case MBT_DYN_LIMIT_AND_MARKET:
-      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true, true>>
-                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
-    default: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynTouch, false, mbt::kRewardGeneral, true, false, false, true>>;
-  }
-}
 RolloutKernel pick_rollout_kernel(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
-  if (c.dynamics_kind == MBT_DYN_SPEED) {
-    if (c.precise_state)
-      return impact_has_state(c) ? mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<true, true, false, true>> : mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<false, true, false, true>>;
-    if (impact_has_state(c)) return speed_powers(c) ? pick_speed_rollout<true, true>(norm) : pick_speed_rollout<true, false>(norm);
-    return speed_powers(c) ? pick_speed_rollout<false, true>(norm) : pick_speed_rollout<false, false>(norm);
-  }
-  if (c.precise_state)
-    return c.arrival_kind == MBT_ARR_HAWKES ? rpick_precise<mbt::kArrHawkes>(c.dynamics_kind, exogenous_fill(c)) : rpick_precise<mbt::kArrPoisson>(c.dynamics_kind, exogenous_fill(c));
-  if (exogenous_fill(c)) {
-    const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
-    if (c.arrival_kind == MBT_ARR_HAWKES)
-      return market ? mbt::rollout_kernel<mbt::Variant<mbt::kArrHawkes, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true>>
-                    : mbt::rollout_kernel<mbt::Variant<mbt::kArrHawkes, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true>>;
-    return market ? mbt::rollout_kernel<mbt::Variant<mbt::kArrPoisson, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true>>
-                  : mbt::rollout_kernel<mbt::Variant<mbt::kArrPoisson, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true>>;
-  }
-  const bool bm = c.midprice_kind == MBT_MID_BROWNIAN;
-  const int rew = reward_weight(c);
-  return c.arrival_kind == MBT_ARR_HAWKES ? rpick_dyn<mbt::kArrHawkes>(c.dynamics_kind, bm, rew, norm) : rpick_dyn<mbt::kArrPoisson>(c.dynamics_kind, bm, rew, norm);
+  if (c.dynamics_kind == MBT_DYN_SPEED) return mbt_table::pick_rollout_speed(c);
+  if (c.precise_state) return mbt_table::pick_rollout_precise(c.arrival_kind == MBT_ARR_HAWKES, c.dynamics_kind, exogenous_fill(c));
+  if (exogenous_fill(c)) return mbt_table::pick_rollout_exogenous(arrival_family(c), c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET);
+  return mbt_table::pick_rollout_order_book(arrival_family(c), c.dynamics_kind, c.midprice_kind == MBT_MID_BROWNIAN, reward_weight(c), norm);
 }
 
 }  // namespace
+
 
 struct mbt_env {
   mbt_config cfg;
@@ -390,8 +215,21 @@ struct mbt_env {
   double* h_sums = nullptr;       // pinned: [sum of rewards, sum of squared per-lane returns]
   bool sums_pending = false;
   // device buffers
+  // Launches that move 80 MB or more update the state IN PLACE (round 5): a lane reads its own row and writes its own row (rows
+  // that leave through LDS are written by other threads of the SAME workgroup, behind the barrier that follows every thread's last
+  // use of its loads; the speed kernels' per-wave spans are whole lines of the wave's own rows), so one buffer is enough, and the
+  // set of lines a launch touches shrinks by a third to a half - which decides on which side of the 256 MB Infinity Cache a
+  // launch lives: Hawkes + OU at 2^22 lanes (76 B rows: 319 -> 218 MB distinct) 49-54 -> 45.9 us, its precise_state tier 57.0 ->
+  // 55.1, Avellaneda-Stoikov at 2^21 lanes 14.2 -> 12.1 us and at 2^23 (default-policy loads) 63.8 -> 51.5 us
+  // (profiles/r05_in_place_state.txt).  Below that size the two-buffer scheme of rounds 1-4 stays (step k reads one, writes the
+  // other): in place, the write-through stores hit lines the loads have just brought into the L2, which measured 1.5-3 % SLOWER
+  // for the 2^20-lane kernels that are not the lightest one (CJP 6.67 -> 6.79 us, precise_state AS 9.38 -> 9.63).
+  // Either way an observation is valid until the next step is ENQUEUED (mbt_env_obs_ptr) - a normalised observation never
+  // outlived that (one `obs` buffer), and a zero-copy consumer that acts on an observation has consumed it before it can enqueue
+  // the next step.  MBT_PING_PONG_STATE = 0 / 1 overrides the choice (measurement knob).
   float* state[2] = {nullptr, nullptr};
   int cur = 0;  // state[cur] holds the current state
+  bool ping_pong = false;
   float* obs = nullptr;
   float* action = nullptr;
   // host-API fast path for small batches: pinned, device-mapped staging [actions (n_pad x A) | obs (n x D) | rewards (n)]
@@ -404,7 +242,9 @@ struct mbt_env {
   float* z = nullptr;
   float* q_init = nullptr;
   int32_t* resid = nullptr;    // precise_state: (n_pad, res) int32 remainders of the float64 state (step_kernel.hpp: exact_join)
-  int res = 0;                 // remainder columns per lane: [cash, midprice] (+ [bid, ask intensity]), speed: [cash, inventory, midprice, y]
+  int res = 0;                 // remainder columns per lane: [cash, midprice] (+ [bid, ask intensity]), speed: [cash, inventory, midprice, y];
+                               // float32 tier with exact Hawkes intensities (Variant::EXACT_LAM): [bid, ask intensity]
+  int res_col[4] = {0, 3, 4, 5};  // the state column behind each remainder column
   uint8_t* events = nullptr;
   float* lane_returns = nullptr;
   double* wave_sums = nullptr;
@@ -470,6 +310,9 @@ struct mbt_env {
 };
 
 namespace {
+
+// index of the buffer the next launch writes the state into (see mbt_env::state)
+inline int next_state(const mbt_env* e) { return e->ping_pong ? (e->cur ^ 1) : e->cur; }
 
 // What the float64 code paths compute with (the precise_state tier; RewardFunction / process evaluation for host callers):
 // the constructor arguments as the reference holds them.
@@ -620,10 +463,17 @@ void fill_static_params(mbt_env* e) {
 // profiles/r01_microbench.txt; the non-temporal loads: 128.3 -> 118.7 us on the copy kernel).  MBT_STREAM_LOADS = 0 / 1 and
 // MBT_STEP_DYNAMIC_LDS = bytes override the choice (measurement knobs).
 void tune_for_size(mbt_env* e) {
-  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + 2u * e->res);
+  const size_t bytes_per_launch = size_t(e->n_pad) * 4u * (2u * e->dim + e->act_dim + 1u + 2u * e->res);  // moved (read + written)
+  e->ping_pong = bytes_per_launch < (size_t(80) << 20);  // see mbt_env::state
+  if (const char* v = std::getenv("MBT_PING_PONG_STATE")) e->ping_pong = std::atoi(v) != 0;
   // (round 4: rows that are NOT 16 bytes wide lose with non-temporal loads far beyond 320 MB - Hawkes + OU at 2^22 lanes: 252 MB
   // float32 43.5 vs 36.6 us, 386 MB precise_state 69.5 vs 56.5 us - and win only around 1 GB, 2^24 lanes: 165.8 vs 177.2 us)
-  const bool hbm_resident = bytes_per_launch > (size_t(e->dim == 4 ? 320 : 640) << 20);
+  // (round 5, state updated in place: what decides is the set of DISTINCT lines a launch touches, which then stays in the Infinity
+  // Cache until the next launch or does not - AS at 2^23 lanes, 235 MB distinct / 369 MB moved: default-policy loads 51.5 us,
+  // non-temporal 53-55; at 2^24, 470 MB distinct: 124-132 vs 114.5.  16-byte rows switch at 300 MB distinct; the other row widths
+  // keep their measured 640 MB moved.)
+  const size_t distinct_bytes = size_t(e->n_pad) * 4u * ((e->ping_pong ? 2u : 1u) * e->dim + e->act_dim + 1u + e->res);
+  const bool hbm_resident = e->dim == 4 ? distinct_bytes > (size_t(300) << 20) : bytes_per_launch > (size_t(640) << 20);
   e->stream_loads = hbm_resident;
   e->step_dynamic_lds = (hbm_resident && !e->speed && e->dim == 4) ? 32u * 1024u : 0u;  // AS 2^24: 115.7 -> 114.2 us; Hawkes (D = 6) loses with it
   // Inside the cache the same cap pays for ONE kernel: the lightest one (Brownian midprice, Poisson arrivals, limit orders,
@@ -719,7 +569,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   mbt::StepBuffers B;
   std::memset(&B, 0, sizeof B);
   B.state_in = e->state[e->cur];
-  B.state_out = e->state[e->cur ^ 1];
+  B.state_out = e->state[next_state(e)];
   B.action = action_dev != nullptr ? action_dev : e->action;
   B.host_fill_p = e->host_fill_p;
   B.host_arrivals = e->host_arrivals;
@@ -750,7 +600,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
     HIP_TRY(hipGetLastError());
   }
   e->time = t_next;
-  e->cur ^= 1;
+  e->cur = next_state(e);
   e->philox_step += 1;
   e->episode_step += 1;
   e->noise_ready = false;
@@ -762,22 +612,8 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
 }
 
 // ---- learned policies (policy_mlp.hpp) --------------------------------------------------------------------------------
-using LearnedRolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams, const mbt::LearnedPolicyParams);
-
-// Two tiers x arrivals x {limit, limit + market} = 8 kernels: Brownian midprice with plain PnL (the reference's default
-// environment, BASELINE configs[1]: the environment part needs ~95 registers there) and the general tier (runtime midprice
-// coefficients, every reward); both with run-time normalisation flags.
-template <int ARR, int DYN>
-LearnedRolloutKernel pick_learned_tier(bool brownian_pnl) {
-  return brownian_pnl ? mbt::learned_rollout_kernel<mbt::Variant<ARR, DYN, true, mbt::kRewardPnl, true, false>>
-                      : mbt::learned_rollout_kernel<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false>>;
-}
 LearnedRolloutKernel pick_learned_rollout(const mbt_config& c) {
-  const bool market = c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET;
-  const bool brownian_pnl = c.midprice_kind == MBT_MID_BROWNIAN && c.reward_kind == MBT_REW_PNL;
-  if (c.arrival_kind == MBT_ARR_HAWKES)
-    return market ? pick_learned_tier<mbt::kArrHawkes, mbt::kDynLimitAndMarket>(brownian_pnl) : pick_learned_tier<mbt::kArrHawkes, mbt::kDynLimit>(brownian_pnl);
-  return market ? pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimitAndMarket>(brownian_pnl) : pick_learned_tier<mbt::kArrPoisson, mbt::kDynLimit>(brownian_pnl);
+  return mbt_table::pick_rollout_learned(arrival_family(c), c.dynamics_kind == MBT_DYN_LIMIT_AND_MARKET, c.midprice_kind == MBT_MID_BROWNIAN && c.reward_kind == MBT_REW_PNL);
 }
 
 // Device image of a learned policy: [w1: 4 x 64 half4 | w2: 8 x 64 half8 | w3: 2 x 64 half8 | b2: 64 f32 | b3: 16 f32 | lin_w: 32 f32 | lin_b: 4 f32]
@@ -1002,7 +838,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   mbt::StepBuffers B;
   std::memset(&B, 0, sizeof B);
   B.state_in = e->state[e->cur];
-  B.state_out = e->state[e->cur ^ 1];
+  B.state_out = e->state[next_state(e)];
   B.action = e->action;  // read by MBT_POLICY_ACTION_BUFFER only
   B.reward = e->reward;
   B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
@@ -1020,10 +856,17 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
     HIP_TRY(hipModuleLaunchKernel(e->jit_rollout, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, 0, e->stream, args, nullptr));
   } else {
     if (e->rollout == nullptr) return fail(MBT_ERR_INVALID, "this environment has no fused rollout kernel");
-    hipLaunchKernelGGL(e->rollout, dim3(e->n_blocks), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R);
+    // A RECORDING rollout is a store stream of 28 B per lane and step out of one long-running kernel: capped at five workgroups
+    // per CU (32 KB of dynamic LDS, like the lightest step kernel) it wrote 5.2 instead of 4.9 TB/s at 2^18 lanes and 5.65 instead
+    // of 5.5 at 2^20 in every A / B of tools/microbench/mb_rollout.hip (profiles/r05_mb_rollout.txt; the store policy itself -
+    // write-back, sc1, nt, system scope - made no reproducible difference: step_kernel.hpp, MBT_RECORD_STORE_POLICY).  Order-book
+    // kernels only (the speed kernels stage rows through LDS of their own).  MBT_ROLLOUT_DYNAMIC_LDS overrides (measurement knob).
+    uint32_t dynamic_lds = (!e->speed && (obs_traj != nullptr || act_traj != nullptr || rew_traj != nullptr)) ? 32u * 1024u : 0u;
+    if (const char* v = std::getenv("MBT_ROLLOUT_DYNAMIC_LDS")) dynamic_lds = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
+    hipLaunchKernelGGL(e->rollout, dim3(e->n_blocks), dim3(mbt::kBlockThreads), dynamic_lds, e->stream, B, P, R);
     HIP_TRY(hipGetLastError());
   }
-  e->cur ^= 1;
+  e->cur = next_state(e);
   e->time = t;
   e->philox_step += steps;
   e->episode_step += steps;
@@ -1079,11 +922,11 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
   row0.s0 = static_cast<float>(x[3]);
   for (int j = 4; j < 8; ++j) row0.extra[j - 4] = static_cast<float>(x[j]);
   row0.res = e->res;
+  row0.precise = c.precise_state ? 1 : 0;
   if (e->res != 0) {  // precise_state: what float32 left of each value (per-lane initial inventories are float32: no remainder)
     float hi;
-    const int order_book[4] = {0, 3, 4, 5}, speed[4] = {0, 1, 3, 4};  // state columns behind the remainder columns
     for (int j = 0; j < e->res; ++j) {
-      const int column = e->speed ? speed[j] : order_book[j];
+      const int column = e->res_col[j];
       exact_split_host(x[column], hi, row0.lo[j]);
       if (column >= e->dim || (column == 1 && per_lane_q0)) row0.lo[j] = 0;
     }
@@ -1294,7 +1137,7 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? (u.state_update[0] != nullptr && u.state_update[0][0] != 0 ? u.state_update[0] : "x0") : "0.0") + "); }\n"
          "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? (u.state_update[1] != nullptr && u.state_update[1][0] != 0 ? u.state_update[1] : "x1") : "0.0") + "); }\n}\n}  // namespace mbt\n";
   src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ">;\n";
+         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ", " + (exact_intensities(c) ? "true" : "false") + ">;\n";
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)  // the small-batch host-API instantiation (step_kernel.hpp: signal_host)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step_mirror(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false, true>(B, P); }\n";
@@ -1592,7 +1435,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   e->host_mask = (host_fill ? mbt::kHostFill : 0) | (host_arrival ? mbt::kHostArrival : 0) | ((host_reward || host_lowered.speed_reward) ? mbt::kHostReward : 0) |
                  (host_impact(*cfg) ? mbt::kHostImpact : 0);
   e->host_reward_replaces = host_lowered.speed_reward;
-  e->res = !cfg->precise_state ? 0 : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
+  e->res = !cfg->precise_state ? (exact_intensities(*cfg) ? 2 : 0) : speed ? 4 : ((cfg->arrival_kind == MBT_ARR_HAWKES || e->user_state_columns > 0) ? 4 : 2);
+  {
+    const int order_book[4] = {0, 3, 4, 5}, speed_cols[4] = {0, 1, 3, 4}, intensities[4] = {4, 5, 4, 5};  // state columns behind the remainder columns
+    for (int j = 0; j < 4; ++j) e->res_col[j] = !cfg->precise_state ? intensities[j] : speed ? speed_cols[j] : order_book[j];
+  }
   tune_for_size(e);
   if (needs_jit) {
     for (int j = 0; j < 8; ++j) {
@@ -1644,7 +1491,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   }
   const size_t np = e->n_pad;
   ENV_TRY(dev_alloc(&e->state[0], np * e->dim, e->stream));
-  ENV_TRY(dev_alloc(&e->state[1], np * e->dim, e->stream));
+  if (e->ping_pong) ENV_TRY(dev_alloc(&e->state[1], np * e->dim, e->stream));
   if (cfg->normalise_observation) ENV_TRY(dev_alloc(&e->obs, np * e->dim, e->stream));
   ENV_TRY(dev_alloc(&e->action, np * e->act_dim, e->stream));
   ENV_TRY(dev_alloc(&e->reward, np, e->stream));
@@ -1921,6 +1768,7 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
   if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "injected noise is consumed one step at a time: use mbt_env_step_device");
   if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows, once
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    e->action_in_stage = false;  // the caller's actions are the newest now: what an earlier host step left in the stage must not be filed over them
     action_device = nullptr;
   }
   if (action_device == nullptr && e->action_in_stage) {
@@ -2106,7 +1954,7 @@ int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   const int d = e->host_state_count;
   HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(mbt::host_columns_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->host_scratch, e->n, d, e->dim, e->host_state_first,
-                     e->state[e->cur], e->resid, e->res, e->speed ? 1 : 0, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
+                     e->state[e->cur], e->cfg.precise_state ? e->resid : nullptr, e->res, e->speed ? 1 : 0, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
@@ -2134,6 +1982,7 @@ int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   if (action_device != nullptr && e->n != e->n_pad) {
     // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    e->action_in_stage = false;  // (as in mbt_env_step_many_device: these are the newest actions, not the stage's)
     action_device = nullptr;
   }
   return launch_step(e, action_device, done);
@@ -2296,6 +2145,7 @@ void* mbt_host_alloc(size_t bytes) {
   else (void)hipGetLastError();
   std::lock_guard<std::mutex> guard(g_pinned_mutex);
   g_pinned_blocks[reinterpret_cast<uintptr_t>(p)] = block;
+  g_pinned_generation.fetch_add(1, std::memory_order_acq_rel);
   return p;
 }
 
@@ -2305,6 +2155,7 @@ void mbt_host_free(void* p) {
     std::lock_guard<std::mutex> guard(g_pinned_mutex);
     g_pinned_blocks.erase(reinterpret_cast<uintptr_t>(p));
   }
+  g_pinned_generation.fetch_add(1, std::memory_order_acq_rel);
   (void)hipHostFree(p);
 }
 
@@ -2329,10 +2180,9 @@ int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (size_t i = 0; i < n * d; ++i) state_host[i] = rows[i];
   if (r != 0) {
-    const int order_book[4] = {0, 3, 4, 5}, speed[4] = {0, 1, 3, 4};  // state columns behind the remainder columns
     for (size_t i = 0; i < n; ++i)
       for (size_t j = 0; j < r; ++j) {
-        const size_t column = static_cast<size_t>(e->speed ? speed[j] : order_book[j]);
+        const size_t column = static_cast<size_t>(e->res_col[j]);
         if (column < d) state_host[i * d + column] = exact_join_host(rows[i * d + column], lo[i * r + j]);
       }
   }
@@ -2365,7 +2215,7 @@ int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uin
   if (e->cfg.normalise_observation) {
     const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
     hipLaunchKernelGGL(mbt::normalise_rows_kernel, dim3(blocks), dim3(threads), 0, e->stream, e->state[e->cur], e->obs,
-                       e->n_pad, e->dim, e->params, e->res != 0 ? 1 : 0);
+                       e->n_pad, e->dim, e->params, e->cfg.precise_state ? 1 : 0);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(e->stream));

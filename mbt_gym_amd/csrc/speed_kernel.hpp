@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_exact_kernel(cons
   }
 }
 
+#ifndef MBT_KERNEL_TU  // (a non-template kernel: defined once, in the host translation unit)
 // the quad stream's normals, written out for tests: tile-split like the kernels (lane = tile * 1024 + slot + 256 * l)
 __global__ void rng_fill_quad_kernel(uint64_t quad_offset, uint32_t step, uint32_t k0, uint32_t k1, uint32_t n_quads, float* z) {
   const uint32_t quad = blockIdx.x * blockDim.x + threadIdx.x;
@@ -522,5 +523,6 @@ __global__ void rng_fill_quad_kernel(uint64_t quad_offset, uint32_t step, uint32
 #pragma unroll
   for (int l = 0; l < 4; ++l) z[lane0 + l * kBlockThreads] = nz.z[l];
 }
+#endif  // MBT_KERNEL_TU
 
 }  // namespace mbt

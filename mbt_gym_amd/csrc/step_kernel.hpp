@@ -59,7 +59,7 @@ enum : int { kHostFill = 1, kHostArrival = 2, kHostReward = 4, kHostImpact = 8 /
 
 template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
           bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false, int USER_STATE_ = 0,
-          bool USER_DRAWS_ = false, int HOST_ = 0>
+          bool USER_DRAWS_ = false, int HOST_ = 0, bool EXACT_LAM_ = false>
 struct Variant {
   static constexpr int ARR = ARR_, DYN = DYN_;
   static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
@@ -78,7 +78,16 @@ struct Variant {
   // and the step is evaluated in double in the reference's own order of operations (lane_step_exact): state and rewards
   // are the reference's float64 results, bit for bit, rounded once to float32 on the way out.  General tier only, like EXO.
   static constexpr bool PRECISE = PRECISE_;
-  static constexpr int RES = PRECISE_ ? ((ARR_ == kArrHawkes || USER_STATE_ != 0) ? 4 : 2) : 0;  // residual columns: [cash, midprice (, the two columns after it)]
+  // Exact Hawkes intensities in the float32 tier (mbt_config::hawkes_float32_intensities == 0, the default): ARR:110-123 keeps
+  // lambda in float64 and decides `u < lambda dt` on it, so a float32 lambda decides ~1e-6 of lane-steps differently.  Here ONLY
+  // the two intensity columns are held exactly (float32 rounding in the row + int32 remainder beside it, exact_join /
+  // exact_split), the recursion and the threshold are evaluated in double in the reference's order; cash and midprice stay
+  // float32 with the increment-form reward.  +16 B per env-step (76 instead of 60); arrivals, fills and inventory are then the
+  // reference's on the same draws in EVERY tier.  Meaningless (and off) under PRECISE, which holds every column exactly.
+  static constexpr bool EXACT_LAM = EXACT_LAM_ && !PRECISE_ && ARR_ == kArrHawkes;
+  static_assert(!EXACT_LAM_ || ARR_ == kArrHawkes, "exact intensities are a property of the Hawkes arrival model");
+  // residual columns: PRECISE [cash, midprice (, the two columns after it)]; EXACT_LAM [bid intensity, ask intensity]
+  static constexpr int RES = PRECISE_ ? ((ARR_ == kArrHawkes || USER_STATE_ != 0) ? 4 : 2) : (EXACT_LAM ? 2 : 0);
   // User-defined plugins (mbt_env_create_jit): this header is compiled at RUN TIME (hiprtc) together with the user's
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
@@ -619,13 +628,16 @@ template <class V>
 __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 lam, const float4 act, const LaneDraw& dr,
                                                 const float q_init, const float t_next, const bool is_terminal,
                                                 const StepParams& P, const float z = 0.f, const double t_now = 0.0, const float2 zu = make_float2(0.f, 0.f),
-                                                const HostStep& hs = HostStep{}, const double t_next_f64 = 0.0) {  // (t_next_f64: the advanced clock in double, for user state-update expressions)
+                                                const HostStep& hs = HostStep{}, const double t_next_f64 = 0.0,  // (t_next_f64: the advanced clock in double, for user state-update expressions)
+                                                const int4 lo = make_int4(0, 0, 0, 0)) {  // (EXACT_LAM: z / w = what float32 left of the two intensities)
   const float cash = core.x, q = core.y, mid = core.w;
   LaneResult r;
   r.lo = make_int4(0, 0, 0, 0);
   const bool norm_act = V::NORM && P.norm_act;
   const UserProcessState ups{V::USER_STATE > 0 ? static_cast<double>(lam.x) : 0.0, V::USER_STATE > 1 ? static_cast<double>(lam.y) : 0.0, zu.x, zu.y};
-  const Decisions D = decide<V>(q, act, dr, static_cast<double>(lam.x), static_cast<double>(lam.y), t_now, norm_act, P, ups, hs);
+  // the intensities ARR:123 compares with: the reference's float64 values (EXACT_LAM) or the float32 state
+  const double lam_bid = V::EXACT_LAM ? exact_join(lam.x, lo.z) : static_cast<double>(lam.x), lam_ask = V::EXACT_LAM ? exact_join(lam.y, lo.w) : static_cast<double>(lam.y);
+  const Decisions D = decide<V>(q, act, dr, lam_bid, lam_ask, t_now, norm_act, P, ups, hs);
   const float arr_bid = D.arr_bid, arr_ask = D.arr_ask, n_bid = D.n_bid, n_ask = D.n_ask;
   r.arr_bid = arr_bid != 0.0f;
   r.arr_ask = arr_ask != 0.0f;
@@ -664,7 +676,13 @@ __device__ __forceinline__ LaneResult lane_step(const float4 core, const float2 
   }
   const float mid_new = mid + d_mid;
   r.lam = lam;
-  if (V::ARR == kArrHawkes) {
+  if (V::EXACT_LAM) {  // ARR:110-119 in double, in the reference's order (= lane_step_exact's), split back into row + remainder
+    const PreciseParams& X = P.X;
+    const double lb = (lam_bid + X.hawkes_speed * (X.hawkes_base_bid - lam_bid) * X.arr_dt) + X.hawkes_jump * static_cast<double>(arr_bid);
+    const double la = (lam_ask + X.hawkes_speed * (X.hawkes_base_ask - lam_ask) * X.arr_dt) + X.hawkes_jump * static_cast<double>(arr_ask);
+    exact_split(lb, r.lam.x, r.lo.z);
+    exact_split(la, r.lam.y, r.lo.w);
+  } else if (V::ARR == kArrHawkes) {
     r.lam.x = __builtin_fmaf(P.hawkes_jump, arr_bid, lam.x + P.hawkes_speed * (P.hawkes_base_bid - lam.x) * P.arr_dt);
     r.lam.y = __builtin_fmaf(P.hawkes_jump, arr_ask, lam.y + P.hawkes_speed * (P.hawkes_base_ask - lam.y) * P.arr_dt);
   }
@@ -913,7 +931,7 @@ __device__ __forceinline__ LaneLoads load_lane(const StepBuffers& B, const StepP
   } else if (V::RES == 2) {
     const ldi2_t* src = reinterpret_cast<const ldi2_t*>(B.resid + static_cast<size_t>(lane) * 2);
     const ldi2_t v = NT ? __builtin_nontemporal_load(src) : *src;
-    L.lo = make_int4(v.x, v.y, 0, 0);
+    L.lo = V::EXACT_LAM ? make_int4(0, 0, v.x, v.y) : make_int4(v.x, v.y, 0, 0);  // (z / w are the intensities' slots in either tier)
   }
   if (V::HOST_FILL) {
     const double* p = B.host_fill_p + static_cast<size_t>(lane) * 2;
@@ -973,10 +991,47 @@ __device__ __forceinline__ void store_through(float* p, const float v) {
   asm volatile("s_nop 0\n\tglobal_store_dword %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
 }
 
+// How a row leaves the kernel.  kStoreThrough: written through the L2 (what the NEXT launch reads: the step kernels' state).
+// kStorePlain: ordinary write-back stores (the host mirror; rows that are not 16 bytes wide).  kStoreRecord: the policy of the
+// fused rollout's trajectory recording - a stream nobody in the kernel reads back, 28 B per lane and step from one long-running
+// kernel (MBT_RECORD_STORE_POLICY, measured in tools/microbench/mb_floor.hip `record` and mb_rollout.hip: 0 plain, 1 sc1, 2 nt).
+#ifndef MBT_RECORD_STORE_POLICY
+#define MBT_RECORD_STORE_POLICY 0
+#endif
+enum : int { kStorePlain = 0, kStoreThrough = 1, kStoreStream = 2, kStoreSystem = 3, kStoreThroughStream = 4, kStoreRecord = MBT_RECORD_STORE_POLICY };
+// (inline assembly like store_through - the builtins offer neither a scope nor sc1 + nt - with the same gfx9 wait states around it)
+#define MBT_STORE_ASM(WIDTH, BITS, NOP_AFTER) asm volatile("s_nop 0\n\tglobal_store_" WIDTH " %0, %1, off " BITS "\n\ts_nop " NOP_AFTER : : "v"(p), "v"(t) : "memory")
+template <int STORE>
+__device__ __forceinline__ void store_as(float4* p, const float4 v) {
+  const v4f_t t = {v.x, v.y, v.z, v.w};
+  if (STORE == kStoreThrough) MBT_STORE_ASM("dwordx4", "sc1", "1");
+  else if (STORE == kStoreStream) MBT_STORE_ASM("dwordx4", "nt", "1");
+  else if (STORE == kStoreSystem) MBT_STORE_ASM("dwordx4", "sc0 sc1", "1");
+  else if (STORE == kStoreThroughStream) MBT_STORE_ASM("dwordx4", "sc1 nt", "1");
+  else *p = v;
+}
+template <int STORE>
+__device__ __forceinline__ void store_as(float2* p, const float2 v) {
+  const v2f_t t = {v.x, v.y};
+  if (STORE == kStoreThrough) MBT_STORE_ASM("dwordx2", "sc1", "0");
+  else if (STORE == kStoreStream) MBT_STORE_ASM("dwordx2", "nt", "0");
+  else if (STORE == kStoreSystem) MBT_STORE_ASM("dwordx2", "sc0 sc1", "0");
+  else if (STORE == kStoreThroughStream) MBT_STORE_ASM("dwordx2", "sc1 nt", "0");
+  else *p = v;
+}
+template <int STORE>
+__device__ __forceinline__ void store_as(float* p, const float t) {
+  if (STORE == kStoreThrough) MBT_STORE_ASM("dword", "sc1", "0");
+  else if (STORE == kStoreStream) MBT_STORE_ASM("dword", "nt", "0");
+  else if (STORE == kStoreSystem) MBT_STORE_ASM("dword", "sc0 sc1", "0");
+  else if (STORE == kStoreThroughStream) MBT_STORE_ASM("dword", "sc1 nt", "0");
+  else *p = t;
+}
+
 // one state row as given
-// THROUGH: write the row through the L2 (what the NEXT launch reads); a trajectory recording, which nobody reads back soon
-// and which streams ~4 TB/s, is better left to the write-back L2 (1.52e11 vs 1.40e11 env-steps/s recorded)
-template <class V, bool THROUGH = true>
+// STORE: kStoreThrough for the state the NEXT launch reads; see above for the others (bool arguments of earlier rounds map onto
+// kStorePlain = false / kStoreThrough = true)
+template <class V, int STORE = kStoreThrough>
 __device__ __forceinline__ void store_row_values(float* base, uint32_t lane, const float4 core, const float2 lam, const float2 best) {
   if (V::DIM == 8) {
     float4* row = reinterpret_cast<float4*>(base) + static_cast<size_t>(lane) * 2;
@@ -992,18 +1047,17 @@ __device__ __forceinline__ void store_row_values(float* base, uint32_t lane, con
     float* row = base + static_cast<size_t>(lane) * 5;
     row[0] = core.x; row[1] = core.y; row[2] = core.z; row[3] = core.w; row[4] = lam.x;
   } else {
-    if (THROUGH) store_through(reinterpret_cast<float4*>(base) + lane, core);
-    else reinterpret_cast<float4*>(base)[lane] = core;
+    store_as<STORE>(reinterpret_cast<float4*>(base) + lane, core);
   }
 }
 
 // one state row (un-normalised, or normalised per TE:112-118 when `normalise`)
-template <class V, bool THROUGH = true>
+template <class V, int STORE = kStoreThrough>
 __device__ __forceinline__ void store_row(float* base, uint32_t lane, float4 core, float2 lam, bool normalise, const StepParams& P) {
   if (normalise) normalise_row(core, lam, P);
   float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);  // the exogenous best depths never move (FILL:168-170)
   if (V::EXO && normalise && P.norm_obs) best = make_float2(normalise_column(best.x, V::EXO_COL, P), normalise_column(best.y, V::EXO_COL + 1, P));
-  store_row_values<V, THROUGH>(base, lane, core, lam, best);
+  store_row_values<V, STORE>(base, lane, core, lam, best);
 }
 
 // precise_state: the normalised observation (TE:112-118) is formed from the float64 state like the reference forms it -
@@ -1014,7 +1068,7 @@ __device__ __forceinline__ float normalise_column_exact(double x, int col, const
 
 // the observation row of the precise_state tier: normalised (when the environment normalises) from the float64 state,
 // `t`: the float64 clock the row's time column stands for
-template <class V, bool THROUGH = true>
+template <class V, int STORE = kStoreThrough>
 __device__ __forceinline__ void store_row_exact(float* base, uint32_t lane, float4 core, float2 lam, const int4 lo, const double t, const StepParams& P) {
   float2 best = make_float2(P.exo_depth[0], P.exo_depth[1]);
   if (P.norm_obs) {
@@ -1026,11 +1080,13 @@ __device__ __forceinline__ void store_row_exact(float* base, uint32_t lane, floa
     if (V::EXTRA > 1) lam.y = normalise_column_exact(exact_join(lam.y, lo.w), 5, P);
     if (V::EXO) best = make_float2(normalise_column_exact(P.exo_depth_f64[0], V::EXO_COL, P), normalise_column_exact(P.exo_depth_f64[1], V::EXO_COL + 1, P));
   }
-  store_row_values<V, THROUGH>(base, lane, core, lam, best);
+  store_row_values<V, STORE>(base, lane, core, lam, best);
 }
 
-__device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int4 lo, int res) {
-  if (res == 4) store_through(reinterpret_cast<float4*>(base) + lane, make_float4(__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y), __builtin_bit_cast(float, lo.z), __builtin_bit_cast(float, lo.w)));
+template <class V>
+__device__ __forceinline__ void store_lo(int32_t* base, uint32_t lane, const int4 lo) {
+  if (V::RES == 4) store_through(reinterpret_cast<float4*>(base) + lane, make_float4(__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y), __builtin_bit_cast(float, lo.z), __builtin_bit_cast(float, lo.w)));
+  else if (V::EXACT_LAM) store_through(reinterpret_cast<float2*>(base) + lane, make_float2(__builtin_bit_cast(float, lo.z), __builtin_bit_cast(float, lo.w)));
   else store_through(reinterpret_cast<float2*>(base) + lane, make_float2(__builtin_bit_cast(float, lo.x), __builtin_bit_cast(float, lo.y)));
 }
 
@@ -1040,8 +1096,8 @@ template <class V, bool MIRROR = false>
 __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepParams& P, uint32_t lane, const LaneLoads& L,
                                              const LaneDraw& d, bool& clipped, float* staged_row, const float z = 0.f, const float2 zu = make_float2(0.f, 0.f)) {
   const LaneResult r = V::PRECISE ? lane_step_exact<V>(L.core, L.lam, L.lo, L.act, d, L.qi, P.is_terminal != 0, P, z, P.t_now, P.t_next_f64, zu, L.hs)
-                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu, L.hs, P.t_next_f64);
-  if (V::PRECISE) store_lo(B.resid, lane, r.lo, V::RES);
+                                  : lane_step<V>(L.core, L.lam, L.act, d, L.qi, P.t_next, P.is_terminal != 0, P, z, P.t_now, zu, L.hs, P.t_next_f64, L.lo);
+  if (V::RES != 0) store_lo<V>(B.resid, lane, r.lo);
   if (V::DIM == 4) {
     store_row<V>(B.state_out, lane, r.core, r.lam, false, P);
   } else if (V::DIM == 5) {  // (20-byte rows are only 4-byte aligned in LDS too)
@@ -1067,8 +1123,8 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
   if (B.lane_returns != nullptr) B.lane_returns[lane] += r.reward;
   if (MIRROR && lane < P.n) {  // small-batch host API: the row and the reward as env.step() returns them, straight into host memory
     B.host_reward[lane] = r.reward;
-    if (V::PRECISE) store_row_exact<V, false>(B.host_obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
-    else store_row<V, false>(B.host_obs, lane, r.core, r.lam, V::NORM, P);
+    if (V::PRECISE) store_row_exact<V, kStorePlain>(B.host_obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
+    else store_row<V, kStorePlain>(B.host_obs, lane, r.core, r.lam, V::NORM, P);
   }
   clipped = r.clipped_q | r.clipped_c;
   return r.reward;
@@ -1217,8 +1273,8 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     qi[l] = L.qi;
     lo[l] = L.lo;
     if (R.obs_traj != nullptr) {
-      if (V::PRECISE) store_row_exact<V, false>(R.obs_traj, lanes[l], core[l], lam[l], lo[l], R.t_start, P);
-      else store_row<V, false>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
+      if (V::PRECISE) store_row_exact<V, kStoreRecord>(R.obs_traj, lanes[l], core[l], lam[l], lo[l], R.t_start, P);
+      else store_row<V, kStoreRecord>(R.obs_traj, lanes[l], core[l], lam[l], V::NORM, P);
     }
   }
   load_initial_inventories<V>(B, lanes[0], lanes[1], qi[0], qi[1]);
@@ -1306,7 +1362,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       // lane values into adjacent registers and SGPR spills from the longer live ranges: 3.48e11 instead of 3.62e11 env-steps/s at
       // 2^20 lanes.  profiles/r03_experiments.txt.  The compiler already packs the two SIDES of a lane where that is free.)
       const LaneResult r = V::PRECISE ? lane_step_exact<V>(core[l], lam[l], lo[l], act[l], make_draw<V>(nz[l], P), qi[l], terminal, P, nz[l].z, t_now, t, zu[l])
-                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l], HostStep{}, t);
+                                      : lane_step<V>(core[l], lam[l], act[l], make_draw<V>(nz[l], P), qi[l], static_cast<float>(t), terminal, P, nz[l].z, t_now, zu[l], HostStep{}, t, lo[l]);
       core[l] = r.core;
       lam[l] = r.lam;
       lo[l] = r.lo;
@@ -1316,22 +1372,22 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       if (B.events != nullptr) last_events[l] = event_byte(r);
       if (R.obs_traj != nullptr) {
         float* slice = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
-        if (V::PRECISE) store_row_exact<V, false>(slice, lanes[l], core[l], lam[l], lo[l], t, P);
-        else store_row<V, false>(slice, lanes[l], core[l], lam[l], V::NORM, P);
+        if (V::PRECISE) store_row_exact<V, kStoreRecord>(slice, lanes[l], core[l], lam[l], lo[l], t, P);
+        else store_row<V, kStoreRecord>(slice, lanes[l], core[l], lam[l], V::NORM, P);
       }
       if (R.act_traj != nullptr) {
         float* dst = R.act_traj + static_cast<size_t>(k) * n_pad * A;
-        if (A == 2) reinterpret_cast<float2*>(dst)[lanes[l]] = make_float2(act[l].x, act[l].y);
-        else reinterpret_cast<float4*>(dst)[lanes[l]] = act[l];
+        if (A == 2) store_as<kStoreRecord>(reinterpret_cast<float2*>(dst) + lanes[l], make_float2(act[l].x, act[l].y));
+        else store_as<kStoreRecord>(reinterpret_cast<float4*>(dst) + lanes[l], act[l]);
       }
-      if (R.rew_traj != nullptr) R.rew_traj[static_cast<size_t>(k) * n_pad + lanes[l]] = r.reward;
+      if (R.rew_traj != nullptr) store_as<kStoreRecord>(R.rew_traj + static_cast<size_t>(k) * n_pad + lanes[l], r.reward);
     }
   }
   float ret_sum = 0.0f;
 #pragma unroll
   for (int l = 0; l < 2; ++l) {  // what step() leaves behind: final state, last rewards (and events) of the final step
     store_row<V>(B.state_out, lanes[l], core[l], lam[l], false, P);
-    if (V::PRECISE) store_lo(B.resid, lanes[l], lo[l], V::RES);
+    if (V::RES != 0) store_lo<V>(B.resid, lanes[l], lo[l]);
     if (V::NORM && B.obs != nullptr) {
       if (V::PRECISE) store_row_exact<V>(B.obs, lanes[l], core[l], lam[l], lo[l], t, P);
       else store_row<V>(B.obs, lanes[l], core[l], lam[l], true, P);
@@ -1363,6 +1419,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void learned_rollout_kernel(const
   rollout_body<V, true>(B, P, R, &LP);
 }
 
+#ifndef MBT_KERNEL_TU  // (a non-template kernel: defined once, in the host translation unit - see kernel_table.hpp)
 // The same policy as a kernel of its own, for a step loop: observation buffer (n_pad, D) -> action buffer (n_pad, A), in
 // the step kernel's lane <-> thread mapping (so the wave-level MLP sees the same rows in the same places as the rollout).
 __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs, float* action, int dim, int act_dim, const LearnedPolicyParams LP,
@@ -1392,9 +1449,12 @@ __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs,
     for (int c = 0; c < act_dim; ++c) row[c] = a[l][c];
   }
 }
+#endif  // MBT_KERNEL_TU
 #endif
 
-#ifndef MBT_JIT_USER_CODE  // the run-time compiled translation unit needs the step and rollout bodies only
+// (neither the run-time compiled translation unit nor the translation units that only instantiate step / rollout kernels
+// - csrc/kernels_*.hip - need what follows: the helper kernels are defined once, in mbt_env.hip)
+#if !defined(MBT_JIT_USER_CODE) && !defined(MBT_KERNEL_TU)
 // ---- small helper kernels ----------------------------------------------------------------------------------
 
 // reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...], zeroed accumulators.
@@ -1405,7 +1465,8 @@ struct ResetRow {
   // initial inventories are per lane) and the int32 remainders of the residual columns (exact_split on the host)
   double exact[8];
   int32_t lo[4];
-  int32_t res;  // residual columns per lane: 0 (float32 tiers), 2 or 4
+  int32_t res;  // residual columns per lane: 0, 2 or 4
+  int32_t precise;  // precise_state: observations are normalised from the float64 values (res != 0 alone may be the float32 tier's exact intensities)
 };
 
 __global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0, const ResetRow row0,
@@ -1421,7 +1482,7 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
     const float v = j == 0 ? row0.cash0 : j == 1 ? (q0 != nullptr ? q0[i] : row0.q0_scalar) : j == 2 ? row0.t0 : j == 3 ? row0.s0 : row0.extra[j - 4];
     row[j] = v;
     if (orow != nullptr) {
-      if (row0.res != 0) {  // precise_state: normalised from the float64 value, like the reference (TE:112-118)
+      if (row0.precise != 0) {  // precise_state: normalised from the float64 value, like the reference (TE:112-118)
         const double x = (j == 1 && q0 != nullptr) ? static_cast<double>(q0[i]) : row0.exact[j];
         orow[j] = P.norm_obs ? normalise_column_exact(x, j, P) : v;
       } else {
@@ -1640,6 +1701,6 @@ __global__ void philox_kat_kernel(const uint32_t* ctr, const uint32_t* key, uint
   out[0] = w.w0; out[1] = w.w1; out[2] = w.w2; out[3] = w.w3;
 }
 
-#endif  // MBT_JIT_USER_CODE
+#endif  // !MBT_JIT_USER_CODE && !MBT_KERNEL_TU
 
 }  // namespace mbt

@@ -10,7 +10,8 @@ no numerics of the step are evaluated here, and there is no CPU fallback.
 Extra keyword arguments (after the reference's): `device`, `trajectory_offset` (global id of lane 0 when the
 trajectory axis is sharded over GPUs), `noise` ("philox" | "injected"), `precise_state` (cash and midprice kept as
 float32 pairs: rewards within 1e-5 of the float64 reference on every lane, +16 B of traffic per env-step),
-`allow_stiff_hawkes` (accept mean_reversion_speed * step_size >= 1, see include/mbt_env.h).
+`allow_stiff_hawkes` (accept mean_reversion_speed * step_size >= 1, see include/mbt_env.h), `hawkes_float32_intensities`
+(True: Hawkes intensities as float32 state, 60 instead of 76 B per env-step, arrivals no longer the reference's to the bit).
 Extra methods: `step_device()` / `obs_device` / `reward_device` (zero-copy, asynchronous), `set_noise()`,
 `record_events()`, `episode_return_sums()`.
 
@@ -63,6 +64,7 @@ def host_callback_role(part):
     RW:10-13 `calculate`, SP:33-35 `update` of a MidpriceModel) - and None for everything else (built-ins and device expressions
     name a `device_kind`)."""
     if getattr(part, "device_kind", None) is not None:
+        _refuse_overridden_builtin(part)
         return None
     if (isinstance(part, StochasticProcessModel) and not isinstance(part, (FillProbabilityModel, ArrivalModel, PriceImpactModel))
             and type(part).update is not StochasticProcessModel.update):
@@ -77,6 +79,31 @@ def host_callback_role(part):
     if isinstance(part, PriceImpactModel) and type(part).get_impact is not PriceImpactModel.get_impact:
         return "impact"  # IMP:25-27
     return None
+
+
+# the NumPy methods of the reference's plugin contract (SP:33-35, ARR:27-29, FILL:22-34, RW:10-13, IMP:25-27): what a user overrides
+_CONTRACT_METHODS = ("update", "get_arrivals", "_get_fill_probabilities", "get_fills", "calculate", "get_impact")
+_USER_KINDS = {"midprice": (_native.MID_USER, _native.MID_LINEAR_SDE), "arrival": (_native.ARR_USER,), "fill": (_native.FILL_USER,), "reward": (_native.REW_USER,)}
+
+
+def _refuse_overridden_builtin(part):
+    """A subclass of a BUILT-IN plugin class (one that names a kernel: `device_kind`) that overrides a NumPy method of the contract -
+    `class MyFill(ExponentialFillFunction): def _get_fill_probabilities(...)`, the most common customisation in the reference - would
+    inherit the parent's kernel and its own method would never run.  The reference calls the override; running the parent's formula
+    instead would be a silent fidelity hole, so it is refused with the two ways out."""
+    classes = type(part).__mro__
+    owner = next((cls for cls in classes if cls.__dict__.get("device_kind") is not None), None)
+    if owner is None or owner is type(part) or not owner.__module__.startswith("mbt_gym_amd."):
+        return
+    if any(owner.__dict__.get("device_kind") in kinds for kinds in _USER_KINDS.values()):
+        return  # the device-expression bases: a subclass states its own formula, and may keep a NumPy twin for host use
+    for cls in classes[:classes.index(owner)]:
+        overridden = [name for name in _CONTRACT_METHODS if name in cls.__dict__]
+        if overridden:
+            raise UnsupportedOnDevice(
+                f"{cls.__name__} overrides {', '.join(overridden)}() of {owner.__name__}, which runs as a kernel (device_kind {owner.__dict__['device_kind']}): the "
+                f"override would never be called.  Derive from the abstract base instead (the NumPy method then runs on the host every step - the "
+                f"host-callback route), or state the formula as a device expression (DeviceExpression* classes) for the fast path.")
 
 
 class TradingEnvironment(_EnvBase):
@@ -106,6 +133,7 @@ class TradingEnvironment(_EnvBase):
         noise: str = "philox",
         precise_state: bool = False,
         allow_stiff_hawkes: bool = False,
+        hawkes_float32_intensities: bool = False,
     ):
         if _EnvBase is not object:
             super().__init__()
@@ -149,6 +177,9 @@ class TradingEnvironment(_EnvBase):
             precise_state = True
         self.precise_state = precise_state
         self.allow_stiff_hawkes = allow_stiff_hawkes
+        # Hawkes intensities are held exactly by default (arrivals = the float64 reference's on the same draws, 76 B per env-step);
+        # True: float32 intensities, 60 B per env-step (include/mbt_env.h: hawkes_float32_intensities)
+        self.hawkes_float32_intensities = hawkes_float32_intensities
         # Seeding protocol of the reference: `if seed:` - seed=0 or None leaves the processes unseeded (TE:70);
         # the environment-level generator (initial inventories) is always default_rng(seed) (TE:72).
         self.seed_ = seed
@@ -258,6 +289,7 @@ class TradingEnvironment(_EnvBase):
         cfg.reward_terminal_time = float(getattr(self.reward_function, "terminal_time", 0.0) or 0.0)
         cfg.precise_state = int(self.precise_state)
         cfg.allow_stiff_hawkes = int(self.allow_stiff_hawkes)
+        cfg.hawkes_float32_intensities = int(self.hawkes_float32_intensities)
         cfg.normalise_observation = int(self.normalise_observation_space_)
         cfg.normalise_action = int(self.normalise_action_space_)
         lo, hi = self.original_observation_space.low, self.original_observation_space.high
@@ -355,6 +387,12 @@ class TradingEnvironment(_EnvBase):
                 updates += fill_state[0]
                 initial += fill_state[1]
                 owners += [2] * len(fill_state[0])
+            # the symbols a state-update expression may read are locals of the generated function (mbt_env.hip: jit_source): a parameter of
+            # the same name would be a redeclaration the user sees as a wall of compiler output
+            reserved = {"S", "t", "dt", "x0", "x1", "z", "z1", "z2", "arr_bid", "arr_ask", "fills_bid", "fills_ask", "S_next", "t_next", "q_next", "cash_next"}
+            taken = sorted(reserved & set(params))
+            if taken:
+                raise UnsupportedOnDevice(f"state-update parameter name(s) {taken} are symbols the expressions themselves may read (reserved: {sorted(reserved)}): rename them")
             state = (updates, params, initial, extra, owners)
         extra_normals = bool(getattr(mid, "uses_extra_normals", False) and mid_code is not None) or bool(getattr(arrival, "uses_extra_normals", False) and arrival_code is not None)
         if state is None and extra_normals:
@@ -483,8 +521,6 @@ class TradingEnvironment(_EnvBase):
                     "fill and arrival models with at most two columns of their own, midprice models with at most two beside the "
                     "price and price impact models with at most one (otherwise: a device expression, DeviceExpressionArrivalModel / DeviceExpressionMidpriceModel)")
             found[role] = part
-            if role in ("fill", "arrival", "midprice", "impact"):
-                part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
         if "midprice" in found:
             if md.price_impact_model is not None and found["midprice"].state_dim > 1:
                 raise UnsupportedOnDevice(f"{type(found['midprice']).__name__} only has host (NumPy) code and owns {found['midprice'].state_dim} columns: "
@@ -508,6 +544,9 @@ class TradingEnvironment(_EnvBase):
                 "State the formula as a device expression (DeviceExpressionFillModel / ...ArrivalModel / ...MidpriceModel / ...Reward; order-book "
                 "dynamics) for the fast path.",
                 HostCallbackWarning, stacklevel=3)
+        for role, part in found.items():  # (only now: every refusal above has passed, the objects are not marked by a construction that failed)
+            if role in ("fill", "arrival", "midprice", "impact"):
+                part._host_callback = True  # its state (if any) lives on the host, advanced by ITS update()
         return found
 
     def _host_owned_columns(self):
@@ -648,10 +687,10 @@ class TradingEnvironment(_EnvBase):
         return pools["action_array"]
 
     def _stage_action(self, action, pools):
-        if type(action) is np.ndarray and action.dtype == np.float32 and action.size <= (1 << 18) and action.flags.c_contiguous:
+        if type(action) is np.ndarray and action.dtype == np.float32 and self._num_trajectories <= 65536 and action.flags.c_contiguous:
             if action.shape != pools["action_shape"]:
                 raise ValueError(f"expected shape {pools['action_shape']}, got {action.shape}")
-            return action  # batches the library stages itself (up to 65536 lanes: one copy into its mapped stage): the caller's array as it is
+            return action  # batches the library stages itself (mbt_env.hip: kHostFastPathLanes = 65536 lanes: one copy into its mapped stage): the caller's array as it is
         staged = self.action_buffer
         if action is staged:
             return staged
@@ -725,7 +764,8 @@ class TradingEnvironment(_EnvBase):
 
     @property
     def obs_device(self):
-        """Observation of the last reset/step.  Valid until the step after next (ping-pong buffers)."""
+        """Observation of the last reset/step, zero-copy.  Valid until the NEXT step is enqueued: the state is updated in place (round 5;
+        like the normalised observation always was) - a consumer that needs it longer copies it on the environment's stream."""
         ptr = _native.load_library().mbt_env_obs_ptr(self._handle)
         return _native.DeviceView(ptr, (self.num_trajectories, self.observation_dim), self)
 

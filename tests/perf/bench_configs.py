@@ -19,7 +19,8 @@ CASES = {
     "cfg1 AS 2^20 (D=4,A=2,44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="pnl"), 20, [0.7, 0.7]),
     "cfg2 CJP cjmm 2^20 (44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="cjmm", phi=0.01, alpha=0.001, max_inventory=100), 20, [0.7, 0.7]),
     "cfg2 CJP running 2^20 (44B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="running", phi=0.01, alpha=0.001, max_inventory=100), 20, [0.7, 0.7]),
-    "cfg3 Hawkes+OU 2^22 (D=6,60B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7]),
+    "cfg3 Hawkes+OU 2^22 (D=6, exact intensities: 60B credited, 76B moved)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7]),
+    "cfg3 Hawkes+OU 2^22, float32 intensities (60B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7], dict(hawkes_float32_intensities=True)),
     "cfg4 limit+market 2^21 (A=4,52B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), dynamics="limit_and_market", reward="pnl", initial_inventory=10), 21, [0.7, 0.7, 0.0, 1.0]),
     "speed temp+perm impact, CjOe 2^20 (D=5,A=1,48B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.015, reward="cjoe", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5]),
     "speed power impact, PnL 2^20 (D=4,A=1,40B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.0, reward="pnl", initial_inventory=10), 20, [0.5]),
@@ -57,9 +58,12 @@ def main():
         _native.check(lib.mbt_env_timer_end(env._handle, C.byref(ms)))
         us = ms.value * 1e3 / steps
         d, a = env.observation_dim, env.action_dim
-        bytes_step = 4 * (d + a + d + 1) + (4 * d if cfg.normalise_observation_space else 0) + (8 * (4 if (cfg.dynamics == "speed" or cfg.arrival == "hawkes") else 2) if env_kw.get("precise_state") else 0)
-        out[name] = {"us_per_step": round(us, 2), "env_steps_per_s": n / us * 1e6, "algorithmic_GBps": bytes_step * n / us * 1e-3,
-                     "frac_of_8TBps": bytes_step * n / us * 1e-3 / 8000}
+        credited = 4 * (d + a + d + 1) + (4 * d if cfg.normalise_observation_space else 0)
+        remainders = (4 if (cfg.dynamics == "speed" or cfg.arrival == "hawkes") else 2) if env_kw.get("precise_state") else (2 if cfg.arrival == "hawkes" and not env_kw.get("hawkes_float32_intensities") else 0)
+        bytes_step = credited + 8 * remainders  # what the kernel moves: + 4 B read and 4 B written per int32 remainder column
+        out[name] = {"us_per_step": round(us, 2), "env_steps_per_s": n / us * 1e6, "credited_bytes_per_env_step": credited, "moved_bytes_per_env_step": bytes_step,
+                     "moved_GBps": bytes_step * n / us * 1e-3, "moved_frac_of_8TBps": bytes_step * n / us * 1e-3 / 8000,
+                     "credited_frac_of_8TBps": credited * n / us * 1e-3 / 8000}
         env.close()
     print(json.dumps(out, indent=1))
 

@@ -15,7 +15,9 @@ tests/perf/parity_report.py measures (profiles/r02_parity_report.txt):
                                                                            has held this episode) + 1e-4
   midprice ............................................................... |err| <= 2e-4   (S ~ 100: ulp = 7.6e-6,
                                                                            random-walk of the per-step rounding; measured 8.4e-5)
-  Hawkes intensities ..................................................... |err| <= 2e-5 + 3e-7 |lambda|
+  Hawkes intensities ..................................................... EQUAL to np.float32(reference) (round 5: the two
+      intensity columns are held exactly - float32 row + int32 remainder - and advanced in double in the reference's order,
+      ARR:110-123; `hawkes_float32_intensities=True` restores float32 state: |err| <= 2e-5 + 3e-7 |lambda|)
   time ................................................................... 1e-6 abs
   normalised observations ................................................ 5e-5 abs (midprice drift / half-width 8)
 The state is float32 in HBM (it IS the float32 observation the API returns), so cash and midprice carry the
@@ -38,7 +40,7 @@ def _is_speed(name):
     return name.startswith("speed_") or name.endswith("_speed")
 
 
-def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
+def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None, exact_intensities=False):
     if normalised:
         np.testing.assert_allclose(got, want, rtol=0, atol=5e-5, err_msg=f"{name} step {k}: normalised obs")
         # inventory is an integer count: exact after de-normalisation
@@ -59,7 +61,9 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
     if want.shape[1] == 5 and not _is_speed(name):  # the second factor of a user's two-column midprice (float32 state, O(1) values)
         np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=2e-6, atol=2e-5, err_msg=f"{name} step {k}: second midprice factor")
     if want.shape[1] > 5:
-        # float32 state: 2e-5 absolute around the baselines (10..50), float32 relative accuracy where arrivals have driven an
+        if exact_intensities:  # the built-in Hawkes model in the default tier: the reference's float64 intensities, rounded once
+            np.testing.assert_array_equal(got[:, 4:6], want[:, 4:6].astype(np.float32), err_msg=f"{name} step {k}: intensities")
+        # float32 state otherwise: 2e-5 absolute around the baselines (10..50), float32 relative accuracy where arrivals have driven an
         # intensity to ~150 (ulp 1.5e-5 there)
         np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=3e-7, atol=2e-5, err_msg=f"{name} step {k}: intensities")
 
@@ -69,13 +73,14 @@ def _check_obs(name, k, got, want, normalised, max_inventory, cash_scale=None):
 def test_step_matches_reference_fixture(name, record):
     cfg, g = load_case(name)
     env = make_env(cfg, noise="injected")
+    exact = cfg.arrival == "hawkes"
     oracle = OracleEnv(cfg, InjectedNoise(g["u_arr"], g["u_fill"], g["z"], g.get("z_user")))
     if record:
         env.record_events(True)
     obs0 = env.reset()
     oracle.reset()
     assert obs0.dtype == np.float32 and obs0.shape == g["obs0"].shape
-    _check_obs(name, -1, obs0, g["obs0"], cfg.normalise_observation_space, cfg.max_inventory)
+    _check_obs(name, -1, obs0, g["obs0"], cfg.normalise_observation_space, cfg.max_inventory, exact_intensities=exact)
     cash_scale = np.abs(g["obs0"][:, 0]) if not cfg.normalise_observation_space else None
     changes = step_size_changes(g)
     for k in range(g["actions"].shape[0]):
@@ -92,7 +97,7 @@ def test_step_matches_reference_fixture(name, record):
             np.testing.assert_array_equal(env.last_fills.astype(np.uint8), g["fills"][k], err_msg=f"{name} step {k}: fills")
         if cash_scale is not None:
             cash_scale = np.maximum(cash_scale, np.abs(g["obs"][k][:, 0]))
-        _check_obs(name, k, obs, g["obs"][k], cfg.normalise_observation_space, cfg.max_inventory, cash_scale)
+        _check_obs(name, k, obs, g["obs"][k], cfg.normalise_observation_space, cfg.max_inventory, cash_scale, exact_intensities=exact)
         # lanes where the clip of TE:283-289 changed cash or inventory, from the oracle; the kernel's event bits agree
         clipped = oracle.last_clipped
         if record:

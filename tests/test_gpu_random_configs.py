@@ -24,17 +24,18 @@ FUZZ_SCALE = int(os.environ.get("MBT_FUZZ_SCALE", "1"))
 FUZZ_SEED = int(os.environ.get("MBT_FUZZ_SEED", "0"))
 
 
-# Hawkes lanes retired by the default tier's fuzz, COUNTED: how many lanes were retired and how many the stated window predicts
-# (test_retired_hawkes_lanes_stay_within_the_stated_rate, at the end of this file, holds the tier to that rate)
+# Hawkes lanes retired by the fuzz of the OPT-OUT tier (hawkes_float32_intensities=True, 60 B per env-step), COUNTED: how many
+# lanes were retired and how many the stated window predicts (test_retired_hawkes_lanes_stay_within_the_stated_rate, at the
+# end of this file, holds that tier to the rate).  The DEFAULT tier holds its intensities exactly and retires nothing.
 HAWKES_LEDGER = {"retired": 0, "expected": 0.0, "lane_steps": 0}
 
 
 def _undecidable_hawkes_lanes(cfg, oracle, u_arr, alive=None):
-    """Lanes whose Hawkes arrival draw sits closer to the threshold lambda dt (ARR:121-123) than the float32 intensity
-    state can resolve (its error bound, asserted below, is 2e-5 + 3e-7 lambda): there the float32 and the float64
-    comparison may legitimately differ, and from then on the lane is a different trajectory.  The draws are uniform, so the
-    window has a known probability - 2 (2e-5 + 3e-7 lambda) dt per side - and the ledger keeps the expected count beside the
-    actual one: about one lane-step in 10^6 at lambda ~ 40, dt ~ 1/40."""
+    """hawkes_float32_intensities=True only.  Lanes whose Hawkes arrival draw sits closer to the threshold lambda dt
+    (ARR:121-123) than the float32 intensity state can resolve (its error bound, asserted below, is 2e-5 + 3e-7 lambda): there
+    the float32 and the float64 comparison may legitimately differ, and from then on the lane is a different trajectory.  The
+    draws are uniform, so the window has a known probability - 2 (2e-5 + 3e-7 lambda) dt per side - and the ledger keeps the
+    expected count beside the actual one: about one lane-step in 10^6 at lambda ~ 40, dt ~ 1/40."""
     if cfg.arrival != "hawkes":
         return np.zeros(cfg.num_trajectories, dtype=bool)
     adt = cfg.arrival_step_size or cfg.step_size
@@ -52,22 +53,42 @@ def _undecidable_hawkes_lanes(cfg, oracle, u_arr, alive=None):
 
 @pytest.mark.parametrize("case", range(150 * FUZZ_SCALE))
 def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
+    """The default tier: float32 cash / midprice, every DECISION the float64 reference's - Hawkes arrivals included (the two
+    intensity columns are held exactly: state64's columns 4:6 EQUAL the oracle's, no lane is retired, no ledger)."""
     rng = np.random.default_rng(FUZZ_SEED + 7000 + case)
     n = int(rng.choice([7, 192, 600]))
     cfg = _random_config(rng, n)
-    env = make_env(cfg, noise="philox")
+    _run_default_tier_case(cfg, rng, n, f"case {case}", float32_intensities=False)
+
+
+@pytest.mark.parametrize("case", range(30 * FUZZ_SCALE))
+def test_random_hawkes_configuration_with_float32_intensities_matches_the_oracle_up_to_the_stated_window(case):
+    """hawkes_float32_intensities=True (the 60-byte rows SURVEY section 8d prices): the intensities are float32 state, a draw
+    inside the window that state cannot resolve retires its lane - counted in the ledger, which the last test of this file audits."""
+    rng = np.random.default_rng(FUZZ_SEED + 17000 + case)
+    n = int(rng.choice([7, 192, 600]))
+    cfg = _random_config(rng, n)
+    cfg.arrival = "hawkes"
+    cfg.hawkes_speed = min(cfg.hawkes_speed, 0.9 / cfg.step_size)
+    _run_default_tier_case(cfg, rng, n, f"float32-intensity case {case}", float32_intensities=True)
+
+
+def _run_default_tier_case(cfg, rng, n, label, float32_intensities):
+    env = make_env(cfg, noise="philox", hawkes_float32_intensities=float32_intensities)
     steps = cfg.n_steps - int(round(cfg.start_time / cfg.step_size))
     actions = _random_actions(rng, cfg, steps)
     draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(steps)]
     oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
     obs = env.reset()
     o_obs = oracle.reset()
-    tag = f"case {case}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
+    tag = f"{label}: {cfg.midprice}/{cfg.arrival}/{cfg.dynamics}/{cfg.reward} norm={cfg.normalise_observation_space} N={n}"
     np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-5, err_msg=tag)
     scale = np.maximum(1.0, np.abs(o_obs[:, 0])) if not cfg.normalise_observation_space else None
     alive = np.ones(n, dtype=bool)
+    exact_intensities = cfg.arrival == "hawkes" and not float32_intensities
     for k in range(steps):
-        alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0], alive)
+        if float32_intensities:
+            alive &= ~_undecidable_hawkes_lanes(cfg, oracle, draws[k][0], alive)
         hip_prev, or_prev = env.state.astype(np.float64), oracle.state.copy()  # raw (un-normalised) states before the step: what the reward bound is made of
         obs, rew, dones, _ = env.step(actions[k])
         o_obs, o_rew, o_dones = oracle.step(actions[k].astype(np.float64))
@@ -76,6 +97,10 @@ def test_random_configuration_matches_the_oracle_on_the_kernels_own_draws(case):
         bound = tier.order_book_reward_bound(cfg, hip_prev, or_prev, oracle.state, o_rew, clipped)[alive]  # include/mbt_env.h: the default tier's guarantee
         if scale is not None:
             scale = np.maximum(scale, np.abs(o_obs[:, 0]))
+        if exact_intensities:  # ARR:110-119 in double on the exact state: the reference's float64 intensities, on every lane
+            np.testing.assert_array_equal(env.state64[:, 4:6], oracle.state[:, 4:6], err_msg=f"{tag} step {k}: float64 intensities")
+            if not cfg.normalise_observation_space:
+                np.testing.assert_array_equal(obs[:, 4:6], oracle.state[:, 4:6].astype(np.float32), err_msg=f"{tag} step {k}: observed intensities")
         obs, rew, o_obs, o_rew, clipped, scale_k = obs[alive], rew[alive], o_obs[alive], o_rew[alive], clipped[alive], (scale[alive] if scale is not None else None)
         if cfg.normalise_observation_space:
             # (rtol: a geometric midprice may leave its Box by orders of magnitude - 53 in normalised units in the round-3 soak -
@@ -326,11 +351,11 @@ def test_random_configuration_rollout_equals_the_step_loop(case):
 
 
 def test_retired_hawkes_lanes_stay_within_the_stated_rate():
-    """The default tier retires a lane whose Hawkes draw falls inside the window the float32 intensity cannot resolve - counted,
+    """The opt-out tier (hawkes_float32_intensities=True) retires a lane whose Hawkes draw falls inside the window the float32 intensity cannot resolve - counted,
     not silently dropped.  The window's probability is known (the draws are uniform): the count must stay within what it predicts
     (Poisson: mean + 5 sigma + 2), i.e. the retirement is the stated ~1e-6-per-lane-step effect and not a hiding place."""
     expected, retired = HAWKES_LEDGER["expected"], HAWKES_LEDGER["retired"]
     if HAWKES_LEDGER["lane_steps"] == 0:
         pytest.skip("no Hawkes configuration ran in this session")
     assert retired <= expected + 5.0 * np.sqrt(expected) + 2.0, HAWKES_LEDGER
-    print(f"Hawkes lanes retired by the float32-tier fuzz: {retired} of {HAWKES_LEDGER['lane_steps']} lane-steps (the window predicts {expected:.2f})")
+    print(f"Hawkes lanes retired by the float32-intensity fuzz: {retired} of {HAWKES_LEDGER['lane_steps']} lane-steps (the window predicts {expected:.2f})")

@@ -1,0 +1,230 @@
+"""Round 5: Hawkes intensities held exactly in the default tier (arrivals = the float64 reference's, 76 B per env-step), the
+stale-stage fix of the small-batch host path, the kernel table split over translation units."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mbt_gym_amd import _native
+from oracle.mbt_oracle import InjectedNoise, OracleConfig, OracleEnv
+from tests.env_factory import make_env
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOAK = int(os.environ.get("MBT_HAWKES_SOAK", "0"))  # MBT_HAWKES_SOAK=1: 2^17 lanes x 800 steps = 1.05e8 lane-steps (about a minute of NumPy)
+
+
+def _cfg(n, **kw):
+    base = dict(num_trajectories=n, n_steps=40, terminal_time=1.0, midprice="bm", volatility=2.0, initial_price=100.0, arrival="poisson",
+                intensity=(140.0, 140.0), fill_exponent=1.5, dynamics="limit", reward="pnl", initial_inventory=0, max_inventory=50, seed=50,
+                normalise_action_space=False, normalise_observation_space=False)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+HAWKES = dict(arrival="hawkes", intensity=(10.0, 10.0), hawkes_jump=40.0, hawkes_speed=60.0, midprice="ou", ou_level=100.0, ou_speed=0.01)  # BASELINE configs[3]
+
+
+def test_hawkes_decisions_of_the_default_tier_are_the_float64_references_over_a_soak():
+    """BASELINE configs[3] (Hawkes arrivals + OU midprice, ARR:89-93 defaults) in the DEFAULT tier, production noise, against the
+    float64 oracle fed with the kernel's own draws: arrivals, fills and inventory array-equal on EVERY lane-step, the float64
+    intensities (state64) equal to the oracle's - no lane retired, no window.  (Round 4: the float32 intensities of this tier
+    decided ~7e-7 of lane-steps differently.)  2^15 lanes x 200 steps in the suite; MBT_HAWKES_SOAK=1: 2^17 x 800 = 1.05e8."""
+    n, n_steps = (1 << 17, 800) if SOAK else (1 << 15, 200)
+    cfg = _cfg(n, n_steps=n_steps, **HAWKES)
+    env = make_env(cfg, noise="philox")
+    env.record_events(True)
+    draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(n_steps)]
+    oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
+    del draws
+    env.reset(), oracle.reset()
+    rng = np.random.default_rng(5)
+    arrivals_seen = 0
+    for k in range(n_steps):
+        action = rng.uniform(0.05, 1.2, size=(n, 2)).astype(np.float32)
+        obs, rew, dones, _ = env.step(action)
+        o_obs, o_rew, _ = oracle.step(action.astype(np.float64))
+        np.testing.assert_array_equal(env.last_arrivals.astype(bool), oracle.last_arrivals.astype(bool), err_msg=f"step {k}: arrivals")
+        np.testing.assert_array_equal(env.last_fills.astype(bool), oracle.last_fills.astype(bool), err_msg=f"step {k}: fills")
+        np.testing.assert_array_equal(obs[:, 1].astype(np.float64), o_obs[:, 1], err_msg=f"step {k}: inventory")
+        np.testing.assert_array_equal(obs[:, 4:6], o_obs[:, 4:6].astype(np.float32), err_msg=f"step {k}: observed intensities")
+        if k % 20 == 0 or k == n_steps - 1:
+            np.testing.assert_array_equal(env.state64[:, 4:6], oracle.state[:, 4:6], err_msg=f"step {k}: float64 intensities")
+        assert np.max(np.abs(rew - o_rew)) <= 1e-5 + 1e-6 * np.max(np.abs(o_rew)) + 60.0 * cfg.ou_speed * 2e-4, f"step {k}: rewards"  # (OU coupling: |q| theta S_err)
+        arrivals_seen += int(env.last_arrivals.sum())
+    assert dones.all() and arrivals_seen > n  # (the process was alive: more than one arrival per lane)
+    env.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(dynamics="limit_and_market", market_half_spread=0.3, reward="cjmm", phi=0.01, alpha=0.02),
+                                dict(dynamics="touch", market_half_spread=0.2, reward="running", phi=0.02, alpha=0.01, midprice="bm"),
+                                dict(normalise_action_space=True, normalise_observation_space=True), dict(fill="exogenous", exo_depth=(0.25, 0.5), base_fill_probability=0.7,
+                                                                                                       exo_depth_lo=(0.0, 0.1), exo_depth_hi=(0.6, 0.9))])
+def test_exact_and_float32_intensity_tiers_agree_wherever_float32_can_tell(kw):
+    """hawkes_float32_intensities=True is the same model with float32 intensity state: over a short episode at a few thousand lanes no
+    draw falls into its ~1e-6 window, so inventories are equal and cash / midprice - which both tiers hold in float32 and advance with
+    the same instructions - are bit-identical; the intensities differ by float32 rounding only.  Step loop and fused rollout."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+
+    n = 3000
+    cfg = _cfg(n, **{**HAWKES, "hawkes_jump": 20.0, "hawkes_speed": 25.0, **kw})
+    exact, f32 = make_env(cfg), make_env(cfg, hawkes_float32_intensities=True)
+    rng = np.random.default_rng(11)
+    o_e, o_f = exact.reset(), f32.reset()
+    np.testing.assert_array_equal(o_e, o_f)
+    lo = -1.0 if cfg.normalise_action_space else 0.0
+    for k in range(cfg.n_steps):
+        a = rng.uniform(lo, 1.0, size=(n, cfg.action_dim)).astype(np.float32)
+        if cfg.dynamics == "touch":
+            a = np.rint(np.abs(a)).astype(np.float32)
+        (o_e, r_e, d_e, _), (o_f, r_f, d_f, _) = exact.step(a), f32.step(a)
+        np.testing.assert_array_equal(o_e[:, :4], o_f[:, :4], err_msg=f"step {k}: cash / inventory / time / midprice")
+        np.testing.assert_allclose(o_e[:, 4:6], o_f[:, 4:6], rtol=1e-6, atol=1e-4, err_msg=f"step {k}: intensities")
+        np.testing.assert_array_equal(r_e, r_f, err_msg=f"step {k}: rewards")
+    assert d_e.all() and d_f.all()
+    # the fused rollout of the exact tier is its own step loop, bit for bit (remainders stay in registers there)
+    fused, twin = make_env(cfg), make_env(cfg)  # (fresh: a reset does not rewind the Philox counters)
+    fixed = np.full(cfg.action_dim, 1.0 if cfg.dynamics == "touch" else 0.3, dtype=np.float32)
+    fused.reset(), twin.reset()
+    obs_r, act_r, rew_r, steps, done = fused.rollout(FixedActionAgent(fixed, fused))
+    for k in range(steps):
+        obs, rew, dones, _ = twin.step(np.tile(fixed, (n, 1)))
+        np.testing.assert_array_equal(obs, obs_r[k + 1], err_msg=f"rollout step {k}: observation")
+        np.testing.assert_array_equal(rew, rew_r[k], err_msg=f"rollout step {k}: rewards")
+    np.testing.assert_array_equal(fused.state64, twin.state64)
+    for env in (exact, f32, fused, twin):
+        env.close()
+
+
+def test_exact_intensities_survive_reset_set_state_and_sharding():
+    """The remainder buffer follows the life cycle: reset() writes what float32 left of the baselines (10.1 is not a float32), set_state()
+    (float32 rows: no remainder) zeroes it, and a shard at a trajectory offset equals the same lanes of the whole environment."""
+    n = 2048
+    market = {**HAWKES, "intensity": (10.1, 14.3), "n_steps": 100}  # (60 x 0.01: inside the recursion's contraction domain)
+    cfg = _cfg(n, **market)
+    whole = make_env(cfg)
+    whole.reset()
+    np.testing.assert_array_equal(whole.state64[:, 4:6], np.tile([10.1, 14.3], (n, 1)))
+    part = make_env(_cfg(1024, **market), trajectory_offset=1024)
+    part.reset()
+    a = np.full((n, 2), 0.35, np.float32)
+    for _ in range(25):
+        whole.step(a), part.step(a[:1024])
+    np.testing.assert_array_equal(whole.state64[1024:], part.state64)
+    rows = whole.state
+    whole.set_state(rows)
+    np.testing.assert_array_equal(whole.state64[:, 4:6], rows[:, 4:6].astype(np.float64))
+    whole.close(), part.close()
+
+
+def test_a_device_step_with_its_own_action_pointer_is_not_overwritten_by_an_earlier_host_step():
+    """after a small-batch host step the newest actions sit in the host stage; a following step_device(ptr) /
+    step_many_device(k, ptr) at N != n_pad copies the CALLER's actions into the library's buffer - and the stale stage must not be
+    filed over them."""
+    n = 1000
+    cfg = _cfg(n)
+    first, second = np.full((n, 2), 0.4, np.float32), np.full((n, 2), 0.9, np.float32)
+    for many in (False, True):
+        a, b, donor = make_env(cfg), make_env(cfg), make_env(cfg)
+        a.reset(), b.reset(), donor.reset()
+        donor.set_action_host(second)  # a device buffer holding `second` (n rows, no pad rows)
+        ptr = donor.action_device.ptr
+        a.step(first)  # host step: `first` sits in a's stage
+        if many:
+            assert a.step_many_device(3, ptr, auto_reset=False)[0] == 3
+        else:
+            for _ in range(3):
+                a.step_device(ptr)
+        b.set_action_host(first)
+        b.step_device()
+        b.set_action_host(second)
+        for _ in range(3):
+            b.step_device()
+        np.testing.assert_array_equal(a.state, b.state, err_msg="step_many_device" if many else "step_device")
+        for env in (a, b, donor):
+            env.close()
+
+
+def test_every_kernel_family_of_the_table_launches():
+    """The step / rollout instantiations live in seven translation units (csrc/kernels_*.hip) and are launched through pointers the
+    table hands out: one environment per unit, a step and - where the family has one - a fused rollout."""
+    from mbt_gym_amd.agents.BaselineAgents import FixedActionAgent
+
+    n = 1500
+    hawkes = dict(HAWKES, hawkes_speed=25.0)
+    families = [dict(), dict(hawkes), dict(hawkes, _float32=True), dict(fill="exogenous", exo_depth=(0.25, 0.5), base_fill_probability=0.7, exo_depth_lo=(0.0, 0.1), exo_depth_hi=(0.6, 0.9)),
+                dict(_precise=True), dict(hawkes, _precise=True),
+                dict(dynamics="speed", arrival="none", impact="temp_perm", temporary_impact=0.02, permanent_impact=0.01, reward="cjoe", phi=0.01, alpha=0.05,
+                     initial_inventory=12, max_inventory=1000, volatility=0.3)]
+    for kw in families:
+        kw = dict(kw)
+        env = make_env(_cfg(n, **{k: v for k, v in kw.items() if not k.startswith("_")}), precise_state=kw.get("_precise", False),
+                       hawkes_float32_intensities=kw.get("_float32", False))
+        obs = env.reset()
+        a = np.full((n, env.action_dim), 0.3, np.float32)
+        obs2, rew, dones, _ = env.step(a)
+        assert np.isfinite(obs2).all() and np.isfinite(rew).all() and not np.array_equal(obs, obs2)
+        env.reset()
+        out = env.rollout(FixedActionAgent(a[0], env))
+        assert out[3] == env.n_steps and out[4]
+        env.close()
+
+
+def _bench(*args, timeout=900):
+    env = dict(os.environ)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_the_bench_line_carries_the_fused_rollout():
+    """the driver-run line itself says what the fused rollout does - returns only (env-steps/s; no HBM fraction, the
+    vector-issue fraction from the committed counters) and recorded (written GB/s at 2^18 and 2^20 lanes against the write-only floor)."""
+    line = _bench("--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-hbm-resident", "--no-configs")
+    block = line["rollout"]
+    assert "error" not in block, block
+    for name in ("returns_only_avellaneda_stoikov_policy", "returns_only_fixed_policy"):
+        row = block[name]
+        assert row["lanes"] == 1 << 20 and row["env_steps_per_s"] > 1e11 and row["hbm_bytes_per_env_step"] == 0 and "frac" not in row
+    for log2n in (18, 20):
+        row = block[f"recorded_avellaneda_stoikov_2^{log2n}"]
+        assert "error" not in row, row
+        assert row["written_bytes_per_env_step"] == 28 and row["lanes"] == 1 << log2n
+        assert row["write_GBps"] == pytest.approx(28.0 * row["lanes"] / row["us_per_env_step_of_all_lanes"] * 1e-3)
+        assert 0.3 < row["frac_of_8TBps"] < 1.0
+        assert 30.0 < row["mean_return_of_the_recording"] < 100.0  # (the AS policy on this market earns ~64 per episode: the recording is a real trajectory)
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_rehearsed_on_one_device():
+    """the 8-GPU box will run `bench.py --gpus 8 --steps 20 --warmup 5` once, unattended.  Rehearsed here with what one
+    device allows - eight self-spawned ranks sharing GPU 0, gloo as the transport (RCCL refuses two ranks on one device), the driver's
+    arguments, BASELINE configs[4] sharded 2^24 lanes over the ranks: rendezvous, port, prewarm drift (every rank must finish the same
+    number of episodes), memory of eight cfg1 + eight cfg4 shards, ONE JSON line - and the mean episode return equal to one rank stepping
+    the same 2^23 global lanes to 1e-12 (Philox is keyed on global lane ids; the 24-byte all-reduce is the only exchange)."""
+    import time
+
+    common = ("--steps", "20", "--warmup", "5", "--prewarm-steps", "2048", "--no-cpu-baseline")
+    t0 = time.time()
+    eight = _bench("--gpus", "8", "--backend", "gloo", "--single-device", *common)
+    wall = time.time() - t0
+    assert eight["n_gpus"] == 8 and eight["steps"] == 20 and eight["warmup"] == 5 and eight["scaling"] == "weak"
+    assert eight["config"]["num_trajectories_total"] == 8 << 20 and eight["config"]["rccl_ranks_seen"] == 8
+    assert eight["value"] == pytest.approx((8 << 20) * 20 / (eight["ms_per_step"] * 1e-3 * 20))
+    assert eight["collective"]["known_answer_ok"] is True
+    span = eight["collective"]["episodes_in_the_log_per_rank"]
+    assert span["min"] == span["max"] == 2, span  # 2048 + 5 + 20 steps of a 1000-step episode, on every rank
+    block = eight["cfg4_sharded"]
+    assert "error" not in block, block
+    assert block["num_trajectories_total"] == 1 << 24 and block["num_trajectories_per_gpu"] == 1 << 21 and block["scaling"] == "strong"
+    assert wall < 120.0, f"the 8-rank line took {wall:.0f} s"
+    one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", *common)
+    assert one["mean_episode_return"] == pytest.approx(eight["mean_episode_return"], rel=1e-12)

@@ -32,8 +32,10 @@ def test_torch_wraps_device_buffers_without_copies():
     o, r, _, _ = twin.step(np.tile(np.array([[0.5, 0.9]], np.float32), (2048, 1)))
     np.testing.assert_array_equal(obs1.cpu().numpy(), o)
     np.testing.assert_array_equal(rew.cpu().numpy(), r)
-    # ping-pong: the previous observation buffer is still intact after one more step
-    assert obs1.data_ptr() != obs.data_ptr()
-    np.testing.assert_array_equal(obs.cpu().numpy(), host_obs)
+    # the contract (include/mbt_env.h: mbt_env_obs_ptr): rows are valid until the NEXT step is enqueued.  Whether the previous
+    # rows outlive that depends on the size (small batches step between two buffers, large ones update the state in place:
+    # mbt_env.hip, mbt_env::state) - at this size they happen to
+    if obs1.data_ptr() != obs.data_ptr():
+        np.testing.assert_array_equal(obs.cpu().numpy(), host_obs)
     env.close()
     twin.close()

@@ -109,6 +109,63 @@ def test_unsupported_plugins_raise_instead_of_falling_back(no_device):
         LimitOrderModelDynamics(midprice_model=GeometricBrownianMotionMidpriceModel())
 
 
+def test_a_builtin_subclass_that_overrides_the_numpy_contract_is_refused_not_silently_ignored(no_device):
+    """`class MyFill(ExponentialFillFunction): def _get_fill_probabilities(...)` - the reference's most common
+    customisation - inherits the parent's kernel (device_kind) and its own method would never run.  Constructing an environment with it
+    raises and names both ways out; the same class derived from the ABSTRACT base takes the host-callback route; a subclass that only
+    changes constructor defaults (overrides nothing of the contract) keeps the kernel."""
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import HostCallbackWarning, host_callback_role
+    from mbt_gym_amd.rewards.RewardFunctions import PnL
+    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction, FillProbabilityModel
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+
+    class HalvedFills(ExponentialFillFunction):
+        def _get_fill_probabilities(self, depths):
+            return 0.5 * np.exp(-self.fill_exponent * depths)
+
+    class DriftingMidprice(BrownianMotionMidpriceModel):
+        def update(self, arrivals, fills, actions, state=None):
+            self.current_state = self.current_state + 0.01
+
+    class ClippedPnL(PnL):
+        def calculate(self, current_state, action, next_state, is_terminal_step=False):
+            return np.zeros(len(current_state))
+
+    class SteeperFills(ExponentialFillFunction):  # constructor defaults only: the parent's kernel is the right one
+        def __init__(self, **kw):
+            super().__init__(fill_exponent=3.0, **kw)
+
+    def market(mid=None, fill=None):
+        return LimitOrderModelDynamics(midprice_model=mid or BrownianMotionMidpriceModel(), arrival_model=PoissonArrivalModel(),
+                                       fill_probability_model=fill or ExponentialFillFunction())
+
+    for kwargs, offender in ((dict(model_dynamics=market(fill=HalvedFills())), "HalvedFills overrides _get_fill_probabilities() of ExponentialFillFunction"),
+                             (dict(model_dynamics=market(mid=DriftingMidprice())), "DriftingMidprice overrides update() of BrownianMotionMidpriceModel"),
+                             (dict(model_dynamics=market(), reward_function=ClippedPnL()), "ClippedPnL overrides calculate() of PnL")):
+        with pytest.raises(UnsupportedOnDevice, match=offender.replace("(", r"\(").replace(")", r"\)")) as refusal:
+            TradingEnvironment(**kwargs)
+        assert "host-callback route" in str(refusal.value) and "device expression" in str(refusal.value)
+    assert host_callback_role(SteeperFills()) is None
+    TradingEnvironment(model_dynamics=market(fill=SteeperFills()))
+
+    class HalvedFillsFromTheBase(FillProbabilityModel):  # the same NumPy code against the abstract base: the host-callback route
+        def __init__(self, **kw):
+            super().__init__(min_value=np.array([[]]), max_value=np.array([[]]), step_size=0.005, terminal_time=0.0, initial_state=np.array([[]]), **kw)
+
+        def _get_fill_probabilities(self, depths):
+            return 0.5 * np.exp(-1.5 * depths)
+
+        @property
+        def max_depth(self):
+            return 3.0
+
+    assert host_callback_role(HalvedFillsFromTheBase()) == "fill"
+    with pytest.warns(HostCallbackWarning):
+        TradingEnvironment(model_dynamics=market(fill=HalvedFillsFromTheBase()))
+
+
 def test_environment_creation_needs_the_hip_device():
     if _native.device_count() > 0:
         pytest.skip("a GPU is visible")
@@ -304,13 +361,44 @@ def test_bench_finds_every_kernel_of_its_line_in_the_committed_rocprof_summary()
     assert path is not None and path.startswith("profiles/r") and len(reference) >= 10
     committed = json.load(open(os.path.join(bench.ROOT, path.replace("_bench_kernel_stats.csv", "_bench.json"))))
     rows = [("cfg1", False, 1 << 20, committed["roofline"]["avg_launch_us"]), ("cfg1", False, 1 << 24, committed["roofline"]["hbm_resident"]["avg_launch_us"])]
-    cases = [("cfg2_cjmm", False), ("cfg2_running", False), ("cfg3", False), ("cfg4", False), ("cfg1", True), ("cfg2_cjmm", True), ("cfg3", True), ("cfg4", True)]
-    assert len(committed["roofline"]["configs"]) == 8
-    rows += [(key, precise, bench.WORKLOADS[key]["lanes"], row["avg_launch_us"]) for (key, precise), row in zip(cases, committed["roofline"]["configs"])]
-    for key, precise, lanes, events_us in rows:
-        name = bench.kernel_name(key, precise, lanes)
+    cases = [("cfg2_cjmm", False, False), ("cfg2_running", False, False), ("cfg3", False, False), ("cfg3", False, True), ("cfg4", False, False),
+             ("cfg1", True, False), ("cfg2_cjmm", True, False), ("cfg3", True, False), ("cfg4", True, False)]
+    assert len(committed["roofline"]["configs"]) == len(cases)
+    rows = [(key, precise, lanes, us, False) for key, precise, lanes, us in rows]
+    rows += [(key, precise, bench.WORKLOADS[key]["lanes"], row["avg_launch_us"], lam32) for (key, precise, lam32), row in zip(cases, committed["roofline"]["configs"])]
+    for key, precise, lanes, events_us, lam32 in rows:
+        name = bench.kernel_name(key, precise, lanes, lam32)
         hits = [v for k, v in reference.items() if name in k]
         assert len(hits) == 1, (key, precise, lanes, name)
         assert abs(hits[0][0] / 1e3 / events_us - 1.0) <= 0.04, (key, precise, hits[0][0] / 1e3, events_us)
-        row = bench.roofline_row(key, precise, lanes, events_us * 1e-6, reference)
+        row = bench.roofline_row(key, precise, lanes, events_us * 1e-6, reference, lam32)
         assert row["frac_rocprof"] is not None and row["frac"] == min(row["frac_events"], row["frac_rocprof"]) and 0.4 < row["frac"] < 0.95
+
+
+def test_bench_moved_bytes_are_what_the_counters_saw():
+    """ADVICE / VERDICT r04: the line's `moved_bytes_per_env_step` once drifted from the header and the counters (76 / 124 / 84 printed
+    where 60 / 92 / 68 is true).  Tied down: for every kernel of the line that the newest committed PMC summary has a row for
+    (profiles/rNN_pmc_all_configs.json: FETCH_SIZE x 2 + WRITE_SIZE per launch, separate passes), bench.moved_bytes() x lanes is the
+    counted traffic within 2 %."""
+    import glob
+    import json
+    import os
+    import re
+
+    import bench
+
+    paths = sorted(p for p in glob.glob(os.path.join(bench.ROOT, "profiles", "r*_pmc_all_configs.json")) if re.fullmatch(r"r\d+_pmc_all_configs\.json", os.path.basename(p)))
+    counted = json.load(open(paths[-1]))
+    assert bench.moved_bytes("cfg1", False) == 44 and bench.moved_bytes("cfg1", True) == 60 and bench.moved_bytes("cfg4", True) == 68
+    assert bench.moved_bytes("cfg3", False, True) == 60 and bench.moved_bytes("cfg3", False) == 76 and bench.moved_bytes("cfg3", True) == 92
+    checked = 0
+    for key, precise, lam32 in [("cfg1", False, False), ("cfg2_cjmm", False, False), ("cfg3", False, False), ("cfg3", False, True), ("cfg4", False, False),
+                                ("cfg1", True, False), ("cfg3", True, False), ("cfg4", True, False)]:
+        lanes = bench.WORKLOADS[key]["lanes"]
+        name = bench.kernel_name(key, precise, lanes, lam32)
+        hits = [row for kernel, row in counted.items() if name in kernel]
+        assert len(hits) == 1, (key, precise, lam32, name, os.path.basename(paths[-1]))
+        per_lane = hits[0]["hbm_bytes_per_launch"] / lanes
+        assert abs(per_lane / bench.moved_bytes(key, precise, lam32) - 1.0) <= 0.02, (key, precise, lam32, per_lane)
+        checked += 1
+    assert checked == 8

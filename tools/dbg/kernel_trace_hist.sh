@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out/dbg; mkdir -p "$OUT"; ROOT=$(pwd); export TMPDIR=/tmp
 D=/tmp/prof_kt_$$; rm -rf "$D"
-(cd /tmp && rocprofv3 --kernel-trace ${MBT_KT_STATS:-} --output-format csv -d "$D" -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --steps 4000 --warmup 500 ${MBT_KT_ARGS:-} > "$ROOT/$OUT/kernel_trace_bench.json" 2> "$ROOT/$OUT/kernel_trace.err")
+(cd /tmp && rocprofv3 --kernel-trace ${MBT_KT_STATS:-} --output-format csv -d "$D" -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-rollout --steps 4000 --warmup 500 ${MBT_KT_ARGS:-} > "$ROOT/$OUT/kernel_trace_bench.json" 2> "$ROOT/$OUT/kernel_trace.err")
 F=$(find "$D" -name '*kernel_trace.csv' | head -1)
 python - "$F" > "$OUT/kernel_trace_hist.txt" <<'PY'
 import csv, sys

@@ -14,6 +14,10 @@
 //   hawkes    6  2  60           2^22 lanes (configs[3])
 //   speed     4  1  40           2^20 lanes
 //   speed+y   5  1  48           2^20 lanes
+//   hawkes+r  6  2  76           2^22 lanes: the float32 tier's Hawkes rows with EXACT intensities (round 5): + an (N, 2) int32
+//                                remainder buffer read and written in place (Variant::EXACT_LAM, 8 + 8 B per lane)
+//   record    -  -  28 written   the fused rollout's trajectory recording (round 5): WRITE-ONLY, time-major (steps, N, 4) observation
+//                                rows + (steps, N, 2) actions + (steps, N) rewards from ONE long-running kernel, under each store policy
 //
 // Two regimes, as in production (mbt_env.hip: tune_for_size).  While a launch's working set fits the Infinity Cache the kernels
 // use default-policy loads at full occupancy; beyond it (every pattern at 2^24 lanes) the production kernels load with the
@@ -26,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -210,6 +215,91 @@ __global__ __launch_bounds__(256) void rows4_quad_kernel(const float* __restrict
   for (int l = 0; l < 4; ++l) { s[l].x += a[l]; st16(reinterpret_cast<v4f*>(s_out) + i + 256 * l, s[l]); st4(rew + i + 256 * l, s[l].y); }
 }
 
+// Hawkes rows with exact intensities (step_kernel.hpp: Variant::EXACT_LAM): the rows6 shape + an (N, 2) int32 remainder buffer
+// that every lane reads and writes in place (dwordx2 per lane: a wave covers four whole lines; written through like the rows).
+template <bool NT = false>
+__global__ __launch_bounds__(256) void rows6_resid_kernel(const float* __restrict__ s_in, float* __restrict__ s_out, const float* __restrict__ act,
+                                                          float* __restrict__ rew, float* __restrict__ resid) {
+  constexpr int D = 6, TILE = 512;
+  __shared__ __attribute__((aligned(16))) float lds[TILE * D];
+  const size_t tile = blockIdx.x;
+  const float* in = s_in + tile * TILE * D;
+  v2f row[2][3], a[2], lo[2];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int lane = threadIdx.x + 256 * l;
+    const v2f* r = reinterpret_cast<const v2f*>(in) + lane * 3;
+    row[l][0] = ld<NT>(&r[0]); row[l][1] = ld<NT>(&r[1]); row[l][2] = ld<NT>(&r[2]);
+    a[l] = ld<NT>(&reinterpret_cast<const v2f*>(act)[tile * TILE + lane]);
+    lo[l] = ld<NT>(&reinterpret_cast<const v2f*>(resid)[tile * TILE + lane]);
+  }
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int lane = threadIdx.x + 256 * l;
+    row[l][0].x += a[l].x;
+    row[l][2].x += lo[l].x;
+    lo[l].y += row[l][2].y;
+    v2f* r = reinterpret_cast<v2f*>(lds) + lane * 3;
+    r[0] = row[l][0]; r[1] = row[l][1]; r[2] = row[l][2];
+    st4(rew + tile * TILE + lane, a[l].y);
+    st8(reinterpret_cast<v2f*>(resid) + tile * TILE + lane, lo[l]);
+  }
+  __syncthreads();
+  v4f* out4 = reinterpret_cast<v4f*>(s_out + tile * TILE * D);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) st16(&out4[threadIdx.x + k * 256], reinterpret_cast<const v4f*>(lds)[threadIdx.x + k * 256]);
+}
+
+// ---- write-only: the fused rollout's recording ---------------------------------------------------------------------------
+// One launch, `steps` iterations per thread; in each, a thread (pair of lanes j, j + 256 of its 512-lane tile, like rollout_body)
+// stores its two observation rows (dwordx4), its two actions (dwordx2) and its two rewards (dword) into the time-major
+// recording - 28 B per lane and step, every wave-level store one contiguous span of whole lines - and reads nothing.
+// POLICY: 0 plain write-back stores | 1 sc1 (agent scope: written through the L2, the step kernels' policy) | 2 nt | 3 sc0 sc1
+// (system scope) | 4 nt sc1.  WORK: multiply-adds between two steps' stores (0: the pure store stream; ~400: the arithmetic of one
+// env-step of a pair, to see how much of it hides behind the stores at this occupancy).
+template <int POLICY>
+__device__ __forceinline__ void rec16(v4f* p, v4f v) {
+  if (POLICY == 0) *p = v;
+  else if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+}
+template <int POLICY>
+__device__ __forceinline__ void rec8(v2f* p, v2f v) {
+  if (POLICY == 0) *p = v;
+  else if (POLICY == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+}
+template <int POLICY>
+__device__ __forceinline__ void rec4(float* p, float v) {
+  if (POLICY == 0) *p = v;
+  else if (POLICY == 1) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 2) asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else if (POLICY == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int POLICY>
+__global__ __launch_bounds__(256) void record_kernel(float* __restrict__ obs, float* __restrict__ act, float* __restrict__ rew, uint32_t n, uint32_t steps, int work) {
+  const uint32_t l0 = blockIdx.x * 512 + threadIdx.x, l1 = l0 + 256;
+  v4f a = {float(l0), 1.f, 0.f, 100.f}, b = {float(l1), -1.f, 0.f, 100.f};
+  float x = 1.0f + 1e-7f * threadIdx.x, y = 0.999f;
+  for (uint32_t k = 0; k < steps; ++k) {
+    for (int w = 0; w < work; ++w) { x = __builtin_fmaf(x, y, 0.25f); y = __builtin_fmaf(y, 0.9999f, 1e-4f * x); }  // dependent chain: not vectorisable away
+    a.x += x; a.w += y; b.x -= y; b.w += x; a.z = b.z = float(k);
+    const size_t t = k;
+    rec16<POLICY>(reinterpret_cast<v4f*>(obs + t * n * 4) + l0, a);
+    rec16<POLICY>(reinterpret_cast<v4f*>(obs + t * n * 4) + l1, b);
+    rec8<POLICY>(reinterpret_cast<v2f*>(act + t * n * 2) + l0, v2f{a.w, a.x});
+    rec8<POLICY>(reinterpret_cast<v2f*>(act + t * n * 2) + l1, v2f{b.w, b.x});
+    rec4<POLICY>(rew + t * n + l0, x);
+    rec4<POLICY>(rew + t * n + l1, y);
+  }
+}
+
 template <typename F>
 float time_it(F launch, int iters) {
   hipEvent_t e0, e1;
@@ -297,7 +387,65 @@ void streaming_patterns(int lg) {
   run("rows: 5 x dword nt loads, LDS-staged stores = PRODUCTION", rows5_kernel<0, true>, 1024, n, 5, 1, it);
 }
 
+void hawkes_exact_pattern(int lg, bool nt) {
+  const size_t n = size_t(1) << lg;
+  Buffers b = make_buffers(n, 6, 2);
+  float* resid;
+  CK(hipMalloc(&resid, n * 8));
+  CK(hipMemcpy(resid, b.s0, n * 8, hipMemcpyDeviceToDevice));
+  float* st[2] = {b.s0, b.s1};
+  const uint32_t blocks = static_cast<uint32_t>(n / 512);
+  const float t = nt ? time_it([&](int i) { hipLaunchKernelGGL(rows6_resid_kernel<true>, dim3(blocks), dim3(256), 0, 0, st[i & 1], st[(i & 1) ^ 1], b.act, b.rew, resid); }, 200)
+                     : time_it([&](int i) { hipLaunchKernelGGL(rows6_resid_kernel<false>, dim3(blocks), dim3(256), 0, 0, st[i & 1], st[(i & 1) ^ 1], b.act, b.rew, resid); }, 200);
+  printf("  %-52s %9.2f us  %7.0f GB/s  (76 B/lane)\n", nt ? "rows + (N, 2) remainders in place, nt loads" : "rows + (N, 2) remainders in place (production)", t, 76.0 * n / t * 1e-3);
+  CK(hipFree(resid));
+  free_buffers(b);
+}
+
+template <int POLICY>
+void record_one(const char* label, int lg, uint32_t steps, int work) {
+  const size_t n = size_t(1) << lg;
+  float *obs, *act, *rew;
+  CK(hipMalloc(&obs, n * 16 * steps)); CK(hipMalloc(&act, n * 8 * steps)); CK(hipMalloc(&rew, n * 4 * steps));
+  const uint32_t blocks = static_cast<uint32_t>(n / 512);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(record_kernel<POLICY>, dim3(blocks), dim3(256), 0, 0, obs, act, rew, uint32_t(n), steps, work);  // (first touch of the pages)
+  CK(hipDeviceSynchronize());
+  const int reps = 9;
+  float all[reps];
+  for (int i = 0; i < reps; ++i) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(record_kernel<POLICY>, dim3(blocks), dim3(256), 0, 0, obs, act, rew, uint32_t(n), steps, work);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&all[i], e0, e1));
+  }
+  std::sort(all, all + reps);
+  const double us_per_step = all[reps / 2] * 1e3 / steps, us_min = all[0] * 1e3 / steps;
+  printf("  %-44s work %3d  median %7.3f (min %7.3f) us/step  %6.0f GB/s written\n", label, work, us_per_step, us_min, 28.0 * n / us_per_step * 1e-3);
+  CK(hipFree(obs)); CK(hipFree(act)); CK(hipFree(rew));
+}
+
+void record_patterns(int lg, uint32_t steps) {
+  printf("record  28 B written per lane and step, 2^%d lanes x %u steps (%.1f GB per launch)\n", lg, steps, 28.0 * (size_t(1) << lg) * steps * 1e-9);
+  for (int work : {0}) {
+    record_one<0>("plain write-back stores", lg, steps, work);
+    record_one<1>("sc1 (written through the L2)", lg, steps, work);
+    record_one<2>("nt", lg, steps, work);
+    record_one<3>("sc0 sc1 (system scope)", lg, steps, work);
+    record_one<4>("sc1 nt", lg, steps, work);
+  }
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'r') {  // mb_floor record: the write-only patterns alone
+    record_patterns(18, 400);
+    record_patterns(20, 200);
+    hawkes_exact_pattern(22, false);
+    hawkes_exact_pattern(22, true);
+    return 0;
+  }
   if (argc > 1) {
     const int lg = atoi(argv[1]);
     all_patterns(lg, lg, lg, lg);
@@ -309,5 +457,11 @@ int main(int argc, char** argv) {
   all_patterns(24, 24, 24, 24);
   printf("== every pattern at 2^24 lanes (HBM-resident), the production policy: non-temporal loads (+ 5 WG/CU where production caps) ==\n");
   streaming_patterns(24);
+  printf("== Hawkes rows with exact intensities (76 B per lane), 2^22 lanes: 319 MB per launch ==\n");
+  hawkes_exact_pattern(22, false);
+  hawkes_exact_pattern(22, true);
+  printf("== the fused rollout's recording: write-only, one long-running kernel ==\n");
+  record_patterns(18, 400);
+  record_patterns(20, 200);
   return 0;
 }

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ in ONE GPU-box call:
-#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r04'   then   cp gpurun_out/profiles_r04/* profiles/
+#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r05'   then   cp gpurun_out/profiles_r05/r05_* profiles/
 # rocprofv3 passes: kernel trace + stats alone; FETCH_SIZE and WRITE_SIZE each in its own --pmc pass (the MI355X guide's
 # HBM recipe); never combined with hip/hsa/sys tracing.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -12,9 +12,15 @@ ROOT=$(pwd)
 t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a "$OUT/timeline.txt"; }
 
-# the bench lines: default arguments, and the driver's (--steps 20 --warmup 5)
-python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"; stamp "bench default rc=$?"
-python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>> "$OUT/bench.stderr"; stamp "bench driver args rc=$?"
+# What bench.py QUOTES from committed files comes first and is put where bench.py looks for it (profiles/ of this scratch copy),
+# so that the lines below carry this round's figures: the write-only floors of the rollout's recording (mb_floor), the shader
+# counters of the returns-only rollout (one small --pmc group per pass), and - further down - the kernel-stats summary.
+make -C tools/microbench > /dev/null 2>&1
+tools/microbench/mb_floor > "$OUT/${TAG}_floors.txt" 2>&1; stamp "floors"
+cp "$OUT/${TAG}_floors.txt" profiles/
+python tools/pmc_rollout_summary.py "$OUT/${TAG}_pmc_rollout.json" > /dev/null 2> "$OUT/pmc_rollout.stderr"; stamp "pmc rollout rc=$?"
+cp "$OUT/${TAG}_pmc_rollout.json" profiles/ 2>/dev/null
+for p in 0 1 2 3 4; do tools/microbench/mb_rollout_p$p; done > "$OUT/${TAG}_mb_rollout.txt" 2>&1; stamp "rollout store policies"
 
 # THE summary of the contract: `rocprofv3 --kernel-trace --stats` of bench.py at its default arguments (minus the CPU baseline,
 # which launches nothing) - the headline kernel, the same kernel at 2^24 lanes (its STREAM instantiation) and the eight kernels
@@ -23,17 +29,21 @@ python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>>
 # mbt_env_set_launch_gate); MBT_BENCH_GATE=0 gives the ungated trace for comparison.
 rm -rf /tmp/prof_main && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/${TAG}_bench_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_main.stderr")
 find /tmp/prof_main -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_bench_kernel_stats.csv"; stamp "kernel stats of bench.py (gated launches)"
-rm -rf /tmp/prof_ungated && (cd /tmp && MBT_BENCH_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ungated -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs > "$ROOT/$OUT/${TAG}_bench_under_rocprof_ungated.json" 2>> "$ROOT/$OUT/rocprof_main.stderr")
+cp "$OUT/${TAG}_bench_kernel_stats.csv" profiles/
+# the bench lines: default arguments, and the driver's (--steps 20 --warmup 5) - after the summary above, which they quote (frac_rocprof)
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"; stamp "bench default rc=$?"
+python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>> "$OUT/bench.stderr"; stamp "bench driver args rc=$?"
+rm -rf /tmp/prof_ungated && (cd /tmp && MBT_BENCH_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ungated -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$ROOT/$OUT/${TAG}_bench_under_rocprof_ungated.json" 2>> "$ROOT/$OUT/rocprof_main.stderr")
 find /tmp/prof_ungated -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_bench_kernel_stats_ungated.csv"; stamp "kernel stats of bench.py (ungated, for comparison)"
 
 profile() {  # profile <name> <bench args...>: kernel trace + stats, then the two PMC passes
   local name=$1; shift
   if [ "$name" != bench ]; then
-  rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs "$@" > "$ROOT/$OUT/${TAG}_${name}_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_${name}.stderr")
+  rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout "$@" > "$ROOT/$OUT/${TAG}_${name}_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_${name}.stderr")
   find /tmp/prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_${name}_kernel_stats.csv"
   fi
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --prewarm-steps 0 "${@:1:2}" --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_${name}_$C.stderr")
+    rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --prewarm-steps 0 "${@:1:2}" --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_${name}_$C.stderr")
   done
   F=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' | head -1)
   W=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' | head -1)
@@ -56,8 +66,8 @@ python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; s
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
 python tests/dbg/gym_loop_breakdown.py > "$OUT/${TAG}_gym_loop_breakdown.json" 2> /dev/null; stamp "gym loop breakdown"
 # the multi-rank code path of bench.py with a world of one (RCCL communicator through the C ABI, collective check): what an 8-GPU run adds
-python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident --no-configs > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident --no-configs > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
+python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
 python tests/perf/bench_timed_region.py > "$OUT/${TAG}_timed_region.json" 2> /dev/null; stamp "timed region"
 
 # per-kernel statistics of the other kernel families (every BASELINE config's step kernel, the fused rollouts, the learned
@@ -72,7 +82,5 @@ stats rollout tools/bench_rollout.py
 stats policy tools/bench_policy.py
 bash tools/pmc_all_configs.sh "$TAG" > /dev/null 2>&1; stamp "pmc all configs"
 
-make -C tools/microbench > /dev/null 2>&1
-tools/microbench/mb_floor > "$OUT/${TAG}_floors.txt" 2>&1; stamp "floors"
 tools/microbench/mb_sync > "$OUT/${TAG}_mb_sync.txt" 2>&1; stamp "sync latency"
 ls -la "$OUT"
