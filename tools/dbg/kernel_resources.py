@@ -18,12 +18,21 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(ROOT, "mbt_gym_amd", "libmbtenv.so")
 
 
-def code_object(workdir):
-    fat, obj = os.path.join(workdir, "fatbin.bin"), os.path.join(workdir, "gfx950.co")
+def code_objects(workdir):
+    """Every gfx950 code object in the library: one offload bundle per translation unit (csrc/kernels_*.hip, mbt_env.hip), concatenated in
+    .hip_fatbin - split at the bundler's magic."""
+    fat = os.path.join(workdir, "fatbin.bin")
     subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", LIB, os.path.join(workdir, "unused.so")], check=True, capture_output=True)
-    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={obj}"],
-                   check=True, capture_output=True)
-    return obj
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    objects = []
+    for k, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        piece, obj = os.path.join(workdir, f"bundle{k}.bin"), os.path.join(workdir, f"gfx950_{k}.co")
+        open(piece, "wb").write(blob[lo:hi])
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={obj}"],
+                       check=True, capture_output=True)
+        objects.append(obj)
+    return objects
 
 
 def kernels(obj):
@@ -53,7 +62,7 @@ def waves_per_simd(vgpr, agpr):
     return max(1, min(8, 512 // max(regs, 8)))
 
 
-DEFAULT = ("step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, false,", "step_kernel<mbt::Variant<0, 0, false, 1, false, false, false, false,",
+DEFAULT = ("step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, false,", "step_kernel<mbt::Variant<0, 0, true, 1, false, false, false, false,",
            "step_kernel<mbt::Variant<1, 0, false, 0,", "step_kernel<mbt::Variant<0, 1, true, 0, false, false, false, false,",
            "step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, true,", "step_kernel<mbt::Variant<1, 0, false, 0, false, false, false, true,",
            "speed_step_kernel<mbt::SpeedVariant<")
@@ -62,7 +71,7 @@ DEFAULT = ("step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, false,"
 def main():
     wanted = tuple(sys.argv[1:]) or DEFAULT
     with tempfile.TemporaryDirectory() as workdir:
-        rows = kernels(code_object(workdir))
+        rows = [row for obj in code_objects(workdir) for row in kernels(obj)]
     for row, name in zip(rows, demangle([r["name"] for r in rows])):
         row["demangled"] = re.sub(r"^void ", "", name).split("(")[0]
     rows = [r for r in rows if any(w in r["demangled"] for w in wanted)]
