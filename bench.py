@@ -640,12 +640,16 @@ def gpu_cfg0_figures(device):
 
     n, n_steps = 1000, 200
     dt = 1.0 / n_steps
-    dynamics = LimitOrderModelDynamics(
-        midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
-        arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
-        fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n), num_trajectories=n)
-    env = TradingEnvironment(terminal_time=1.0, n_steps=n_steps, model_dynamics=dynamics, initial_inventory=0, max_inventory=200, seed=SEED,
-                             num_trajectories=n, normalise_action_space=False, normalise_observation_space=False, device=device)
+
+    def build():
+        dynamics = LimitOrderModelDynamics(
+            midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
+            arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
+            fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n), num_trajectories=n)
+        return TradingEnvironment(terminal_time=1.0, n_steps=n_steps, model_dynamics=dynamics, initial_inventory=0, max_inventory=200, seed=SEED,
+                                  num_trajectories=n, normalise_action_space=False, normalise_observation_space=False, device=device)
+
+    env = build()
     agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
 
     def loop_episode():
@@ -683,6 +687,33 @@ def gpu_cfg0_figures(device):
             step(action)
         out[name] = (time.perf_counter() - t0) / 150 * 1e6
     env.close()
+    # the same calls with the opt-in resident kernel (MBT_RESIDENT_STEP=1: env.step() rings the doorbell of a kernel that stays on the
+    # device instead of launching one; it slows kernels on OTHER streams by 20-27 %, profiles/r05_resident_step.txt - hence opt-in)
+    os.environ["MBT_RESIDENT_STEP"] = "1"
+    try:
+        env = build()
+    finally:
+        del os.environ["MBT_RESIDENT_STEP"]
+    agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
+    vec_env = StableBaselinesTradingEnvironment(trading_env=env)
+    resident = {}
+    loop_episode()
+    t0, count = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.5:
+        loop_episode()
+        count += 1
+    resident["host_api_loop_env_steps_per_s"] = n * n_steps * count / (time.perf_counter() - t0)
+    for name, reset, step in (("env_step_us", env.reset, env.step), ("sb3_vec_env_step_us", vec_env.reset, vec_env.step)):
+        reset()
+        for _ in range(50):
+            step(action)
+        reset()
+        t0 = time.perf_counter()
+        for _ in range(150):
+            step(action)
+        resident[name] = (time.perf_counter() - t0) / 150 * 1e6
+    env.close()
+    out["resident_step_opt_in"] = resident
     out["note"] = "N = 1000 x 200 steps: a launch-latency regime (140 KB of state), not a bandwidth one; reported beside the CPU port's configs0 figure"
     return out
 

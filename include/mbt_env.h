@@ -379,7 +379,15 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
  * done (scalar; lane-invariant, TE:218-220).  Any output pointer may be NULL.
  * Batches of up to 65536 lanes (the reference's own regime is N ~ 1000) take ONE launch and no interrupt: the step kernel
  * reads the actions from, and mirrors observation rows and rewards into, pinned device-mapped host memory and raises a
- * completion flag there that this call spins on. */
+ * completion flag there that this call spins on.
+ * Opt-in, environment variable MBT_RESIDENT_STEP=1 at creation (batches of up to 4096 lanes, float32 tier, built-in order-book
+ * models, production noise): the first such call of an episode starts a RESIDENT kernel of at most four workgroups that stays on the
+ * device; this call then only writes the actions and a 64-byte mailbox line (into device memory through the PCIe BAR where the
+ * platform allows, host memory otherwise) and spins on the flag - no launch per step: 13.3-13.9 -> 8.7-9.3 us per env.step() at
+ * N = 1000.  Results are the one-launch path's to the bit (same kernel code, counters and clock arithmetic).  The kernel leaves at
+ * the episode's end, when any other entry point is called on the environment (which waits for it), after 2 ms without a call
+ * (MBT_RESIDENT_IDLE_US) and after 30 s in any case; while it is there, kernels on OTHER streams of the device run 20-27 % slower
+ * (profiles/r05_resident_step.txt) - which is why it is not the default. */
 int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);
 /* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
 int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);

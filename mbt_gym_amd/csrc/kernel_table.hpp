@@ -18,6 +18,7 @@ namespace mbt_table {
 using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
 using LearnedRolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams, const mbt::LearnedPolicyParams);
+using ResidentKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::ResidentParams);
 
 // Which instantiation of a production-noise step kernel: default-policy loads | non-temporal loads (launches beyond the
 // Infinity Cache, tune_for_size) | the small-batch host-API kernel that mirrors its outputs into host memory and raises a
@@ -78,6 +79,8 @@ StepKernel pick_step_speed(const mbt_config& c, int mode);                      
 RolloutKernel pick_rollout_speed(const mbt_config& c);                                                              // kernels_speed.hip
 // fused rollouts, float32 state: arrivals as for pick_step_exogenous
 RolloutKernel pick_rollout_order_book(int arrivals, int dyn, bool brownian, int reward_weight, bool norm);          // kernels_rollout.hip
+// the resident small-batch step (opt-in): float32 tier, production noise; nullptr where the family has no resident form
+ResidentKernel pick_resident(int arrivals, int dyn, bool brownian, int reward_weight, bool norm);                   // kernels_resident.hip
 // a linear / MLP policy evaluated in the kernel (policy_mlp.hpp)
 LearnedRolloutKernel pick_rollout_learned(int arrivals, bool market, bool brownian_pnl);                            // kernels_misc.hip
 

@@ -8,6 +8,9 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen (see rccl_api below), never linked
 
 #include <dlfcn.h>
+#include <immintrin.h>
+#include <setjmp.h>
+#include <signal.h>
 
 #include <atomic>
 #include <chrono>
@@ -159,6 +162,7 @@ constexpr uint32_t kHostFastPathLanes = 65536;
 using mbt_table::StepKernel;
 using mbt_table::RolloutKernel;
 using mbt_table::LearnedRolloutKernel;
+using mbt_table::ResidentKernel;
 using mbt_table::kPlain;
 using mbt_table::kStream;
 using mbt_table::kMirror;
@@ -307,6 +311,19 @@ struct mbt_env {
   int host_state_first = 0, host_state_count = 0;  // the state columns host-callback processes own: one block in registry order (TE:303-318)
   bool host_reward_replaces = false; // MBT_REW_HOST on the speed kernels: the kernel filed its PnL, mbt_env_set_host_rewards takes it back out
   bool host_mid = false;             // MBT_MID_HOST: cfg.midprice_kind reads MBT_MID_CONSTANT, the caller moves the midprice between launches
+  // resident small-batch stepping (opt-in: MBT_RESIDENT_STEP=1; step_kernel.hpp: resident_step_kernel)
+  ResidentKernel resident_kernel = nullptr;   // nullptr: this configuration has no resident form (or the mode is off)
+  bool resident_active = false;               // a resident kernel is (or may still be) running on the stream
+  bool resident_vram = false;                 // mailbox and action stage are device memory the host writes through the BAR
+  mbt::ResidentMailbox* mailbox_host = nullptr;  // where the HOST writes the mailbox line ...
+  mbt::ResidentMailbox* mailbox_dev = nullptr;   // ... and the same line as the device addresses it
+  float* resident_action_host = nullptr;      // (n_pad, A) action stage of the resident kernel, host view / device view
+  float* resident_action_dev = nullptr;
+  void* resident_vram_block = nullptr;        // the fine-grained device allocation behind both (nullptr: they live in host memory)
+  void* resident_host_block = nullptr;        // ... or the pinned host allocation
+  size_t stage_exit = 0;                      // offset (in floats) of the word in the stage where a kernel says it left before a step
+  bool action_in_resident_stage = false;      // the newest actions sit in resident_action_dev (file_staged_action)
+  uint32_t resident_generation = 0;           // resident kernels launched so far
 };
 
 namespace {
@@ -529,11 +546,93 @@ void gate_open(mbt_env* e) {
 // The newest actions were handed over through the stage (mbt_env_step_host, small batches); anything that reads the
 // library's own action buffer afterwards - step_device(NULL), an action-repeat rollout, a consumer of mbt_env_action_ptr -
 // finds them there.
+int resident_stop(mbt_env* e);
 int file_staged_action(mbt_env* e) {
   if (!e->action_in_stage) return MBT_OK;
-  HIP_TRY(hipMemcpyAsync(e->action, e->h_stage + e->stage_action, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  const int rc_stop = resident_stop(e);  // (the copy below is queued on the stream a resident kernel would hold)
+  if (rc_stop != MBT_OK) return rc_stop;
+  if (e->action_in_resident_stage) {  // (the resident kernel's own stage; a device address in either placement)
+    HIP_TRY(hipMemcpyAsync(e->action, e->resident_action_dev, size_t(e->n) * e->act_dim * sizeof(float), e->resident_vram ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(e->action, e->h_stage + e->stage_action, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));  // the stage is overwritten by the next host step
-  e->action_in_stage = false;
+  e->action_in_stage = e->action_in_resident_stage = false;
+  return MBT_OK;
+}
+
+// ---- resident small-batch stepping (opt-in) ------------------------------------------------------------------------------------
+// Tells a resident kernel to leave and waits until it has (it polls its mailbox every microsecond or so): everything that is not
+// the next mbt_env_step_host starts from an idle stream and a state the host's bookkeeping describes.
+int resident_stop(mbt_env* e) {
+  if (!e->resident_active) return MBT_OK;
+  e->mailbox_host->seq = mbt::kResidentExit;
+  _mm_sfence();
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->resident_active = false;
+  return MBT_OK;
+}
+#define RESIDENT_STOP(e)                  \
+  do {                                    \
+    const int rc_stop_ = resident_stop(e); \
+    if (rc_stop_ != MBT_OK) return rc_stop_; \
+  } while (0)
+
+sigjmp_buf g_probe_jump;
+// Can the host write this device allocation (fine-grained memory through the PCIe BAR)?  Probed once per environment, under a
+// SIGSEGV / SIGBUS guard that is removed again at once.
+bool host_can_write(void* device_ptr) {
+  struct sigaction guard, old_segv, old_bus;
+  std::memset(&guard, 0, sizeof guard);
+  guard.sa_handler = [](int) { siglongjmp(g_probe_jump, 1); };
+  sigaction(SIGSEGV, &guard, &old_segv);
+  sigaction(SIGBUS, &guard, &old_bus);
+  bool ok = false;
+  if (sigsetjmp(g_probe_jump, 1) == 0) {
+    volatile uint32_t* word = static_cast<volatile uint32_t*>(device_ptr);
+    *word = 0x5EEDu;
+    _mm_sfence();
+    ok = *word == 0x5EEDu;
+    *word = 0u;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr);
+  sigaction(SIGBUS, &old_bus, nullptr);
+  return ok;
+}
+
+// Mailbox + action stage of the resident kernel: device memory the host can write if the platform has it (the kernel then polls and
+// reads LOCAL memory: 9.6 instead of 12.1 us per step at N = 1000, profiles/r05_resident_step.txt), pinned device-mapped host memory
+// otherwise.  MBT_RESIDENT_VRAM=0 forces the latter (measurement knob).
+int resident_allocate(mbt_env* e) {
+  const size_t action_bytes = size_t(e->n_pad) * e->act_dim * sizeof(float), bytes = 4096 + ((action_bytes + 4095) / 4096) * 4096;
+  const char* knob = std::getenv("MBT_RESIDENT_VRAM");
+  if (knob == nullptr || std::atoi(knob) != 0) {
+    void* block = nullptr;
+    if (hipExtMallocWithFlags(&block, bytes, hipDeviceMallocFinegrained) == hipSuccess && block != nullptr) {
+      if (hipMemset(block, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess && host_can_write(block)) {
+        e->resident_vram_block = block;
+        e->resident_vram = true;
+        e->mailbox_host = e->mailbox_dev = static_cast<mbt::ResidentMailbox*>(block);  // (one address space: the same pointer on both sides)
+        e->resident_action_host = e->resident_action_dev = reinterpret_cast<float*>(static_cast<char*>(block) + 4096);
+        return MBT_OK;
+      }
+      (void)hipFree(block);
+    }
+    (void)hipGetLastError();
+  }
+  void* host = nullptr;
+  HIP_TRY(hipHostMalloc(&host, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(host, 0, bytes);
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+    (void)hipHostFree(host);
+    return fail(MBT_ERR_HIP, "the resident kernel's mailbox could not be mapped for the device");
+  }
+  e->resident_host_block = host;
+  e->mailbox_host = static_cast<mbt::ResidentMailbox*>(host);
+  e->mailbox_dev = static_cast<mbt::ResidentMailbox*>(dev);
+  e->resident_action_host = reinterpret_cast<float*>(static_cast<char*>(host) + 4096);
+  e->resident_action_dev = reinterpret_cast<float*>(static_cast<char*>(dev) + 4096);
   return MBT_OK;
 }
 
@@ -608,6 +707,113 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   e->host_fill_ready = e->host_arrivals_ready = false;
   e->host_reward_pending = (e->host_mask & mbt::kHostReward) != 0;
   if (done != nullptr) *done = terminal ? 1 : 0;
+  return MBT_OK;
+}
+
+// Starts a resident kernel whose first step carries the sequence number `first_seq` (step_kernel.hpp: resident_step_kernel); the
+// mailbox must not hold that number yet.
+int resident_launch(mbt_env* e, uint32_t first_seq) {
+  mbt::StepParams P = e->params;
+  P.philox_step = e->philox_step;
+  mbt::StepBuffers B;
+  std::memset(&B, 0, sizeof B);
+  B.state_in = e->state[e->cur];
+  B.state_out = e->state[next_state(e)];
+  B.action = e->resident_action_dev;
+  B.done_counter = e->done_counter;
+  B.host_flag = reinterpret_cast<uint32_t*>(e->d_stage + e->stage_flag);
+  B.reward = e->reward;
+  B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
+  B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.resid = e->resid;
+  B.events = e->record_events ? e->events : nullptr;
+  B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
+  B.wave_sums = e->wave_sums;
+  B.clip_count = e->clip_count;
+  mbt::ResidentParams R;
+  std::memset(&R, 0, sizeof R);
+  R.mailbox = e->mailbox_dev;
+  R.host_exit = reinterpret_cast<uint32_t*>(e->d_stage + e->stage_exit);
+  R.control = e->done_counter + 16;  // (the second line of the counter block)
+  R.generation = ++e->resident_generation;
+  R.first_seq = first_seq;
+  R.n_tiles = e->n_blocks;
+  R.t_start = e->time;
+  R.dt_f64 = e->dt;
+  R.terminal_time = e->cfg.terminal_time;
+  R.idle_ticks = 200000ull;        // 2 ms of the 100 MHz wall clock without a doorbell: leave (the next step starts another kernel)
+  R.life_ticks = 3000000000ull;    // 30 s in any case
+  if (const char* v = std::getenv("MBT_RESIDENT_IDLE_US")) R.idle_ticks = std::strtoull(v, nullptr, 10) * 100ull;
+  R.ping_pong = e->ping_pong ? 1 : 0;
+  const uint32_t groups = e->n_blocks < 4u ? e->n_blocks : 4u;  // (one or two tiles per workgroup: see kResidentMaxTiles)
+  hipLaunchKernelGGL(e->resident_kernel, dim3(groups), dim3(mbt::kBlockThreads), 0, e->stream, B, P, R);
+  HIP_TRY(hipGetLastError());
+  e->resident_active = true;
+  return MBT_OK;
+}
+
+// One env.step() of a small batch through the resident kernel: actions into its stage, the mailbox line (where the outputs go + the
+// step's sequence number) behind them, spin on the completion flag.  The host's bookkeeping advances exactly as in launch_step.
+int resident_step(mbt_env* e, const float* action_host, float* obs_host, float* reward_host, int32_t* done) {
+  if (!e->was_reset) return fail(MBT_ERR_STATE, "step() before reset()");
+  const size_t n_obs = size_t(e->n) * e->dim;
+  float* direct_obs = static_cast<float*>(device_alias(obs_host, n_obs * sizeof(float)));
+  float* direct_rew = static_cast<float*>(device_alias(reward_host, size_t(e->n) * sizeof(float)));
+  if (direct_obs == nullptr || direct_rew == nullptr || reinterpret_cast<uintptr_t>(direct_obs) % 16 != 0) direct_obs = direct_rew = nullptr;
+  const double t_next = e->time + e->dt;
+  const bool terminal = t_next >= e->cfg.terminal_time - e->dt / 2;
+  const uint32_t seq = ++e->flag_seq;
+  if (!e->resident_active) {
+    e->mailbox_host->seq = seq - 1u;  // (idle: whatever an earlier kernel was told is gone)
+    _mm_sfence();
+    // ... and so is what an earlier kernel said on leaving: told to leave while it waited for THIS sequence number, it wrote that
+    // number - which below would read as "the kernel left before your step" and start a second one
+    __atomic_store_n(reinterpret_cast<uint32_t*>(e->h_stage + e->stage_exit), 0u, __ATOMIC_RELEASE);
+    const int rc = resident_launch(e, seq);
+    if (rc != MBT_OK) return rc;
+  }
+  std::memcpy(e->resident_action_host, action_host, size_t(e->n) * e->act_dim * sizeof(float));
+  _mm_sfence();  // the actions are on their way before the line that announces them (device memory is write-combining on the host side)
+  mbt::ResidentMailbox line;
+  std::memset(&line, 0, sizeof line);
+  line.host_obs = reinterpret_cast<uint64_t>(direct_obs != nullptr ? direct_obs : e->d_stage + e->stage_obs);
+  line.host_reward = reinterpret_cast<uint64_t>(direct_rew != nullptr ? direct_rew : e->d_stage + e->stage_reward);
+  line.seq = seq;
+  std::memcpy(e->mailbox_host, &line, sizeof line);  // one 64-byte line
+  _mm_sfence();
+  const uint32_t* flag = reinterpret_cast<const uint32_t*>(e->h_stage + e->stage_flag);
+  uint32_t* left = reinterpret_cast<uint32_t*>(e->h_stage + e->stage_exit);
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    if (__atomic_load_n(left, __ATOMIC_ACQUIRE) == seq) {  // the kernel left (idle, or its lifetime) before this step: another one takes it
+      __atomic_store_n(left, 0u, __ATOMIC_RELEASE);
+      const int rc = resident_launch(e, seq);
+      if (rc != MBT_OK) return rc;
+    }
+    if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      e->mailbox_host->seq = mbt::kResidentExit;
+      _mm_sfence();
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      e->resident_active = false;
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(MBT_ERR_HIP, "the resident step kernel did not answer step %u within 200 ms", seq);
+      break;
+    }
+  }
+  e->time = t_next;
+  e->cur = next_state(e);
+  e->philox_step += 1;
+  e->episode_step += 1;
+  e->action_in_stage = e->action_in_resident_stage = true;
+  if (terminal) {  // the kernel has left by itself (it computed the same flag); nothing is queued behind it
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->resident_active = false;
+  }
+  if (done != nullptr) *done = terminal ? 1 : 0;
+  if (direct_obs == nullptr) {
+    if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
+    if (reward_host != nullptr) std::memcpy(reward_host, e->h_stage + e->stage_reward, size_t(e->n) * sizeof(float));
+  }
   return MBT_OK;
 }
 
@@ -1509,7 +1715,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   ENV_TRY(dev_alloc(&e->clip_count, mbt::kClipSlots, e->stream));
   ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
   ENV_TRY(dev_alloc(&e->log_dev, 3 * mbt_env::kLogSlots, e->stream));
-  ENV_TRY(dev_alloc(&e->done_counter, 1, e->stream));
+  ENV_TRY(dev_alloc(&e->done_counter, 32, e->stream));  // [0]: workgroups finished (signal_host); [16]: the resident kernel's control word
   if (e->host_mask != 0) {
     if (host_fill || host_impact(*cfg)) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));  // (N, 2) fill probabilities / (N) price impacts
     if (host_arrival) ENV_TRY(dev_alloc(&e->host_arrivals, np * 2, e->stream));
@@ -1531,7 +1737,8 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     e->stage_obs = np * e->act_dim;
     e->stage_reward = e->stage_obs + size_t(e->n) * e->dim;
     e->stage_flag = ((e->stage_reward + e->n + 15u) / 16u) * 16u;  // the completion flag of signal_host, on a cache line of its own
-    const size_t floats = e->stage_flag + 16u;
+    e->stage_exit = e->stage_flag + 16u;                           // where a resident kernel says it left before a step, on the next line
+    const size_t floats = e->stage_exit + 16u;
     // (coherent: the host reads the flag, and then the mirror, while the GPU context is live - not after a synchronisation)
     if (hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(e->h_stage, 0, floats * sizeof(float));
@@ -1542,6 +1749,19 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     } else {
       e->h_stage = nullptr;  // not fatal: the DMA path below serves every size
       (void)hipGetLastError();
+    }
+  }
+  {  // opt-in: MBT_RESIDENT_STEP=1 - small batches of the float32 tier's built-in order-book models step through a kernel that stays on the device
+    const char* resident = std::getenv("MBT_RESIDENT_STEP");
+    const mbt_config& c = *cfg;
+    // up to 8 tiles (4096 lanes): beyond that four workgroups walking the tiles one after the other lose to a launch that steps them all
+    // at once (N = 65536: 72 vs 62 us per env.step, profiles/r05_resident_step.txt)
+    constexpr uint32_t kResidentMaxTiles = 8;
+    if (resident != nullptr && std::atoi(resident) != 0 && e->h_stage != nullptr && !needs_jit && !speed && !c.precise_state && !exogenous_fill(c) &&
+        e->host_mask == 0 && c.noise_mode == MBT_NOISE_PHILOX && e->n_blocks <= kResidentMaxTiles) {
+      const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
+      e->resident_kernel = mbt_table::pick_resident(arrival_family(c), c.dynamics_kind, c.midprice_kind == MBT_MID_BROWNIAN, reward_weight(c), norm);
+      if (e->resident_kernel != nullptr) ENV_TRY(resident_allocate(e));
     }
   }
 #undef ENV_TRY
@@ -1594,7 +1814,10 @@ int mbt_jit_check(const mbt_config* cfg, const mbt_user_code* code) {
 void mbt_env_destroy(mbt_env* e) {
   if (e == nullptr) return;
   (void)hipSetDevice(e->cfg.device);
+  if (e->stream != nullptr) (void)resident_stop(e);
   if (e->stream != nullptr) (void)hipStreamSynchronize(e->stream);
+  if (e->resident_vram_block != nullptr) (void)hipFree(e->resident_vram_block);
+  if (e->resident_host_block != nullptr) (void)hipHostFree(e->resident_host_block);
   void* bufs[] = {e->z_user, e->resid, e->state[0], e->state[1], e->obs,    e->action,       e->reward,    e->u_arr,      e->u_fill,
                   e->z,        e->q_init,   e->events, e->lane_returns, e->wave_sums, e->clip_count, e->reduce_out,
                   e->policy_table, e->log_dev, e->traj_stage[0], e->traj_stage[1], e->traj_stage[2], e->learned_dev};
@@ -1619,6 +1842,7 @@ void mbt_env_destroy(mbt_env* e) {
 int mbt_env_set_stream(mbt_env* e, void* hip_stream) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->own_stream && e->stream != nullptr) (void)hipStreamDestroy(e->stream);
   e->stream = static_cast<hipStream_t>(hip_stream);
@@ -1629,6 +1853,7 @@ int mbt_env_set_stream(mbt_env* e, void* hip_stream) {
 int mbt_env_synchronize(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   // A blocking wait costs a wake-up (an interrupt round trip, tens of microseconds) - more than a step at 2^20 lanes.
   // Poll first: short waits, the common case between a consumer's launches, end within a microsecond of the stream.
   const auto t0 = std::chrono::steady_clock::now();
@@ -1645,6 +1870,10 @@ int mbt_env_synchronize(mbt_env* e) {
 int mbt_env_set_step_size(mbt_env* e, double step_size) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (!(step_size > 0.0)) return fail(MBT_ERR_INVALID, "step_size must be positive");
+  if (e->resident_active) {  // (a resident kernel holds the old step size)
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    RESIDENT_STOP(e);
+  }
   if (e->cfg.arrival_kind == MBT_ARR_HAWKES && !e->cfg.allow_stiff_hawkes && !(e->cfg.hawkes_speed * step_size < 1.0))  // the same domain mbt_env_create enforces
     return fail(MBT_ERR_INVALID, "Hawkes mean_reversion_speed * step_size = %g >= 1 with the new step size: the intensity recursion (ARR:110-119) "
                 "oscillates (>= 2: diverges); set allow_stiff_hawkes to run it anyway", e->cfg.hawkes_speed * step_size);
@@ -1660,6 +1889,10 @@ int mbt_env_set_step_size(mbt_env* e, double step_size) {
 
 int mbt_env_seed(mbt_env* e, uint64_t seed) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (e->resident_active) {  // (a resident kernel holds the old key)
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    RESIDENT_STOP(e);
+  }
   e->seed = seed;
   e->philox_step = 0;
   key_from_seed(e);
@@ -1669,6 +1902,7 @@ int mbt_env_seed(mbt_env* e, uint64_t seed) {
 int mbt_env_reset(mbt_env* e, double start_time, const float* q0_host) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   return do_reset(e, start_time, q0_host);
 }
 
@@ -1684,6 +1918,7 @@ int mbt_env_reset_host(mbt_env* e, double start_time, const float* q0_host, floa
 int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, float* reward_host, int32_t* done) {
   if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->resident_kernel != nullptr && e->h_stage != nullptr && e->gate_chunk == 0) return resident_step(e, action_host, obs_host, reward_host, done);
   if (e->h_stage != nullptr) {
     // Small batch (the reference's own regime, N ~ 1000): a DMA copy costs ~15-25 us per call whatever its size, a second
     // launch ~5 us, a blocking wait an interrupt round trip.  None of them here: the actions are read by the step kernel
@@ -1765,6 +2000,7 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
                              uint32_t* episodes_ended) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "injected noise is consumed one step at a time: use mbt_env_step_device");
   if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows, once
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -1809,6 +2045,7 @@ int mbt_env_episode_log_pop(mbt_env* e, double sums[3], int32_t wait) {
   if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (e->log_count == 0) return 0;
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (!wait) {
     const hipError_t q = hipEventQuery(e->log_event[e->log_head]);
     if (q == hipErrorNotReady) return 0;
@@ -1829,6 +2066,7 @@ int mbt_env_allreduce_returns(mbt_env* e, void* nccl_comm, double sums[3]) {
   const RcclApi& api = rccl();
   if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   // h_sums (pinned) -> reduce_out (device) -> all-reduce in place -> h_sums; ordered on the environment's stream
   if (e->sums_pending) return fail(MBT_ERR_STATE, "a return-sums request is in flight: call mbt_env_return_sums_end first");
   for (int j = 0; j < 3; ++j) e->h_sums[j] = sums[j];
@@ -1891,6 +2129,7 @@ int mbt_env_set_launch_gate(mbt_env* e, uint32_t burst) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (burst > 4096u) return fail(MBT_ERR_INVALID, "a burst of more than 4096 launches may not fit the hardware queue behind a closed gate");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (burst != 0 && e->h_gate == nullptr) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_gate), 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(e->h_gate, 0, 64);
@@ -1907,6 +2146,7 @@ int mbt_env_host_depths(mbt_env* e, const float* action_host, double* depths_hos
   if (e->speed || e->cfg.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "only limit-order dynamics quote depths (MD:104-106)");
   if (e->host_scratch == nullptr) return fail(MBT_ERR_STATE, "this environment has no host-callback plugin (MBT_FILL_HOST / MBT_ARR_HOST / MBT_REW_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
   e->action_in_stage = false;
   hipLaunchKernelGGL(mbt::host_depths_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->action, e->act_dim, e->n, e->params, e->host_scratch);
@@ -1920,6 +2160,7 @@ int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_
   if (e == nullptr || probabilities_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostFill)) return fail(MBT_ERR_STATE, "the fill model of this environment is not a host callback (MBT_FILL_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->host_fill_ready = true;
@@ -1930,6 +2171,7 @@ int mbt_env_set_host_impacts(mbt_env* e, const double* impacts_host) {
   if (e == nullptr || impacts_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostImpact)) return fail(MBT_ERR_STATE, "the price impact model of this environment is not a host callback (MBT_IMPACT_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->host_fill_p, impacts_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));  // the caller's array may go away
   e->host_fill_ready = true;
@@ -1940,6 +2182,7 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
   if (e == nullptr || arrivals_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostArrival)) return fail(MBT_ERR_STATE, "the arrival model of this environment is not a host callback (MBT_ARR_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->host_arrivals_ready = true;
@@ -1951,6 +2194,7 @@ int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   if (e->host_state_count == 0)
     return fail(MBT_ERR_STATE, "this environment has no host-callback process that owns state columns (MBT_MID_HOST, or MBT_ARR_HOST with state)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   const int d = e->host_state_count;
   HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(mbt::host_columns_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->host_scratch, e->n, d, e->dim, e->host_state_first,
@@ -1965,6 +2209,7 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
   if (!(e->host_mask & mbt::kHostReward)) return fail(MBT_ERR_STATE, "the reward function of this environment is not a host callback (MBT_REW_HOST)");
   if (!e->host_reward_pending) return fail(MBT_ERR_STATE, "no step is waiting for its host-computed rewards");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->host_scratch, rewards_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
   const uint32_t blocks = (e->n + 255u) / 256u;
   hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
@@ -1979,6 +2224,7 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
 int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (action_device != nullptr && e->n != e->n_pad) {
     // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -1993,6 +2239,7 @@ int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   if (policy->kind != MBT_POLICY_LINEAR && policy->kind != MBT_POLICY_MLP) return fail(MBT_ERR_INVALID, "mbt_env_policy_device evaluates learned policies (MBT_POLICY_LINEAR / MBT_POLICY_MLP)");
   if (!e->was_reset) return fail(MBT_ERR_STATE, "policy evaluation before reset()");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   mbt::LearnedPolicyParams LP;
   int rc = prepare_learned_policy(e, policy, LP);
   if (rc != MBT_OK) return rc;
@@ -2009,6 +2256,7 @@ int mbt_env_rollout_device(mbt_env* e, const mbt_policy* policy, uint32_t max_st
                            float* rew_traj, uint32_t* steps_done, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   return launch_rollout(e, policy, max_steps, obs_traj, act_traj, rew_traj, steps_done, done);
 }
 
@@ -2016,6 +2264,7 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
                          float* rew_traj, uint32_t* steps_done, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends); the buffers
   // are kept by the environment (grow-only, up to 8 GiB each), so a consumer that records every episode allocates once
   const uint32_t remaining = static_cast<uint32_t>(std::ceil((e->cfg.terminal_time - e->time) / e->dt)) + 1;
@@ -2070,6 +2319,7 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
 int mbt_env_release_staging(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (int j = 0; j < 3; ++j) {
     if (e->traj_stage[j] != nullptr) (void)hipFree(e->traj_stage[j]);
@@ -2087,6 +2337,7 @@ int mbt_env_set_user_noise_host(mbt_env* e, const float* z_user) {
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
   if (!e->user_draws || e->z_user == nullptr) return fail(MBT_ERR_STATE, "this environment's user processes draw no extra normals (mbt_user_code.extra_normals)");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->z_user, z_user, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->user_noise_ready = true;
@@ -2097,6 +2348,7 @@ int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, 
   if (e == nullptr || z == nullptr || (!e->speed && (u_arr == nullptr || u_fill == nullptr))) return fail(MBT_ERR_INVALID, "null argument");
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (!e->speed) {
     HIP_TRY(hipMemcpyAsync(e->u_arr, u_arr, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->u_fill, u_fill, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -2120,6 +2372,7 @@ int mbt_env_action_dim(mbt_env* e) { return e != nullptr ? e->act_dim : 0; }
 int mbt_env_get_state_host(mbt_env* e, float* state_host) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(state_host, e->state[e->cur], size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
@@ -2172,6 +2425,7 @@ double mbt_exact_join(float hi, int32_t lo) { return exact_join_host(hi, lo); }
 int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   const size_t n = e->n, d = static_cast<size_t>(e->dim), r = static_cast<size_t>(e->res);
   std::vector<float> rows(n * d);
   std::vector<int32_t> lo(n * r);
@@ -2193,6 +2447,7 @@ int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
 int mbt_env_get_obs_host(mbt_env* e, float* obs_host) {
   if (e == nullptr || obs_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(obs_host, current_obs(e), size_t(e->n) * e->dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
@@ -2201,6 +2456,7 @@ int mbt_env_get_obs_host(mbt_env* e, float* obs_host) {
 int mbt_env_set_action_host(mbt_env* e, const float* action_host) {
   if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->action_in_stage = false;  // these are the newest actions now
@@ -2210,6 +2466,7 @@ int mbt_env_set_action_host(mbt_env* e, const float* action_host) {
 int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uint32_t philox_step) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(e->state[e->cur], state_host, size_t(e->n) * e->dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
   if (e->resid != nullptr) HIP_TRY(hipMemsetAsync(e->resid, 0, size_t(e->n_pad) * e->res * sizeof(int32_t), e->stream));  // a float32 state has no remainder
   if (e->cfg.normalise_observation) {
@@ -2237,6 +2494,7 @@ int mbt_env_get_clock(mbt_env* e, double* time, uint32_t* episode_step, uint32_t
 int mbt_env_record_events(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (enabled && e->events == nullptr) {
     int rc = dev_alloc(&e->events, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;
@@ -2249,6 +2507,7 @@ int mbt_env_get_events_host(mbt_env* e, uint8_t* events_host) {
   if (e == nullptr || events_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!e->record_events) return fail(MBT_ERR_STATE, "event recording is off");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipMemcpyAsync(events_host, e->events, size_t(e->n), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MBT_OK;
@@ -2257,6 +2516,7 @@ int mbt_env_get_events_host(mbt_env* e, uint8_t* events_host) {
 int mbt_env_clip_count(mbt_env* e, uint64_t* count) {
   if (e == nullptr || count == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
   std::vector<unsigned long long> slots(mbt::kClipSlots);
   HIP_TRY(hipMemcpyAsync(slots.data(), e->clip_count, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -2270,6 +2530,7 @@ int mbt_env_clip_count(mbt_env* e, uint64_t* count) {
 int mbt_env_track_lane_returns(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   if (enabled && e->lane_returns == nullptr) {
     int rc = dev_alloc(&e->lane_returns, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;
@@ -2281,6 +2542,7 @@ int mbt_env_track_lane_returns(mbt_env* e, int enabled) {
 int mbt_env_return_sums(mbt_env* e, double sums[3]) {
   if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   hipLaunchKernelGGL(mbt::reduce_returns_kernel, dim3(1), dim3(256), 0, e->stream, e->wave_sums, e->n_waves,
                      e->track_returns ? e->lane_returns : nullptr, e->n, e->reduce_out);
   HIP_TRY(hipGetLastError());
@@ -2297,6 +2559,7 @@ int mbt_env_return_sums_begin(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (e->sums_pending) return fail(MBT_ERR_STATE, "a return-sums request is already in flight: call mbt_env_return_sums_end first");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   hipLaunchKernelGGL(mbt::reduce_returns_kernel, dim3(1), dim3(256), 0, e->stream, e->wave_sums, e->n_waves,
                      e->track_returns ? e->lane_returns : nullptr, e->n, e->reduce_out);
   HIP_TRY(hipGetLastError());
@@ -2310,6 +2573,7 @@ int mbt_env_return_sums_end(mbt_env* e, double sums[3]) {
   if (e == nullptr || sums == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!e->sums_pending) return fail(MBT_ERR_STATE, "no return-sums request in flight");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipEventSynchronize(e->ev_sums));  // waits for the reduction only: later launches keep running
   e->sums_pending = false;
   sums[0] = e->h_sums[0];
@@ -2470,6 +2734,7 @@ int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key
 int mbt_env_timer_begin(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
   return MBT_OK;
 }
@@ -2477,6 +2742,7 @@ int mbt_env_timer_begin(mbt_env* e) {
 int mbt_env_timer_stop(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   HIP_TRY(hipEventRecord(e->ev_end, e->stream));
   return MBT_OK;
 }
@@ -2484,6 +2750,7 @@ int mbt_env_timer_stop(mbt_env* e) {
 int mbt_env_timer_elapsed(mbt_env* e, float* elapsed_ms) {
   if (e == nullptr || elapsed_ms == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
   const auto t0 = std::chrono::steady_clock::now();  // poll before blocking, like mbt_env_synchronize
   while (hipEventQuery(e->ev_end) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {
   }

@@ -1158,11 +1158,13 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
 // the hint.)
 // MIRROR: small batches over the host API (mbt_env_step_host, N <= 65536): the kernel also mirrors its outputs into
 // device-mapped host memory and raises a completion flag there (signal_host) - ONE launch per env.step(), no interrupt.
+// `tile`: the 512-lane tile this workgroup steps (blockIdx.x for the ordinary kernels: one tile per workgroup; the resident
+// small-batch kernel walks several tiles per workgroup and step)
 template <class V, bool STREAM = false, bool MIRROR = false>
-__device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {
+__device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams& P, const uint32_t tile) {
   static_assert(!(STREAM && MIRROR), "streaming loads are for launches beyond the Infinity Cache, the mirror for small batches");
-  const uint32_t lane0 = blockIdx.x * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
-  const uint64_t pair = P.pair_offset + blockIdx.x * kBlockThreads + threadIdx.x;
+  const uint32_t lane0 = tile * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
+  const uint64_t pair = P.pair_offset + tile * kBlockThreads + threadIdx.x;
   LaneLoads L0 = load_lane<V, STREAM>(B, P, lane0), L1 = load_lane<V, STREAM>(B, P, lane1);  // issue every load ...
   load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
   LaneNoise nz0, nz1;
@@ -1191,13 +1193,13 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
     __syncthreads();
     constexpr int kTileVectors = kTileLanes * V::DIM / 4;  // float4 per tile: 3 (D = 6) or 4 (D = 8) per thread; 2.5 for D = 5
     const float4* staged = reinterpret_cast<const float4*>(staged_rows);
-    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(blockIdx.x) * kTileVectors;
+    float4* out = reinterpret_cast<float4*>(B.state_out) + static_cast<size_t>(tile) * kTileVectors;
 #pragma unroll
     for (int k = 0; k * kBlockThreads < kTileVectors; ++k)
       if ((k + 1) * kBlockThreads <= kTileVectors || threadIdx.x + k * kBlockThreads < kTileVectors)
         store_through(out + threadIdx.x + k * kBlockThreads, staged[threadIdx.x + k * kBlockThreads]);
   }
-  if ((blockIdx.x + 1u) * kTileLanes > P.n) {  // only the last tile can hold pad lanes: computed, never reported
+  if ((tile + 1u) * kTileLanes > P.n) {  // only the last tile can hold pad lanes: computed, never reported
     const bool real0 = lane0 < P.n, real1 = lane1 < P.n;
     r0 = real0 ? r0 : 0.0f;
     r1 = real1 ? r1 : 0.0f;
@@ -1211,10 +1213,15 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
   //    fire-and-forget hardware fp64 atomic per wave, no contention
   const float total = wave_sum(r_sum);
   if ((threadIdx.x & 63u) == 0u) {
-    const uint32_t wave = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t wave = tile * (kBlockThreads / 64) + (threadIdx.x >> 6);
     unsafeAtomicAdd(&B.wave_sums[wave], static_cast<double>(total));
     if (__builtin_expect(clips != 0u, 0)) atomicAdd(&B.clip_count[wave & (kClipSlots - 1u)], static_cast<unsigned long long>(clips));
   }
+}
+
+template <class V, bool STREAM = false, bool MIRROR = false>
+__device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {
+  step_tile<V, STREAM, MIRROR>(B, P, blockIdx.x);
   if (MIRROR) signal_host(B);
 }
 
@@ -1223,6 +1230,118 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
 template <class V, bool STREAM = false, bool MIRROR = false>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
   step_body<V, STREAM, MIRROR>(B, P);
+}
+
+// ---- resident small-batch stepping (opt-in: MBT_RESIDENT_STEP=1; mbt_env.hip: resident_step) ---------------------------------
+// In the reference's own regime (N ~ 1000) one env.step() is ONE launch of the MIRROR instantiation, and what is left of its 14 us is
+// mostly the ~6 us between the launch call and the kernel's first instruction.  This kernel removes it by staying on the device:
+// at most four workgroups (each walks its share of the tiles) wait for the host to ring a doorbell - a sequence number in a MAILBOX
+// line that also carries where this step's observation rows and rewards are to be mirrored - step every lane exactly like
+// step_kernel<V, false, true> (same step_tile, same Philox counters, same clock arithmetic as the host: t += dt in double, TE:216;
+// terminal per TE:218-220), raise the completion flag (signal_host) and go back to waiting.  It leaves by itself when the episode
+// ends, when told to (kResidentExit: any other call on the environment), after `idle_ticks` without a doorbell and after
+// `life_ticks` in any case - every wait on the device has a wall-clock bound (100 MHz wall_clock64): a host that died cannot leave
+// the device spinning.  On leaving without having handled step `seq` it says so in host memory (`host_exit`), so a host that rang
+// the doorbell in the same instant starts another kernel at that step instead of waiting for an answer that will not come.
+// Measured (tools/microbench/mb_resident.hip, profiles/r05_resident_step.txt): 16.1 -> 9.6 us per mock step at N = 1000 with the
+// mailbox and the actions in device memory the host writes through the PCIe BAR, 12.1 us with both in host memory; a bandwidth-bound
+// kernel on ANOTHER stream runs 20-27 % slower beside it - which is why this is opt-in.
+constexpr uint32_t kResidentExit = 0xFFFFFFFFu;
+struct ResidentMailbox {  // one 64-byte line, written by the host as a whole (write-combined) before every step
+  uint64_t host_obs;      // where this step's (n, D) observation rows go (the device's address of device-visible host memory)
+  uint64_t host_reward;   // ... and its (n) rewards
+  uint32_t seq;           // the step's sequence number = the value its completion flag will take; kResidentExit: leave
+  uint32_t reserved[11];
+};
+struct ResidentParams {
+  const ResidentMailbox* mailbox;  // device memory the host can write (fine-grained, through the BAR) or device-mapped host memory
+  uint32_t* host_exit;             // host memory: the sequence number of the step the kernel left BEFORE handling
+  uint32_t* control;               // device memory: workgroup 0's decision for the current step, read by the other workgroups
+  uint32_t first_seq, n_tiles;
+  double t_start, dt_f64, terminal_time;  // the host's clock (mbt_env.hip: launch_step), advanced here with the same arithmetic
+  uint64_t idle_ticks, life_ticks;
+  int32_t ping_pong;
+  uint32_t generation;             // of this launch (the host counts them): tags the "leave" word in `control`
+};
+
+template <class V>
+__device__ __forceinline__ void resident_body(const StepBuffers& B0, const StepParams& P0, const ResidentParams& R) {
+  StepBuffers B = B0;
+  StepParams P = P0;
+  __shared__ uint32_t s_cmd;
+  __shared__ uint64_t s_out[2];
+  double t = R.t_start;
+  const uint64_t born = wall_clock64();
+  // ONE decision per step for the whole grid: workgroup 0 watches the mailbox and publishes "go(seq)" or "leave" in device memory
+  // (`control`), the others watch that word.  (Every workgroup deciding for itself was wrong: one timed out while its neighbour saw
+  // the doorbell that was rung in the same microsecond, and half a step ran.)  The leave token carries the launch's generation, so a
+  // word left behind by an earlier kernel is never mistaken for this one's.
+  const uint32_t leave = 0x80000000u | (R.generation & 0x7FFFFFFFu);
+  for (uint32_t seq = R.first_seq;; ++seq) {
+    if (threadIdx.x == 0) {
+      const uint64_t t0 = wall_clock64();
+      uint32_t cmd;
+      if (blockIdx.x == 0) {
+        for (;;) {
+          cmd = __hip_atomic_load(&R.mailbox->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (cmd == kResidentExit || static_cast<int32_t>(cmd - seq) >= 0) break;
+          const uint64_t now = wall_clock64();
+          if (now - t0 > R.idle_ticks || now - born > R.life_ticks) { cmd = kResidentExit; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __hip_atomic_store(R.control, cmd == kResidentExit ? leave : seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (;;) {
+          const uint32_t word = __hip_atomic_load(R.control, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (word == seq) { cmd = seq; break; }
+          if (word == leave || wall_clock64() - born > 2 * R.life_ticks) { cmd = kResidentExit; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      s_cmd = cmd;
+      if (cmd != kResidentExit) {  // (the line was written as a whole and stays as it is until this step's flag is up)
+        s_out[0] = __hip_atomic_load(&R.mailbox->host_obs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_out[1] = __hip_atomic_load(&R.mailbox->host_reward, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();
+    const uint32_t cmd = s_cmd;
+    B.host_obs = reinterpret_cast<float*>(s_out[0]);
+    B.host_reward = reinterpret_cast<float*>(s_out[1]);
+    __syncthreads();
+    // Every wave drops what its CU's vector cache still holds: the actions the host has just rewritten, and the state rows this
+    // very kernel wrote a step ago (a kernel boundary does this for the one-launch-per-step path).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (cmd == kResidentExit) {
+      if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(R.host_exit, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    const double t_next = t + R.dt_f64;  // TE:216, exactly as launch_step advances the host's clock
+    const bool terminal = t_next >= R.terminal_time - R.dt_f64 / 2;  // TE:218-220
+    P.is_terminal = terminal ? 1 : 0;
+    P.t_next = static_cast<float>(t_next);
+    P.t_now = t;
+    P.t_next_f64 = t_next;
+    B.flag_value = seq;
+    for (uint32_t tile = blockIdx.x; tile < R.n_tiles; tile += gridDim.x) {
+      step_tile<V, false, true>(B, P, tile);
+      if (V::DIM > 4) __syncthreads();  // (the next tile re-uses the staged rows)
+    }
+    signal_host(B);
+    if (terminal) return;  // the episode is over: the host (which computed the same flag) resets before it steps again
+    t = t_next;
+    P.philox_step += 1;
+    if (R.ping_pong) {
+      float* previous = const_cast<float*>(B.state_in);
+      B.state_in = B.state_out;
+      B.state_out = previous;
+    }
+  }
+}
+
+template <class V>
+__global__ __launch_bounds__(kBlockThreads) void resident_step_kernel(const StepBuffers B, const StepParams P, const ResidentParams R) {
+  resident_body<V>(B, P, R);
 }
 
 // ---- fused rollout -----------------------------------------------------------------------

@@ -228,3 +228,49 @@ def test_eight_ranks_rehearsed_on_one_device():
     assert wall < 120.0, f"the 8-rank line took {wall:.0f} s"
     one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", *common)
     assert one["mean_episode_return"] == pytest.approx(eight["mean_episode_return"], rel=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(normalise_action_space=True, normalise_observation_space=True), dict(hawkes=True, midprice="ou", ou_level=100.0, ou_speed=0.02, reward="running", phi=0.01, alpha=0.02),
+                                dict(dynamics="limit_and_market", market_half_spread=0.4, reward="cjmm", phi=0.01, alpha=0.05, initial_inventory=(-2, 3))])
+@pytest.mark.parametrize("n", [1000, 37, 4000])
+def test_resident_small_batch_stepping_is_the_one_launch_path_bit_for_bit(n, kw, monkeypatch):
+    """MBT_RESIDENT_STEP=1 (opt-in): env.step() of a small batch rings the doorbell of a kernel that stays on the device instead of
+    launching one.  Same step_tile, same Philox counters, the clock advanced with the host's arithmetic: observations, rewards, dones,
+    episode sums and the state afterwards equal the one-launch path's to the bit - over two episodes, with calls in between that make
+    the kernel leave (reset, a device step, a state read, an idle pause longer than its time-out)."""
+    import time
+
+    kw = dict(kw)
+    if kw.pop("hawkes", False):
+        kw.update(arrival="hawkes", intensity=(20.0, 15.0), hawkes_jump=20.0, hawkes_speed=15.0)
+    cfg = _cfg(n, **kw)
+    plain = make_env(cfg)
+    monkeypatch.setenv("MBT_RESIDENT_STEP", "1")
+    monkeypatch.setenv("MBT_RESIDENT_IDLE_US", "300")
+    resident = make_env(cfg)
+    monkeypatch.delenv("MBT_RESIDENT_STEP")
+    rng = np.random.default_rng(3)
+    lo = -1.0 if cfg.normalise_action_space else 0.0
+    for episode in range(2):
+        np.testing.assert_array_equal(plain.reset(), resident.reset())
+        for k in range(cfg.n_steps):
+            a = rng.uniform(lo, 1.0, size=(n, cfg.action_dim)).astype(np.float32)
+            if cfg.action_dim == 4:
+                a[:, 2:] = rng.choice([lo, 1.0], p=[0.9, 0.1], size=(n, 2))
+            (o_p, r_p, d_p, _), (o_r, r_r, d_r, _) = plain.step(a), resident.step(a)
+            np.testing.assert_array_equal(o_r, o_p, err_msg=f"episode {episode} step {k}: observation")
+            np.testing.assert_array_equal(r_r, r_p, err_msg=f"episode {episode} step {k}: rewards")
+            np.testing.assert_array_equal(d_r, d_p)
+            if d_p[0]:
+                break
+            if k == 5:
+                np.testing.assert_array_equal(resident.state, plain.state)  # a state read: the kernel leaves, the next step starts another
+            if k == 9:
+                time.sleep(0.002)  # longer than the kernel's idle time-out: it leaves by itself, the next step notices and relaunches
+            if k == 13:  # a device step in between (the actions of the last host step are filed from the resident stage)
+                plain.step_device(), resident.step_device()
+                np.testing.assert_array_equal(resident.state, plain.state)
+        assert plain.clock == resident.clock
+        np.testing.assert_array_equal(resident.state, plain.state)
+        assert resident.episode_return_sums()[0] == plain.episode_return_sums()[0]
+    plain.close(), resident.close()
