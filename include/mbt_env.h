@@ -334,6 +334,12 @@ int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_h
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
 int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
 int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
+/* Small batches (up to 65536 lanes), order-book dynamics, host-callback plugins: the step kernel also mirrors its un-normalised rows,
+ * their int32 remainders and the event bytes into host memory, so what the caller's update() / calculate() are handed needs no
+ * further round trip.  state_host: (N, D) float64 as mbt_env_get_state_f64_host assembles it (may be NULL); events_host: (N) bytes as
+ * mbt_env_get_events_host returns them (may be NULL).  MBT_ERR_STATE when the last call on the environment was not such a step
+ * (use the two functions named instead). */
+int mbt_env_host_step_outputs(mbt_env* env, double* state_host, uint8_t* events_host);
 int mbt_env_set_host_impacts(mbt_env* env, const double* impacts_host);
 /* The state columns host-callback processes OWN (SP:8-53), ONE contiguous block in registry order (TE:303-318): with
  * MBT_MID_HOST the midprice column 3 and the midprice model's further columns (declared through mbt_user_code.state_columns /

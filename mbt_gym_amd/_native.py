@@ -208,6 +208,7 @@ SIGNATURES = {
     "mbt_env_set_host_arrivals": (C.c_int, [_ENV, _F]),
     "mbt_env_set_host_impacts": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_set_host_rewards": (C.c_int, [_ENV, C.POINTER(C.c_double), _F]),
+    "mbt_env_host_step_outputs": (C.c_int, [_ENV, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
     "mbt_env_set_host_state_columns": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_step_many_device": (C.c_int, [_ENV, C.c_uint32, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mbt_env_rollout_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -311,6 +311,12 @@ struct mbt_env {
   int host_state_first = 0, host_state_count = 0;  // the state columns host-callback processes own: one block in registry order (TE:303-318)
   bool host_reward_replaces = false; // MBT_REW_HOST on the speed kernels: the kernel filed its PnL, mbt_env_set_host_rewards takes it back out
   bool host_mid = false;             // MBT_MID_HOST: cfg.midprice_kind reads MBT_MID_CONSTANT, the caller moves the midprice between launches
+  // small batches (round 5): what goes to and comes from the caller's NumPy code travels through ONE pinned, device-mapped block per
+  // direction instead of a DMA copy + synchronisation each - host_fill_p / host_arrivals / host_scratch then point INTO h_callback_in
+  // (the kernels read it across the link), and the step's mirror instantiation writes rows + remainders + event bytes into the stage
+  char* h_callback_in = nullptr;     // host view of [fill probabilities (n_pad, 2) f64 | arrivals (n_pad, 2) f32 | scratch (n_pad, 4) f64]
+  size_t stage_state = 0, stage_resid = 0, stage_events = 0;  // offsets (in floats) inside the stage; 0 = not mirrored
+  bool stage_outputs_valid = false;  // the stage holds the state / remainders / events of the step that ran last
   // resident small-batch stepping (opt-in: MBT_RESIDENT_STEP=1; step_kernel.hpp: resident_step_kernel)
   ResidentKernel resident_kernel = nullptr;   // nullptr: this configuration has no resident form (or the mode is off)
   bool resident_active = false;               // a resident kernel is (or may still be) running on the stream
@@ -672,7 +678,13 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   B.action = action_dev != nullptr ? action_dev : e->action;
   B.host_fill_p = e->host_fill_p;
   B.host_arrivals = e->host_arrivals;
+  e->stage_outputs_valid = false;
   if (mirror) {
+    if (e->stage_state != 0) {  // host-callback plugins, order-book dynamics: rows, remainders and events for the caller's update() / calculate()
+      B.host_state = e->d_stage + e->stage_state;
+      B.host_resid = e->res != 0 ? reinterpret_cast<int32_t*>(e->d_stage + e->stage_resid) : nullptr;
+      B.host_events = reinterpret_cast<uint8_t*>(e->d_stage + e->stage_events);
+    }
     B.host_obs = mirror_obs != nullptr ? mirror_obs : e->d_stage + e->stage_obs;
     B.host_reward = mirror_reward != nullptr ? mirror_reward : e->d_stage + e->stage_reward;
     B.done_counter = e->done_counter;
@@ -1083,6 +1095,7 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
 
 // reuse_q0: an automatic reset (mbt_env_step_many_device) restarts from the initial inventories of the last explicit one
 int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 = false) {
+  e->stage_outputs_valid = false;
   const mbt_config& c = e->cfg;
   if (!(start_time >= 0.0 && start_time < c.terminal_time))
     return fail(MBT_ERR_INVALID, "start time %g is not within [0, terminal_time)", start_time);  // TE:267
@@ -1738,7 +1751,13 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     e->stage_reward = e->stage_obs + size_t(e->n) * e->dim;
     e->stage_flag = ((e->stage_reward + e->n + 15u) / 16u) * 16u;  // the completion flag of signal_host, on a cache line of its own
     e->stage_exit = e->stage_flag + 16u;                           // where a resident kernel says it left before a step, on the next line
-    const size_t floats = e->stage_exit + 16u;
+    size_t floats = e->stage_exit + 16u;
+    if (e->host_mask != 0 && !speed) {  // host-callback plugins: the step also mirrors rows, remainders and event bytes (launch_step)
+      e->stage_state = floats;
+      e->stage_resid = e->stage_state + ((size_t(e->n) * e->dim + 3u) / 4u) * 4u;
+      e->stage_events = e->stage_resid + ((size_t(e->n) * e->res + 3u) / 4u) * 4u;
+      floats = e->stage_events + (e->n + 3u) / 4u + 4u;
+    }
     // (coherent: the host reads the flag, and then the mirror, while the GPU context is live - not after a synchronisation)
     if (hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(e->h_stage, 0, floats * sizeof(float));
@@ -1749,6 +1768,26 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     } else {
       e->h_stage = nullptr;  // not fatal: the DMA path below serves every size
       (void)hipGetLastError();
+    }
+    if (e->h_stage == nullptr) e->stage_state = e->stage_resid = e->stage_events = 0;
+    if (e->h_stage != nullptr && e->host_mask != 0) {
+      // ... and what the caller's NumPy code computed goes DOWN through one mapped block the kernels read in place (no copy, no wait)
+      const size_t fill_bytes = np * 2 * sizeof(double), arrival_bytes = np * 2 * sizeof(float), scratch_bytes = np * 4 * sizeof(double);
+      char* host = nullptr;
+      char* dev = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&host), fill_bytes + arrival_bytes + scratch_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+          hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) == hipSuccess) {
+        std::memset(host, 0, fill_bytes + arrival_bytes + scratch_bytes);
+        for (void* b : {static_cast<void*>(e->host_fill_p), static_cast<void*>(e->host_arrivals), static_cast<void*>(e->host_scratch)})
+          if (b != nullptr) (void)hipFree(b);
+        e->h_callback_in = host;
+        e->host_fill_p = reinterpret_cast<double*>(dev);
+        e->host_arrivals = reinterpret_cast<float*>(dev + fill_bytes);
+        e->host_scratch = reinterpret_cast<double*>(dev + fill_bytes + arrival_bytes);
+      } else {
+        if (host != nullptr) (void)hipHostFree(host);
+        (void)hipGetLastError();
+      }
     }
   }
   {  // opt-in: MBT_RESIDENT_STEP=1 - small batches of the float32 tier's built-in order-book models step through a kernel that stays on the device
@@ -1762,6 +1801,14 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
       const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
       e->resident_kernel = mbt_table::pick_resident(arrival_family(c), c.dynamics_kind, c.midprice_kind == MBT_MID_BROWNIAN, reward_weight(c), norm);
       if (e->resident_kernel != nullptr) ENV_TRY(resident_allocate(e));
+    }
+    const char* vram_stage = std::getenv("MBT_VRAM_ACTION_STAGE");  // (measurement knob, see mbt_env_step_host)
+    if (e->resident_kernel == nullptr && vram_stage != nullptr && std::atoi(vram_stage) != 0 && e->h_stage != nullptr) {
+      ENV_TRY(resident_allocate(e));
+      if (!e->resident_vram) {  // (host memory would be the existing stage again)
+        (void)hipHostFree(e->resident_host_block);
+        e->resident_host_block = nullptr;
+      }
     }
   }
 #undef ENV_TRY
@@ -1826,6 +1873,12 @@ void mbt_env_destroy(mbt_env* e) {
   if (e->log_host != nullptr) (void)hipHostFree(e->log_host);
   for (hipEvent_t ev : e->log_event)
     if (ev != nullptr) (void)hipEventDestroy(ev);
+  if (e->h_callback_in != nullptr) {  // (the three callback buffers point into this one mapped block)
+    (void)hipHostFree(e->h_callback_in);
+    e->host_fill_p = nullptr;
+    e->host_arrivals = nullptr;
+    e->host_scratch = nullptr;
+  }
   for (void* b : {static_cast<void*>(e->done_counter), static_cast<void*>(e->host_fill_p), static_cast<void*>(e->host_arrivals), static_cast<void*>(e->host_scratch)})
     if (b != nullptr) (void)hipFree(b);
   if (e->h_gate != nullptr) (void)hipHostFree(e->h_gate);
@@ -1925,16 +1978,25 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
     // from, and its observation rows and rewards written by it into, pinned device-mapped host memory; the last workgroup
     // to finish raises a flag there and this thread spins on it (step_kernel.hpp: signal_host).  ONE launch per env.step().
     const size_t n_obs = size_t(e->n) * e->dim;
-    std::memcpy(e->h_stage + e->stage_action, action_host, size_t(e->n) * e->act_dim * sizeof(float));
+    // (MBT_VRAM_ACTION_STAGE=1, measurement knob: the actions go into device memory through the PCIe BAR instead - the kernel then reads
+    // them locally rather than across the link; profiles/r05_resident_step.txt)
+    const bool vram_actions = e->resident_vram && e->resident_kernel == nullptr;
+    if (vram_actions) {
+      std::memcpy(e->resident_action_host, action_host, size_t(e->n) * e->act_dim * sizeof(float));
+      _mm_sfence();
+    } else {
+      std::memcpy(e->h_stage + e->stage_action, action_host, size_t(e->n) * e->act_dim * sizeof(float));
+    }
     e->action_in_stage = false;  // (set below: launch_step must not file the PREVIOUS stage contents first)
     const bool mirror = e->jit_step != nullptr ? e->jit_step_mirror != nullptr : e->kernel_mirror != nullptr;
     // the caller's arrays are blocks of mbt_host_alloc (the Python layer's output pools are): the kernel writes them directly
     float* direct_obs = mirror ? static_cast<float*>(device_alias(obs_host, n_obs * sizeof(float))) : nullptr;
     float* direct_rew = mirror ? static_cast<float*>(device_alias(reward_host, size_t(e->n) * sizeof(float))) : nullptr;
     if (direct_obs == nullptr || direct_rew == nullptr || reinterpret_cast<uintptr_t>(direct_obs) % 16 != 0) direct_obs = direct_rew = nullptr;  // (rows leave as 16-byte vectors)
-    int rc = launch_step(e, e->d_stage + e->stage_action, done, mirror, direct_obs, direct_rew);
+    int rc = launch_step(e, vram_actions ? e->resident_action_dev : e->d_stage + e->stage_action, done, mirror, direct_obs, direct_rew);
     if (rc != MBT_OK) return rc;
     e->action_in_stage = true;
+    e->action_in_resident_stage = vram_actions;
     if (!mirror) {  // (injected-noise kernels have no mirror instantiation: a second launch exports, the stream is waited for)
       const uint32_t threads = 256, blocks = static_cast<uint32_t>((n_obs + threads - 1) / threads);
       hipLaunchKernelGGL(mbt::export_step_kernel, dim3(blocks), dim3(threads), 0, e->stream, current_obs(e), e->reward, e->d_stage + e->stage_obs,
@@ -1955,6 +2017,7 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
         }
       }
     }
+    e->stage_outputs_valid = mirror && e->stage_state != 0;
     if (direct_obs != nullptr) return MBT_OK;  // already where the caller wants them
     if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
     if (reward_host != nullptr) std::memcpy(reward_host, e->h_stage + e->stage_reward, size_t(e->n) * sizeof(float));
@@ -2145,14 +2208,18 @@ int mbt_env_host_depths(mbt_env* e, const float* action_host, double* depths_hos
   if (e == nullptr || action_host == nullptr || depths_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (e->speed || e->cfg.dynamics_kind == MBT_DYN_AT_THE_TOUCH) return fail(MBT_ERR_INVALID, "only limit-order dynamics quote depths (MD:104-106)");
   if (e->host_scratch == nullptr) return fail(MBT_ERR_STATE, "this environment has no host-callback plugin (MBT_FILL_HOST / MBT_ARR_HOST / MBT_REW_HOST)");
-  HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
-  HIP_TRY(hipMemcpyAsync(e->action, action_host, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  e->action_in_stage = false;
-  hipLaunchKernelGGL(mbt::host_depths_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->action, e->act_dim, e->n, e->params, e->host_scratch);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(depths_host, e->host_scratch, size_t(e->n) * 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  // The quotes the caller's _get_fill_probabilities(depths) is asked about are an affine map of the ACTION the caller has just handed
+  // over (TE:124) - host data in, host data out.  Rounds 4's version sent it through the device and back (two copies, a launch, a
+  // wait: ~45 us at N = 1000); this is the same arithmetic - float32 action and float32 Box bounds promoted, (a + 1) * gradient + low
+  // in double, one rounding per operation (the library is built with -ffp-contract=off on both sides) - as decide<V>() evaluates it
+  // in the kernel, so the depths are the kernel's to the bit (tests/test_gpu_host_callbacks.py compares them with mbt_env_action... ).
+  const mbt::StepParams& P = e->params;
+  const int a = e->act_dim;
+  for (size_t i = 0; i < e->n; ++i)
+    for (int side = 0; side < 2; ++side) {
+      const double x = action_host[i * a + side];
+      depths_host[i * 2 + side] = P.norm_act ? (x + 1.0) * static_cast<double>(P.act_grad[side]) + static_cast<double>(P.act_lo[side]) : x;
+    }
   return MBT_OK;
 }
 
@@ -2161,8 +2228,12 @@ int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_
   if (!(e->host_mask & mbt::kHostFill)) return fail(MBT_ERR_STATE, "the fill model of this environment is not a host callback (MBT_FILL_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
-  HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->h_callback_in != nullptr) {  // small batches: the kernel reads the block in place (the previous step has finished: its flag was waited for)
+    std::memcpy(e->h_callback_in, probabilities_host, size_t(e->n) * 2 * sizeof(double));
+  } else {
+    HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   e->host_fill_ready = true;
   return MBT_OK;
 }
@@ -2172,8 +2243,12 @@ int mbt_env_set_host_impacts(mbt_env* e, const double* impacts_host) {
   if (!(e->host_mask & mbt::kHostImpact)) return fail(MBT_ERR_STATE, "the price impact model of this environment is not a host callback (MBT_IMPACT_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
-  HIP_TRY(hipMemcpyAsync(e->host_fill_p, impacts_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));  // the caller's array may go away
+  if (e->h_callback_in != nullptr) {
+    std::memcpy(e->h_callback_in, impacts_host, size_t(e->n) * sizeof(double));
+  } else {
+    HIP_TRY(hipMemcpyAsync(e->host_fill_p, impacts_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the caller's array may go away
+  }
   e->host_fill_ready = true;
   return MBT_OK;
 }
@@ -2183,8 +2258,12 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
   if (!(e->host_mask & mbt::kHostArrival)) return fail(MBT_ERR_STATE, "the arrival model of this environment is not a host callback (MBT_ARR_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
-  HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->h_callback_in != nullptr) {
+    std::memcpy(e->h_callback_in + size_t(e->n_pad) * 2 * sizeof(double), arrivals_host, size_t(e->n) * 2 * sizeof(float));
+  } else {
+    HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   e->host_arrivals_ready = true;
   return MBT_OK;
 }
@@ -2196,7 +2275,13 @@ int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
   const int d = e->host_state_count;
-  HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  e->stage_outputs_valid = false;  // (the rows change under the mirror)
+  if (e->h_callback_in != nullptr) {  // (the scratch block is mapped host memory: the kernel reads the values in place)
+    HIP_TRY(hipStreamSynchronize(e->stream));  // a reward-filing kernel of this step may still be reading the block
+    std::memcpy(e->h_callback_in + size_t(e->n_pad) * (2 * sizeof(double) + 2 * sizeof(float)), columns_host, size_t(e->n) * d * sizeof(double));
+  } else {
+    HIP_TRY(hipMemcpyAsync(e->host_scratch, columns_host, size_t(e->n) * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  }
   hipLaunchKernelGGL(mbt::host_columns_kernel, dim3((e->n + 255u) / 256u), dim3(256), 0, e->stream, e->host_scratch, e->n, d, e->dim, e->host_state_first,
                      e->state[e->cur], e->cfg.precise_state ? e->resid : nullptr, e->res, e->speed ? 1 : 0, e->cfg.normalise_observation ? e->obs : nullptr, e->params);
   HIP_TRY(hipGetLastError());
@@ -2210,14 +2295,47 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
   if (!e->host_reward_pending) return fail(MBT_ERR_STATE, "no step is waiting for its host-computed rewards");
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
-  HIP_TRY(hipMemcpyAsync(e->host_scratch, rewards_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
   const uint32_t blocks = (e->n + 255u) / 256u;
+  if (e->h_callback_in != nullptr) {
+    // small batches: the filing kernel reads the caller's values in place and nobody waits for it - what it files is a function of
+    // values the host holds (float32(scale * r), exactly host_reward_kernel's expression), so the caller's copy is formed here
+    double* scratch = reinterpret_cast<double*>(e->h_callback_in + size_t(e->n_pad) * (2 * sizeof(double) + 2 * sizeof(float)));
+    std::memcpy(scratch, rewards_host, size_t(e->n) * sizeof(double));
+    hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
+                       e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves, e->host_reward_replaces ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    if (reward_out_host != nullptr)
+      for (size_t i = 0; i < e->n; ++i) reward_out_host[i] = static_cast<float>(e->cfg.reward_scale * rewards_host[i]);
+    e->host_reward_pending = false;
+    return MBT_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(e->host_scratch, rewards_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
                      e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves, e->host_reward_replaces ? 1 : 0);
   HIP_TRY(hipGetLastError());
   if (reward_out_host != nullptr) HIP_TRY(hipMemcpyAsync(reward_out_host, e->reward, size_t(e->n) * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->host_reward_pending = false;
+  return MBT_OK;
+}
+
+int mbt_env_host_step_outputs(mbt_env* e, double* state_host, uint8_t* events_host) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (!e->stage_outputs_valid) return fail(MBT_ERR_STATE, "no mirrored outputs: the last call was not a small-batch mbt_env_step_host of a host-callback environment");
+  const size_t n = e->n, d = static_cast<size_t>(e->dim), r = static_cast<size_t>(e->res);
+  const float* rows = e->h_stage + e->stage_state;
+  const int32_t* lo = reinterpret_cast<const int32_t*>(e->h_stage + e->stage_resid);
+  if (state_host != nullptr) {  // (the same assembly as mbt_env_get_state_f64_host, from the mirror instead of two device copies)
+    for (size_t i = 0; i < n * d; ++i) state_host[i] = rows[i];
+    for (size_t i = 0; i < n; ++i) {
+      for (size_t j = 0; j < r; ++j) {
+        const size_t column = static_cast<size_t>(e->res_col[j]);
+        if (column < d) state_host[i * d + column] = exact_join_host(rows[i * d + column], lo[i * r + j]);
+      }
+      state_host[i * d + 2] = e->time;
+    }
+  }
+  if (events_host != nullptr) std::memcpy(events_host, e->h_stage + e->stage_events, n);
   return MBT_OK;
 }
 

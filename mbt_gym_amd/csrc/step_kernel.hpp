@@ -260,6 +260,11 @@ struct StepBuffers {
   // host-callback plugins (Variant::HOST): what the host computed for this step
   const double* host_fill_p;   // (n_pad, 2) fill probabilities of this step's depths; speed dynamics with a host-callback impact model: (n_pad) price impacts
   const float* host_arrivals;  // (n_pad, 2) arrivals as 0.0f / 1.0f
+  // ... and, for small batches, what the host needs back to call the user's update() / calculate() without a further round trip
+  // (round 5; the MIRROR instantiation of a Variant::HOST kernel writes them into device-mapped host memory like the observation):
+  float* host_state;           // (n, D) the un-normalised state rows (float32 roundings), or nullptr
+  int32_t* host_resid;         // (n, RES) their int32 remainders (precise_state / exact intensities), or nullptr
+  uint8_t* host_events;        // (n) the step's event bytes (arrivals, fills, market orders, clips), or nullptr
 };
 
 // ---- structure of the arithmetic --------------------------------------------------------------------------------
@@ -1125,6 +1130,12 @@ __device__ __forceinline__ float finish_lane(const StepBuffers& B, const StepPar
     B.host_reward[lane] = r.reward;
     if (V::PRECISE) store_row_exact<V, kStorePlain>(B.host_obs, lane, r.core, r.lam, r.lo, P.t_next_f64, P);
     else store_row<V, kStorePlain>(B.host_obs, lane, r.core, r.lam, V::NORM, P);
+    if (V::HOST != 0 && B.host_state != nullptr) {  // host-callback plugins: the float64 state (row + remainders) and the events, for update() / calculate()
+      store_row<V, kStorePlain>(B.host_state, lane, r.core, r.lam, false, P);
+      if (V::RES == 4) reinterpret_cast<int4*>(B.host_resid)[lane] = r.lo;
+      else if (V::RES == 2) reinterpret_cast<int2*>(B.host_resid)[lane] = V::EXACT_LAM ? make_int2(r.lo.z, r.lo.w) : make_int2(r.lo.x, r.lo.y);
+      B.host_events[lane] = static_cast<uint8_t>(event_byte(r));
+    }
   }
   clipped = r.clipped_q | r.clipped_c;
   return r.reward;

@@ -106,6 +106,17 @@ def _refuse_overridden_builtin(part):
                 f"host-callback route), or state the formula as a device expression (DeviceExpression* classes) for the fast path.")
 
 
+def _is_a_no_op(function) -> bool:
+    """True for a Python function whose body does nothing (`pass`, `return None`, a docstring alone)."""
+    import dis
+
+    try:
+        ops = [ins for ins in dis.get_instructions(function) if ins.opname not in ("RESUME", "NOP")]
+    except TypeError:
+        return False
+    return [ins.opname for ins in ops] == ["LOAD_CONST", "RETURN_VALUE"] and ops[0].argval is None
+
+
 class TradingEnvironment(_EnvBase):
     metadata = {"render.modes": ["human"]}
 
@@ -219,8 +230,12 @@ class TradingEnvironment(_EnvBase):
         self._handle = self._create_handle(num_trajectories, self.reward_scaling)
         self._events_on = False
         self._last_events = None
-        # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills
-        self._host_needs_events = any(role in self._host_plugins for role in ("fill", "arrival", "midprice")) and self.model_dynamics.arrival_model is not None
+        # host-callback processes are handed what the reference hands every process after the step (TE:206-211): arrivals, fills and the
+        # state matrix - assembled only for processes whose update() DOES something (a body of `pass`, which is what a stateless model of
+        # the reference has, FILL:60-61, is not called: skipping it is unobservable, and the step then needs neither the float64 state
+        # nor the event bytes back)
+        self._host_updating = [role for role in ("midprice", "arrival", "fill", "impact") if role in self._host_plugins and not _is_a_no_op(type(self._host_plugins[role]).update)]
+        self._host_needs_events = bool(self._host_updating) and self.model_dynamics.arrival_model is not None
         if self._host_needs_events and self._handle is not None:
             _native.check(_native.load_library().mbt_env_record_events(self._handle, 1))
         # the reference materialises the initial state in the constructor (TE:74), consuming one draw of the
@@ -586,9 +601,11 @@ class TradingEnvironment(_EnvBase):
 
     def _step_with_host_plugins(self, action):
         """TE:103-110 with the user's NumPy methods where the reference calls them and the fused kernel for everything else:
-        depths (device, float64) -> _get_fill_probabilities / get_fills (host) -> probabilities (device); get_arrivals (host)
-        -> arrivals (device); ONE step launch; update() of the user's processes in registry order (host) -> the columns they own
-        (device); float64 states (device) -> calculate (host) -> rewards (device)."""
+        depths (the action de-normalised like the kernel does, float64) -> _get_fill_probabilities / get_fills (host) -> probabilities;
+        get_arrivals (host) -> arrivals; ONE step launch; update() of the user's processes in registry order (host) -> the columns they
+        own (device); float64 states -> calculate (host) -> rewards.  Small batches (round 5): what goes down travels through one mapped
+        block the kernel reads in place, what comes back (rows, remainders, event bytes) is mirrored by the step kernel itself - the
+        launch and its completion flag are the only synchronisation of a step, unless a process files state columns of its own."""
         lib, handle, n, plugins = _native.load_library(), self._handle, self.num_trajectories, self._host_plugins
         dptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
         pools = self._host_buffers()
@@ -596,8 +613,8 @@ class TradingEnvironment(_EnvBase):
         if act.shape != (n, self.action_dim):
             raise ValueError(f"expected shape {(n, self.action_dim)}, got {act.shape}")
         fill, arrival, reward = plugins.get("fill"), plugins.get("arrival"), plugins.get("reward")
-        if self._host_state64 is None:  # a step right after the constructor or the batch-size setter (TE:74: the state exists from there on)
-            self._host_state64 = self.state64
+        if self._host_state64 is None and (self._host_updating or reward is not None or "midprice" in plugins):
+            self._host_state64 = self.state64  # (a step right after the constructor or the batch-size setter - TE:74: the state exists from there on)
         if fill is not None:
             depths = np.empty((n, 2), dtype=np.float64)
             _native.check(lib.mbt_env_host_depths(handle, _native.fptr(act), dptr(depths)))
@@ -618,34 +635,52 @@ class TradingEnvironment(_EnvBase):
         rewards = pools["rewards"].acquire()[0]
         done = C.c_int32(0)
         _native.check(lib.mbt_env_step_host(handle, act.ctypes.data, obs.ctypes.data, rewards.ctypes.data, C.byref(done)))
-        if self._events_on or self._host_needs_events:
-            self._fetch_events()
-        following = self.state64  # float64 (N, D): with precise_state the reference's own values; the TIME column is the float64 clock
+        needs_reward = reward is not None or "midprice" in plugins
+        if not self._host_updating and not needs_reward and not self._events_on:
+            # nothing on the host reads the state or the events of this step (a stateless fill / arrival / impact model whose update() is
+            # `pass`): the step is the caller's method, one launch and the flag
+            self._host_state64 = None
+            dones = pools["dones"].acquire()[0]
+            dones.fill(bool(done.value))
+            return obs, rewards, dones, self._infos()
+        # float64 (N, D) state after the step - with precise_state the reference's own values; the TIME column is the float64 clock - and
+        # the step's event bytes: small batches get both from what the step kernel mirrored into host memory (no further round trip)
+        following = np.empty((n, self.observation_dim), dtype=np.float64)
+        events = np.empty((n,), dtype=np.uint8) if (self._events_on or self._host_needs_events) else None
+        mirrored = lib.mbt_env_host_step_outputs(handle, dptr(following), None if events is None else events.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+        if mirrored:
+            if events is not None:
+                self._last_events = events
+        else:
+            if events is not None:
+                self._fetch_events()
+            following = self.state64
         raw_action = self.normalise_action(np.asarray(action, dtype=np.float64), inverse=True)  # TE:104: what the plugins are handed
         current = self._host_state64
-        # StochasticProcessModel.update of the user's processes, in registry order (TE:206-211), with the step's arrivals and
-        # (masked) fills and the state matrix AS THE REFERENCE'S STANDS AT THAT POINT: cash, inventory and time already advanced
-        # (TE:213-216), the columns of the processes earlier in the registry advanced, the process's own and later ones not yet.
-        matrix = current.copy()
-        matrix[:, :3] = following[:, :3]
-        host_parts = {id(part) for part in plugins.values()}
         moved = False
-        # (trading-with-speed dynamics have no order flow: the reference hands update() None, None - MD:273-275, TE:199-204)
-        arrivals, fills = (self.last_arrivals, self.last_fills.astype(np.float64)) if self._host_needs_events else (None, None)
-        for name, process in self.stochastic_processes.items():
-            lo, hi = self.stochastic_process_indices[name]
-            if id(process) in host_parts:
-                process.update(arrivals, fills, raw_action, matrix)
-                if hi > lo:
-                    matrix[:, lo:hi] = process.current_state  # TE:209-211
-                    moved = True
-            else:
-                matrix[:, lo:hi] = following[:, lo:hi]
+        if self._host_updating:
+            # StochasticProcessModel.update of the user's processes, in registry order (TE:206-211), with the step's arrivals and
+            # (masked) fills and the state matrix AS THE REFERENCE'S STANDS AT THAT POINT: cash, inventory and time already advanced
+            # (TE:213-216), the columns of the processes earlier in the registry advanced, the process's own and later ones not yet.
+            matrix = current.copy()
+            matrix[:, :3] = following[:, :3]
+            updating = {id(plugins[role]) for role in self._host_updating}
+            # (trading-with-speed dynamics have no order flow: the reference hands update() None, None - MD:273-275, TE:199-204)
+            arrivals, fills = (self.last_arrivals, self.last_fills.astype(np.float64)) if self._host_needs_events else (None, None)
+            for name, process in self.stochastic_processes.items():
+                lo, hi = self.stochastic_process_indices[name]
+                if id(process) in updating:
+                    process.update(arrivals, fills, raw_action, matrix)
+                    if hi > lo:
+                        matrix[:, lo:hi] = process.current_state  # TE:209-211
+                        moved = True
+                else:
+                    matrix[:, lo:hi] = following[:, lo:hi]
         if moved:
             lo, hi, columns = self._file_host_columns(obs)
             following = following.copy()
             following[:, lo:hi] = columns if self.precise_state else columns.astype(np.float32)  # what the device holds
-        if reward is not None or "midprice" in plugins:
+        if needs_reward:
             # TE:108 - a built-in class evaluates it on the device, on these float64 matrices (mbt_reward_calculate_host)
             r = np.asarray(self.reward_function.calculate(current, raw_action, following, bool(done.value)), dtype=np.float64)
             r = np.ascontiguousarray(np.broadcast_to(r, (n,)))

@@ -68,6 +68,50 @@ def pcie_wire(n, obs_dim, act_dim, reps=20):
     return (time.perf_counter() - t0) / reps
 
 
+def host_callback_rows(n=1000, n_steps=200, steps=1500):
+    """env.step() at N = 1000 with plugin classes that only have NumPy code (examples/bring_your_own_numpy_plugins.py: a power-law fill
+    model, an exponential-inventory-cost reward), i.e. the host-callback route: the user's method runs on the host every step."""
+    import warnings
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "examples"))
+    from bring_your_own_numpy_plugins import ExponentialInventoryCost, PowerLawFill  # noqa: E402
+
+    from mbt_gym_amd.gym.ModelDynamics import LimitOrderModelDynamics
+    from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
+    from mbt_gym_amd.rewards.RewardFunctions import PnL
+    from mbt_gym_amd.stochastic_processes.arrival_models import PoissonArrivalModel
+    from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
+    from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
+
+    def build(user_fill, user_reward, normalised=False):
+        dt = 1.0 / n_steps
+        fill = PowerLawFill(1.25, 1.5, step_size=dt, num_trajectories=n) if user_fill else ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return TradingEnvironment(
+                terminal_time=1.0, n_steps=n_steps, num_trajectories=n, seed=7, max_inventory=20, reward_function=ExponentialInventoryCost(0.05, 0.3) if user_reward else PnL(),
+                model_dynamics=LimitOrderModelDynamics(
+                    midprice_model=BrownianMotionMidpriceModel(volatility=2.0, step_size=dt, num_trajectories=n),
+                    arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
+                    fill_probability_model=fill, num_trajectories=n),
+                normalise_action_space=normalised, normalise_observation_space=normalised)
+
+    rows = {}
+    for name, args in (("fill_model_in_numpy", (True, False)), ("fill_model_in_numpy_normalised_spaces", (True, False, True)), ("reward_in_numpy", (False, True)),
+                       ("fill_model_and_reward_in_numpy", (True, True))):
+        env = build(*args)
+        action = np.full((n, 2), -0.7 if len(args) > 2 else 0.6, np.float32)
+        t = env_only(env, action, steps)
+        depths = np.full((n, 2), 0.6)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            env.model_dynamics.fill_probability_model._get_fill_probabilities(depths) if args[0] else None
+        own = (time.perf_counter() - t0) / 2000
+        rows[name] = {"us_per_step": t * 1e6, "env_steps_per_s": n / t, "of_which_the_users_fill_method_us": own * 1e6 if args[0] else 0.0}
+        env.close()
+    return rows
+
+
 def main():
     out = {}
     for log2n, reps, steps in ((None, 20, 2000), (16, 5, 600), (20, 2, 120)):
@@ -159,6 +203,7 @@ def main():
             row["oracle"] = {"ms_per_episode": orc_s * 1e3, "env_steps_per_s": n * cfg.n_steps / orc_s}
         out[f"N={n}"] = row
         env.close()
+    out["host_callbacks_N=1000"] = host_callback_rows()
     print(json.dumps(out, indent=1))
 
 
