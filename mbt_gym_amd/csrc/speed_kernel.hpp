@@ -243,8 +243,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 // precise_state: the quad is advanced as kSpeedPreciseGroups groups of lanes (loads, arithmetic, stores of one group before
 // the loads of the next): the double-precision step on top of sixteen loaded vectors needed 140-147 registers - three waves
 // per SIMD, and the counters said that is what bounds it (waves stalled on memory 60 % of the time, profiles/r03_experiments.txt).
+// (round 5, tools/dbg/r05_speed_variants.sh, speed + impact state at 2^20 lanes, two alternating runs: 4 groups 14.30 us | 2 groups
+// 13.98 / 13.99 | 1 group 15.38 (139 registers, three waves) | 2 groups with five waves forced through __launch_bounds__ 16.7 and 4
+// groups with six 16.7 - the forced ones spill 12 registers to scratch.  profiles/r05_experiments.txt)
 #ifndef MBT_SPEED_PRECISE_GROUPS
-#define MBT_SPEED_PRECISE_GROUPS 4
+#define MBT_SPEED_PRECISE_GROUPS 2
 #endif
 #ifndef MBT_SPEED_PRECISE_WAVES
 #define MBT_SPEED_PRECISE_WAVES 1
