@@ -224,6 +224,29 @@ def test_sb3_adapter_auto_reset_and_terminal_observation():
     assert inner.seeded == 7
 
 
+def test_sb3_adapter_implements_the_abstract_surface_of_stable_baselines3_vec_env():
+    """stable_baselines3 is not installable here, so the adapter has never been constructed against the real `VecEnv` (README says so).
+    What CAN be pinned: the abstract methods of `stable_baselines3.common.vec_env.base_vec_env.VecEnv` in the version the reference pins
+    (1.6.2, requirements.txt: reset, step_async, step_wait, close, get_attr, set_attr, env_method, env_is_wrapped, seed) and the concrete
+    ones its consumers call (step, get_images, render via `getattr`) - each must exist on the adapter with the parameters SB3 passes
+    (SBE:22-58), so that deriving from the real base leaves no abstract method behind."""
+    import inspect
+
+    expected = {"reset": [], "step_async": ["actions"], "step_wait": [], "close": [], "get_attr": ["attr_name", "indices"], "set_attr": ["attr_name", "value", "indices"],
+                "env_method": ["method_name", "indices"], "env_is_wrapped": ["wrapper_class", "indices"], "seed": ["seed"], "step": ["actions"], "get_images": []}
+    for name, parameters in expected.items():
+        method = getattr(StableBaselinesTradingEnvironment, name, None)
+        assert callable(method), f"StableBaselinesTradingEnvironment.{name} is missing"
+        have = [p for p in inspect.signature(method).parameters if p != "self"]
+        for parameter in parameters:
+            assert parameter in have or any(inspect.signature(method).parameters[p].kind in (inspect.Parameter.VAR_KEYWORD, inspect.Parameter.VAR_POSITIONAL) for p in have), \
+                f"{name}() lacks the parameter `{parameter}` SB3 passes"
+    venv = StableBaselinesTradingEnvironment(_ScriptedEnv())
+    assert (venv.num_envs, venv.observation_space.shape, venv.action_space.shape) == (3, (4,), (2,))  # what VecEnv.__init__ receives (SBE:20)
+    assert venv.get_attr("n_steps") == [3, 3, 3] and venv.set_attr("n_steps", 4) is None and venv.env_method("reset") is None  # SBE:39-49
+    assert venv.env_is_wrapped(object, indices=[0, 1]) == [False, False, False]  # SBE:51-52: one answer per trajectory, whatever the indices
+
+
 def test_sb3_adapter_terminal_infos_are_lazy_for_large_batches(monkeypatch):
     """Above LAZY_INFOS_ABOVE lanes the terminal infos are a sequence that builds a lane's dict on demand (same reads as the
     list of dicts of SBE:31-35, no O(N) Python loop at the episode boundary)."""
