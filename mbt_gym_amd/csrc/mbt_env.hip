@@ -588,6 +588,8 @@ sigjmp_buf g_probe_jump;
 // Can the host write this device allocation (fine-grained memory through the PCIe BAR)?  Probed once per environment, under a
 // SIGSEGV / SIGBUS guard that is removed again at once.
 bool host_can_write(void* device_ptr) {
+  static std::mutex probe_mutex;  // (the jump buffer and the handlers are process-wide: one probe at a time - shards are created from several threads)
+  std::lock_guard<std::mutex> one_at_a_time(probe_mutex);
   struct sigaction guard, old_segv, old_bus;
   std::memset(&guard, 0, sizeof guard);
   guard.sa_handler = [](int) { siglongjmp(g_probe_jump, 1); };
