@@ -641,13 +641,13 @@ def gpu_cfg0_figures(device):
     n, n_steps = 1000, 200
     dt = 1.0 / n_steps
 
-    def build():
+    def build(resident=False):
         dynamics = LimitOrderModelDynamics(
             midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
             arrival_model=PoissonArrivalModel(intensity=np.array([140.0, 140.0]), step_size=dt, num_trajectories=n),
             fill_probability_model=ExponentialFillFunction(fill_exponent=1.5, step_size=dt, num_trajectories=n), num_trajectories=n)
         return TradingEnvironment(terminal_time=1.0, n_steps=n_steps, model_dynamics=dynamics, initial_inventory=0, max_inventory=200, seed=SEED,
-                                  num_trajectories=n, normalise_action_space=False, normalise_observation_space=False, device=device)
+                                  num_trajectories=n, normalise_action_space=False, normalise_observation_space=False, device=device, resident_step=resident)
 
     env = build()
     agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
@@ -687,13 +687,9 @@ def gpu_cfg0_figures(device):
             step(action)
         out[name] = (time.perf_counter() - t0) / 150 * 1e6
     env.close()
-    # the same calls with the opt-in resident kernel (MBT_RESIDENT_STEP=1: env.step() rings the doorbell of a kernel that stays on the
+    # the same calls with the opt-in resident kernel (TradingEnvironment(resident_step=True): env.step() rings the doorbell of a kernel that stays on the
     # device instead of launching one; it slows kernels on OTHER streams by 20-27 %, profiles/r05_resident_step.txt - hence opt-in)
-    os.environ["MBT_RESIDENT_STEP"] = "1"
-    try:
-        env = build()
-    finally:
-        del os.environ["MBT_RESIDENT_STEP"]
+    env = build(resident=True)
     agent = AvellanedaStoikovAgent(risk_aversion=0.1, env=env)
     vec_env = StableBaselinesTradingEnvironment(trading_env=env)
     resident = {}

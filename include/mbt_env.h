@@ -194,7 +194,10 @@ typedef struct mbt_config {
    *   lambda) dt can then decide differently from the reference (probability 2 (2e-5 + 3e-7 lambda) dt per draw and side:
    *   ~1e-6 per lane-step at lambda ~ 40, dt ~ 1/40), after which that lane's path is another sample of the same process. */
   int32_t hawkes_float32_intensities;
-  int32_t reserved2;
+  /* 1: small batches (up to 4096 lanes; float32 tier, built-in order-book models, production noise - ignored otherwise) step through a
+   * RESIDENT kernel: see mbt_env_step_host.  The environment variable MBT_RESIDENT_STEP=1 does the same for every environment a process
+   * creates.  Costs kernels on other streams of the device 20-27 % while it is there, hence 0 by default. */
+  int32_t resident_step;
 } mbt_config;
 
 typedef struct mbt_env mbt_env; /* opaque: device state, buffers, stream */
@@ -386,7 +389,7 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
  * Batches of up to 65536 lanes (the reference's own regime is N ~ 1000) take ONE launch and no interrupt: the step kernel
  * reads the actions from, and mirrors observation rows and rewards into, pinned device-mapped host memory and raises a
  * completion flag there that this call spins on.
- * Opt-in, environment variable MBT_RESIDENT_STEP=1 at creation (batches of up to 4096 lanes, float32 tier, built-in order-book
+ * Opt-in, mbt_config.resident_step or the environment variable MBT_RESIDENT_STEP=1 at creation (batches of up to 4096 lanes, float32 tier, built-in order-book
  * models, production noise): the first such call of an episode starts a RESIDENT kernel of at most four workgroups that stays on the
  * device; this call then only writes the actions and a 64-byte mailbox line (into device memory through the PCIe BAR where the
  * platform allows, host memory otherwise) and spins on the flag - no launch per step: 13.3-13.9 -> 8.7-9.3 us per env.step() at

@@ -53,7 +53,7 @@ class MbtConfig(C.Structure):
         ("exogenous_depth", C.c_double * 2), ("base_fill_probability", C.c_double),
         ("reward_terminal_time", C.c_double), ("mid_coef_add", C.c_double), ("mid_coef_mul", C.c_double),
         ("precise_state", C.c_int32), ("allow_stiff_hawkes", C.c_int32),
-        ("hawkes_float32_intensities", C.c_int32), ("reserved2", C.c_int32),  # ABI 7
+        ("hawkes_float32_intensities", C.c_int32), ("resident_step", C.c_int32),  # ABI 7
     ]
 
 

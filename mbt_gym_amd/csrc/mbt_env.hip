@@ -788,12 +788,13 @@ int resident_step(mbt_env* e, const float* action_host, float* obs_host, float* 
   }
   std::memcpy(e->resident_action_host, action_host, size_t(e->n) * e->act_dim * sizeof(float));
   _mm_sfence();  // the actions are on their way before the line that announces them (device memory is write-combining on the host side)
-  mbt::ResidentMailbox line;
-  std::memset(&line, 0, sizeof line);
-  line.host_obs = reinterpret_cast<uint64_t>(direct_obs != nullptr ? direct_obs : e->d_stage + e->stage_obs);
-  line.host_reward = reinterpret_cast<uint64_t>(direct_rew != nullptr ? direct_rew : e->d_stage + e->stage_reward);
-  line.seq = seq;
-  std::memcpy(e->mailbox_host, &line, sizeof line);  // one 64-byte line
+  // where the outputs go first, the sequence number that announces them behind a fence of its own: a write-combining buffer is
+  // USUALLY flushed as one 64-byte burst, but nothing promises it, and a kernel that saw the new number with the old pointers would
+  // mirror into arrays the caller has already been handed
+  e->mailbox_host->host_obs = reinterpret_cast<uint64_t>(direct_obs != nullptr ? direct_obs : e->d_stage + e->stage_obs);
+  e->mailbox_host->host_reward = reinterpret_cast<uint64_t>(direct_rew != nullptr ? direct_rew : e->d_stage + e->stage_reward);
+  _mm_sfence();
+  e->mailbox_host->seq = seq;
   _mm_sfence();
   const uint32_t* flag = reinterpret_cast<const uint32_t*>(e->h_stage + e->stage_flag);
   uint32_t* left = reinterpret_cast<uint32_t*>(e->h_stage + e->stage_exit);
@@ -1795,10 +1796,11 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   {  // opt-in: MBT_RESIDENT_STEP=1 - small batches of the float32 tier's built-in order-book models step through a kernel that stays on the device
     const char* resident = std::getenv("MBT_RESIDENT_STEP");
     const mbt_config& c = *cfg;
+    const bool resident_wanted = c.resident_step != 0 || (resident != nullptr && std::atoi(resident) != 0);
     // up to 8 tiles (4096 lanes): beyond that four workgroups walking the tiles one after the other lose to a launch that steps them all
     // at once (N = 65536: 72 vs 62 us per env.step, profiles/r05_resident_step.txt)
     constexpr uint32_t kResidentMaxTiles = 8;
-    if (resident != nullptr && std::atoi(resident) != 0 && e->h_stage != nullptr && !needs_jit && !speed && !c.precise_state && !exogenous_fill(c) &&
+    if (resident_wanted && e->h_stage != nullptr && !needs_jit && !speed && !c.precise_state && !exogenous_fill(c) &&
         e->host_mask == 0 && c.noise_mode == MBT_NOISE_PHILOX && e->n_blocks <= kResidentMaxTiles) {
       const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
       e->resident_kernel = mbt_table::pick_resident(arrival_family(c), c.dynamics_kind, c.midprice_kind == MBT_MID_BROWNIAN, reward_weight(c), norm);

@@ -11,7 +11,8 @@ Extra keyword arguments (after the reference's): `device`, `trajectory_offset` (
 trajectory axis is sharded over GPUs), `noise` ("philox" | "injected"), `precise_state` (cash and midprice kept as
 float32 pairs: rewards within 1e-5 of the float64 reference on every lane, +16 B of traffic per env-step),
 `allow_stiff_hawkes` (accept mean_reversion_speed * step_size >= 1, see include/mbt_env.h), `hawkes_float32_intensities`
-(True: Hawkes intensities as float32 state, 60 instead of 76 B per env-step, arrivals no longer the reference's to the bit).
+(True: Hawkes intensities as float32 state, 60 instead of 76 B per env-step, arrivals no longer the reference's to the bit),
+`resident_step` (True: small batches step through a kernel that stays on the device - lower latency, opt-in).
 Extra methods: `step_device()` / `obs_device` / `reward_device` (zero-copy, asynchronous), `set_noise()`,
 `record_events()`, `episode_return_sums()`.
 
@@ -145,6 +146,7 @@ class TradingEnvironment(_EnvBase):
         precise_state: bool = False,
         allow_stiff_hawkes: bool = False,
         hawkes_float32_intensities: bool = False,
+        resident_step: bool = False,
     ):
         if _EnvBase is not object:
             super().__init__()
@@ -191,6 +193,9 @@ class TradingEnvironment(_EnvBase):
         # Hawkes intensities are held exactly by default (arrivals = the float64 reference's on the same draws, 76 B per env-step);
         # True: float32 intensities, 60 B per env-step (include/mbt_env.h: hawkes_float32_intensities)
         self.hawkes_float32_intensities = hawkes_float32_intensities
+        # small batches (up to 4096 lanes) step through a kernel that stays on the device: env.step() at N = 1000 13.5 -> 9 us, at the price
+        # of 20-27 % on every other stream of the device while it is there (include/mbt_env.h: mbt_env_step_host); MBT_RESIDENT_STEP=1 likewise
+        self.resident_step = resident_step
         # Seeding protocol of the reference: `if seed:` - seed=0 or None leaves the processes unseeded (TE:70);
         # the environment-level generator (initial inventories) is always default_rng(seed) (TE:72).
         self.seed_ = seed
@@ -305,6 +310,7 @@ class TradingEnvironment(_EnvBase):
         cfg.precise_state = int(self.precise_state)
         cfg.allow_stiff_hawkes = int(self.allow_stiff_hawkes)
         cfg.hawkes_float32_intensities = int(self.hawkes_float32_intensities)
+        cfg.resident_step = int(self.resident_step)
         cfg.normalise_observation = int(self.normalise_observation_space_)
         cfg.normalise_action = int(self.normalise_action_space_)
         lo, hi = self.original_observation_space.low, self.original_observation_space.high

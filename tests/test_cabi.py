@@ -44,7 +44,7 @@ def test_config_struct_layout_matches_a_c_compiler(lib, tmp_path):
               "intensity", "fill_exponent", "inventory_exponent", "initial_inventory", "reward_scale", "seed",
               "normalise_observation", "obs_lo", "act_hi", "midprice_step_size", "impact_kind", "temporary_impact",
               "impact_step_size", "exogenous_depth", "reward_terminal_time", "mid_coef_mul", "precise_state", "allow_stiff_hawkes",
-              "hawkes_float32_intensities"]
+              "hawkes_float32_intensities", "resident_step"]
     others = {"mbt_policy": (_native.MbtPolicy, ["kind", "params", "table", "table_rows", "table_cols", "table_q_offset"]),
               "mbt_user_code": (_native.MbtUserCode, ["fill_probability", "fill_param_names", "fill_params", "reward", "reward_param_names", "reward_params"])}
     body = "\n".join(f'  printf("mbt_config.{f} %zu\\n", offsetof(mbt_config, {f}));' for f in fields)

@@ -245,10 +245,8 @@ def test_resident_small_batch_stepping_is_the_one_launch_path_bit_for_bit(n, kw,
         kw.update(arrival="hawkes", intensity=(20.0, 15.0), hawkes_jump=20.0, hawkes_speed=15.0)
     cfg = _cfg(n, **kw)
     plain = make_env(cfg)
-    monkeypatch.setenv("MBT_RESIDENT_STEP", "1")
     monkeypatch.setenv("MBT_RESIDENT_IDLE_US", "300")
-    resident = make_env(cfg)
-    monkeypatch.delenv("MBT_RESIDENT_STEP")
+    resident = make_env(cfg, resident_step=True)
     rng = np.random.default_rng(3)
     lo = -1.0 if cfg.normalise_action_space else 0.0
     for episode in range(2):
