@@ -500,6 +500,12 @@ def rollout_block(lib, device):
             row = {"lanes": n, "env_steps_per_s": n * env.n_steps / t, "us_per_env_step_of_all_lanes": us, "written_bytes_per_env_step": 28,
                    "write_GBps": 28.0 * n / us * 1e-3, "frac_of_8TBps": 28.0 * n / us * 1e-3 / HBM_PEAK_GBPS, "GB_per_episode": 28e-9 * n * env.n_steps,
                    "mean_return_of_the_recording": float(rew[:, :n].sum(dim=0).mean())}
+            hit = (counters or {}).get(f"recorded_avellaneda_stoikov_2^{log2n}")
+            if hit is not None and "wave_cycles_issuing" in hit:  # what the committed counters say the waves of this launch wait for
+                row["counters"] = {"source": counters["source"], "wave_cycles_issuing": hit["wave_cycles_issuing"],
+                                   "wave_cycles_stalled_at_issue": hit["wave_cycles_stalled_at_issue"], "wave_cycles_parked_on_waitcnt": hit["wave_cycles_parked_on_waitcnt"],
+                                   "l2_write_request_stall_cycles_per_request": hit.get("l2_write_requests_stalled_cycles_per_request"),
+                                   "dram_credit_stall_cycles_per_write_request": hit.get("TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", 0.0) / max(hit.get("TCC_EA0_WRREQ_sum", 1.0), 1.0)}
             if log2n in floors:
                 row["write_only_floor_us"] = floors[log2n]
                 row["floor_over_kernel"] = floors[log2n] / us

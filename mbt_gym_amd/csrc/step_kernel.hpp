@@ -1382,6 +1382,14 @@ struct RolloutParams {
 struct LearnedPolicyParams {};  // (learned policies are not part of the run-time compiled translation unit)
 #endif
 
+// A loaded value is waited for HERE, inside the branch that loaded it.  On gfx9 loads and stores share one counter (vmcnt), so a
+// wait for a load also waits for every store issued before it.  The rollout's policy is a run-time switch: two of its branches load
+// (a tabulated policy, the action buffer), and the wait the compiler put where the branches MERGE - inside the step loop, in front
+// of the first use of the action - made the closed-form policies, which load nothing, wait every step for the previous step's
+// recording stores to be acknowledged: waves parked on s_waitcnt 38 % (2^18 lanes) / 47 % (2^20) of their cycles
+// (profiles/r05_pmc_rollout.json).  With the wait in the loading branch the loop of the other policies has no vmcnt wait at all.
+__device__ __forceinline__ void settle_load(float4& v) { asm volatile("; loaded value settled in its own branch" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // LEARNED: the policy is a linear map or an MLP evaluated on the matrix cores (policy_mlp.hpp) instead of a closed form;
 // separate instantiations, so that the closed-form rollouts keep their register budget.
 template <class V, bool LEARNED = false>
@@ -1414,6 +1422,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
     for (int l = 0; l < 2; ++l) {
       if (A == 4) held[l] = reinterpret_cast<const float4*>(B.action)[lanes[l]];
       else { const float2 a = reinterpret_cast<const float2*>(B.action)[lanes[l]]; held[l] = make_float4(a.x, a.y, 0.f, 0.f); }
+      settle_load(held[l]);
     }
   }
   uint32_t wave_clips = 0;  // clipped lane-steps of this WAVE: a popcount of a ballot, i.e. scalar-unit work (a per-thread counter cost two
@@ -1464,7 +1473,9 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       act[1] = held[1];
     } else if (R.policy == kPolicyTimeTable) {  // open-loop schedule over time steps
       const float* row = reinterpret_cast<const float*>(R.table) + static_cast<size_t>(min(R.table_row0 + k, R.table_rows - 1u)) * A;
-      act[0] = act[1] = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);
+      act[0] = make_float4(row[0], row[1], A == 4 ? row[2] : 0.f, A == 4 ? row[3] : 0.f);
+      settle_load(act[0]);
+      act[1] = act[0];
     } else if (R.policy == kPolicyTable) {  // quotes tabulated over (time step, inventory), e.g. Cartea-Jaimungal
       const uint32_t row = min(R.table_row0 + k, R.table_rows - 1u);
 #pragma unroll
@@ -1472,6 +1483,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
         const int col = min(max(static_cast<int>(core[l].y) + R.table_q_offset, 0), static_cast<int>(R.table_cols) - 1);
         const float2 d = R.table[static_cast<size_t>(row) * R.table_cols + col];
         act[l] = make_float4(d.x, d.y, 0.f, 0.f);
+        settle_load(act[l]);
       }
     } else {  // Avellaneda-Stoikov quotes from (inventory, time) of the current observation
       const float tau = static_cast<float>(R.terminal_time - t);

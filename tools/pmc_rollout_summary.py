@@ -21,14 +21,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = ["SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY SQ_WAIT_ANY", "SQ_WAVE_CYCLES SQ_BUSY_CYCLES",
           "SQ_INSTS_VALU_TRANS", "GRBM_GUI_ACTIVE"]
+# the recorded rollout: what the waves wait for, and whether the memory side pushes back on its writes
+RECORD_GROUPS = GROUPS + ["SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM", "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_LEVEL_sum",
+                          "TCC_EA0_WRREQ_64B_sum", "TA_BUSY_avr"]
 
 
-def collect(policy):
+def collect(policy, record=0):
     acc = {}
-    for group in GROUPS:
-        out = f"/tmp/pmc_ro_{policy}_{group.split()[0]}"
+    for group in (RECORD_GROUPS if record else GROUPS):
+        out = f"/tmp/pmc_ro_{policy}_{record}_{group.split()[0]}"
         subprocess.run(["rm", "-rf", out])
-        env = dict(os.environ, TMPDIR="/tmp", MBT_ROLLOUT_POLICY=policy)
+        env = dict(os.environ, TMPDIR="/tmp", MBT_ROLLOUT_POLICY=policy, MBT_ROLLOUT_RECORD=str(record))
         rc = subprocess.run(["rocprofv3", "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools/dbg/rollout_once.py")],
                             cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -48,7 +51,15 @@ def collect(policy):
         acc["launch_cycles"] = cycles
         acc["valu_issue_fraction"] = acc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles)
         acc["valu_instructions_per_wave_and_step"] = acc["SQ_INSTS_VALU"] / acc["SQ_WAVES"] / 1000.0
-    acc["lanes"], acc["steps_per_launch"] = 1 << 20, 1000
+    acc["lanes"], acc["steps_per_launch"] = 1 << (record or 20), 1000
+    if record and "SQ_WAVE_CYCLES" in acc:  # where a wave's resident cycles go (the three are disjoint and add up to SQ_WAVE_CYCLES)
+        total = acc["SQ_WAVE_CYCLES"]
+        acc["wave_cycles_issuing"] = acc.get("SQ_ACTIVE_INST_ANY", 0.0) / total
+        acc["wave_cycles_stalled_at_issue"] = acc.get("SQ_WAIT_INST_ANY", 0.0) / total
+        acc["wave_cycles_parked_on_waitcnt"] = acc.get("SQ_WAIT_ANY", 0.0) / total
+    if record and acc.get("TCC_EA0_WRREQ_sum"):
+        acc["l2_write_requests_stalled_cycles_per_request"] = acc.get("TCC_EA0_WRREQ_STALL_sum", 0.0) / acc["TCC_EA0_WRREQ_sum"]
+        acc["l2_write_request_bytes_per_launch_if_64B"] = acc.get("TCC_EA0_WRREQ_64B_sum", 0.0) * 64.0
     return acc
 
 
@@ -56,6 +67,7 @@ def main():
     out_path = sys.argv[1]
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
     result = {"avellaneda_stoikov_policy": collect("as"), "fixed_policy": collect("fixed"),
+              "recorded_avellaneda_stoikov_2^18": collect("as", 18), "recorded_avellaneda_stoikov_2^20": collect("as", 20),
               "formula": "valu_issue_fraction = SQ_INSTS_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); one counter group per rocprofv3 pass"}
     json.dump(result, open(out_path, "w"), indent=1)
     print(json.dumps(result, indent=1))
