@@ -406,6 +406,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_kernel(const Step
   if (R.policy == kPolicyBuffer) {  // action repeat: each lane keeps its entry of the action buffer
 #pragma unroll
     for (int l = 0; l < 4; ++l) held[l] = B.action[lane0 + l * kBlockThreads];
+    asm volatile("; loaded actions settled before the loop (step_kernel.hpp: settle_load)" : "+v"(held[0]), "+v"(held[1]), "+v"(held[2]), "+v"(held[3]));
   }
   uint32_t clipped = 0;
   for (uint32_t k = 0; k < R.n_steps; ++k) {
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kBlockThreads) void speed_rollout_exact_kernel(cons
   if (R.policy == kPolicyBuffer) {
 #pragma unroll
     for (int l = 0; l < 4; ++l) held[l] = B.action[lane0 + l * kBlockThreads];
+    asm volatile("; loaded actions settled before the loop (step_kernel.hpp: settle_load)" : "+v"(held[0]), "+v"(held[1]), "+v"(held[2]), "+v"(held[3]));
   }
   uint32_t clipped = 0;
   for (uint32_t k = 0; k < R.n_steps; ++k) {
