@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Static ISA statistics of the library's kernels, without a GPU: compiles csrc/mbt_env.hip for the device only (same
-flags as mbt_gym_amd/build.py) and reports, per kernel whose demangled name matches the regular expression, the register
+"""Static ISA statistics of the library's kernels, without a GPU: takes the gfx950 code objects out of the built
+library (one per translation unit) and reports, per kernel whose demangled name matches the regular expression, the register
 budget (from the code object's metadata notes) and the instruction mix (from the disassembly).
 
     python tools/isa_stats.py 'step_kernel<mbt::Variant<0, 0, true, 0, false, false' [--keep /tmp/isa]
@@ -18,22 +18,23 @@ sys.path.insert(0, ROOT)
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def build_code_object(out_dir):
+def code_objects(out_dir):
+    """Every gfx950 code object of the built library (one per translation unit: csrc/kernels_*.hip, mbt_env.hip), taken out of
+    libmbtenv.so the way tools/dbg/kernel_resources.py does - the library is what runs, and build.py keeps it current."""
     from mbt_gym_amd import build as b
 
-    b.write_embedded_sources()
-    co = os.path.join(out_dir, "mbt_env.co")
-    flags = [f for f in b.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
-    cmd = ["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-c", os.path.join(b.CSRC, "mbt_env.hip"), "-o", co]
-    subprocess.run(cmd, check=True, cwd=b.CSRC)
-    return unbundle(co)
-
-
-def unbundle(co):
-    """hipcc wraps even a device-only object in an offload bundle: take the gfx950 ELF out of it."""
-    elf = os.path.splitext(co)[0] + ".gfx950.o"
-    subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={co}", f"--output={elf}"], check=True)
-    return elf
+    lib = b.build_native()
+    fat = os.path.join(out_dir, "fatbin.bin")
+    subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(out_dir, "unused.so")], check=True, capture_output=True)
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    out = []
+    for k, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        piece, elf = os.path.join(out_dir, f"bundle{k}.bin"), os.path.join(out_dir, f"unit{k}.gfx950.o")
+        open(piece, "wb").write(blob[lo:hi])
+        subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={piece}", f"--output={elf}"], check=True)
+        out.append(elf)
+    return out
 
 
 def kernel_metadata(co):
@@ -96,23 +97,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("pattern", help="regular expression on the demangled kernel name")
     ap.add_argument("--keep", default="/tmp/isa", help="directory for the device-only code object")
-    ap.add_argument("--reuse", action="store_true", help="use the code object already in --keep")
     args = ap.parse_args()
     os.makedirs(args.keep, exist_ok=True)
-    co = os.path.join(args.keep, "mbt_env.gfx950.o")
-    if not (args.reuse and os.path.exists(co)):
-        co = build_code_object(args.keep)
-    meta = kernel_metadata(co)
-    names = demangle(list(meta))
     rx = re.compile(args.pattern)
-    for mangled, pretty in sorted(names.items(), key=lambda kv: kv[1]):
-        if not rx.search(pretty):
-            continue
-        m, mix = meta[mangled], instruction_mix(co, mangled)
-        print(pretty)
-        print("   vgpr %s agpr %s sgpr %s lds %s scratch %s vgpr_spill %s" % (m.get("vgpr_count"), m.get("agpr_count"), m.get("sgpr_count"),
-                                                                              m.get("group_segment_fixed_size"), m.get("private_segment_fixed_size"), m.get("vgpr_spill_count")))
-        print("   " + " ".join(f"{k} {v}" for k, v in mix.items()))
+    for co in code_objects(args.keep):
+        meta = kernel_metadata(co)
+        names = demangle(list(meta))
+        for mangled, pretty in sorted(names.items(), key=lambda kv: kv[1]):
+            if not rx.search(pretty):
+                continue
+            m, mix = meta[mangled], instruction_mix(co, mangled)
+            print(pretty)
+            print("   vgpr %s agpr %s sgpr %s lds %s scratch %s vgpr_spill %s" % (m.get("vgpr_count"), m.get("agpr_count"), m.get("sgpr_count"),
+                                                                                  m.get("group_segment_fixed_size"), m.get("private_segment_fixed_size"), m.get("vgpr_spill_count")))
+            print("   " + " ".join(f"{k} {v}" for k, v in mix.items()))
 
 
 if __name__ == "__main__":
