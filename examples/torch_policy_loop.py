@@ -42,7 +42,7 @@ def main():
     action = torch.as_tensor(env.action_device, device="cuda")  # (N, 2) float32, the buffer the step kernel reads
 
     def one_step():
-        obs = torch.as_tensor(env.obs_device, device="cuda")  # ping-pongs between two buffers: re-wrap every step
+        obs = torch.as_tensor(env.obs_device, device="cuda")  # re-wrap every step (small batches alternate between two buffers; rows are valid until the next step is enqueued)
         with torch.no_grad():
             action.copy_(policy(obs.half()))
         if env.step_device():  # True when the episode ended

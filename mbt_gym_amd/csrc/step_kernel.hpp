@@ -7,8 +7,10 @@
 //           2 action rows: float2 (A=2) or float4 (A=4)
 //   draws   2 Philox4x32-10 blocks = all the noise of the pair (philox.hpp), or loads injected noise
 //   writes  2 next-state rows, 2 rewards
-// The state is row-major (N, D) float32 - exactly the un-normalised observation the API returns - and is
-// ping-ponged between two buffers, so the observation of step k stays valid while step k+1 is computed.
+// The state is row-major (N, D) float32 - exactly the un-normalised observation the API returns.  state_out may BE state_in: a lane
+// reads its own row and writes its own row, and rows that leave through LDS are written by threads of the same workgroup behind the
+// barrier that follows the last use of the loads - the host updates the state in place from 80 MB moved per launch up (which keeps
+// launches like Hawkes + OU at 2^22 lanes inside the Infinity Cache) and steps between two buffers below (mbt_env.hip: mbt_env::state).
 // Nothing else touches HBM: `dones` is a host scalar (TE:218-220), time is a kernel argument, the generator is
 // stateless.  Algorithmic traffic per env-step: 4*(D + A + D + 1) bytes = 44 B for D=4, A=2.
 //
