@@ -776,9 +776,10 @@ int resident_step(mbt_env* e, const float* action_host, float* obs_host, float* 
   if (direct_obs == nullptr || direct_rew == nullptr || reinterpret_cast<uintptr_t>(direct_obs) % 16 != 0) direct_obs = direct_rew = nullptr;
   const double t_next = e->time + e->dt;
   const bool terminal = t_next >= e->cfg.terminal_time - e->dt / 2;
-  const uint32_t seq = ++e->flag_seq;
+  uint32_t seq = ++e->flag_seq;
+  if (seq == mbt::kResidentExit) seq = ++e->flag_seq;  // (the one value that means "leave": skipped when the counter wraps, after 4e9 steps)
   if (!e->resident_active) {
-    e->mailbox_host->seq = seq - 1u;  // (idle: whatever an earlier kernel was told is gone)
+    e->mailbox_host->seq = (seq - 1u == mbt::kResidentExit) ? seq - 2u : seq - 1u;  // (idle: whatever an earlier kernel was told is gone)
     _mm_sfence();
     // ... and so is what an earlier kernel said on leaving: told to leave while it waited for THIS sequence number, it wrote that
     // number - which below would read as "the kernel left before your step" and start a second one

@@ -1302,11 +1302,11 @@ __device__ __forceinline__ void resident_body(const StepBuffers& B0, const StepP
           if (now - t0 > R.idle_ticks || now - born > R.life_ticks) { cmd = kResidentExit; break; }
           __builtin_amdgcn_s_sleep(2);
         }
-        __hip_atomic_store(R.control, cmd == kResidentExit ? leave : seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(R.control, cmd == kResidentExit ? leave : (seq & 0x7FFFFFFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ("go" tokens live in the lower half, "leave" tokens in the upper)
       } else {
         for (;;) {
           const uint32_t word = __hip_atomic_load(R.control, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          if (word == seq) { cmd = seq; break; }
+          if (word == (seq & 0x7FFFFFFFu)) { cmd = seq; break; }
           if (word == leave || wall_clock64() - born > 2 * R.life_ticks) { cmd = kResidentExit; break; }
           __builtin_amdgcn_s_sleep(1);
         }
