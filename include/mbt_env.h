@@ -337,7 +337,8 @@ int mbt_env_host_depths(mbt_env* env, const float* action_host, double* depths_h
 int mbt_env_set_host_fill_probabilities(mbt_env* env, const double* probabilities_host);
 int mbt_env_set_host_arrivals(mbt_env* env, const float* arrivals_host);
 int mbt_env_set_host_rewards(mbt_env* env, const double* rewards_host, float* reward_out_host);
-/* Small batches (up to 65536 lanes), order-book dynamics, host-callback plugins: the step kernel also mirrors its un-normalised rows,
+/* What TE:206-211 hands a process's update() and RW:10-13 a reward's calculate() AFTER the step - the state matrix, the step's arrivals
+ * and fills - without a device round trip.  Small batches (up to 65536 lanes), order-book dynamics, host-callback plugins: the step kernel also mirrors its un-normalised rows,
  * their int32 remainders and the event bytes into host memory, so what the caller's update() / calculate() are handed needs no
  * further round trip.  state_host: (N, D) float64 as mbt_env_get_state_f64_host assembles it (may be NULL); events_host: (N) bytes as
  * mbt_env_get_events_host returns them (may be NULL).  MBT_ERR_STATE when the last call on the environment was not such a step
