@@ -14,7 +14,7 @@ from tests.env_factory import make_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOAK = int(os.environ.get("MBT_HAWKES_SOAK", "0"))  # MBT_HAWKES_SOAK=1: 2^17 lanes x 800 steps = 1.05e8 lane-steps (about a minute of NumPy)
+SOAK = int(os.environ.get("MBT_HAWKES_SOAK", "0"))  # MBT_HAWKES_SOAK=k: k seeds x 2^17 lanes x 800 steps = k x 1.05e8 lane-steps (15 s of NumPy each)
 
 
 def _cfg(n, **kw):
@@ -32,16 +32,21 @@ def test_hawkes_decisions_of_the_default_tier_are_the_float64_references_over_a_
     """BASELINE configs[3] (Hawkes arrivals + OU midprice, ARR:89-93 defaults) in the DEFAULT tier, production noise, against the
     float64 oracle fed with the kernel's own draws: arrivals, fills and inventory array-equal on EVERY lane-step, the float64
     intensities (state64) equal to the oracle's - no lane retired, no window.  (Round 4: the float32 intensities of this tier
-    decided ~7e-7 of lane-steps differently.)  2^15 lanes x 200 steps in the suite; MBT_HAWKES_SOAK=1: 2^17 x 800 = 1.05e8."""
+    decided ~7e-7 of lane-steps differently.)  2^15 lanes x 200 steps in the suite; MBT_HAWKES_SOAK=k: k seeds of 2^17 x 800 = 1.05e8 each."""
+    for seed in range(50, 50 + max(SOAK, 1)):
+        _hawkes_soak_of_one_seed(seed)
+
+
+def _hawkes_soak_of_one_seed(seed):
     n, n_steps = (1 << 17, 800) if SOAK else (1 << 15, 200)
-    cfg = _cfg(n, n_steps=n_steps, **HAWKES)
+    cfg = _cfg(n, n_steps=n_steps, seed=seed, **HAWKES)
     env = make_env(cfg, noise="philox")
     env.record_events(True)
     draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(n_steps)]
     oracle = OracleEnv(cfg, InjectedNoise(*[np.stack(x) for x in zip(*draws)]))
     del draws
     env.reset(), oracle.reset()
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed - 45)
     arrivals_seen = 0
     for k in range(n_steps):
         action = rng.uniform(0.05, 1.2, size=(n, 2)).astype(np.float32)
