@@ -315,6 +315,11 @@ struct mbt_env {
   // direction instead of a DMA copy + synchronisation each - host_fill_p / host_arrivals / host_scratch then point INTO h_callback_in
   // (the kernels read it across the link), and the step's mirror instantiation writes rows + remainders + event bytes into the stage
   char* h_callback_in = nullptr;     // host view of [fill probabilities (n_pad, 2) f64 | arrivals (n_pad, 2) f32 | scratch (n_pad, 4) f64]
+  // a kernel that reads the block in place may still be queued: set where one is enqueued and nobody waits (a device-API step of a
+  // host-callback environment, the reward-filing kernel), cleared by mbt_env_step_host's completion flag / any stream wait; the
+  // setters wait for the stream before they overwrite a region that is busy (never in the env.step() loop, whose flag wait precedes them)
+  bool callback_inputs_busy = false;   // probabilities / arrivals / impacts: read by the step kernel
+  bool callback_scratch_busy = false;  // scratch: read by host_reward_kernel / host_columns_kernel
   size_t stage_state = 0, stage_resid = 0, stage_events = 0;  // offsets (in floats) inside the stage; 0 = not mirrored
   bool stage_outputs_valid = false;  // the stage holds the state / remainders / events of the step that ran last
   // resident small-batch stepping (opt-in: MBT_RESIDENT_STEP=1; step_kernel.hpp: resident_step_kernel)
@@ -584,6 +589,22 @@ int resident_stop(mbt_env* e) {
     if (rc_stop_ != MBT_OK) return rc_stop_; \
   } while (0)
 
+// Before the host overwrites a region of the mapped callback block (h_callback_in): has every kernel that reads it in place finished?
+int settle_callback_block(mbt_env* e, bool& busy) {
+  if (busy) HIP_TRY(hipStreamSynchronize(e->stream));
+  e->callback_inputs_busy = e->callback_scratch_busy = false;  // (one in-order stream: a wait settles both)
+  busy = false;
+  return MBT_OK;
+}
+
+#define SETTLE_CALLBACK_BLOCK(e, region)                            \
+  do {                                                              \
+    if ((e)->region) {                                              \
+      const int rc_busy_ = settle_callback_block((e), (e)->region); \
+      if (rc_busy_ != MBT_OK) return rc_busy_;                      \
+    }                                                               \
+  } while (0)
+
 sigjmp_buf g_probe_jump;
 // Can the host write this device allocation (fine-grained memory through the PCIe BAR)?  Probed once per environment, under a
 // SIGSEGV / SIGBUS guard that is removed again at once.
@@ -720,6 +741,7 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   e->user_noise_ready = false;
   e->host_fill_ready = e->host_arrivals_ready = false;
   e->host_reward_pending = (e->host_mask & mbt::kHostReward) != 0;
+  if (e->h_callback_in != nullptr && (e->host_mask & (mbt::kHostFill | mbt::kHostArrival | mbt::kHostImpact))) e->callback_inputs_busy = true;
   if (done != nullptr) *done = terminal ? 1 : 0;
   return MBT_OK;
 }
@@ -2022,6 +2044,7 @@ int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, flo
         }
       }
     }
+    e->callback_inputs_busy = e->callback_scratch_busy = false;  // (the flag / the wait above: everything queued before it has run)
     e->stage_outputs_valid = mirror && e->stage_state != 0;
     if (direct_obs != nullptr) return MBT_OK;  // already where the caller wants them
     if (obs_host != nullptr) std::memcpy(obs_host, e->h_stage + e->stage_obs, n_obs * sizeof(float));
@@ -2234,6 +2257,7 @@ int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
   if (e->h_callback_in != nullptr) {  // small batches: the kernel reads the block in place (the previous step has finished: its flag was waited for)
+    SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);  // (... unless it was a device-API step)
     std::memcpy(e->h_callback_in, probabilities_host, size_t(e->n) * 2 * sizeof(double));
   } else {
     HIP_TRY(hipMemcpyAsync(e->host_fill_p, probabilities_host, size_t(e->n) * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -2249,6 +2273,7 @@ int mbt_env_set_host_impacts(mbt_env* e, const double* impacts_host) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
   if (e->h_callback_in != nullptr) {
+    SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);
     std::memcpy(e->h_callback_in, impacts_host, size_t(e->n) * sizeof(double));
   } else {
     HIP_TRY(hipMemcpyAsync(e->host_fill_p, impacts_host, size_t(e->n) * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -2264,6 +2289,7 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
   if (e->h_callback_in != nullptr) {
+    SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);
     std::memcpy(e->h_callback_in + size_t(e->n_pad) * 2 * sizeof(double), arrivals_host, size_t(e->n) * 2 * sizeof(float));
   } else {
     HIP_TRY(hipMemcpyAsync(e->host_arrivals, arrivals_host, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -2305,12 +2331,14 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
     // small batches: the filing kernel reads the caller's values in place and nobody waits for it - what it files is a function of
     // values the host holds (float32(scale * r), exactly host_reward_kernel's expression), so the caller's copy is formed here
     double* scratch = reinterpret_cast<double*>(e->h_callback_in + size_t(e->n_pad) * (2 * sizeof(double) + 2 * sizeof(float)));
+    SETTLE_CALLBACK_BLOCK(e, callback_scratch_busy);  // (the previous step's filing kernel, if nothing waited since)
     std::memcpy(scratch, rewards_host, size_t(e->n) * sizeof(double));
     hipLaunchKernelGGL(mbt::host_reward_kernel, dim3(blocks), dim3(256), 0, e->stream, e->host_scratch, e->cfg.reward_scale, e->n, e->reward,
                        e->track_returns ? e->lane_returns : nullptr, e->wave_sums, e->n_waves, e->host_reward_replaces ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (reward_out_host != nullptr)
       for (size_t i = 0; i < e->n; ++i) reward_out_host[i] = static_cast<float>(e->cfg.reward_scale * rewards_host[i]);
+    e->callback_scratch_busy = true;
     e->host_reward_pending = false;
     return MBT_OK;
   }
