@@ -1286,8 +1286,8 @@ __device__ __forceinline__ void resident_body(const StepBuffers& B0, const StepP
   double t = R.t_start;
   const uint64_t born = wall_clock64();
   // ONE decision per step for the whole grid: workgroup 0 watches the mailbox and publishes "go(seq)" or "leave" in device memory
-  // (`control`), the others watch that word.  (Every workgroup deciding for itself was wrong: one timed out while its neighbour saw
-  // the doorbell that was rung in the same microsecond, and half a step ran.)  The leave token carries the launch's generation, so a
+  // (`control`), the others watch that word, and a step is taken by every workgroup or by none.  (Every workgroup deciding for itself
+  // was wrong: one timed out while its neighbour saw the doorbell that was rung in the same microsecond, and half a step ran.)  The leave token carries the launch's generation, so a
   // word left behind by an earlier kernel is never mistaken for this one's.
   const uint32_t leave = 0x80000000u | (R.generation & 0x7FFFFFFFu);
   for (uint32_t seq = R.first_seq;; ++seq) {
@@ -1295,6 +1295,15 @@ __device__ __forceinline__ void resident_body(const StepBuffers& B0, const StepP
       const uint64_t t0 = wall_clock64();
       uint32_t cmd;
       if (blockIdx.x == 0) {
+        // `control` changes only once EVERY workgroup has finished the previous step (the last to arrive zeroes the counter,
+        // signal_host; this workgroup has arrived, so the counter is non-zero until then) - and the idle clock below starts only
+        // then.  Without this, on a busy device: this workgroup finishes step n and waits for doorbell n + 1, which the host rings
+        // only after flag n, which needs a neighbour that has not even seen "go(n)" yet; the idle bound runs out, "leave" replaces
+        // "go(n)", the neighbour leaves without its tiles, the flag never rises and a third of the lanes is a step behind (found
+        // by a soak with eight processes in resident mode, profiles/r05_soak.txt; the lifetime bound and the host's answer
+        // time-out had the same hole).  In the ordinary course this load finds 0 while the host is still reading the results.
+        if (seq != R.first_seq)
+          while (__hip_atomic_load(B.done_counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u && wall_clock64() - born <= 2 * R.life_ticks) __builtin_amdgcn_s_sleep(1);
         for (;;) {
           cmd = __hip_atomic_load(&R.mailbox->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
           if (cmd == kResidentExit || static_cast<int32_t>(cmd - seq) >= 0) break;

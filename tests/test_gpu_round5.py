@@ -341,3 +341,27 @@ def test_callback_inputs_are_not_overwritten_under_a_queued_device_step():
     np.testing.assert_array_equal(by_device.state64, by_host.state64)
     assert np.abs(by_host.state64[:, 1]).max() > 0  # (fills happened)
     by_host.close(), by_device.close()
+
+
+def test_a_resident_kernel_that_does_not_answer_hands_the_environment_back_to_the_one_launch_path(monkeypatch, capfd):
+    """The safety net of the resident mode: a step the kernel does not answer within MBT_RESIDENT_ANSWER_MS (200) is taken by a launch
+    instead - the kernel takes a step whole or not at all - and the environment stays on that route (a latency optimisation, not a
+    contract).  MBT_RESIDENT_ANSWER_MS=0 forces it at the first step: results equal the plain environment's to the bit, and the
+    library says once what happened."""
+    cfg = _cfg(1000, n_steps=30)
+    plain = make_env(cfg)
+    monkeypatch.setenv("MBT_RESIDENT_ANSWER_MS", "0")
+    impatient = make_env(cfg, resident_step=True)
+    rng = np.random.default_rng(9)
+    np.testing.assert_array_equal(plain.reset(), impatient.reset())
+    for k in range(cfg.n_steps):
+        a = rng.uniform(0.0, 1.0, size=(1000, 2)).astype(np.float32)
+        (o_p, r_p, d_p, _), (o_i, r_i, d_i, _) = plain.step(a), impatient.step(a)
+        np.testing.assert_array_equal(o_i, o_p, err_msg=f"step {k}")
+        np.testing.assert_array_equal(r_i, r_p, err_msg=f"step {k}")
+        assert d_i[0] == d_p[0]
+    np.testing.assert_array_equal(impatient.state, plain.state)
+    assert impatient.clock == plain.clock and impatient.episode_return_sums()[0] == plain.episode_return_sums()[0]
+    said = capfd.readouterr().err
+    assert said.count("steps through one launch per step from here on") <= 1  # (once at most: the kernel may have answered the first doorbell within the first poll)
+    plain.close(), impatient.close()
