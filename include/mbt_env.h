@@ -397,7 +397,9 @@ int mbt_env_reset_host(mbt_env* env, double start_time, const float* q0_host, fl
  * N = 1000.  Results are the one-launch path's to the bit (same kernel code, counters and clock arithmetic).  The kernel leaves at
  * the episode's end, when any other entry point is called on the environment (which waits for it), after 2 ms without a call
  * (MBT_RESIDENT_IDLE_US) and after 30 s in any case; while it is there, kernels on OTHER streams of the device run 20-27 % slower
- * (profiles/r05_resident_step.txt) - which is why it is not the default. */
+ * (profiles/r05_resident_step.txt) - which is why it is not the default.  A latency optimisation, not a contract: a step the kernel
+ * does not answer within 200 ms (MBT_RESIDENT_ANSWER_MS) is taken by a launch instead - the kernel takes a step whole or not at all -
+ * and the environment keeps to one launch per step from there on (one line on stderr says so). */
 int mbt_env_step_host(mbt_env* env, const float* action_host, float* obs_host, float* reward_host, int32_t* done);
 /* action_device == NULL uses the buffer returned by mbt_env_action_ptr().  Asynchronous. */
 int mbt_env_step_device(mbt_env* env, const float* action_device, int32_t* done);
