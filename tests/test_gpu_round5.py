@@ -365,3 +365,35 @@ def test_a_resident_kernel_that_does_not_answer_hands_the_environment_back_to_th
     said = capfd.readouterr().err
     assert said.count("steps through one launch per step from here on") <= 1  # (once at most: the kernel may have answered the first doorbell within the first poll)
     plain.close(), impatient.close()
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_environments_stepped_from_several_threads_at_once_equal_their_sequential_selves(resident):
+    """The C ABI's threading contract: one host thread per environment handle, any number of handles at once (what
+    MultiDeviceTradingEnvironment does with its shards).  Six threads step six small environments concurrently through env.step() - the
+    one-launch path and the resident kernel, whose flag spins, mapped stages and signal-handler probe are per environment or behind a
+    mutex - and each must reproduce, to the bit, what the same environment does alone."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads, n, n_steps = 6, 700, 60
+
+    def run(seed):
+        cfg = _cfg(n, n_steps=n_steps, seed=seed)
+        env = make_env(cfg, resident_step=resident)
+        rng = np.random.default_rng(seed)
+        out = [env.reset().copy()]
+        for _ in range(n_steps):
+            obs, rew, dones, _ = env.step(rng.uniform(0.0, 1.0, size=(n, 2)).astype(np.float32))
+            out.append(obs.copy()), out.append(rew.copy())
+        assert dones.all()
+        total = env.episode_return_sums()[0]
+        env.close()
+        return out, total
+
+    alone = [run(100 + k) for k in range(threads)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        together = list(pool.map(run, [100 + k for k in range(threads)]))
+    for (a, ta), (b, tb) in zip(alone, together):
+        assert ta == tb
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
