@@ -765,7 +765,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:  # (no launcher: a world of one, and nobody else has to know the port - any free one)
+            with socket.socket() as probe:
+                probe.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(probe.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     visible = torch.cuda.device_count()
