@@ -501,7 +501,9 @@ float* mbt_env_action_ptr(mbt_env* env);
 /* (N, D) observation of the last reset/step; without normalisation this IS the state, which the next step updates IN PLACE: the
  * rows are valid until the next step / rollout / reset is enqueued on the environment's stream (copy them there to keep them). */
 float* mbt_env_obs_ptr(mbt_env* env);
-float* mbt_env_reward_ptr(mbt_env* env);   /* (N) rewards of the last step */
+/* (N) rewards of the last step.  After a HOST step (mbt_env_step_host, mbt_env_set_host_rewards) the buffer is complete when this
+ * returns; after a device step it is complete once the environment's stream has reached that step (mbt_env_synchronize). */
+float* mbt_env_reward_ptr(mbt_env* env);
 int mbt_env_obs_dim(mbt_env* env);
 int mbt_env_action_dim(mbt_env* env);
 

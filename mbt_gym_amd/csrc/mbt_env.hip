@@ -1954,11 +1954,15 @@ int mbt_env_synchronize(mbt_env* e) {
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     const hipError_t q = hipStreamQuery(e->stream);
-    if (q == hipSuccess) return MBT_OK;
+    if (q == hipSuccess) {
+      e->callback_inputs_busy = e->callback_scratch_busy = false;
+      return MBT_OK;
+    }
     if (q != hipErrorNotReady) return fail(MBT_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
     if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
+  e->callback_inputs_busy = e->callback_scratch_busy = false;
   return MBT_OK;
 }
 
@@ -2531,7 +2535,13 @@ float* mbt_env_action_ptr(mbt_env* e) {
   return e->action;
 }
 float* mbt_env_obs_ptr(mbt_env* e) { return e != nullptr ? current_obs(e) : nullptr; }
-float* mbt_env_reward_ptr(mbt_env* e) { return e != nullptr ? e->reward : nullptr; }
+float* mbt_env_reward_ptr(mbt_env* e) {
+  if (e == nullptr) return nullptr;
+  // host-computed rewards of a small batch are filed by a kernel nobody waited for (mbt_env_set_host_rewards): a reader on another
+  // stream - this getter is its way in - finds them filed, as it did when that call still waited
+  if (e->callback_scratch_busy && hipSetDevice(e->cfg.device) == hipSuccess) (void)settle_callback_block(e, e->callback_scratch_busy);
+  return e->reward;
+}
 int mbt_env_obs_dim(mbt_env* e) { return e != nullptr ? e->dim : 0; }
 int mbt_env_action_dim(mbt_env* e) { return e != nullptr ? e->act_dim : 0; }
 

@@ -813,6 +813,9 @@ class TradingEnvironment(_EnvBase):
 
     @property
     def reward_device(self):
+        """(N,) rewards of the last step, zero-copy (`torch.as_tensor(env.reward_device, device="cuda")`).  Fetch it after the step it
+        is wanted for: after `env.step()` the buffer is complete when this property returns (host-computed rewards of a small batch
+        are filed by a kernel the step itself does not wait for); after `step_device()` order your stream behind `env.synchronize()`."""
         ptr = _native.load_library().mbt_env_reward_ptr(self._handle)
         return _native.DeviceView(ptr, (self.num_trajectories,), self)
 
