@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MBT_ABI_VERSION 7u
+#define MBT_ABI_VERSION 8u
 
 typedef enum mbt_status {
   MBT_OK = 0,
@@ -418,6 +418,62 @@ int mbt_env_step_many_device(mbt_env* env, uint32_t k, const float* action_devic
  * 0.5-1.8 us longer than in the untraced run being profiled); not for production - the device idles while a burst is
  * queued.  The gate kernel gives up by itself after 1 s.  burst <= 4096; 0 = off (default). */
 int mbt_env_set_launch_gate(mbt_env* env, uint32_t burst);
+
+/* ---- graph-capturable stepping: the clock on the device (ABI 8) -----------------------------------
+ * For consumers whose POLICY lives on the device (torch; the consumer the reference trains through
+ * gym/StableBaselinesTradingEnvironment.py:25-37): the loop "policy forward -> action buffer -> mbt_env_step_device" costs
+ * 4-5 us of host time per enqueued launch (profiles/r05_timed_region.json), more than a step takes below ~2^19 lanes.  A HIP
+ * graph removes that - but mbt_env_step_device hands the step kernel its clock (time, terminal flag, Philox step) as kernel
+ * ARGUMENTS computed on the host (TE:216-220), so a captured graph would replay one and the same step.  Between
+ * mbt_env_device_clock_begin and mbt_env_device_clock_end the clock lives in device memory instead: the step kernel reads it
+ * there and its last workgroup advances it with the host's arithmetic (t += dt in double; done = t >= T - dt/2), the launch
+ * arguments no longer depend on the step, and
+ *     mbt_env_set_stream(env, s); mbt_env_device_clock_begin(env, MBT_CLOCK_AUTO_RESET);
+ *     hipStreamBeginCapture(s) / torch.cuda.graph(g, stream=s):  k x [policy forward into mbt_env_action_ptr(), mbt_env_step_device_captured(env, NULL)]
+ *     hipGraphLaunch(...) as often as wanted;  mbt_env_device_clock_end(env)
+ * steps the environment k steps per replay - results identical, bit for bit, to the same number of mbt_env_step_device calls
+ * (with MBT_CLOCK_AUTO_RESET: to mbt_env_step_many_device(auto_reset = 1), the episode log included).  The state is stepped in
+ * place in this mode: mbt_env_obs_ptr() / mbt_env_action_ptr() / mbt_env_reward_ptr() keep ONE address each from begin to end.
+ * Every plugin family that steps without the host: built-in models of every tier, speed dynamics, device expressions
+ * (mbt_env_create_jit); not injected noise, not host-callback plugins (MBT_ERR_STATE / MBT_ERR_INVALID).
+ * While the mode is on, entry points that read or advance the HOST's clock, or change what a launch is handed (reset, step_host,
+ * step_device, rollouts, seed, set_step_size, set_state, record_events, track_lane_returns ...), answer MBT_ERR_STATE; buffer
+ * pointers, mbt_env_synchronize, the timers, clip_count, return_sums, set_action_host, get_obs_host / get_state_host stay
+ * available, and mbt_env_get_clock reads the device's clock (waiting for the stream).  A graph captured in the mode must not be
+ * replayed after mbt_env_device_clock_end (the host's clock has taken over again and would know nothing of those steps). */
+enum {
+  /* SB3's VecEnv contract (SBE:28-37): the launch that ends an episode also logs the episode's return sums (device side, popped by
+   * mbt_env_episode_log_pop after mbt_env_device_clock_end: the 16 newest) and resets every lane with the start time and initial
+   * inventories of the last mbt_env_reset* - the observation buffer then holds the first observation of the new episode.
+   * Without it the clock runs on past the terminal time like the reference's (done stays 1). */
+  MBT_CLOCK_AUTO_RESET = 1,
+  /* ... and the observation of the episode's LAST step (SBE:32 `terminal_observation`) is kept in the (padded lanes, D) buffer of
+   * mbt_env_terminal_obs_ptr() until the next episode ends. */
+  MBT_CLOCK_TERMINAL_OBSERVATION = 2
+};
+typedef struct mbt_device_clock {   /* the first 32 bytes of the clock block, as device code lays them out */
+  double time;             /* the clock at the beginning of the next step (TE:216) */
+  uint32_t episode_step;   /* steps since the last reset */
+  uint32_t philox_step;    /* Philox counter of the next step */
+  uint32_t steps;          /* steps taken since mbt_env_device_clock_begin */
+  uint32_t episodes;       /* steps among them that ended an episode */
+  int32_t done;            /* the last step ended an episode (TE:218-220) */
+  uint32_t log_count;      /* episodes logged since begin (MBT_CLOCK_AUTO_RESET) */
+} mbt_device_clock;
+int mbt_env_device_clock_begin(mbt_env* env, uint32_t flags);
+/* Enqueues ONE step on the environment's stream and touches no host state: safe inside a stream capture, valid for every replay.
+ * action_device == NULL: the buffer of mbt_env_action_ptr(). */
+int mbt_env_step_device_captured(mbt_env* env, const float* action_device);
+/* Waits for the environment's stream and reads the clock block. */
+int mbt_env_device_clock_read(mbt_env* env, mbt_device_clock* out);
+/* The block itself (device memory, laid out as struct mbt_device_clock), for device code that wants `done` or the step count
+ * without a host round trip - e.g. a bootstrap mask in a captured training step.  Read-only for callers. */
+void* mbt_env_device_clock_ptr(mbt_env* env);
+float* mbt_env_terminal_obs_ptr(mbt_env* env);  /* NULL until a mbt_env_device_clock_begin asked for MBT_CLOCK_TERMINAL_OBSERVATION */
+/* Waits for the stream, hands the clock back to the host (mbt_env_get_clock, mbt_env_step_device ... continue from where the
+ * graph left off) and files the episodes that ended in the mode in the episode log (all-reduced over the communicator of
+ * mbt_env_set_communicator, if any).  No-op when the mode is off. */
+int mbt_env_device_clock_end(mbt_env* env);
 
 /* ---- fused rollout: many steps in one launch with an on-device closed-form policy ---------------
  * Replaces the caller's per-time-step loop (gym/helpers/generate_trajectory.py:21-34) for policies that are closed

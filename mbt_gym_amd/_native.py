@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER, MID_HOST = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ARR_POISSON, ARR_HAWKES, ARR_POISSON_NONLINEAR, ARR_NONE, ARR_USER, ARR_HOST = 0, 1, 2, 3, 4, 5
@@ -97,6 +97,16 @@ def user_code(fill=None, reward=None, arrival=None, midprice=None, state=None) -
         for j, value in enumerate(params.values()):
             getattr(code, prefix + "_params")[j] = float(value)
     return code
+
+
+CLOCK_AUTO_RESET, CLOCK_TERMINAL_OBSERVATION = 1, 2
+
+
+class MbtDeviceClock(C.Structure):
+    """struct mbt_device_clock (include/mbt_env.h): the first 32 bytes of the device's clock block."""
+
+    _fields_ = [("time", C.c_double), ("episode_step", C.c_uint32), ("philox_step", C.c_uint32), ("steps", C.c_uint32),
+                ("episodes", C.c_uint32), ("done", C.c_int32), ("log_count", C.c_uint32)]
 
 
 POLICY_FIXED, POLICY_AVELLANEDA_STOIKOV, POLICY_TIME_INVENTORY_TABLE, POLICY_TIME_TABLE, POLICY_ACTION_BUFFER = 0, 1, 2, 3, 4
@@ -203,6 +213,12 @@ SIGNATURES = {
     "mbt_env_step_host": (C.c_int, [_ENV, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),  # (float*: addresses are passed as they are)
     "mbt_env_step_device": (C.c_int, [_ENV, C.c_void_p, C.POINTER(C.c_int32)]),
     "mbt_env_set_launch_gate": (C.c_int, [_ENV, C.c_uint32]),
+    "mbt_env_device_clock_begin": (C.c_int, [_ENV, C.c_uint32]),
+    "mbt_env_step_device_captured": (C.c_int, [_ENV, C.c_void_p]),
+    "mbt_env_device_clock_read": (C.c_int, [_ENV, C.c_void_p]),
+    "mbt_env_device_clock_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_terminal_obs_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_device_clock_end": (C.c_int, [_ENV]),
     "mbt_env_host_depths": (C.c_int, [_ENV, _F, C.POINTER(C.c_double)]),
     "mbt_env_set_host_fill_probabilities": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_env_set_host_arrivals": (C.c_int, [_ENV, _F]),
@@ -499,12 +515,12 @@ class DeviceView:
     """A borrowed (N, D) / (N,) float32 device buffer owned by libmbtenv, exposed through
     `__cuda_array_interface__` so that `torch.as_tensor(view, device="cuda")` wraps it without a copy."""
 
-    def __init__(self, ptr, shape, owner):
-        self.ptr, self.shape, self._owner = int(ptr), tuple(shape), owner
+    def __init__(self, ptr, shape, owner, typestr="<f4"):
+        self.ptr, self.shape, self._owner, self.typestr = int(ptr), tuple(shape), owner, typestr
 
     @property
     def __cuda_array_interface__(self):
-        return {"shape": self.shape, "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
+        return {"shape": self.shape, "typestr": self.typestr, "data": (self.ptr, False), "version": 2, "strides": None}
 
 
 def reward_calculate(kind, phi, alpha, exponent, current_state, next_state, is_terminal, q_init=None, episode_length=None,

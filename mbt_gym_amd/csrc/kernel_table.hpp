@@ -19,20 +19,31 @@ using StepKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams);
 using RolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams);
 using LearnedRolloutKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::RolloutParams, const mbt::LearnedPolicyParams);
 using ResidentKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::ResidentParams);
+// the graph-capturable step (step_kernel.hpp: captured_step_kernel) takes a third argument; the pick functions hand its address out
+// under the two-argument type (as_step_kernel) and mbt_env.hip turns it back (as_captured_kernel) before the launch - a round trip
+// between function pointer types, never a call through the wrong one
+using CapturedKernel = void (*)(const mbt::StepBuffers, const mbt::StepParams, const mbt::CapturedParams);
 
 // Which instantiation of a production-noise step kernel: default-policy loads | non-temporal loads (launches beyond the
 // Infinity Cache, tune_for_size) | the small-batch host-API kernel that mirrors its outputs into host memory and raises a
 // completion flag (mbt_env_step_host; step_kernel.hpp: signal_host).  Injected-noise kernels (parity mode) exist in the
 // first form only: asked for a mirror they answer nullptr and the host path takes its two-launch fallback.
-enum LoadMode : int { kPlain = 0, kStream = 1, kMirror = 2 };
+// kCaptured / kCapturedStream: the graph-capturable instantiations (the clock on the device, mbt_env_step_device_captured) with
+// default-policy / non-temporal loads; production noise only.
+enum LoadMode : int { kPlain = 0, kStream = 1, kMirror = 2, kCaptured = 3, kCapturedStream = 4 };
+
+inline StepKernel as_step_kernel(CapturedKernel k) { return reinterpret_cast<StepKernel>(k); }
+inline CapturedKernel as_captured_kernel(StepKernel k) { return reinterpret_cast<CapturedKernel>(k); }
 
 template <class V>
 StepKernel pick_mode(int mode) {
+  if (mode == kCaptured) return as_step_kernel(mbt::captured_step_kernel<V, false>);
+  if (mode == kCapturedStream) return as_step_kernel(mbt::captured_step_kernel<V, true>);
   return mode == kStream ? mbt::step_kernel<V, true, false> : mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
 }
 template <class V_INJECT>
 StepKernel pick_injected(int mode) {
-  return mode == kMirror ? nullptr : mbt::step_kernel<V_INJECT>;
+  return (mode == kMirror || mode == kCaptured || mode == kCapturedStream) ? nullptr : mbt::step_kernel<V_INJECT>;
 }
 
 // ---- predicates on a configuration that both the table and the C ABI use ------------------------------------------------

@@ -11,6 +11,7 @@ template <int ARR, bool XL, int DYN>
 StepKernel pick_exogenous(bool inject, int mode) {
   if (inject) return pick_injected<Exo<ARR, XL, DYN, true>>(mode);
   using V = Exo<ARR, XL, DYN, false>;
+  if (mode == kCaptured || mode == kCapturedStream) return as_step_kernel(mbt::captured_step_kernel<V, false>);
   return mode == kMirror ? mbt::step_kernel<V, false, true> : mbt::step_kernel<V, false, false>;
 }
 template <int ARR, bool XL>

@@ -9,7 +9,11 @@ namespace mbt_table {
 namespace {
 template <class V, class V_INJECT, bool STATE>
 StepKernel pick_speed_mode(bool inject, int mode) {
-  if (inject) return mode == kMirror ? nullptr : mbt::speed_step_kernel<V_INJECT>;
+  if (inject) return (mode == kMirror || mode == kCaptured || mode == kCapturedStream) ? nullptr : mbt::speed_step_kernel<V_INJECT>;
+  if (mode == kCaptured || mode == kCapturedStream) {
+    if constexpr (V::HOST_IMPACT) return nullptr;  // (the host is consulted every step)
+    else return mode == kCaptured ? as_step_kernel(mbt::captured_speed_step_kernel<V, STATE>) : as_step_kernel(mbt::captured_speed_step_kernel<V, false, true>);
+  }
   if (mode == kStream) return mbt::speed_step_kernel<V, false, true>;
   if (mode == kMirror) return mbt::speed_step_kernel<V, STATE, false, true>;
   return mbt::speed_step_kernel<V, STATE>;

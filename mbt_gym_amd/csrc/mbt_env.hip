@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -336,6 +337,17 @@ struct mbt_env {
   bool action_in_resident_stage = false;      // the newest actions sit in resident_action_dev (file_staged_action)
   uint32_t resident_generation = 0;           // resident kernels launched so far
   int resident_answer_ms = 200;               // how long a step waits for the resident kernel before it falls back to one launch per step (MBT_RESIDENT_ANSWER_MS; 0 in a test: at once)
+  // graph-capturable stepping (mbt_env_device_clock_begin ... _end; step_kernel.hpp: captured_step_kernel): between the two calls the
+  // clock - time, episode step, Philox step - lives in `clock_dev` and the host's copy above is stale
+  StepKernel kernel_captured = nullptr;       // (a CapturedKernel under the two-argument type: kernel_table.hpp, as_captured_kernel)
+  hipFunction_t jit_step_captured = nullptr;
+  mbt::DeviceClock* clock_dev = nullptr;
+  mbt::DeviceClock* clock_host = nullptr;     // pinned: what travels to and from clock_dev
+  uint32_t* clock_counters = nullptr;         // the captured launches' arrival counters (captured_arrive)
+  bool device_clock = false;                  // the mode is on
+  bool clock_auto_reset = false;
+  float* terminal_obs = nullptr;              // (n_pad, D), on demand: the observation of an episode's last step (MBT_CLOCK_TERMINAL_OBSERVATION)
+  bool clock_terminal_obs = false;
 };
 
 namespace {
@@ -588,6 +600,16 @@ int resident_stop(mbt_env* e) {
   do {                                    \
     const int rc_stop_ = resident_stop(e); \
     if (rc_stop_ != MBT_OK) return rc_stop_; \
+  } while (0)
+// ... and for every entry point that reads or advances the HOST's clock (time, episode step, Philox step), or changes what a step
+// launch is given: refused while the clock lives on the device (mbt_env_device_clock_begin) - a graph captured in that mode holds
+// the launches' arguments, and the host's copy of the clock is stale until mbt_env_device_clock_end brings it back.
+#define HOST_CLOCK(e)                                                                                                              \
+  do {                                                                                                                             \
+    RESIDENT_STOP(e);                                                                                                              \
+    if ((e)->device_clock)                                                                                                         \
+      return fail(MBT_ERR_STATE, "%s: the environment's clock is on the device (mbt_env_device_clock_begin): call "               \
+                                 "mbt_env_device_clock_end first", __func__);                                                      \
   } while (0)
 
 // Before the host overwrites a region of the mapped callback block (h_callback_in): has every kernel that reads it in place finished?
@@ -1133,27 +1155,10 @@ int launch_rollout(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, flo
   return MBT_OK;
 }
 
-// reuse_q0: an automatic reset (mbt_env_step_many_device) restarts from the initial inventories of the last explicit one
-int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 = false) {
-  e->stage_outputs_valid = false;
+// The row a reset writes into every lane (TE:131-140, SP:48-53): the reference's float64 values, their float32 roundings and - for
+// the columns a tier holds exactly - what float32 left of them.
+mbt::ResetRow make_reset_row(const mbt_env* e, double start_time, bool per_lane_q0) {
   const mbt_config& c = e->cfg;
-  if (!(start_time >= 0.0 && start_time < c.terminal_time))
-    return fail(MBT_ERR_INVALID, "start time %g is not within [0, terminal_time)", start_time);  // TE:267
-  if (!reuse_q0) {
-    e->q_init_per_lane = false;
-    e->q0_per_lane_reset = q0_host != nullptr;
-    if (q0_host != nullptr) {
-      HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-      e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM || c.reward_kind == MBT_REW_CJ_OE;
-    }
-  }
-  const bool per_lane_q0 = reuse_q0 ? e->q0_per_lane_reset : q0_host != nullptr;
-  e->time = e->start_time = start_time;
-  e->episode_step = 0;
-  e->cur = 0;
-  mbt::StepParams& P = e->params;
-  fill_episode_params(e);
-  const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
   mbt::ResetRow row0;
   std::memset(&row0, 0, sizeof row0);
   double* x = row0.exact;  // the row as the reference's float64 values (TE:131-140, SP:48-53), then its float32 rounding
@@ -1190,6 +1195,31 @@ int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 
       if (column >= e->dim || (column == 1 && per_lane_q0)) row0.lo[j] = 0;
     }
   }
+  return row0;
+}
+
+// reuse_q0: an automatic reset (mbt_env_step_many_device) restarts from the initial inventories of the last explicit one
+int do_reset(mbt_env* e, double start_time, const float* q0_host, bool reuse_q0 = false) {
+  e->stage_outputs_valid = false;
+  const mbt_config& c = e->cfg;
+  if (!(start_time >= 0.0 && start_time < c.terminal_time))
+    return fail(MBT_ERR_INVALID, "start time %g is not within [0, terminal_time)", start_time);  // TE:267
+  if (!reuse_q0) {
+    e->q_init_per_lane = false;
+    e->q0_per_lane_reset = q0_host != nullptr;
+    if (q0_host != nullptr) {
+      HIP_TRY(hipMemcpyAsync(e->q_init, q0_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+      e->q_init_per_lane = c.reward_kind == MBT_REW_CJ_MM || c.reward_kind == MBT_REW_CJ_OE;
+    }
+  }
+  const bool per_lane_q0 = reuse_q0 ? e->q0_per_lane_reset : q0_host != nullptr;
+  e->time = e->start_time = start_time;
+  e->episode_step = 0;
+  e->cur = 0;
+  mbt::StepParams& P = e->params;
+  fill_episode_params(e);
+  const uint32_t threads = 256, blocks = (e->n_pad + threads - 1) / threads;
+  const mbt::ResetRow row0 = make_reset_row(e, start_time, per_lane_q0);
   hipLaunchKernelGGL(mbt::reset_kernel, dim3(blocks > 0 ? blocks : 1), dim3(threads), 0, e->stream, e->state[0],
                      c.normalise_observation ? e->obs : nullptr, e->lane_returns, e->wave_sums,
                      per_lane_q0 ? e->q_init : nullptr, row0, e->n_pad, e->n_waves, e->dim, P, e->resid);
@@ -1319,7 +1349,7 @@ int jit_compile(const std::string& source, std::vector<char>& code) {
 
 struct JitKernels {
   hipModule_t module = nullptr;
-  hipFunction_t step = nullptr, rollout = nullptr, step_mirror = nullptr;
+  hipFunction_t step = nullptr, rollout = nullptr, step_mirror = nullptr, step_captured = nullptr;
 };
 
 // One module per distinct (device, generated source): environments that share plugins share the compiled code.  Modules
@@ -1345,6 +1375,10 @@ int jit_build(int device, const std::string& source, bool with_rollout, JitKerne
   if (hipModuleGetFunction(&k.step_mirror, k.module, "mbt_user_step_mirror") != hipSuccess) {  // (injected-noise units have none)
     (void)hipGetLastError();
     k.step_mirror = nullptr;
+  }
+  if (hipModuleGetFunction(&k.step_captured, k.module, "mbt_user_step_captured") != hipSuccess) {  // (nor do units with host callbacks)
+    (void)hipGetLastError();
+    k.step_captured = nullptr;
   }
   cache.emplace(key, k);
   out = k;
@@ -1400,6 +1434,9 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)  // the small-batch host-API instantiation (step_kernel.hpp: signal_host)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step_mirror(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false, true>(B, P); }\n";
+  if (!inject && host_mask == 0)  // the graph-capturable instantiation (step_kernel.hpp: captured_step_kernel)
+    src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step_captured(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::CapturedParams C) { "
+           "mbt::captured_step_body<V, false>(B, P, C); }\n";
   if (!inject && host_mask == 0)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_rollout(const mbt::StepBuffers B, const mbt::StepParams P, const mbt::RolloutParams R) { "
            "mbt::rollout_body<V>(B, P, R); }\n";
@@ -1719,10 +1756,12 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
     e->jit_step = kernels.step;
     e->jit_rollout = kernels.rollout;
     e->jit_step_mirror = kernels.step_mirror;
+    e->jit_step_captured = kernels.step_captured;
     e->stream_loads = false;  // one instantiation is compiled: default-policy loads
   } else {
     e->kernel = pick_kernel(*cfg, e->stream_loads ? kStream : kPlain);
     e->kernel_mirror = pick_kernel(*cfg, kMirror);
+    e->kernel_captured = pick_kernel(*cfg, e->stream_loads ? mbt_table::kCapturedStream : mbt_table::kCaptured);  // (nullptr: injected noise, host callbacks)
     e->rollout = pick_rollout_kernel(*cfg);
   }
   fill_static_params(e);
@@ -1769,6 +1808,13 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
   ENV_TRY(dev_alloc(&e->reduce_out, 3, e->stream));
   ENV_TRY(dev_alloc(&e->log_dev, 3 * mbt_env::kLogSlots, e->stream));
   ENV_TRY(dev_alloc(&e->done_counter, 32, e->stream));  // [0]: workgroups finished (signal_host); [16]: the resident kernel's control word
+  // graph-capturable stepping: the clock block and the arrival counters of its launches (a 64-byte line for the top level + one per group of 32 workgroups)
+  ENV_TRY(dev_alloc(&e->clock_dev, 1, e->stream));
+  ENV_TRY(dev_alloc(&e->clock_counters, 16u * (1u + (e->n_blocks + 31u) / 32u), e->stream));
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->clock_host), sizeof(mbt::DeviceClock), hipHostMallocDefault) != hipSuccess) {
+    mbt_env_destroy(e);
+    return fail(MBT_ERR_HIP, "hipHostMalloc failed");
+  }
   if (e->host_mask != 0) {
     if (host_fill || host_impact(*cfg)) ENV_TRY(dev_alloc(&e->host_fill_p, np * 2, e->stream));  // (N, 2) fill probabilities / (N) price impacts
     if (host_arrival) ENV_TRY(dev_alloc(&e->host_arrivals, np * 2, e->stream));
@@ -1921,8 +1967,10 @@ void mbt_env_destroy(mbt_env* e) {
     e->host_arrivals = nullptr;
     e->host_scratch = nullptr;
   }
-  for (void* b : {static_cast<void*>(e->done_counter), static_cast<void*>(e->host_fill_p), static_cast<void*>(e->host_arrivals), static_cast<void*>(e->host_scratch)})
+  for (void* b : {static_cast<void*>(e->done_counter), static_cast<void*>(e->host_fill_p), static_cast<void*>(e->host_arrivals), static_cast<void*>(e->host_scratch),
+                  static_cast<void*>(e->clock_dev), static_cast<void*>(e->clock_counters), static_cast<void*>(e->terminal_obs)})
     if (b != nullptr) (void)hipFree(b);
+  if (e->clock_host != nullptr) (void)hipHostFree(e->clock_host);
   if (e->h_gate != nullptr) (void)hipHostFree(e->h_gate);
   if (e->h_stage != nullptr) (void)hipHostFree(e->h_stage);
   if (e->h_bounce != nullptr) (void)hipHostFree(e->h_bounce);
@@ -1969,10 +2017,8 @@ int mbt_env_synchronize(mbt_env* e) {
 int mbt_env_set_step_size(mbt_env* e, double step_size) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (!(step_size > 0.0)) return fail(MBT_ERR_INVALID, "step_size must be positive");
-  if (e->resident_active) {  // (a resident kernel holds the old step size)
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    RESIDENT_STOP(e);
-  }
+  if (e->resident_active) HIP_TRY(hipSetDevice(e->cfg.device));  // (a resident kernel holds the old step size)
+  HOST_CLOCK(e);
   if (e->cfg.arrival_kind == MBT_ARR_HAWKES && !e->cfg.allow_stiff_hawkes && !(e->cfg.hawkes_speed * step_size < 1.0))  // the same domain mbt_env_create enforces
     return fail(MBT_ERR_INVALID, "Hawkes mean_reversion_speed * step_size = %g >= 1 with the new step size: the intensity recursion (ARR:110-119) "
                 "oscillates (>= 2: diverges); set allow_stiff_hawkes to run it anyway", e->cfg.hawkes_speed * step_size);
@@ -1988,10 +2034,8 @@ int mbt_env_set_step_size(mbt_env* e, double step_size) {
 
 int mbt_env_seed(mbt_env* e, uint64_t seed) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
-  if (e->resident_active) {  // (a resident kernel holds the old key)
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    RESIDENT_STOP(e);
-  }
+  if (e->resident_active) HIP_TRY(hipSetDevice(e->cfg.device));  // (a resident kernel holds the old key)
+  HOST_CLOCK(e);
   e->seed = seed;
   e->philox_step = 0;
   key_from_seed(e);
@@ -2001,7 +2045,7 @@ int mbt_env_seed(mbt_env* e, uint64_t seed) {
 int mbt_env_reset(mbt_env* e, double start_time, const float* q0_host) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   return do_reset(e, start_time, q0_host);
 }
 
@@ -2017,6 +2061,7 @@ int mbt_env_reset_host(mbt_env* e, double start_time, const float* q0_host, floa
 int mbt_env_step_host(mbt_env* e, const float* action_host, float* obs_host, float* reward_host, int32_t* done) {
   if (e == nullptr || action_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->device_clock) return fail(MBT_ERR_STATE, "mbt_env_step_host: the environment's clock is on the device (mbt_env_device_clock_begin): call mbt_env_device_clock_end first");
   if (e->resident_kernel != nullptr && e->h_stage != nullptr && e->gate_chunk == 0) return resident_step(e, action_host, obs_host, reward_host, done);
   if (e->h_stage != nullptr) {
     // Small batch (the reference's own regime, N ~ 1000): a DMA copy costs ~15-25 us per call whatever its size, a second
@@ -2110,7 +2155,7 @@ int mbt_env_step_many_device(mbt_env* e, uint32_t k, const float* action_device,
                              uint32_t* episodes_ended) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "injected noise is consumed one step at a time: use mbt_env_step_device");
   if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows, once
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -2239,7 +2284,7 @@ int mbt_env_set_launch_gate(mbt_env* e, uint32_t burst) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (burst > 4096u) return fail(MBT_ERR_INVALID, "a burst of more than 4096 launches may not fit the hardware queue behind a closed gate");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (burst != 0 && e->h_gate == nullptr) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_gate), 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(e->h_gate, 0, 64);
@@ -2274,7 +2319,7 @@ int mbt_env_set_host_fill_probabilities(mbt_env* e, const double* probabilities_
   if (e == nullptr || probabilities_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostFill)) return fail(MBT_ERR_STATE, "the fill model of this environment is not a host callback (MBT_FILL_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (e->h_callback_in != nullptr) {  // small batches: the kernel reads the block in place (the previous step has finished: its flag was waited for)
     SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);  // (... unless it was a device-API step)
     std::memcpy(e->h_callback_in, probabilities_host, size_t(e->n) * 2 * sizeof(double));
@@ -2290,7 +2335,7 @@ int mbt_env_set_host_impacts(mbt_env* e, const double* impacts_host) {
   if (e == nullptr || impacts_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostImpact)) return fail(MBT_ERR_STATE, "the price impact model of this environment is not a host callback (MBT_IMPACT_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (e->h_callback_in != nullptr) {
     SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);
     std::memcpy(e->h_callback_in, impacts_host, size_t(e->n) * sizeof(double));
@@ -2306,7 +2351,7 @@ int mbt_env_set_host_arrivals(mbt_env* e, const float* arrivals_host) {
   if (e == nullptr || arrivals_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (!(e->host_mask & mbt::kHostArrival)) return fail(MBT_ERR_STATE, "the arrival model of this environment is not a host callback (MBT_ARR_HOST)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (e->h_callback_in != nullptr) {
     SETTLE_CALLBACK_BLOCK(e, callback_inputs_busy);
     std::memcpy(e->h_callback_in + size_t(e->n_pad) * 2 * sizeof(double), arrivals_host, size_t(e->n) * 2 * sizeof(float));
@@ -2323,7 +2368,7 @@ int mbt_env_set_host_state_columns(mbt_env* e, const double* columns_host) {
   if (e->host_state_count == 0)
     return fail(MBT_ERR_STATE, "this environment has no host-callback process that owns state columns (MBT_MID_HOST, or MBT_ARR_HOST with state)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   const int d = e->host_state_count;
   e->stage_outputs_valid = false;  // (the rows change under the mirror)
   if (e->h_callback_in != nullptr) {  // (the scratch block is mapped host memory: the kernel reads the values in place)
@@ -2344,7 +2389,7 @@ int mbt_env_set_host_rewards(mbt_env* e, const double* rewards_host, float* rewa
   if (!(e->host_mask & mbt::kHostReward)) return fail(MBT_ERR_STATE, "the reward function of this environment is not a host callback (MBT_REW_HOST)");
   if (!e->host_reward_pending) return fail(MBT_ERR_STATE, "no step is waiting for its host-computed rewards");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   const uint32_t blocks = (e->n + 255u) / 256u;
   if (e->h_callback_in != nullptr) {
     // small batches: the filing kernel reads the caller's values in place and nobody waits for it - what it files is a function of
@@ -2394,7 +2439,7 @@ int mbt_env_host_step_outputs(mbt_env* e, double* state_host, uint8_t* events_ho
 int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (action_device != nullptr && e->n != e->n_pad) {
     // the kernel reads actions in pairs of rows: stage a caller buffer that has no pad row
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -2404,12 +2449,150 @@ int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
   return launch_step(e, action_device, done);
 }
 
+// ---- graph-capturable stepping: the clock on the device (step_kernel.hpp: captured_step_kernel) ----------------------------------
+static int clock_download(mbt_env* e) {
+  HIP_TRY(hipMemcpyAsync(e->clock_host, e->clock_dev, sizeof(mbt::DeviceClock), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MBT_OK;
+}
+
+int mbt_env_device_clock_begin(mbt_env* e, uint32_t flags) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (flags & ~(MBT_CLOCK_AUTO_RESET | MBT_CLOCK_TERMINAL_OBSERVATION)) return fail(MBT_ERR_INVALID, "unknown flag bits 0x%x", flags);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HOST_CLOCK(e);  // (one begin per end)
+  if (!e->was_reset) return fail(MBT_ERR_STATE, "mbt_env_device_clock_begin before reset()");
+  if (e->cfg.noise_mode != MBT_NOISE_PHILOX) return fail(MBT_ERR_STATE, "injected noise is handed over by the host before every step: such an environment cannot step from a graph");
+  if (e->host_mask != 0) return fail(MBT_ERR_INVALID, "host-callback plugins (NumPy-only subclasses) are consulted between launches: such an environment cannot step from a graph");
+  if (e->gate_chunk != 0) return fail(MBT_ERR_STATE, "the launch gate (mbt_env_set_launch_gate) belongs to mbt_env_step_many_device");
+  if (e->jit_step != nullptr ? e->jit_step_captured == nullptr : e->kernel_captured == nullptr)
+    return fail(MBT_ERR_INVALID, "this configuration has no graph-capturable step kernel");
+  if ((flags & MBT_CLOCK_TERMINAL_OBSERVATION) && !(flags & MBT_CLOCK_AUTO_RESET))
+    return fail(MBT_ERR_INVALID, "MBT_CLOCK_TERMINAL_OBSERVATION keeps what an automatic reset would overwrite: it needs MBT_CLOCK_AUTO_RESET");
+  const int rc_file = file_staged_action(e);  // (the newest actions of an earlier host step belong in the action buffer the launches will read)
+  if (rc_file != MBT_OK) return rc_file;
+  if ((flags & MBT_CLOCK_TERMINAL_OBSERVATION) && e->terminal_obs == nullptr) {
+    const int rc = dev_alloc(&e->terminal_obs, size_t(e->n_pad) * e->dim, e->stream);
+    if (rc != MBT_OK) return rc;
+  }
+  std::memset(e->clock_host, 0, sizeof(mbt::DeviceClock));
+  e->clock_host->time = e->time;
+  e->clock_host->episode_step = e->episode_step;
+  e->clock_host->philox_step = e->philox_step;
+  HIP_TRY(hipMemcpyAsync(e->clock_dev, e->clock_host, sizeof(mbt::DeviceClock), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->clock_auto_reset = (flags & MBT_CLOCK_AUTO_RESET) != 0;
+  e->clock_terminal_obs = (flags & MBT_CLOCK_TERMINAL_OBSERVATION) != 0;
+  e->device_clock = true;
+  return MBT_OK;
+}
+
+// Nothing but launches on the environment's stream, with arguments that do not depend on the step: what a stream capture records
+// is valid for every replay.
+int mbt_env_step_device_captured(mbt_env* e, const float* action_device) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (!e->device_clock) return fail(MBT_ERR_STATE, "mbt_env_step_device_captured outside mbt_env_device_clock_begin ... _end");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows (a copy node in a capture)
+    HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    action_device = nullptr;
+  }
+  mbt::StepBuffers B;
+  std::memset(&B, 0, sizeof B);
+  B.state_in = B.state_out = e->state[e->cur];  // in place: the observation a captured policy reads has ONE address
+  B.action = action_device != nullptr ? action_device : e->action;
+  B.reward = e->reward;
+  B.obs = e->cfg.normalise_observation ? e->obs : nullptr;
+  B.q_init = e->q_init_per_lane ? e->q_init : nullptr;
+  B.resid = e->resid;
+  B.events = e->record_events ? e->events : nullptr;
+  B.lane_returns = e->track_returns ? e->lane_returns : nullptr;
+  B.wave_sums = e->wave_sums;
+  B.clip_count = e->clip_count;
+  mbt::StepParams P = e->params;  // (philox_step, is_terminal, t_next, t_now: set by the kernel from the device's clock)
+  P.philox_step = 0;
+  P.is_terminal = 0;
+  mbt::CapturedParams X;
+  std::memset(&X, 0, sizeof X);
+  X.clock = e->clock_dev;
+  X.counters = e->clock_counters;
+  X.dt_f64 = e->dt;
+  X.terminal_time = e->cfg.terminal_time;
+  X.t_start = e->start_time;
+  X.auto_reset = e->clock_auto_reset ? 1 : 0;
+  X.dim = e->dim;
+  X.tile_lanes = e->speed ? mbt::kSpeedTileLanes : mbt::kTileLanes;
+  X.n_waves = e->n_waves;
+  X.obs = B.obs;
+  X.terminal_obs = e->clock_terminal_obs ? e->terminal_obs : nullptr;
+  X.q0 = e->q0_per_lane_reset ? e->q_init : nullptr;
+  X.row0 = make_reset_row(e, e->start_time, e->q0_per_lane_reset);
+  if (e->jit_step != nullptr) {
+    void* args[] = {&B, &P, &X};
+    HIP_TRY(hipModuleLaunchKernel(e->jit_step_captured, e->n_blocks, 1, 1, mbt::kBlockThreads, 1, 1, e->step_dynamic_lds, e->stream, args, nullptr));
+  } else {
+    hipLaunchKernelGGL(mbt_table::as_captured_kernel(e->kernel_captured), dim3(e->n_blocks), dim3(mbt::kBlockThreads), e->step_dynamic_lds, e->stream, B, P, X);
+    HIP_TRY(hipGetLastError());
+  }
+  return MBT_OK;
+}
+
+int mbt_env_device_clock_read(mbt_env* e, mbt_device_clock* out) {
+  if (e == nullptr || out == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (!e->device_clock) return fail(MBT_ERR_STATE, "the environment's clock is on the host (mbt_env_get_clock)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rc = clock_download(e);
+  if (rc != MBT_OK) return rc;
+  static_assert(sizeof(mbt_device_clock) == 32 && offsetof(mbt::DeviceClock, log) == 32, "struct mbt_device_clock is the clock block's first 32 bytes");
+  std::memcpy(out, e->clock_host, sizeof *out);
+  return MBT_OK;
+}
+
+void* mbt_env_device_clock_ptr(mbt_env* e) { return e != nullptr ? e->clock_dev : nullptr; }
+float* mbt_env_terminal_obs_ptr(mbt_env* e) { return e != nullptr ? e->terminal_obs : nullptr; }
+
+int mbt_env_device_clock_end(mbt_env* e) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (!e->device_clock) return MBT_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rc = clock_download(e);
+  if (rc != MBT_OK) return rc;
+  const mbt::DeviceClock& now = *e->clock_host;
+  e->time = now.time;
+  e->episode_step = now.episode_step;
+  e->philox_step = now.philox_step;
+  e->device_clock = false;
+  // the episodes that ended in the mode, oldest first, into the episode log (mbt_env_episode_log_pop) - through the communicator, if
+  // one is set: every rank replays the same graph, so every rank files the same number of entries
+  const uint32_t kept = now.log_count < mbt::kClockLogSlots ? now.log_count : mbt::kClockLogSlots;
+  for (uint32_t k = now.log_count - kept; k != now.log_count; ++k) {
+    if (e->log_count == mbt_env::kLogSlots) {
+      double dropped[3];
+      const int rc_drop = log_wait_oldest(e, dropped);
+      if (rc_drop < 0) return rc_drop;
+    }
+    const uint32_t slot = (e->log_head + e->log_count) % mbt_env::kLogSlots;
+    double* dev = e->log_dev + 3 * slot;
+    HIP_TRY(hipMemcpyAsync(dev, &e->clock_dev->log[k % mbt::kClockLogSlots][0], 3 * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (e->comm != nullptr) {
+      const RcclApi& api = rccl();
+      if (!api.ok) return fail(MBT_ERR_HIP, "%s", api.why.c_str());
+      ncclResult_t r = api.all_reduce(dev, dev, 3, ncclDouble, ncclSum, static_cast<ncclComm_t>(e->comm), e->stream);
+      if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+    }
+    HIP_TRY(hipMemcpyAsync(e->log_host + 3 * slot, dev, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(e->log_event[slot], e->stream));
+    e->log_count += 1;
+  }
+  return MBT_OK;
+}
+
 int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   if (e == nullptr || policy == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   if (policy->kind != MBT_POLICY_LINEAR && policy->kind != MBT_POLICY_MLP) return fail(MBT_ERR_INVALID, "mbt_env_policy_device evaluates learned policies (MBT_POLICY_LINEAR / MBT_POLICY_MLP)");
   if (!e->was_reset) return fail(MBT_ERR_STATE, "policy evaluation before reset()");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   mbt::LearnedPolicyParams LP;
   int rc = prepare_learned_policy(e, policy, LP);
   if (rc != MBT_OK) return rc;
@@ -2426,7 +2609,7 @@ int mbt_env_rollout_device(mbt_env* e, const mbt_policy* policy, uint32_t max_st
                            float* rew_traj, uint32_t* steps_done, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   return launch_rollout(e, policy, max_steps, obs_traj, act_traj, rew_traj, steps_done, done);
 }
 
@@ -2434,7 +2617,7 @@ int mbt_env_rollout_host(mbt_env* e, const mbt_policy* policy, uint32_t max_step
                          float* rew_traj, uint32_t* steps_done, int32_t* done) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   // staging in HBM, sized by the number of steps that will actually run (at most until the episode ends); the buffers
   // are kept by the environment (grow-only, up to 8 GiB each), so a consumer that records every episode allocates once
   const uint32_t remaining = static_cast<uint32_t>(std::ceil((e->cfg.terminal_time - e->time) / e->dt)) + 1;
@@ -2507,7 +2690,7 @@ int mbt_env_set_user_noise_host(mbt_env* e, const float* z_user) {
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
   if (!e->user_draws || e->z_user == nullptr) return fail(MBT_ERR_STATE, "this environment's user processes draw no extra normals (mbt_user_code.extra_normals)");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   HIP_TRY(hipMemcpyAsync(e->z_user, z_user, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->user_noise_ready = true;
@@ -2518,7 +2701,7 @@ int mbt_env_set_noise_host(mbt_env* e, const float* u_arr, const float* u_fill, 
   if (e == nullptr || z == nullptr || (!e->speed && (u_arr == nullptr || u_fill == nullptr))) return fail(MBT_ERR_INVALID, "null argument");
   if (e->cfg.noise_mode != MBT_NOISE_INJECTED) return fail(MBT_ERR_STATE, "environment was not created in injected-noise mode");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (!e->speed) {
     HIP_TRY(hipMemcpyAsync(e->u_arr, u_arr, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->u_fill, u_fill, size_t(e->n) * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -2601,7 +2784,7 @@ double mbt_exact_join(float hi, int32_t lo) { return exact_join_host(hi, lo); }
 int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   const size_t n = e->n, d = static_cast<size_t>(e->dim), r = static_cast<size_t>(e->res);
   std::vector<float> rows(n * d);
   std::vector<int32_t> lo(n * r);
@@ -2642,7 +2825,7 @@ int mbt_env_set_action_host(mbt_env* e, const float* action_host) {
 int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uint32_t philox_step) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   HIP_TRY(hipMemcpyAsync(e->state[e->cur], state_host, size_t(e->n) * e->dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
   if (e->resid != nullptr) HIP_TRY(hipMemsetAsync(e->resid, 0, size_t(e->n_pad) * e->res * sizeof(int32_t), e->stream));  // a float32 state has no remainder
   if (e->cfg.normalise_observation) {
@@ -2661,6 +2844,15 @@ int mbt_env_set_state_host(mbt_env* e, const float* state_host, double time, uin
 
 int mbt_env_get_clock(mbt_env* e, double* time, uint32_t* episode_step, uint32_t* philox_step) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (e->device_clock) {  // the clock lives on the device: wait for the stream and read it there
+    mbt_device_clock now;
+    const int rc = mbt_env_device_clock_read(e, &now);
+    if (rc != MBT_OK) return rc;
+    if (time != nullptr) *time = now.time;
+    if (episode_step != nullptr) *episode_step = now.episode_step;
+    if (philox_step != nullptr) *philox_step = now.philox_step;
+    return MBT_OK;
+  }
   if (time != nullptr) *time = e->time;
   if (episode_step != nullptr) *episode_step = e->episode_step;
   if (philox_step != nullptr) *philox_step = e->philox_step;
@@ -2670,7 +2862,7 @@ int mbt_env_get_clock(mbt_env* e, double* time, uint32_t* episode_step, uint32_t
 int mbt_env_record_events(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (enabled && e->events == nullptr) {
     int rc = dev_alloc(&e->events, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;
@@ -2706,7 +2898,7 @@ int mbt_env_clip_count(mbt_env* e, uint64_t* count) {
 int mbt_env_track_lane_returns(mbt_env* e, int enabled) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  RESIDENT_STOP(e);
+  HOST_CLOCK(e);
   if (enabled && e->lane_returns == nullptr) {
     int rc = dev_alloc(&e->lane_returns, size_t(e->n_pad), e->stream);
     if (rc != MBT_OK) return rc;

@@ -252,10 +252,18 @@ __device__ __forceinline__ void wave_lds_fence() {
 #ifndef MBT_SPEED_PRECISE_WAVES
 #define MBT_SPEED_PRECISE_WAVES 1
 #endif
-template <class V, bool STAGED = false, bool STREAM = false, bool MIRROR = false>
-__global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES : 1) void speed_step_kernel(const StepBuffers B, const StepParams P) {
+// CAPTURED: the graph-capturable instantiation (step_kernel.hpp: captured_prologue / captured_epilogue) - the step's clock is read
+// from device memory between the loads and the generator.
+template <class V, bool STAGED = false, bool STREAM = false, bool MIRROR = false, bool CAPTURED = false>
+__device__ __forceinline__ void speed_step_body(const StepBuffers& B, const StepParams& P_in, const CapturedParams* C = nullptr, CapturedStep* captured = nullptr) {
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
+  static_assert(!(CAPTURED && (MIRROR || V::INJECT || V::HOST_IMPACT)), "a captured step has no host in its loop");
+  clock_words_t clock_words = {0u, 0u, 0u, 0u};
+  if (CAPTURED) clock_words = captured_clock_issue(C->clock);
+  StepParams P_step;  // (CAPTURED only: the kernel arguments with this step's clock filled in by captured_prologue, below)
+  if (CAPTURED) P_step = P_in;
+  const StepParams& P = CAPTURED ? P_step : P_in;
   const uint32_t lane0 = blockIdx.x * kSpeedTileLanes + threadIdx.x;  // the quad: lane0 + 256 * l
   const uint64_t quad = (P.pair_offset >> 1) + blockIdx.x * kBlockThreads + threadIdx.x;
   __shared__ __attribute__((aligned(16))) float staged_rows[V::DIM == 5 ? kSpeedTileLanes * 5 : 4];  // 20 KB: 5 KB per wave
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES
     qi[l] = P.q_init_scalar;
   }
   if (!V::INJECT && g == 0) {
+    if (CAPTURED) *captured = captured_prologue(clock_words, *C, P_step);
     const QuadNoise nz = philox_quad_noise(quad, P.philox_step, P.key0, P.key1);
 #pragma unroll
     for (int l = 0; l < 4; ++l) z[l] = nz.z[l];
@@ -381,6 +390,19 @@ __global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES
     if (__builtin_expect(n_clipped != 0u, 0)) atomicAdd(&B.clip_count[wave_id & (kClipSlots - 1u)], static_cast<unsigned long long>(n_clipped));
   }
   if (MIRROR) signal_host(B);
+}
+
+template <class V, bool STAGED = false, bool STREAM = false, bool MIRROR = false>
+__global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES : 1) void speed_step_kernel(const StepBuffers B, const StepParams P) {
+  speed_step_body<V, STAGED, STREAM, MIRROR>(B, P);
+}
+
+template <class V, bool STAGED = false, bool STREAM = false>
+__global__ __launch_bounds__(kBlockThreads, V::PRECISE ? MBT_SPEED_PRECISE_WAVES : 1) void captured_speed_step_kernel(const StepBuffers B, const StepParams P,
+                                                                                                                         const CapturedParams C) {
+  CapturedStep s = {0.0, 0.0, 0u, false};
+  speed_step_body<V, STAGED, STREAM, false, true>(B, P, &C, &s);
+  captured_epilogue(B, P, C, s);
 }
 
 // Fused rollout for the speed family: fixed speed, or an open-loop schedule tabulated over time steps (e.g. the

@@ -1163,6 +1163,217 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
   }
 }
 
+// ---- graph-capturable stepping: the clock on the device (mbt_env_device_clock_begin / mbt_env_step_device_captured) -------------
+// A launch of step_kernel carries the step's clock as kernel ARGUMENTS the host computed (philox_step, t_next, is_terminal:
+// mbt_env.hip, launch_step) - so a HIP graph that captured [policy, step] x k would replay the same k steps forever, and a consumer
+// whose policy lives on the device (torch) pays 4-5 us of host time per enqueued launch: below ~2^19 lanes its loop is launch-bound.
+// These instantiations read the clock from a block of device memory instead and the LAST workgroup of the launch advances it, with
+// the host's arithmetic (t += dt in double, TE:216; terminal per TE:218-220; the Philox step counts on) - the kernel arguments are
+// then the same for every step, and a captured graph replays correctly.  An episode's end is handled inside the same launch, the way
+// mbt_env_step_many_device(auto_reset) handles it with two more launches (SBE:28-37): every workgroup overwrites the rows of its own
+// tile with the reset row (after saving the terminal observation, if asked to), the last workgroup reduces the episode's return sums
+// - in reduce_returns_kernel's order of additions: the same bits - into a log in the clock block and zeroes the accumulators.
+// Results are those of the launch_step loop to the bit: same step_tile / speed_step_body, same counters, same clock arithmetic.
+//
+// Cost on the hot path: one 16-byte load of the clock per wave + a workgroup barrier in front of the generator (every wave of the
+// workgroup has read the clock before thread 0 can report the workgroup finished), and one or two relaxed atomics per workgroup
+// behind it (a two-level count: 32 workgroups share a counter line, so a launch of 2048 workgroups does not queue 2048 atomics on
+// one address).  The state is stepped IN PLACE (state_out == state_in), so the observation a captured policy reads has one address.
+
+// reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...]
+struct ResetRow {
+  float cash0, t0, s0, q0_scalar;
+  float extra[4];  // columns 4..: Hawkes baselines (ARR:103), exogenous best depths (FILL:148-154), or the impact model's initial state (IMP:81, IMP:121)
+  // precise_state: the same row as the reference's float64 values (column order of the state row; [1] is unused when the
+  // initial inventories are per lane) and the int32 remainders of the residual columns (exact_split on the host)
+  double exact[8];
+  int32_t lo[4];
+  int32_t res;  // residual columns per lane: 0, 2 or 4
+  int32_t precise;  // precise_state: observations are normalised from the float64 values (res != 0 alone may be the float32 tier's exact intensities)
+};
+
+// one lane of a reset: its state row, its remainders, its (normalised) observation row, its running return
+__device__ __forceinline__ void reset_lane(uint32_t i, float* state, float* obs, float* lane_returns, const float* q0, const ResetRow& row0, int dim,
+                                           const StepParams& P, int32_t* resid) {
+  if (resid != nullptr)
+    for (int j = 0; j < row0.res; ++j) resid[static_cast<size_t>(i) * row0.res + j] = row0.lo[j];  // what float32 left of the initial values
+  float* row = state + static_cast<size_t>(i) * dim;
+  float* orow = obs != nullptr ? obs + static_cast<size_t>(i) * dim : nullptr;
+  for (int j = 0; j < dim; ++j) {
+    const float v = j == 0 ? row0.cash0 : j == 1 ? (q0 != nullptr ? q0[i] : row0.q0_scalar) : j == 2 ? row0.t0 : j == 3 ? row0.s0 : row0.extra[j - 4];
+    row[j] = v;
+    if (orow != nullptr) {
+      if (row0.precise != 0) {  // precise_state: normalised from the float64 value, like the reference (TE:112-118)
+        const double x = (j == 1 && q0 != nullptr) ? static_cast<double>(q0[i]) : row0.exact[j];
+        orow[j] = P.norm_obs ? normalise_column_exact(x, j, P) : v;
+      } else {
+        orow[j] = P.norm_obs ? normalise_column(v, j, P) : v;
+      }
+    }
+  }
+  if (lane_returns != nullptr) lane_returns[i] = 0.0f;
+}
+
+constexpr uint32_t kClockLogSlots = 16;
+// The clock block.  Its first 32 bytes are `struct mbt_device_clock` of include/mbt_env.h (what mbt_env_device_clock_read returns
+// and what a device consumer may read through mbt_env_device_clock_ptr, e.g. `done` as a mask).
+struct DeviceClock {
+  double time;             // the clock at the beginning of the next step (TE:216)
+  uint32_t episode_step;   // steps since the last (explicit or automatic) reset
+  uint32_t philox_step;    // Philox counter word 2 of the next step
+  uint32_t steps;          // steps taken since mbt_env_device_clock_begin
+  uint32_t episodes;       // episodes that ended since then
+  int32_t done;            // the last step ended an episode (TE:218-220)
+  uint32_t log_count;      // entries written to `log` since begin (entry k sits in slot k % kClockLogSlots)
+  double log[kClockLogSlots][3];  // [sum R, sum R^2 (NaN unless per-lane returns are tracked), lanes] of the newest finished episodes
+};
+struct CapturedParams {
+  DeviceClock* clock;
+  uint32_t* counters;      // the launch's arrival counters: [0] the top level, [16 (1 + g)] the g-th group of 32 workgroups (a 64-byte line each)
+  double dt_f64, terminal_time, t_start;  // the host's clock arithmetic (mbt_env.hip: launch_step); where an automatic reset restarts
+  int32_t auto_reset;      // an episode's end resets the lanes and logs the return sums inside the launch
+  int32_t dim;
+  uint32_t tile_lanes;     // lanes per workgroup: 512 (order book) or 1024 (speed dynamics)
+  uint32_t n_waves;        // slots of wave_sums
+  float* obs;              // the normalised observation buffer (nullptr: the state row is the observation)
+  float* terminal_obs;     // (n_pad, D): receives the observation of an episode's last step before the reset overwrites it; or nullptr
+  const float* q0;         // per-lane initial inventories of the last explicit reset, or nullptr
+  ResetRow row0;           // the row an automatic reset writes
+};
+
+struct CapturedStep {  // the clock of the step a launch takes
+  double t, t_next;
+  uint32_t philox_step;
+  bool terminal;
+};
+
+// The clock of this step, wave-uniform (SGPRs), in two halves.  captured_clock_issue: ONE scalar load of the block's first 16 bytes
+// [time, episode step, Philox step], issued before the state / action loads of the tile.  captured_prologue: waits for it (scalar
+// loads have a counter of their own - lgkmcnt - so the vector loads stay in flight, which a wait for a vector load issued behind
+// them would not allow: vmcnt counts in order), sets P's per-step fields from it, and ends in a bare workgroup barrier (no fence:
+// nothing is communicated through memory here) - every wave of the workgroup has read the clock before thread 0 can report the
+// workgroup finished.  The block was written by the PREVIOUS launch's last workgroup, and is rewritten by this launch's only once
+// every workgroup has passed this point: the scalar cache, invalid at the launch's start like every cache, cannot hold a stale copy.
+typedef uint32_t clock_words_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ clock_words_t captured_clock_issue(const DeviceClock* clock) {
+  clock_words_t w;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(w) : "s"(clock) : "memory");
+  return w;
+}
+__device__ __forceinline__ CapturedStep captured_prologue(clock_words_t w, const CapturedParams& C, StepParams& P) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w) : : "memory");
+  CapturedStep s;
+  s.t = __builtin_bit_cast(double, (static_cast<uint64_t>(w.y) << 32) | w.x);
+  s.t_next = s.t + C.dt_f64;                                      // TE:216, exactly as launch_step advances the host's clock
+  s.terminal = s.t_next >= C.terminal_time - C.dt_f64 / 2;        // TE:218-220
+  s.philox_step = w.w;
+  P.philox_step = w.w;
+  P.is_terminal = s.terminal ? 1 : 0;
+  P.t_next = static_cast<float>(s.t_next);
+  P.t_now = s.t;
+  P.t_next_f64 = s.t_next;
+  __builtin_amdgcn_s_barrier();
+  return s;
+}
+
+// This workgroup has finished; true in the LAST workgroup of the launch to say so (which re-arms the counters).
+__device__ __forceinline__ bool captured_arrive(uint32_t* counters, bool ordered) {
+  const uint32_t group = blockIdx.x >> 5, groups = (gridDim.x + 31u) >> 5;
+  const uint32_t members = gridDim.x - (group << 5) < 32u ? gridDim.x - (group << 5) : 32u;
+  uint32_t* mine = counters + 16u * (1u + group);
+  // `ordered` (an episode's end): the last workgroup reads what the others wrote - release / acquire at device scope.  Otherwise it
+  // only has to know that every workgroup has READ the clock (the barrier of captured_prologue precedes this): counting is enough.
+  const uint32_t a = ordered ? __hip_atomic_fetch_add(mine, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a + 1u != members) return false;
+  __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t b = ordered ? __hip_atomic_fetch_add(counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b + 1u != groups) return false;
+  __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// reduce_returns_kernel's sums by ONE wave, in that kernel's order of additions: its thread t accumulates the elements t, t + 256,
+// ... and a tree over shared memory folds thread t + s into thread t for s = 128, 64, ..., 1.  Here lane l of the wave plays the
+// threads l, l + 64, l + 128, l + 192 (four accumulators), the folds s = 128 and s = 64 are additions between its own accumulators,
+// the folds s = 32 ... 1 shuffles within the wave.  `zero`: the accumulators are cleared behind the reads (an automatic reset).
+__device__ __forceinline__ void captured_reduce_returns(double* wave_sums, uint32_t n_waves, float* lane_returns, uint32_t n, double out[3]) {
+  const uint32_t l = threadIdx.x & 63u;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    for (uint32_t i = l + 64u * v; i < n_waves; i += 256u) {
+      a[v] += __hip_atomic_load(wave_sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wave_sums + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane_returns != nullptr)
+      for (uint32_t i = l + 64u * v; i < n; i += 256u) {
+        const float r = __hip_atomic_load(lane_returns + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b[v] += static_cast<double>(r) * r;
+      }
+  }
+  a[0] += a[2]; a[1] += a[3]; b[0] += b[2]; b[1] += b[3];  // s = 128
+  a[0] += a[1]; b[0] += b[1];                              // s = 64
+  for (int s = 32; s > 0; s >>= 1) {
+    a[0] += __shfl_down(a[0], s, 64);
+    b[0] += __shfl_down(b[0], s, 64);
+  }
+  out[0] = a[0];
+  out[1] = lane_returns != nullptr ? b[0] : __builtin_nan("");
+  out[2] = static_cast<double>(n);
+}
+
+// Behind the step of a tile: the episode's end (every workgroup, its own rows), then the count, then - in the last workgroup to
+// finish - the episode's log entry and the clock of the next step.
+__device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const StepParams& P, const CapturedParams& C, const CapturedStep s) {
+  const bool episode_end = s.terminal && C.auto_reset != 0;
+  if (__builtin_expect(episode_end, 0)) {
+    // this workgroup's own stores of the step are complete and visible to all its threads before any of its rows is rewritten
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t first = blockIdx.x * C.tile_lanes;
+    float* state = B.state_out;
+    if (C.terminal_obs != nullptr) {
+      const float* shown = C.obs != nullptr ? C.obs : state;
+      const size_t base = static_cast<size_t>(first) * C.dim, count = static_cast<size_t>(C.tile_lanes) * C.dim;
+      for (size_t k = threadIdx.x; k < count; k += kBlockThreads) C.terminal_obs[base + k] = shown[base + k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+    }
+    // (the running returns are cleared by the last workgroup, which needs them all for the sum of squares first)
+    for (uint32_t i = first + threadIdx.x; i < first + C.tile_lanes; i += kBlockThreads) reset_lane(i, state, C.obs, nullptr, C.q0, C.row0, C.dim, P, B.resid);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64u) return;
+  uint32_t last = 0u;
+  if (threadIdx.x == 0u) last = captured_arrive(C.counters, episode_end) ? 1u : 0u;
+  if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
+  DeviceClock* clock = C.clock;
+  uint32_t log_count = clock->log_count;
+  if (episode_end) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double sums[3];
+    captured_reduce_returns(B.wave_sums, C.n_waves, B.lane_returns, P.n, sums);
+    if (B.lane_returns != nullptr)
+      for (uint32_t i = threadIdx.x; i < 2u * P.n_pairs; i += 64u) B.lane_returns[i] = 0.0f;
+    if (threadIdx.x == 0u) {
+      double* entry = clock->log[log_count % kClockLogSlots];
+      entry[0] = sums[0]; entry[1] = sums[1]; entry[2] = sums[2];
+    }
+    log_count += 1u;
+  }
+  if (threadIdx.x == 0u) {
+    clock->time = episode_end ? C.t_start : s.t_next;
+    clock->episode_step = episode_end ? 0u : clock->episode_step + 1u;
+    clock->philox_step = s.philox_step + 1u;
+    clock->steps += 1u;
+    clock->episodes += s.terminal ? 1u : 0u;
+    clock->done = s.terminal ? 1 : 0;
+    clock->log_count = log_count;
+  }
+}
+
 // STREAM: the state / action loads carry the non-temporal bit.  Chosen by the host (mbt_env.hip: tune_for_size) when one
 // launch's working set exceeds the Infinity Cache - nothing read now is still cached at the next step, so it should not
 // displace lines on its way in: 128.3 -> 118.7 us for the 44-byte copy kernel at 2^24 lanes (profiles/r01_microbench.txt) -
@@ -1173,13 +1384,25 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
 // device-mapped host memory and raises a completion flag there (signal_host) - ONE launch per env.step(), no interrupt.
 // `tile`: the 512-lane tile this workgroup steps (blockIdx.x for the ordinary kernels: one tile per workgroup; the resident
 // small-batch kernel walks several tiles per workgroup and step)
-template <class V, bool STREAM = false, bool MIRROR = false>
-__device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams& P, const uint32_t tile) {
+// CAPTURED: the graph-capturable instantiation - the step's clock comes from device memory (`C`, see above), `P_in` holds what
+// does not change from step to step; `captured` receives the step's clock for captured_epilogue.
+template <class V, bool STREAM = false, bool MIRROR = false, bool CAPTURED = false>
+__device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams& P_in, const uint32_t tile, const CapturedParams* C = nullptr,
+                                          CapturedStep* captured = nullptr) {
   static_assert(!(STREAM && MIRROR), "streaming loads are for launches beyond the Infinity Cache, the mirror for small batches");
+  static_assert(!(CAPTURED && (MIRROR || V::INJECT || V::HOST != 0)), "a captured step has no host in its loop");
   const uint32_t lane0 = tile * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
-  const uint64_t pair = P.pair_offset + tile * kBlockThreads + threadIdx.x;
-  LaneLoads L0 = load_lane<V, STREAM>(B, P, lane0), L1 = load_lane<V, STREAM>(B, P, lane1);  // issue every load ...
+  clock_words_t clock_words = {0u, 0u, 0u, 0u};
+  if (CAPTURED) clock_words = captured_clock_issue(C->clock);
+  LaneLoads L0 = load_lane<V, STREAM>(B, P_in, lane0), L1 = load_lane<V, STREAM>(B, P_in, lane1);  // issue every load ...
   load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
+  StepParams P_step;  // (CAPTURED only: the kernel arguments with this step's clock filled in)
+  if (CAPTURED) {
+    P_step = P_in;
+    *captured = captured_prologue(clock_words, *C, P_step);
+  }
+  const StepParams& P = CAPTURED ? P_step : P_in;
+  const uint64_t pair = P.pair_offset + tile * kBlockThreads + threadIdx.x;
   LaneNoise nz0, nz1;
   LaneDraw d0, d1;
   float2 zu0 = L0.zu, zu1 = L1.zu;
@@ -1243,6 +1466,18 @@ __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams
 template <class V, bool STREAM = false, bool MIRROR = false>
 __global__ __launch_bounds__(kBlockThreads) void step_kernel(const StepBuffers B, const StepParams P) {
   step_body<V, STREAM, MIRROR>(B, P);
+}
+
+template <class V, bool STREAM = false>
+__device__ __forceinline__ void captured_step_body(const StepBuffers& B, const StepParams& P0, const CapturedParams& C) {
+  CapturedStep s = {0.0, 0.0, 0u, false};
+  step_tile<V, STREAM, false, true>(B, P0, blockIdx.x, &C, &s);
+  captured_epilogue(B, P0, C, s);
+}
+
+template <class V, bool STREAM = false>
+__global__ __launch_bounds__(kBlockThreads) void captured_step_kernel(const StepBuffers B, const StepParams P, const CapturedParams C) {
+  captured_step_body<V, STREAM>(B, P, C);
 }
 
 // ---- resident small-batch stepping (opt-in: MBT_RESIDENT_STEP=1; mbt_env.hip: resident_step) ---------------------------------
@@ -1610,40 +1845,13 @@ __global__ __launch_bounds__(kBlockThreads) void policy_kernel(const float* obs,
 #if !defined(MBT_JIT_USER_CODE) && !defined(MBT_KERNEL_TU)
 // ---- small helper kernels ----------------------------------------------------------------------------------
 
-// reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...], zeroed accumulators.
-struct ResetRow {
-  float cash0, t0, s0, q0_scalar;
-  float extra[4];  // columns 4..: Hawkes baselines (ARR:103), exogenous best depths (FILL:148-154), or the impact model's initial state (IMP:81, IMP:121)
-  // precise_state: the same row as the reference's float64 values (column order of the state row; [1] is unused when the
-  // initial inventories are per lane) and the int32 remainders of the residual columns (exact_split on the host)
-  double exact[8];
-  int32_t lo[4];
-  int32_t res;  // residual columns per lane: 0, 2 or 4
-  int32_t precise;  // precise_state: observations are normalised from the float64 values (res != 0 alone may be the float32 tier's exact intensities)
-};
-
+// reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...] (reset_lane), zeroed accumulators.
 __global__ void reset_kernel(float* state, float* obs, float* lane_returns, double* wave_sums, const float* q0, const ResetRow row0,
                              uint32_t n_pad, uint32_t n_waves, int dim, const StepParams P, int32_t* resid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
-  if (resid != nullptr)
-    for (int j = 0; j < row0.res; ++j) resid[static_cast<size_t>(i) * row0.res + j] = row0.lo[j];  // what float32 left of the initial values
-  float* row = state + static_cast<size_t>(i) * dim;
-  float* orow = obs != nullptr ? obs + static_cast<size_t>(i) * dim : nullptr;
-  for (int j = 0; j < dim; ++j) {
-    const float v = j == 0 ? row0.cash0 : j == 1 ? (q0 != nullptr ? q0[i] : row0.q0_scalar) : j == 2 ? row0.t0 : j == 3 ? row0.s0 : row0.extra[j - 4];
-    row[j] = v;
-    if (orow != nullptr) {
-      if (row0.precise != 0) {  // precise_state: normalised from the float64 value, like the reference (TE:112-118)
-        const double x = (j == 1 && q0 != nullptr) ? static_cast<double>(q0[i]) : row0.exact[j];
-        orow[j] = P.norm_obs ? normalise_column_exact(x, j, P) : v;
-      } else {
-        orow[j] = P.norm_obs ? normalise_column(v, j, P) : v;
-      }
-    }
-  }
-  if (lane_returns != nullptr) lane_returns[i] = 0.0f;
+  reset_lane(i, state, obs, lane_returns, q0, row0, dim, P, resid);
 }
 
 // Small batches over the host API for kernels WITHOUT a mirror instantiation (injected-noise mode): observation rows and rewards

@@ -780,6 +780,50 @@ class TradingEnvironment(_EnvBase):
             self._handle, int(k), action_ptr, int(bool(auto_reset)), C.byref(steps), C.byref(episodes)))
         return int(steps.value), int(episodes.value)
 
+    # ---- graph-capturable stepping: the clock on the device (include/mbt_env.h, "graph-capturable stepping") ----
+    def device_clock_begin(self, auto_reset: bool = True, keep_terminal_observation: bool = False):
+        """Hand the clock (time, episode step, Philox step) to the device: from here to `device_clock_end()` a step is
+        `step_device_captured()` - launches whose arguments do not depend on the step, so `torch.cuda.graph` / a HIP stream capture
+        of [policy forward into `action_device`, `step_device_captured()`] x k replays correctly.  `obs_device`, `action_device` and
+        `reward_device` keep one address each while the mode is on (the state is stepped in place).  With `auto_reset` the launch
+        that ends an episode logs its return sums and resets the lanes (SB3's VecEnv contract, SBE:28-37), bit-identical to
+        `step_many_device(auto_reset=True)`; `keep_terminal_observation` also keeps that episode's last observation in
+        `terminal_obs_device` (SBE:32)."""
+        flags = (_native.CLOCK_AUTO_RESET if auto_reset else 0) | (_native.CLOCK_TERMINAL_OBSERVATION if keep_terminal_observation else 0)
+        _native.check(_native.load_library().mbt_env_device_clock_begin(self._handle, flags))
+
+    def step_device_captured(self, action_ptr: int = None):
+        """Enqueue one step in device-clock mode: nothing but launches on the environment's stream - capturable."""
+        code = _native.load_library().mbt_env_step_device_captured(self._handle, action_ptr)
+        if code < 0:
+            _native.check(code)
+
+    def device_clock_read(self) -> dict:
+        """Waits for the stream; {time, episode_step, philox_step, steps, episodes, done, log_count} as the device holds them."""
+        out = _native.MbtDeviceClock()
+        _native.check(_native.load_library().mbt_env_device_clock_read(self._handle, C.byref(out)))
+        return {name: getattr(out, name) for name, _ in out._fields_}
+
+    def device_clock_end(self):
+        """Waits for the stream and hands the clock back to the host; the episodes that ended in the mode are then in the episode
+        log (`episode_log_pop`).  A graph captured in the mode must not be replayed afterwards."""
+        _native.check(_native.load_library().mbt_env_device_clock_end(self._handle))
+
+    @property
+    def device_clock_view(self):
+        """The clock block as 8 int32 words on the device (`torch.as_tensor(env.device_clock_view, device="cuda")`): word 6 is
+        `done` of the last step - e.g. a bootstrap mask for a captured training step."""
+        ptr = _native.load_library().mbt_env_device_clock_ptr(self._handle)
+        return _native.DeviceView(ptr, (8,), self, typestr="<i4")
+
+    @property
+    def terminal_obs_device(self):
+        """(N, D) observation of the last finished episode's final step (`device_clock_begin(keep_terminal_observation=True)`)."""
+        ptr = _native.load_library().mbt_env_terminal_obs_ptr(self._handle)
+        if not ptr:
+            raise RuntimeError("terminal observations are kept from device_clock_begin(keep_terminal_observation=True) on")
+        return _native.DeviceView(ptr, (self.num_trajectories, self.observation_dim), self)
+
     def episode_log_pop(self, wait: bool = True):
         """Oldest finished episode's [sum R, sum R^2, lanes] (global when a communicator is set), or None when the log is
         empty (or, with wait=False, not ready yet)."""
