@@ -557,6 +557,12 @@ float* mbt_env_action_ptr(mbt_env* env);
 /* (N, D) observation of the last reset/step; without normalisation this IS the state, which the next step updates IN PLACE: the
  * rows are valid until the next step / rollout / reset is enqueued on the environment's stream (copy them there to keep them). */
 float* mbt_env_obs_ptr(mbt_env* env);
+/* Which of the two regimes this environment steps in (mbt_env.hip: mbt_env::state): 1 = the state is updated IN PLACE - launches that
+ * move 80 MB or more, every environment that normalises observations (one observation buffer), and every environment while its clock
+ * is on the device - so the pointer above is the same after every step and the rows of step k are overwritten by step k + 1 (a
+ * consumer that keeps `obs` next to `next_obs`, e.g. a replay buffer, copies the former on the environment's stream first); 0 = two
+ * buffers alternate and the rows of step k stay valid until step k + 2 is enqueued.  MBT_PING_PONG_STATE = 0 / 1 forces a regime. */
+int mbt_env_state_in_place(mbt_env* env);
 /* (N) rewards of the last step.  After a HOST step (mbt_env_step_host, mbt_env_set_host_rewards) the buffer is complete when this
  * returns; after a device step it is complete once the environment's stream has reached that step (mbt_env_synchronize). */
 float* mbt_env_reward_ptr(mbt_env* env);

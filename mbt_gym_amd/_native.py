@@ -237,6 +237,7 @@ SIGNATURES = {
     "mbt_env_set_user_noise_host": (C.c_int, [_ENV, _F]),
     "mbt_env_action_ptr": (C.c_void_p, [_ENV]),
     "mbt_env_obs_ptr": (C.c_void_p, [_ENV]),
+    "mbt_env_state_in_place": (C.c_int, [_ENV]),
     "mbt_env_reward_ptr": (C.c_void_p, [_ENV]),
     "mbt_env_obs_dim": (C.c_int, [_ENV]),
     "mbt_env_action_dim": (C.c_int, [_ENV]),

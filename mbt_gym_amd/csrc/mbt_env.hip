@@ -9,8 +9,6 @@
 
 #include <dlfcn.h>
 #include <immintrin.h>
-#include <setjmp.h>
-#include <signal.h>
 
 #include <atomic>
 #include <chrono>
@@ -628,28 +626,34 @@ int settle_callback_block(mbt_env* e, bool& busy) {
     }                                                               \
   } while (0)
 
-sigjmp_buf g_probe_jump;
-// Can the host write this device allocation (fine-grained memory through the PCIe BAR)?  Probed once per environment, under a
-// SIGSEGV / SIGBUS guard that is removed again at once.
-bool host_can_write(void* device_ptr) {
-  static std::mutex probe_mutex;  // (the jump buffer and the handlers are process-wide: one probe at a time - shards are created from several threads)
-  std::lock_guard<std::mutex> one_at_a_time(probe_mutex);
-  struct sigaction guard, old_segv, old_bus;
-  std::memset(&guard, 0, sizeof guard);
-  guard.sa_handler = [](int) { siglongjmp(g_probe_jump, 1); };
-  sigaction(SIGSEGV, &guard, &old_segv);
-  sigaction(SIGBUS, &guard, &old_bus);
-  bool ok = false;
-  if (sigsetjmp(g_probe_jump, 1) == 0) {
-    volatile uint32_t* word = static_cast<volatile uint32_t*>(device_ptr);
-    *word = 0x5EEDu;
-    _mm_sfence();
-    ok = *word == 0x5EEDu;
-    *word = 0u;
+// Can the host write this device allocation (fine-grained memory through the PCIe BAR)?  Decided WITHOUT touching it - rounds 4-5
+// wrote a probe word under temporary SIGSEGV / SIGBUS handlers, which are process-wide: a fault on any other thread during the
+// probe would have jumped into this thread's frame.  Two facts answer the question instead: the device says its whole memory is
+// visible through the BAR (hipDeviceAttributeIsLargeBar), and the kernel's own list of this process's mappings shows the block's
+// address range mapped readable and writable (the runtime maps device memory into the host's address space exactly when the BAR
+// reaches it) - an address that is not mapped, or mapped without access (a reservation), would fault.
+bool host_can_write(const void* device_ptr, size_t bytes, int device) {
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || large_bar == 0) {
+    (void)hipGetLastError();
+    return false;
   }
-  sigaction(SIGSEGV, &old_segv, nullptr);
-  sigaction(SIGBUS, &old_bus, nullptr);
-  return ok;
+  std::FILE* maps = std::fopen("/proc/self/maps", "r");
+  if (maps == nullptr) return false;
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(device_ptr), hi = lo + bytes;
+  uintptr_t covered = lo;  // [lo, covered) is known to be mapped read-write; the list is sorted by address
+  char line[512];
+  while (covered < hi && std::fgets(line, sizeof line, maps) != nullptr) {
+    unsigned long long a = 0, b = 0;
+    char perms[8] = {0};
+    if (std::sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3) continue;
+    if (b <= covered) continue;
+    if (a > covered) break;  // a hole in front of the next mapping
+    if (perms[0] != 'r' || perms[1] != 'w') break;
+    covered = static_cast<uintptr_t>(b);
+  }
+  std::fclose(maps);
+  return covered >= hi;
 }
 
 // Mailbox + action stage of the resident kernel: device memory the host can write if the platform has it (the kernel then polls and
@@ -661,7 +665,8 @@ int resident_allocate(mbt_env* e) {
   if (knob == nullptr || std::atoi(knob) != 0) {
     void* block = nullptr;
     if (hipExtMallocWithFlags(&block, bytes, hipDeviceMallocFinegrained) == hipSuccess && block != nullptr) {
-      if (hipMemset(block, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess && host_can_write(block)) {
+      // (on the environment's own stream: a fill on the null stream and a device-wide wait would block behind ANOTHER environment's resident kernel)
+      if (hipMemsetAsync(block, 0, bytes, e->stream) == hipSuccess && hipStreamSynchronize(e->stream) == hipSuccess && host_can_write(block, bytes, e->cfg.device)) {
         e->resident_vram_block = block;
         e->resident_vram = true;
         e->mailbox_host = e->mailbox_dev = static_cast<mbt::ResidentMailbox*>(block);  // (one address space: the same pointer on both sides)
@@ -1890,6 +1895,7 @@ static int create_env(const mbt_config* cfg, const mbt_user_code* code, mbt_env*
       if (e->resident_kernel != nullptr) ENV_TRY(resident_allocate(e));
       if (const char* v = std::getenv("MBT_RESIDENT_ANSWER_MS")) e->resident_answer_ms = std::atoi(v) > 0 ? std::atoi(v) : 0;
     }
+    if (const char* v = std::getenv("MBT_TEST_FLAG_SEQ")) e->flag_seq = static_cast<uint32_t>(std::strtoul(v, nullptr, 0));  // (test hook: start the sequence numbers of the completion flag near their wrap)
     const char* vram_stage = std::getenv("MBT_VRAM_ACTION_STAGE");  // (measurement knob, see mbt_env_step_host)
     if (e->resident_kernel == nullptr && vram_stage != nullptr && std::atoi(vram_stage) != 0 && e->h_stage != nullptr) {
       ENV_TRY(resident_allocate(e));
@@ -2718,6 +2724,7 @@ float* mbt_env_action_ptr(mbt_env* e) {
   return e->action;
 }
 float* mbt_env_obs_ptr(mbt_env* e) { return e != nullptr ? current_obs(e) : nullptr; }
+int mbt_env_state_in_place(mbt_env* e) { return e != nullptr && (!e->ping_pong || e->cfg.normalise_observation != 0 || e->device_clock) ? 1 : 0; }
 float* mbt_env_reward_ptr(mbt_env* e) {
   if (e == nullptr) return nullptr;
   // host-computed rewards of a small batch are filed by a kernel nobody waited for (mbt_env_set_host_rewards): a reader on another

@@ -1525,7 +1525,9 @@ __device__ __forceinline__ void resident_body(const StepBuffers& B0, const StepP
   // was wrong: one timed out while its neighbour saw the doorbell that was rung in the same microsecond, and half a step ran.)  The leave token carries the launch's generation, so a
   // word left behind by an earlier kernel is never mistaken for this one's.
   const uint32_t leave = 0x80000000u | (R.generation & 0x7FFFFFFFu);
-  for (uint32_t seq = R.first_seq;; ++seq) {
+  // (sequence numbers count up and wrap, skipping kResidentExit - the one value that means "leave" - exactly as the host's counter does,
+  // mbt_env.hip: resident_step: a kernel alive across the wrap, after 4.29e9 steps, keeps answering the number the host waits for)
+  for (uint32_t seq = R.first_seq;; seq = (seq + 1u == kResidentExit) ? seq + 2u : seq + 1u) {
     if (threadIdx.x == 0) {
       const uint64_t t0 = wall_clock64();
       uint32_t cmd;

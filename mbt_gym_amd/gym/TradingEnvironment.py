@@ -856,6 +856,13 @@ class TradingEnvironment(_EnvBase):
         return _native.DeviceView(ptr, (self.num_trajectories, self.observation_dim), self)
 
     @property
+    def obs_device_aliases_next(self) -> bool:
+        """True when `obs_device` of step k is the memory step k + 1 writes (the state is stepped in place: large batches, normalised
+        observations, device-clock mode): a consumer that needs `obs` beside `next_obs` copies it on the environment's stream first.
+        False: two buffers alternate, the rows stay valid until step k + 2 is enqueued (mbt_env_state_in_place)."""
+        return bool(_native.load_library().mbt_env_state_in_place(self._handle))
+
+    @property
     def reward_device(self):
         """(N,) rewards of the last step, zero-copy (`torch.as_tensor(env.reward_device, device="cuda")`).  Fetch it after the step it
         is wanted for: after `env.step()` the buffer is complete when this property returns (host-computed rewards of a small batch

@@ -345,3 +345,29 @@ def test_what_the_mode_refuses():
     with pytest.raises(_native.NativeError, match="injected noise"):
         injected.device_clock_begin()
     injected.close()
+
+
+def test_the_resident_kernel_lives_across_the_wrap_of_its_sequence_numbers(monkeypatch):
+    """the host's sequence counter skips the value that means "leave" (0xFFFFFFFF) when it wraps; the resident kernel's own
+    count has to skip it too, or a kernel alive across the wrap answers a number the host is not waiting for.  The test hook starts the
+    counter twelve steps before the wrap; thirty steps through the resident kernel equal the one-launch-per-step path."""
+    n = 1000
+    cfg = _cfg(n, n_steps=40)
+    action = _actions(cfg, n)
+    reference = make_env(cfg, noise="philox")
+    reference.reset()
+    want = [reference.step(action) for _ in range(30)]
+    reference.close()
+    monkeypatch.setenv("MBT_TEST_FLAG_SEQ", "0xFFFFFFF2")
+    monkeypatch.setenv("MBT_RESIDENT_IDLE_US", "2000000")  # (the kernel must not leave by itself between two steps of the test)
+    env = make_env(cfg, noise="philox", resident_step=True)
+    env.reset()
+    import time
+
+    t0 = time.perf_counter()
+    for k in range(30):
+        obs, rew, done, _ = env.step(action)
+        np.testing.assert_array_equal(obs, want[k][0], err_msg=f"step {k}")
+        np.testing.assert_array_equal(rew, want[k][1], err_msg=f"step {k}")
+    assert time.perf_counter() - t0 < 0.15, "a step waited for its 200 ms answer time-out: the kernel answered another sequence number"
+    env.close()
