@@ -346,6 +346,9 @@ struct mbt_env {
   bool clock_auto_reset = false;
   float* terminal_obs = nullptr;              // (n_pad, D), on demand: the observation of an episode's last step (MBT_CLOCK_TERMINAL_OBSERVATION)
   bool clock_terminal_obs = false;
+  bool capture_open = false;                  // the last mbt_env_step_device_captured was recorded by a stream capture ...
+  unsigned long long capture_id = 0;          // ... this one (hipStreamGetCaptureInfo)
+  uint32_t capture_parity = 0;                // the clock slot the next launch of that capture reads
 };
 
 namespace {
@@ -2459,6 +2462,9 @@ int mbt_env_step_device(mbt_env* e, const float* action_device, int32_t* done) {
 static int clock_download(mbt_env* e) {
   HIP_TRY(hipMemcpyAsync(e->clock_host, e->clock_dev, sizeof(mbt::DeviceClock), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->clock_host->faults != 0)  // (captured_epilogue's wall-clock bound: a launch lost a workgroup - the state is not to be trusted)
+    return fail(MBT_ERR_HIP, "%u captured step launch(es) gave up waiting for their workgroups after 2 s: the device is not healthy, the environment's state is undefined",
+                e->clock_host->faults);
   return MBT_OK;
 }
 
@@ -2482,23 +2488,39 @@ int mbt_env_device_clock_begin(mbt_env* e, uint32_t flags) {
     if (rc != MBT_OK) return rc;
   }
   std::memset(e->clock_host, 0, sizeof(mbt::DeviceClock));
-  e->clock_host->time = e->time;
-  e->clock_host->episode_step = e->episode_step;
-  e->clock_host->philox_step = e->philox_step;
+  e->clock_host->slot[0].time = e->time;
+  e->clock_host->slot[0].episode_step = e->episode_step;
+  e->clock_host->slot[0].philox_step = e->philox_step;
+  e->clock_host->shown = e->clock_host->slot[0];  // (current = 0)
   HIP_TRY(hipMemcpyAsync(e->clock_dev, e->clock_host, sizeof(mbt::DeviceClock), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->clock_counters, 0, 16u * (1u + (e->n_blocks + 31u) / 32u) * sizeof(uint32_t), e->stream));  // (armed: a launch leaves them at zero)
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->clock_auto_reset = (flags & MBT_CLOCK_AUTO_RESET) != 0;
   e->clock_terminal_obs = (flags & MBT_CLOCK_TERMINAL_OBSERVATION) != 0;
   e->device_clock = true;
+  e->capture_open = false;
   return MBT_OK;
 }
 
 // Nothing but launches on the environment's stream, with arguments that do not depend on the step: what a stream capture records
-// is valid for every replay.
+// is valid for every replay.  The clock slot a launch reads (step_kernel.hpp: CapturedParams::parity) alternates from call to call
+// WITHIN one stream capture, whose first call is preceded by the align kernel (the current slot becomes slot 0) - as is every call
+// outside a capture: whatever ran before (another graph, a single call), the launch behind an align kernel reads slot 0.
 int mbt_env_step_device_captured(mbt_env* e, const float* action_device) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   if (!e->device_clock) return fail(MBT_ERR_STATE, "mbt_env_step_device_captured outside mbt_env_device_clock_begin ... _end");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  unsigned long long capture_id = 0;
+  HIP_TRY(hipStreamGetCaptureInfo(e->stream, &capture, &capture_id));
+  const bool capturing = capture == hipStreamCaptureStatusActive;
+  if (!capturing || !e->capture_open || capture_id != e->capture_id) {
+    hipLaunchKernelGGL(mbt::captured_align_kernel, dim3(1), dim3(1), 0, e->stream, e->clock_dev);
+    HIP_TRY(hipGetLastError());
+    e->capture_parity = 0;
+  }
+  e->capture_open = capturing;
+  e->capture_id = capture_id;
   if (action_device != nullptr && e->n != e->n_pad) {  // see mbt_env_step_device: stage a caller buffer that has no pad rows (a copy node in a capture)
     HIP_TRY(hipMemcpyAsync(e->action, action_device, size_t(e->n) * e->act_dim * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     action_device = nullptr;
@@ -2522,6 +2544,8 @@ int mbt_env_step_device_captured(mbt_env* e, const float* action_device) {
   std::memset(&X, 0, sizeof X);
   X.clock = e->clock_dev;
   X.counters = e->clock_counters;
+  X.parity = e->capture_parity;
+  e->capture_parity ^= 1u;
   X.dt_f64 = e->dt;
   X.terminal_time = e->cfg.terminal_time;
   X.t_start = e->start_time;
@@ -2549,8 +2573,9 @@ int mbt_env_device_clock_read(mbt_env* e, mbt_device_clock* out) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int rc = clock_download(e);
   if (rc != MBT_OK) return rc;
-  static_assert(sizeof(mbt_device_clock) == 32 && offsetof(mbt::DeviceClock, log) == 32, "struct mbt_device_clock is the clock block's first 32 bytes");
-  std::memcpy(out, e->clock_host, sizeof *out);
+  static_assert(sizeof(mbt_device_clock) == sizeof(mbt::ClockSlot) && offsetof(mbt::DeviceClock, shown) == 0 && offsetof(mbt_device_clock, log_count) == offsetof(mbt::ClockSlot, reserved),
+                "struct mbt_device_clock is the clock block's first 32 bytes");
+  std::memcpy(out, &e->clock_host->shown, sizeof *out);
   return MBT_OK;
 }
 
@@ -2562,16 +2587,21 @@ int mbt_env_device_clock_end(mbt_env* e) {
   if (!e->device_clock) return MBT_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int rc = clock_download(e);
-  if (rc != MBT_OK) return rc;
-  const mbt::DeviceClock& now = *e->clock_host;
+  if (rc != MBT_OK) {
+    e->device_clock = false;  // (the mode ends either way: the caller resets)
+    e->was_reset = false;
+    return rc;
+  }
+  const mbt::DeviceClock& block = *e->clock_host;
+  const mbt::ClockSlot& now = block.slot[block.current & 1u];
   e->time = now.time;
   e->episode_step = now.episode_step;
   e->philox_step = now.philox_step;
   e->device_clock = false;
   // the episodes that ended in the mode, oldest first, into the episode log (mbt_env_episode_log_pop) - through the communicator, if
   // one is set: every rank replays the same graph, so every rank files the same number of entries
-  const uint32_t kept = now.log_count < mbt::kClockLogSlots ? now.log_count : mbt::kClockLogSlots;
-  for (uint32_t k = now.log_count - kept; k != now.log_count; ++k) {
+  const uint32_t logged = block.shown.reserved, kept = logged < mbt::kClockLogSlots ? logged : mbt::kClockLogSlots;
+  for (uint32_t k = logged - kept; k != logged; ++k) {
     if (e->log_count == mbt_env::kLogSlots) {
       double dropped[3];
       const int rc_drop = log_wait_oldest(e, dropped);

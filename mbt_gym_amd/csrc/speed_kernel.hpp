@@ -260,7 +260,7 @@ __device__ __forceinline__ void speed_step_body(const StepBuffers& B, const Step
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
   static_assert(!(CAPTURED && (MIRROR || V::INJECT || V::HOST_IMPACT)), "a captured step has no host in its loop");
   clock_words_t clock_words = {0u, 0u, 0u, 0u};
-  if (CAPTURED) clock_words = captured_clock_issue(C->clock);
+  if (CAPTURED) clock_words = captured_clock_issue(&C->clock->slot[C->parity]);
   StepParams P_step;  // (CAPTURED only: the kernel arguments with this step's clock filled in by captured_prologue, below)
   if (CAPTURED) P_step = P_in;
   const StepParams& P = CAPTURED ? P_step : P_in;

@@ -1175,10 +1175,20 @@ __device__ __forceinline__ void signal_host(const StepBuffers& B) {
 // - in reduce_returns_kernel's order of additions: the same bits - into a log in the clock block and zeroes the accumulators.
 // Results are those of the launch_step loop to the bit: same step_tile / speed_step_body, same counters, same clock arithmetic.
 //
-// Cost on the hot path: one 16-byte load of the clock per wave + a workgroup barrier in front of the generator (every wave of the
-// workgroup has read the clock before thread 0 can report the workgroup finished), and one or two relaxed atomics per workgroup
-// behind it (a two-level count: 32 workgroups share a counter line, so a launch of 2048 workgroups does not queue 2048 atomics on
-// one address).  The state is stepped IN PLACE (state_out == state_in), so the observation a captured policy reads has one address.
+// Who may write the next step's clock, and when?  Every workgroup of a launch reads the clock, so whoever overwrites it has to know
+// that all of them have - and on this device finding that out costs more than the arithmetic of a step: atomics on one cache line are
+// serialised at ~12 ns each (8192 waves counting on one word: 97 us for a 6.6 us launch), a returning atomic per workgroup on 64 lines
+// + a top-level word still adds 1.7 us at 2^20 lanes, fire-and-forget atomics polled by the last workgroup 4 us
+// (tools/microbench/mb_captured.hip, profiles/r06_graph_step.txt).  So nobody counts: the clock has TWO slots, a launch reads slot
+// `parity` and its workgroup 0 writes slot `parity ^ 1` - which no workgroup of the launch reads - whenever it gets there.  `parity`
+// is a kernel argument that the HOST alternates from one mbt_env_step_device_captured call to the next; inside a captured graph it is
+// therefore baked into the nodes, and the first call of every capture (and every call outside one) is preceded by a one-thread
+// ALIGN kernel that copies the current slot into slot 0 - so a graph of any length, replayed any number of times in any order with
+// other graphs or single calls, always starts from slot 0 with parity 0.  Cost on the hot path: one 16-byte SCALAR load per wave in
+// front of the generator (+0.2 us at 2^20 lanes, +0.4 us where a launch is latency-bound) and a few stores in workgroup 0.
+// Only the launch that ENDS an episode counts its waves (fire-and-forget atomics, polled by the workgroup dispatched last, which
+// then files the episode's return sums): once per episode, 4 us.
+// The state is stepped IN PLACE (state_out == state_in), so the observation a captured policy reads has one address.
 
 // reset (TE:131-140): rows [initial_cash, q0, start_time, initial_price, process columns...]
 struct ResetRow {
@@ -1215,21 +1225,31 @@ __device__ __forceinline__ void reset_lane(uint32_t i, float* state, float* obs,
 }
 
 constexpr uint32_t kClockLogSlots = 16;
-// The clock block.  Its first 32 bytes are `struct mbt_device_clock` of include/mbt_env.h (what mbt_env_device_clock_read returns
-// and what a device consumer may read through mbt_env_device_clock_ptr, e.g. `done` as a mask).
-struct DeviceClock {
+// The clock block.  Its first 32 bytes are `struct mbt_device_clock` of include/mbt_env.h: a MIRROR of the current slot that no step
+// kernel reads (what mbt_env_device_clock_read returns and what a device consumer may read through mbt_env_device_clock_ptr,
+// e.g. `done` as a mask).
+struct ClockSlot {
   double time;             // the clock at the beginning of the next step (TE:216)
   uint32_t episode_step;   // steps since the last (explicit or automatic) reset
   uint32_t philox_step;    // Philox counter word 2 of the next step
   uint32_t steps;          // steps taken since mbt_env_device_clock_begin
-  uint32_t episodes;       // episodes that ended since then
+  uint32_t episodes;       // steps among them that ended an episode
   int32_t done;            // the last step ended an episode (TE:218-220)
-  uint32_t log_count;      // entries written to `log` since begin (entry k sits in slot k % kClockLogSlots)
+  uint32_t reserved;
+};
+struct DeviceClock {
+  ClockSlot shown;         // the mirror; `shown.reserved` is mbt_device_clock::log_count: entries written to `log` since begin (entry k sits in slot k % kClockLogSlots)
+  ClockSlot slot[2];       // a launch reads slot[parity] (the first 16 bytes, as one scalar load), its workgroup 0 writes slot[parity ^ 1]
+  uint32_t current;        // the slot the NEXT launch is to read (captured_align_kernel brings it to 0)
+  uint32_t faults;         // episode-end launches whose last workgroup gave up waiting for the others (never, on a healthy device): mbt_env_device_clock_read reports it
+  uint32_t reserved[6];
   double log[kClockLogSlots][3];  // [sum R, sum R^2 (NaN unless per-lane returns are tracked), lanes] of the newest finished episodes
 };
 struct CapturedParams {
   DeviceClock* clock;
-  uint32_t* counters;      // the launch's arrival counters: [0] the top level, [16 (1 + g)] the g-th group of 32 workgroups (a 64-byte line each)
+  uint32_t* counters;      // an episode-end launch counts its waves: word 16 g those of the g-th group of 32 workgroups that have finished (a 64-byte line each)
+  uint32_t parity;         // the clock slot this launch reads (it writes the other)
+  uint32_t reserved_pad;
   double dt_f64, terminal_time, t_start;  // the host's clock arithmetic (mbt_env.hip: launch_step); where an automatic reset restarts
   int32_t auto_reset;      // an episode's end resets the lanes and logs the return sums inside the launch
   int32_t dim;
@@ -1247,17 +1267,16 @@ struct CapturedStep {  // the clock of the step a launch takes
   bool terminal;
 };
 
-// The clock of this step, wave-uniform (SGPRs), in two halves.  captured_clock_issue: ONE scalar load of the block's first 16 bytes
+// The clock of this step, wave-uniform (SGPRs), in two halves.  captured_clock_issue: ONE scalar load of the slot's first 16 bytes
 // [time, episode step, Philox step], issued before the state / action loads of the tile.  captured_prologue: waits for it (scalar
 // loads have a counter of their own - lgkmcnt - so the vector loads stay in flight, which a wait for a vector load issued behind
-// them would not allow: vmcnt counts in order), sets P's per-step fields from it, and ends in a bare workgroup barrier (no fence:
-// nothing is communicated through memory here) - every wave of the workgroup has read the clock before thread 0 can report the
-// workgroup finished.  The block was written by the PREVIOUS launch's last workgroup, and is rewritten by this launch's only once
-// every workgroup has passed this point: the scalar cache, invalid at the launch's start like every cache, cannot hold a stale copy.
+// them would not allow: vmcnt counts in order) and sets P's per-step fields from it.  The slot was written by the PREVIOUS launch
+// (its workgroup 0, or the align kernel) and nobody writes it during this one: the scalar cache, invalid at the launch's start like
+// every cache, cannot hold a stale copy.
 typedef uint32_t clock_words_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ clock_words_t captured_clock_issue(const DeviceClock* clock) {
+__device__ __forceinline__ clock_words_t captured_clock_issue(const ClockSlot* slot) {
   clock_words_t w;
-  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(w) : "s"(clock) : "memory");
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(w) : "s"(slot) : "memory");
   return w;
 }
 __device__ __forceinline__ CapturedStep captured_prologue(clock_words_t w, const CapturedParams& C, StepParams& P) {
@@ -1272,24 +1291,7 @@ __device__ __forceinline__ CapturedStep captured_prologue(clock_words_t w, const
   P.t_next = static_cast<float>(s.t_next);
   P.t_now = s.t;
   P.t_next_f64 = s.t_next;
-  __builtin_amdgcn_s_barrier();
   return s;
-}
-
-// This workgroup has finished; true in the LAST workgroup of the launch to say so (which re-arms the counters).
-__device__ __forceinline__ bool captured_arrive(uint32_t* counters, bool ordered) {
-  const uint32_t group = blockIdx.x >> 5, groups = (gridDim.x + 31u) >> 5;
-  const uint32_t members = gridDim.x - (group << 5) < 32u ? gridDim.x - (group << 5) : 32u;
-  uint32_t* mine = counters + 16u * (1u + group);
-  // `ordered` (an episode's end): the last workgroup reads what the others wrote - release / acquire at device scope.  Otherwise it
-  // only has to know that every workgroup has READ the clock (the barrier of captured_prologue precedes this): counting is enough.
-  const uint32_t a = ordered ? __hip_atomic_fetch_add(mine, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a + 1u != members) return false;
-  __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t b = ordered ? __hip_atomic_fetch_add(counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (b + 1u != groups) return false;
-  __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
 }
 
 // reduce_returns_kernel's sums by ONE wave, in that kernel's order of additions: its thread t accumulates the elements t, t + 256,
@@ -1322,8 +1324,8 @@ __device__ __forceinline__ void captured_reduce_returns(double* wave_sums, uint3
   out[2] = static_cast<double>(n);
 }
 
-// Behind the step of a tile: the episode's end (every workgroup, its own rows), then the count, then - in the last workgroup to
-// finish - the episode's log entry and the clock of the next step.
+// Behind the step of a tile: the episode's end (every workgroup, its own rows), the next step's clock (workgroup 0), and - at an
+// episode's end - the count and the episode's log entry (the workgroup dispatched last, once every wave of the launch is in).
 __device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const StepParams& P, const CapturedParams& C, const CapturedStep s) {
   const bool episode_end = s.terminal && C.auto_reset != 0;
   if (__builtin_expect(episode_end, 0)) {
@@ -1345,32 +1347,60 @@ __device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const St
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
   }
-  if (threadIdx.x >= 64u) return;
-  uint32_t last = 0u;
-  if (threadIdx.x == 0u) last = captured_arrive(C.counters, episode_end) ? 1u : 0u;
-  if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
   DeviceClock* clock = C.clock;
-  uint32_t log_count = clock->log_count;
-  if (episode_end) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double sums[3];
-    captured_reduce_returns(B.wave_sums, C.n_waves, B.lane_returns, P.n, sums);
-    if (B.lane_returns != nullptr)
-      for (uint32_t i = threadIdx.x; i < 2u * P.n_pairs; i += 64u) B.lane_returns[i] = 0.0f;
-    if (threadIdx.x == 0u) {
-      double* entry = clock->log[log_count % kClockLogSlots];
-      entry[0] = sums[0]; entry[1] = sums[1]; entry[2] = sums[2];
-    }
-    log_count += 1u;
+  // workgroup 0 writes the next step's clock into the slot no workgroup of this launch reads, and its mirror
+  if (blockIdx.x == 0u && threadIdx.x == 0u) {
+    const ClockSlot& mine = clock->slot[C.parity];
+    ClockSlot next;
+    next.time = episode_end ? C.t_start : s.t_next;
+    next.episode_step = episode_end ? 0u : mine.episode_step + 1u;
+    next.philox_step = s.philox_step + 1u;
+    next.steps = mine.steps + 1u;
+    next.episodes = mine.episodes + (s.terminal ? 1u : 0u);
+    next.done = s.terminal ? 1 : 0;
+    next.reserved = 0u;
+    clock->slot[C.parity ^ 1u] = next;
+    clock->current = C.parity ^ 1u;
+    clock->shown.time = next.time; clock->shown.episode_step = next.episode_step; clock->shown.philox_step = next.philox_step;
+    clock->shown.steps = next.steps; clock->shown.episodes = next.episodes; clock->shown.done = next.done;  // (shown.reserved = log_count: the episode filer's, below)
   }
+  if (!episode_end) return;
+  // An episode's end, once in n_steps launches: every wave counts itself in (fire and forget) behind its stores ...
+  constexpr uint32_t kWaves = kBlockThreads / 64;
+  if ((threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(C.counters + 16u * (blockIdx.x >> 5), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x + 1u != gridDim.x || threadIdx.x >= 64u) return;
+  // ... the first wave of the workgroup that is dispatched last stays until all the others are in (one counter line per lane and poll;
+  // a wall-clock bound like every wait on the device: a launch that lost a workgroup must not leave this one spinning), re-arms the
+  // counters ...
+  {
+    const uint32_t groups = (gridDim.x + 31u) >> 5;
+    const uint64_t t0 = wall_clock64();
+    for (;;) {
+      bool all_in = true;
+      for (uint32_t g = threadIdx.x; g < groups; g += 64u) {
+        const uint32_t members = gridDim.x - (g << 5) < 32u ? gridDim.x - (g << 5) : 32u;
+        all_in &= __hip_atomic_load(C.counters + 16u * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members * kWaves;
+      }
+      if (__builtin_amdgcn_ballot_w64(!all_in) == 0ull) break;
+      if (wall_clock64() - t0 > 200000000ull) {  // 2 s of the 100 MHz wall clock
+        if (threadIdx.x == 0u) clock->faults += 1u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    for (uint32_t g = threadIdx.x; g < groups; g += 64u) __hip_atomic_store(C.counters + 16u * g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ... and, alone on the launch now, files the episode: its return sums into the log, the accumulators back to zero
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double sums[3];
+  captured_reduce_returns(B.wave_sums, C.n_waves, B.lane_returns, P.n, sums);
+  if (B.lane_returns != nullptr)
+    for (uint32_t i = threadIdx.x; i < 2u * P.n_pairs; i += 64u) B.lane_returns[i] = 0.0f;
   if (threadIdx.x == 0u) {
-    clock->time = episode_end ? C.t_start : s.t_next;
-    clock->episode_step = episode_end ? 0u : clock->episode_step + 1u;
-    clock->philox_step = s.philox_step + 1u;
-    clock->steps += 1u;
-    clock->episodes += s.terminal ? 1u : 0u;
-    clock->done = s.terminal ? 1 : 0;
-    clock->log_count = log_count;
+    const uint32_t log_count = clock->shown.reserved;
+    double* entry = clock->log[log_count % kClockLogSlots];
+    entry[0] = sums[0]; entry[1] = sums[1]; entry[2] = sums[2];
+    clock->shown.reserved = log_count + 1u;
   }
 }
 
@@ -1393,7 +1423,7 @@ __device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams
   static_assert(!(CAPTURED && (MIRROR || V::INJECT || V::HOST != 0)), "a captured step has no host in its loop");
   const uint32_t lane0 = tile * kTileLanes + threadIdx.x, lane1 = lane0 + kBlockThreads;
   clock_words_t clock_words = {0u, 0u, 0u, 0u};
-  if (CAPTURED) clock_words = captured_clock_issue(C->clock);
+  if (CAPTURED) clock_words = captured_clock_issue(&C->clock->slot[C->parity]);
   LaneLoads L0 = load_lane<V, STREAM>(B, P_in, lane0), L1 = load_lane<V, STREAM>(B, P_in, lane1);  // issue every load ...
   load_initial_inventories<V>(B, lane0, lane1, L0.qi, L1.qi);
   StepParams P_step;  // (CAPTURED only: the kernel arguments with this step's clock filled in)
@@ -1854,6 +1884,15 @@ __global__ void reset_kernel(float* state, float* obs, float* lane_returns, doub
   if (i < n_waves) wave_sums[i] = 0.0;
   if (i >= n_pad) return;
   reset_lane(i, state, obs, lane_returns, q0, row0, dim, P, resid);
+}
+
+// Graph-capturable stepping: in front of the first step of every capture, and of every step outside one - the current clock slot
+// becomes slot 0, so that the first launch behind it reads slot 0 (parity 0) whatever ran before.  One thread.
+__global__ void captured_align_kernel(DeviceClock* clock) {
+  if (clock->current != 0u) {
+    clock->slot[0] = clock->slot[1];
+    clock->current = 0u;
+  }
 }
 
 // Small batches over the host API for kernels WITHOUT a mirror instantiation (injected-noise mode): observation rows and rewards

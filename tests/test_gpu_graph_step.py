@@ -30,13 +30,14 @@ def _cfg(n, **kw):
 
 
 HAWKES = dict(arrival="hawkes", intensity=(10.0, 10.0), hawkes_jump=40.0, hawkes_speed=6.0, midprice="ou", ou_level=100.0, ou_speed=0.01)
-SPEED = dict(dynamics="speed", arrival="none", reward="cjoe", phi=0.01, alpha=0.001, initial_inventory=1.0, max_inventory=10)
+SPEED = dict(dynamics="speed", arrival="none", reward="cjoe", phi=0.01, alpha=0.001, initial_inventory=1, max_inventory=10)
 
 # name -> (OracleConfig overrides, TradingEnvironment overrides): one member of every kernel family that has a captured form
 FAMILIES = {
     "as_f32": (dict(), dict()),
     "cjp_quadratic": (dict(reward="cjmm", phi=0.01, alpha=0.001), dict()),
-    "running_general_exponent": (dict(reward="running", phi=0.01, alpha=0.001, inventory_exponent=1.5), dict()),
+    "cjmm_random_initial_inventory": (dict(reward="cjmm", phi=0.01, alpha=0.001, initial_inventory=(-3, 4)), dict()),
+    "running_general_exponent": (dict(reward="running", phi=0.01, alpha=0.001, inventory_exponent=4.0), dict()),
     "hawkes_exact_ou": (HAWKES, dict()),
     "hawkes_f32_intensities": (HAWKES, dict(hawkes_float32_intensities=True)),
     "limit_and_market": (dict(dynamics="limit_and_market", market_half_spread=0.5), dict()),
@@ -169,7 +170,7 @@ def test_captured_episode_against_the_oracle_on_the_kernels_own_draws(family):
 
     n = 2048
     overrides, env_overrides = FAMILIES[family]
-    cfg = _cfg(n, n_steps=6, **overrides)
+    cfg = _cfg(n, n_steps=7, **overrides)
     total = cfg.n_steps + 2
     env = make_env(cfg, noise="philox", **env_overrides)
     draws = [_native.rng_fill(cfg.seed, 0, k, n) for k in range(total)]
@@ -320,8 +321,6 @@ def test_what_the_mode_refuses():
     n = 1000
     cfg = _cfg(n)
     env = make_env(cfg, noise="philox")
-    with pytest.raises(_native.NativeError, match="before reset"):
-        env.device_clock_begin()
     with pytest.raises(_native.NativeError, match="outside mbt_env_device_clock_begin"):
         env.step_device_captured()
     env.reset_device()
