@@ -738,6 +738,7 @@ def main():
                     "reduction, 24-byte all-reduce, reset, all enqueued in-stream - inside the timed region")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the extra 2^24-lane measurement (N = 1 only)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the fused-rollout block (N = 1 only)")
+    ap.add_argument("--no-device-loop", action="store_true", help="skip the zero-copy consumer-loop block (torch policy on the device, eager vs HIP graph; N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-distributed", action="store_true", help="testing: take the multi-rank code path (process group, C-ABI communicator, collective check) even with one rank")
@@ -996,6 +997,15 @@ def main():
                 out["rollout"] = rollout_block(lib, gpu)
             except Exception as exc:  # noqa: BLE001
                 out["rollout"] = {"error": str(exc)}
+        if world == 1 and not args.no_device_loop:
+            # a policy that lives on the device writes `action_device`, the environment steps on the same stream - one Python
+            # call per step (host clock) against a torch.cuda.graph of [policy, mbt_env_step_device_captured] x 50 (device clock)
+            try:
+                from tools.bench_device_loop import device_policy_loop_block
+
+                out["device_policy_loop"] = device_policy_loop_block(gpu)
+            except Exception as exc:  # noqa: BLE001
+                out["device_policy_loop"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             try:

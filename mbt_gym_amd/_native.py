@@ -10,7 +10,9 @@ import time
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmbtenv.so")
+# MBT_LIBRARY_VARIANT=asan / tsan: the sanitizer build of the host side (mbt_gym_amd/build.py, MBT_SANITIZE; README "Sanitizers")
+_VARIANT = os.environ.get("MBT_LIBRARY_VARIANT", "").strip()
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"libmbtenv.{_VARIANT}.so" if _VARIANT else "libmbtenv.so")
 ABI_VERSION = 8
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER, MID_HOST = 0, 1, 2, 3, 4, 5, 6, 7, 8

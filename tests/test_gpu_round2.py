@@ -178,7 +178,7 @@ def _bench(*args):
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(key, None)
     # (the per-configuration block and the sharded cfg4 block have tests of their own: tests/test_gpu_round4.py)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-resident", "--no-configs", "--no-rollout", "--cfg4-total-lanes", "0", *args],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-resident", "--no-configs", "--no-rollout", "--no-device-loop", "--cfg4-total-lanes", "0", *args],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -163,7 +163,7 @@ def _bench(*args, timeout=900):
     env = dict(os.environ)
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(key, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-resident", "--no-rollout", *args], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-hbm-resident", "--no-rollout", "--no-device-loop", *args], capture_output=True, text=True,
                          timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -232,7 +232,7 @@ def test_eight_ranks_rehearsed_on_one_device():
     assert "error" not in block, block
     assert block["num_trajectories_total"] == 1 << 24 and block["num_trajectories_per_gpu"] == 1 << 21 and block["scaling"] == "strong"
     assert wall < 120.0, f"the 8-rank line took {wall:.0f} s"
-    one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", *common)
+    one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", "--no-device-loop", *common)
     assert one["mean_episode_return"] == pytest.approx(eight["mean_episode_return"], rel=1e-12)
 
 

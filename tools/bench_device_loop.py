@@ -108,14 +108,15 @@ def measure(n, device=0, seconds=0.4):
                         act()
                     env.step_device_captured()
             row["graph_us_per_step"] = _rate(graph.replay, GRAPH_STEPS, seconds, sync)
-            # the captured kernel issued WITHOUT a graph (one library call per step): what the clock on the device costs by itself
+            # the captured step issued OUTSIDE a capture: one library call = the align kernel + the step (two launches) - the mode's slow
+            # way in, for debugging and for the tests' step-by-step comparisons; an eager loop belongs to step_device()
             def captured_eager_chunk():
                 for _ in range(GRAPH_STEPS):
                     if policy != "constant_action":
                         act()
                     env.step_device_captured()
 
-            row["captured_kernel_eager_us_per_step"] = _rate(captured_eager_chunk, GRAPH_STEPS, seconds, sync)
+            row["captured_step_outside_a_graph_us_per_step"] = _rate(captured_eager_chunk, GRAPH_STEPS, seconds, sync)
             now = env.device_clock_read()
             row["steps_taken_in_device_clock_mode"], row["episodes_ended_there"] = now["steps"], now["episodes"]
             env.device_clock_end()

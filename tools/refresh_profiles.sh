@@ -33,17 +33,17 @@ cp "$OUT/${TAG}_bench_kernel_stats.csv" profiles/
 # the bench lines: default arguments, and the driver's (--steps 20 --warmup 5) - after the summary above, which they quote (frac_rocprof)
 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"; stamp "bench default rc=$?"
 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>> "$OUT/bench.stderr"; stamp "bench driver args rc=$?"
-rm -rf /tmp/prof_ungated && (cd /tmp && MBT_BENCH_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ungated -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$ROOT/$OUT/${TAG}_bench_under_rocprof_ungated.json" 2>> "$ROOT/$OUT/rocprof_main.stderr")
+rm -rf /tmp/prof_ungated && (cd /tmp && MBT_BENCH_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ungated -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop > "$ROOT/$OUT/${TAG}_bench_under_rocprof_ungated.json" 2>> "$ROOT/$OUT/rocprof_main.stderr")
 find /tmp/prof_ungated -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_bench_kernel_stats_ungated.csv"; stamp "kernel stats of bench.py (ungated, for comparison)"
 
 profile() {  # profile <name> <bench args...>: kernel trace + stats, then the two PMC passes
   local name=$1; shift
   if [ "$name" != bench ]; then
-  rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout "$@" > "$ROOT/$OUT/${TAG}_${name}_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_${name}.stderr")
+  rm -rf /tmp/prof_stats && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop "$@" > "$ROOT/$OUT/${TAG}_${name}_under_rocprof.json" 2> "$ROOT/$OUT/rocprof_${name}.stderr")
   find /tmp/prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_${name}_kernel_stats.csv"
   fi
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --prewarm-steps 0 "${@:1:2}" --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_${name}_$C.stderr")
+    rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop --prewarm-steps 0 "${@:1:2}" --steps 200 --warmup 20 > /dev/null 2> "$ROOT/$OUT/rocprof_${name}_$C.stderr")
   done
   F=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' | head -1)
   W=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' | head -1)
@@ -66,8 +66,8 @@ python tools/bench_policy.py > "$OUT/${TAG}_policy_rollout.json" 2> /dev/null; s
 python tests/perf/bench_host_path.py > "$OUT/${TAG}_host_path.json" 2> /dev/null; stamp "host path"
 python tests/dbg/gym_loop_breakdown.py > "$OUT/${TAG}_gym_loop_breakdown.json" 2> /dev/null; stamp "gym loop breakdown"
 # the multi-rank code path of bench.py with a world of one (RCCL communicator through the C ABI, collective check): what an 8-GPU run adds
-python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
+python bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop > "$OUT/${TAG}_bench_forced_distributed.json" 2>> "$OUT/bench.stderr"; stamp "bench forced distributed rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop > "$OUT/${TAG}_bench_torchrun_world1.json" 2>> "$OUT/bench.stderr"; stamp "bench under torchrun rc=$?"
 python tests/perf/bench_timed_region.py > "$OUT/${TAG}_timed_region.json" 2> /dev/null; stamp "timed region"
 
 # per-kernel statistics of the other kernel families (every BASELINE config's step kernel, the fused rollouts, the learned
