@@ -385,12 +385,13 @@ def cpu_baseline(single_budget_s=10.0, multi_steps=24, process_counts=(16, 32, 6
     return out
 
 
-def hbm_resident_measurement(lib, device, reference, steps=600, warmup=100):
+def hbm_resident_measurement(lib, device, reference, steps=600, warmup=100, lanes=None):
     """The same kernel on 2^24 lanes: 738 MB of state + actions + rewards per launch, beyond the 256 MB Infinity Cache,
     so every byte comes from / goes to HBM.  Reported beside the headline (cache-resident) figure, never instead of it."""
     import torch
 
-    env = build_env(HBM_RESIDENT_LANES, 0, device)
+    lanes = HBM_RESIDENT_LANES if lanes is None else lanes
+    env = build_env(lanes, 0, device)
 
     def sync_all(barrier=True):
         env.synchronize()
@@ -402,12 +403,12 @@ def hbm_resident_measurement(lib, device, reference, steps=600, warmup=100):
     finally:
         env.close()
     launch_s = event_s / steps
-    row = roofline_row("cfg1", False, HBM_RESIDENT_LANES, launch_s, reference)
+    row = roofline_row("cfg1", False, lanes, launch_s, reference)
     return {
-        "lanes": HBM_RESIDENT_LANES, "steps": steps, "bytes_per_launch": BYTES_PER_ENV_STEP * HBM_RESIDENT_LANES,
+        "lanes": lanes, "steps": steps, "bytes_per_launch": BYTES_PER_ENV_STEP * lanes,
         "avg_launch_us": launch_s * 1e6, "avg_launch_us_rocprof": row["avg_launch_us_rocprof"], "achieved": row["achieved"], "frac": row["frac"],
         "frac_events": row["frac_events"], "frac_rocprof": row["frac_rocprof"], "kernel": row["kernel"],
-        "env_steps_per_s": HBM_RESIDENT_LANES * steps / wall,
+        "env_steps_per_s": lanes * steps / wall,
         "note": "working set 738 MB per launch > 256 MB Infinity Cache: HBM-resident; the achievable copy rate of the chip "
                 "is ~6.3 TB/s (0.79 of the spec peak)",
     }
@@ -608,18 +609,24 @@ class Watchdog:
         return False
 
 
-def pin_to_gpu_numa_node(gpu):
-    """Keep this rank's host threads on the cores of its GPU's NUMA node (the launch path is one host thread per GPU; a
-    cross-socket hop adds to every launch).  Best effort: returns a description, or the reason nothing was done."""
+def gpu_placement(gpu, pin):
+    """Where this rank's GPU sits - PCI bus id, NUMA node - and, with `pin`, the host threads kept on that node's cores (the launch
+    path is one host thread per GPU; a cross-socket hop adds to every launch).  Best effort: ({facts}, description)."""
+    facts = {"device_ordinal": gpu, "pci_bus_id": None, "numa_node": None, "cores_pinned": None, "device_name": None}
     try:
         import torch
 
         props = torch.cuda.get_device_properties(gpu)
+        facts["device_name"] = getattr(props, "gcnArchName", None) or props.name
         bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        facts["pci_bus_id"] = bdf
         with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
             node = int(f.read().strip())
+        facts["numa_node"] = node
+        if not pin:
+            return facts, "not pinned"
         if node < 0:
-            return f"GPU {gpu} ({bdf}): no NUMA affinity reported"
+            return facts, f"GPU {gpu} ({bdf}): no NUMA affinity reported"
         with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
             cpus = set()
             for part in f.read().strip().split(","):
@@ -627,11 +634,12 @@ def pin_to_gpu_numa_node(gpu):
                 cpus.update(range(int(lo), int(hi or lo) + 1))
         allowed = cpus & os.sched_getaffinity(0)
         if not allowed:
-            return f"GPU {gpu} ({bdf}): NUMA node {node} has no core this process may use"
+            return facts, f"GPU {gpu} ({bdf}): NUMA node {node} has no core this process may use"
         os.sched_setaffinity(0, allowed)
-        return f"GPU {gpu} ({bdf}): NUMA node {node}, {len(allowed)} cores"
+        facts["cores_pinned"] = len(allowed)
+        return facts, f"GPU {gpu} ({bdf}): NUMA node {node}, {len(allowed)} cores"
     except Exception as exc:  # noqa: BLE001 - affinity is an optimisation, never a requirement
-        return f"not pinned: {exc}"
+        return facts, f"not pinned: {exc}"
 
 
 def gpu_cfg0_figures(device):
@@ -742,6 +750,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the launcher-side barrier (nccl = RCCL; gloo only for testing)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-distributed", action="store_true", help="testing: take the multi-rank code path (process group, C-ABI communicator, collective check) even with one rank")
+    ap.add_argument("--per-rank-hbm-lanes", type=int, default=HBM_RESIDENT_LANES,
+                    help="N > 1: every rank also measures the step kernel at this many lanes (2^24: beyond the Infinity Cache) for the per-rank block of the line; 0 = skip")
     ap.add_argument("--comm-timeout", type=float, default=180.0, help="hard deadline (s) for creating the RCCL communicator and for each collective check")
     args = ap.parse_args()
 
@@ -778,15 +788,18 @@ def main():
     # one process per GPU; a launcher that narrows each rank's visible devices leaves fewer ordinals than ranks
     gpu = 0 if args.single_device else local_rank % max(1, visible)
     torch.cuda.set_device(gpu)
-    affinity = pin_to_gpu_numa_node(gpu) if (multi and os.environ.get("MBT_BENCH_PIN", "1") != "0") else "not pinned"
+    placement, affinity = gpu_placement(gpu, pin=multi and os.environ.get("MBT_BENCH_PIN", "1") != "0")
+    seconds = {"rendezvous_and_first_barrier": None, "comm_init_rank": None, "first_collective": None}  # where this rank's set-up time went
     if multi:
         # (generous: on a fresh box the ranks finish their first `import torch` minutes apart, and the early ones wait here)
         with Watchdog(max(args.comm_timeout, 480.0), "torch.distributed rendezvous + first barrier", rank):
+            t_phase = time.perf_counter()
             if args.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
             else:
                 dist.init_process_group(backend=args.backend)
             dist.barrier()  # every rank waits for rank 0's build check before it loads the library
+            seconds["rendezvous_and_first_barrier"] = time.perf_counter() - t_phase
     lib = _native.load_library()
 
     n = args.lanes
@@ -808,8 +821,13 @@ def main():
             ok = True
             with Watchdog(args.comm_timeout, "mbt_comm_init_rank (C-ABI RCCL communicator)", rank):
                 try:
+                    t_phase = time.perf_counter()
                     comm = RcclCommunicator(rank, world, gpu)
+                    seconds["comm_init_rank"] = time.perf_counter() - t_phase
                     env.set_communicator(comm)
+                    t_phase = time.perf_counter()  # the communicator's FIRST collective (RCCL sets its channels up lazily: seconds, on some fabrics)
+                    env.allreduce_return_sums(comm, [1.0, 0.0, 1.0])
+                    seconds["first_collective"] = time.perf_counter() - t_phase
                 except Exception as exc:  # noqa: BLE001
                     print(f"[rank {rank}] C-ABI RCCL communicator unavailable ({exc}); using torch.distributed", file=sys.stderr)
                     ok = False
@@ -841,6 +859,7 @@ def main():
     # clocks up (untimed, not part of --warmup), then the warm-up the caller asked for
     prewarm, prewarm_target = 0, args.prewarm_steps if args.prewarm_steps >= 0 else default_prewarm_steps(n)
     with Watchdog(max(args.comm_timeout, 600.0), "warm-up steps (including the all-reduces of the episodes that end in them)", rank):
+        t_warm = time.perf_counter()
         while prewarm < prewarm_target:
             prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
             env.synchronize()
@@ -848,9 +867,11 @@ def main():
             env.step_many_device(args.warmup, auto_reset=True)
         sync_all()
         warm_episodes = drain_log()
+        seconds["warm_up_steps_and_their_collectives"] = time.perf_counter() - t_warm
 
         wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
         episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
+    event_s_own = event_s  # (this rank's own; `event_s` becomes the slowest rank's below)
     launch_us_min = launch_us_max = event_s / args.steps * 1e6  # per-rank mean launch-to-launch time: a straggler shows here
     if dist is not None:
         dist.barrier()
@@ -874,7 +895,9 @@ def main():
     if multi:
         with Watchdog(args.comm_timeout, "known-answer all-reduce", rank):
             reduce_once = (lambda v: env.allreduce_return_sums(comm, v)) if comm is not None else (lambda v: allreduce_return_sums(v, device=tdev))
+            t_phase = time.perf_counter()
             got = reduce_once([float(rank + 1), 0.0, 1.0])
+            seconds["known_answer_collective"] = time.perf_counter() - t_phase
             correct = bool(got[0] == world * (world + 1) / 2 and got[2] == world)
             sync_all()
             reps = 50
@@ -934,6 +957,27 @@ def main():
                         "avg_launch_us_slowest_rank": launch4 * 1e6, "avg_launch_us_fastest_rank": -float(t4[2]) / args.cfg4_steps * 1e6,
                         "frac_per_gpu": credited_bytes("cfg4") * n4 / launch4 / 1e9 / HBM_PEAK_GBPS, "kernel": kernel_name("cfg4", False, n4)}
 
+    # One line has to explain a scaling curve that bends (the 8-GPU run is unattended): what every rank used and where its time went -
+    # device, PCI bus id, NUMA node, what RCCL says the communicator spans, rendezvous / communicator / first-collective seconds, its own
+    # launch-to-launch time in the timed region, and the step kernel's HBM-resident rate on ITS device (2^24 lanes: a slow HBM stack,
+    # a throttled or shared device shows here and nowhere else).
+    ranks_block = None
+    if multi:
+        mine = dict(placement, rank=rank, local_rank=local_rank, host=socket.gethostname(), rccl_comm_count=(comm.count() if comm is not None else None),
+                    return_allreduce=transport, seconds=seconds, avg_launch_us=event_s_own / args.steps * 1e6, visible_devices=visible,
+                    hip_visible_devices=os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+        if args.per_rank_hbm_lanes > 0:
+            with Watchdog(max(args.comm_timeout, 300.0), "per-rank HBM-resident measurement", rank):
+                try:
+                    big = hbm_resident_measurement(lib, gpu, {}, steps=200, warmup=50, lanes=args.per_rank_hbm_lanes)
+                    mine["hbm_resident"] = {"lanes": big["lanes"], "avg_launch_us": big["avg_launch_us"], "frac": big["frac_events"], "GBps": big["achieved"],
+                                            "concurrent_with_the_other_ranks": True}
+                except Exception as exc:  # noqa: BLE001 - one rank short of memory must not cost the line
+                    mine["hbm_resident"] = {"error": f"{type(exc).__name__}: {exc}"}
+        with Watchdog(args.comm_timeout, "gathering the per-rank blocks", rank):
+            gathered = [None] * dist.get_world_size()
+            dist.all_gather_object(gathered, mine)
+        ranks_block = gathered
     if rank == 0:
         reference, reference_file = rocprof_reference()
         headline = roofline_row("cfg1", False, n, event_s / args.steps, reference)
@@ -983,6 +1027,8 @@ def main():
             out["collective"] = collective
         if cfg4 is not None:
             out["cfg4_sharded"] = cfg4
+        if ranks_block is not None:
+            out["ranks"] = ranks_block
     env.close()
     if rank == 0:
         if world == 1 and not args.no_hbm_resident:

@@ -55,6 +55,11 @@ class UnsupportedOnDevice(NotImplementedError):
     """The requested plugin combination has no HIP implementation (and there is no CPU path to fall back to)."""
 
 
+class Float32ClipWarning(UserWarning):
+    """The clip of TE:283-289 fired in the float32 tier: the one case in which its rewards are not 1e-5-accurate (see
+    `TradingEnvironment._note_clip_count`)."""
+
+
 class HostCallbackWarning(UserWarning):
     """A plugin subclass that only has NumPy code is consulted on the host every step: it works, slowly."""
 
@@ -476,8 +481,32 @@ class TradingEnvironment(_EnvBase):
             state = np.append(state, process.initial_vector_state, axis=1)
         return state
 
+    def _note_clip_count(self, count: int) -> bool:
+        """`count`: mbt_env_clip_count now.  Warns ONCE per environment when it has grown in the float32 tier (the reference prints
+        every time, TE:291-297): on a lane-step whose inventory or cash is clipped the reward holds float32 cash / midprice LEVELS
+        (the increment form cannot cancel them), so it is accurate to ~1.2e-4 there instead of 1e-5 (include/mbt_env.h, "Numerics
+        tier"; tests/float32_tier_bounds.py) - exact again with `precise_state=True`.  Returns whether it warned."""
+        grew = count > getattr(self, "_clips_seen", 0)
+        self._clips_seen = count
+        if not grew or self.precise_state or getattr(self, "_clip_warned", False):
+            return False
+        self._clip_warned = True
+        warnings.warn(
+            f"{count} lane-step(s) had inventory or cash clipped to max_inventory / max_cash (TE:283-289).  In the float32 tier the reward of "
+            "such a lane-step is accurate to ~1.2e-4 (float32 cash and midprice levels enter it), not to the 1e-5 that holds everywhere "
+            "else; decisions and inventory stay exact.  Construct the environment with precise_state=True for the reference's float64 "
+            "rewards on clipped steps too, or widen max_inventory / max_cash.  (Shown once per environment; env.clip_count keeps counting.)",
+            Float32ClipWarning, stacklevel=3)
+        return True
+
+    def _warn_if_clipped(self):
+        """At an episode boundary of the host API (reset() waits for the stream anyway): has the clip fired since the last look?"""
+        if getattr(self, "_handle", None) is not None and not self.precise_state and not getattr(self, "_clip_warned", False):
+            self._note_clip_count(self.clip_count)
+
     def reset(self):
         """Re-initialise every lane (TE:96-101) and return the (N, D) float32 observation."""
+        self._warn_if_clipped()
         obs = self._host_buffers()["obs"].acquire()[0]
         self._reset_device(obs)
         if self._host_plugins:

@@ -244,6 +244,13 @@ def test_the_multi_rank_code_path_of_bench_runs_on_rccl_with_a_world_of_one():
     c = line["collective"]
     assert c["known_answer_ok"] is True and 0.0 < c["us"] < 5000.0 and c["per_episode_share_of_stepping"] < 0.2
     assert 60.0 < line["mean_episode_return"] < 75.0
+    # the per-rank block of the multi-rank line (round 6), through the RCCL route: what RCCL says the communicator spans, the seconds
+    # of its creation and of its FIRST collective, this rank's own launch-to-launch time, the kernel's HBM-resident rate on its device
+    (only,) = line["ranks"]
+    assert only["rank"] == 0 and only["rccl_comm_count"] == 1 and only["device_name"].startswith("gfx950")
+    assert only["seconds"]["comm_init_rank"] > 0.0 and only["seconds"]["first_collective"] > 0.0 and only["seconds"]["rendezvous_and_first_barrier"] > 0.0
+    assert only["avg_launch_us"] == pytest.approx(line["roofline"]["avg_launch_us_per_rank"]["max"], rel=1e-6)
+    assert only["hbm_resident"]["lanes"] == 1 << 24 and 0.5 < only["hbm_resident"]["frac"] < 1.0, only["hbm_resident"]
     plain = _bench("--gpus", "1", "--steps", "1100", "--warmup", "5", "--prewarm-steps", "64")
     assert "collective" not in plain and plain["mean_episode_return"] == pytest.approx(line["mean_episode_return"], rel=1e-12)
 

@@ -210,30 +210,45 @@ def test_the_bench_line_carries_the_fused_rollout():
 
 
 @pytest.mark.timeout(600)
-def test_eight_ranks_rehearsed_on_one_device():
-    """the 8-GPU box will run `bench.py --gpus 8 --steps 20 --warmup 5` once, unattended.  Rehearsed here with what one
-    device allows - eight self-spawned ranks sharing GPU 0, gloo as the transport (RCCL refuses two ranks on one device), the driver's
-    arguments, BASELINE configs[4] sharded 2^24 lanes over the ranks: rendezvous, port, prewarm drift (every rank must finish the same
-    number of episodes), memory of eight cfg1 + eight cfg4 shards, ONE JSON line - and the mean episode return equal to one rank stepping
-    the same 2^23 global lanes to 1e-12 (Philox is keyed on global lane ids; the 24-byte all-reduce is the only exchange)."""
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_ranks_rehearsed_on_one_device(ranks):
+    """the 8-GPU box will run `bench.py --gpus N --steps 20 --warmup 5` for N = 2, 4, 8 once, unattended.
+    Rehearsed here with what one device allows - N self-spawned ranks sharing GPU 0, gloo as the transport (RCCL refuses two ranks on one
+    device), the driver's arguments, BASELINE configs[4] sharded 2^24 lanes over the ranks: rendezvous, port, prewarm drift (every rank
+    must finish the same number of episodes), memory of N cfg1 + N cfg4 shards, ONE JSON line - which carries a block PER RANK (device,
+    PCI bus id, NUMA node, what the communicator spans, where the set-up seconds went, its own launch-to-launch time, the step kernel's
+    rate at a size beyond the Infinity Cache on its device), so that a scaling curve that bends explains itself without a second run -
+    and, for N = 8, the mean episode return equal to one rank stepping the same 2^23 global lanes to 1e-12 (Philox is keyed on global lane
+    ids; the 24-byte all-reduce is the only exchange)."""
     import time
 
     common = ("--steps", "20", "--warmup", "5", "--prewarm-steps", "2048", "--no-cpu-baseline")
     t0 = time.time()
-    eight = _bench("--gpus", "8", "--backend", "gloo", "--single-device", *common)
+    line = _bench("--gpus", str(ranks), "--backend", "gloo", "--single-device", "--per-rank-hbm-lanes", str(1 << 22), *common)
     wall = time.time() - t0
-    assert eight["n_gpus"] == 8 and eight["steps"] == 20 and eight["warmup"] == 5 and eight["scaling"] == "weak"
-    assert eight["config"]["num_trajectories_total"] == 8 << 20 and eight["config"]["rccl_ranks_seen"] == 8
-    assert eight["value"] == pytest.approx((8 << 20) * 20 / (eight["ms_per_step"] * 1e-3 * 20))
-    assert eight["collective"]["known_answer_ok"] is True
-    span = eight["collective"]["episodes_in_the_log_per_rank"]
+    assert line["n_gpus"] == ranks and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["config"]["num_trajectories_total"] == ranks << 20 and line["config"]["rccl_ranks_seen"] == ranks
+    assert line["value"] == pytest.approx((ranks << 20) * 20 / (line["ms_per_step"] * 1e-3 * 20))
+    assert line["collective"]["known_answer_ok"] is True
+    span = line["collective"]["episodes_in_the_log_per_rank"]
     assert span["min"] == span["max"] == 2, span  # 2048 + 5 + 20 steps of a 1000-step episode, on every rank
-    block = eight["cfg4_sharded"]
+    block = line["cfg4_sharded"]
     assert "error" not in block, block
-    assert block["num_trajectories_total"] == 1 << 24 and block["num_trajectories_per_gpu"] == 1 << 21 and block["scaling"] == "strong"
-    assert wall < 120.0, f"the 8-rank line took {wall:.0f} s"
-    one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", "--no-device-loop", *common)
-    assert one["mean_episode_return"] == pytest.approx(eight["mean_episode_return"], rel=1e-12)
+    assert block["num_trajectories_total"] == 1 << 24 and block["num_trajectories_per_gpu"] == (1 << 24) // ranks and block["scaling"] == "strong"
+    assert wall < 150.0, f"the {ranks}-rank line took {wall:.0f} s"
+    per_rank = line["ranks"]
+    assert [r["rank"] for r in per_rank] == list(range(ranks))
+    for r in per_rank:
+        assert r["device_ordinal"] == 0 and r["device_name"].startswith("gfx950") and r["pci_bus_id"].count(":") == 2 and isinstance(r["numa_node"], int)
+        assert r["seconds"]["rendezvous_and_first_barrier"] > 0.0 and r["seconds"]["warm_up_steps_and_their_collectives"] > 0.0 and r["seconds"]["known_answer_collective"] > 0.0
+        assert r["seconds"]["comm_init_rank"] is None and r["rccl_comm_count"] is None and "gloo" in r["return_allreduce"]  # (no RCCL communicator between ranks of one device)
+        assert 1.0 < r["avg_launch_us"] < 500.0
+        assert r["hbm_resident"]["lanes"] == 1 << 22 and 0.0 < r["hbm_resident"]["frac"] < 1.0, r["hbm_resident"]
+    slowest = max(r["avg_launch_us"] for r in per_rank)
+    assert slowest == pytest.approx(line["roofline"]["avg_launch_us_per_rank"]["max"], rel=1e-6)
+    if ranks == 8:
+        one = _bench("--gpus", "1", "--lanes", str(8 << 20), "--no-hbm-resident", "--no-configs", "--no-rollout", "--no-device-loop", *common)
+        assert one["mean_episode_return"] == pytest.approx(line["mean_episode_return"], rel=1e-12)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(normalise_action_space=True, normalise_observation_space=True), dict(hawkes=True, midprice="ou", ou_level=100.0, ou_speed=0.02, reward="running", phi=0.01, alpha=0.02),

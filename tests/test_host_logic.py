@@ -425,3 +425,27 @@ def test_bench_moved_bytes_are_what_the_counters_saw():
         assert abs(per_lane / bench.moved_bytes(key, precise, lam32) - 1.0) <= 0.02, (key, precise, lam32, per_lane)
         checked += 1
     assert checked == 8
+
+
+def test_the_float32_tiers_clip_warning_fires_once_and_only_where_it_applies(no_device):
+    """The one standing exception to the 1e-5 reward tolerance (TE:283-289: a clipped lane-step in the float32 tier) is announced
+    when it is actually hit - once per environment, never under precise_state, never while the count stands still."""
+    import warnings
+
+    from mbt_gym_amd.gym.TradingEnvironment import Float32ClipWarning
+
+    cfg, _ = load_case("clip_cash")
+    env = make_env(cfg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", Float32ClipWarning)
+        assert env._note_clip_count(0) is False  # nothing clipped
+    with pytest.warns(Float32ClipWarning, match=r"3 lane-step\(s\).*1\.2e-4.*precise_state=True"):
+        assert env._note_clip_count(3) is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", Float32ClipWarning)
+        assert env._note_clip_count(9) is False  # once per environment; the count is still followed
+    assert env._clips_seen == 9
+    exact = make_env(cfg, precise_state=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", Float32ClipWarning)
+        assert exact._note_clip_count(5) is False  # exact there: nothing to announce
