@@ -40,6 +40,10 @@ VARIANT = {"": "", "address,undefined": "asan", "address": "asan", "undefined": 
 if VARIANT is None:
     raise RuntimeError(f"MBT_SANITIZE={SANITIZE!r}: use address,undefined or thread")
 SANITIZE_FLAGS = [f"-fsanitize={SANITIZE}", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"] if SANITIZE else []
+# Experiments (tools/dbg/build_variant.py): MBT_BUILD_VARIANT=name with MBT_EXTRA_HIPCC_FLAGS="-D..." builds libmbtenv.<name>.so beside the
+# production library; a process loads it with MBT_LIBRARY_VARIANT=name and the same MBT_EXTRA_HIPCC_FLAGS (they are part of the source hash).
+if not VARIANT:
+    VARIANT = os.environ.get("MBT_BUILD_VARIANT", "").strip()
 
 
 def variant_path(variant: str) -> str:
@@ -173,7 +177,7 @@ def _build_locked(hipcc, target, force, verbose, jobs):
         flags = HIPCC_FLAGS + ([f'-DMBT_SOURCE_HASH="{digest}"'] + SANITIZE_FLAGS if name == "mbt_env" else [])
         obj = os.path.join(OBJ_DIR, f"{name}.{_object_key(unit, flags)[:16]}.o")
         if force or not os.path.exists(obj):
-            if not SANITIZE:  # (a sanitizer build leaves the production objects in the cache)
+            if not VARIANT:  # (a sanitizer / experiment build leaves the production objects in the cache)
                 for old in glob.glob(os.path.join(OBJ_DIR, f"{name}.*.o")):
                     os.remove(old)
             cmd = [hipcc] + flags + ["-c", unit, "-o", obj + mine]

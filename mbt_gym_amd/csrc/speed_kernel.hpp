@@ -128,7 +128,7 @@ __device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s,
   if (V::HOST_IMPACT) {
     impact = host_impact;  // price_impact_model.get_impact(action) (MD:263), evaluated by the caller's own class on the host
   } else switch (P.impact_kind) {
-    case kImpactTempPower: impact = X.temp_coef * (V::POWERS ? numpy_power(v, X.impact_exponent) : numpy_power_1_or_2(v, X.impact_exponent)); break;  // IMP:55-56
+    case kImpactTempPower: impact = X.temp_coef * (V::POWERS ? numpy_power_out_of_line(v, X.impact_exponent) : numpy_power_1_or_2(v, X.impact_exponent)); break;  // IMP:55-56
     case kImpactTempPerm:
       impact = X.temp_coef * v + s.y;                         // IMP:90-91
       y_new = s.y + X.perm_coef * v * X.impact_dt;            // IMP:87-88
@@ -150,7 +150,8 @@ __device__ __forceinline__ SpeedResultExact speed_lane_exact(const SpeedExact s,
   r.next = SpeedExact{c_clip, q_clip, mid_new, y_new};
   // (POWERS = false: the host knows every exponent is 1 or 2 and the reward is not the exponential utility - the same operations
   // without pow() / exp() in the instruction stream, which is what kept this kernel at 143 registers and 3 waves per SIMD)
-  r.reward = static_cast<float>(reward_exact<V::POWERS ? kRewardGeneral : kRewardQuadratic>(s.cash, s.q, s.mid, c_clip, q_clip, mid_new, q_init, v, is_terminal, t_now, t_next, P));
+  // (POWERS = true: pow() / exp() out of line - one body each per kernel instead of up to sixteen: 47-59 KB and 131-133 registers inlined)
+  r.reward = static_cast<float>(reward_exact<V::POWERS ? kRewardGeneral : kRewardQuadratic, true>(s.cash, s.q, s.mid, c_clip, q_clip, mid_new, q_init, v, is_terminal, t_now, t_next, P));
   r.events = (q_clip != q_new ? 64u : 0u) | (c_clip != cash_new ? 128u : 0u);
   return r;
 }

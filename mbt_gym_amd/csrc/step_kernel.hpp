@@ -464,6 +464,13 @@ __device__ __forceinline__ void exact_split(double x, float& hi, int32_t& lo) {
 
 // numpy's `q ** p` for the exponents it special-cases (2: a multiplication, 1: the value itself) and pow() otherwise
 __device__ __forceinline__ double numpy_power(double q, double p) { return p == 2.0 ? q * q : (p == 1.0 ? q : pow(q, p)); }
+// The same with the library functions OUT OF LINE: one body of pow() / exp() per kernel instead of one per call site.  For kernels
+// that advance several lanes per thread in double (the speed family's precise_state tier: four lanes, up to four pow() each - 47-59 KB
+// of code and 131-133 registers inlined, round 5) and take these paths only for exponents no reference configuration uses.  Same
+// code, same flags (-ffp-contract=off): the same bits as the inlined call.
+static __device__ __attribute__((noinline, cold)) double pow_out_of_line(double q, double p) { return pow(q, p); }
+static __device__ __attribute__((noinline, cold)) double exp_out_of_line(double x) { return exp(x); }
+__device__ __forceinline__ double numpy_power_out_of_line(double q, double p) { return p == 2.0 ? q * q : (p == 1.0 ? q : pow_out_of_line(q, p)); }
 
 // One Euler step of the midprice in double, each model in the operation order of ITS update() (MID:60-65, :95-103,
 // :140-143, :222-227, :264-270; MBT_MID_LINEAR_SDE: the order LinearSdeMidpriceModel documents).  n_bid / n_ask: 1.0 where
@@ -491,17 +498,20 @@ __device__ __forceinline__ double numpy_power_1_or_2(double q, double p) { retur
 // TIER (the float32 kernels' reward tiers): kRewardPnl - the mark-to-market change alone; kRewardQuadratic - the penalised rewards
 // with inventory exponents of 1 or 2 and no exponential utility (no pow, no exp in the instruction stream); kRewardGeneral -
 // everything.  The operations and their order are the SAME in every tier: which one runs changes no bit of the result.
-template <int TIER = kRewardGeneral>
+// OUT_OF_LINE: pow() / exp() as calls (numpy_power_out_of_line), for kernels that inline this function several times.
+template <int TIER = kRewardGeneral, bool OUT_OF_LINE = false>
 __device__ __forceinline__ double reward_exact(double cash, double q, double mid, double cash_new, double q_new, double mid_new, double q_init,
                                                double speed, bool is_terminal, double t_now, double t_next, const StepParams& P) {
   const PreciseParams& X = P.X;
   const double wealth_new = cash_new + q_new * mid_new;
   const double pnl = wealth_new - (cash + q * mid);
   if (TIER == kRewardPnl) return X.reward_scale * pnl;
-  const auto power = [](double base, double p) { return TIER == kRewardQuadratic ? numpy_power_1_or_2(base, p) : numpy_power(base, p); };
+  const auto power = [](double base, double p) {
+    return TIER == kRewardQuadratic ? numpy_power_1_or_2(base, p) : (OUT_OF_LINE ? numpy_power_out_of_line(base, p) : numpy_power(base, p));
+  };
   double reward = pnl;
   if (TIER == kRewardGeneral && P.reward_kind == kRewExpUtility) {
-    reward = is_terminal ? -exp(-X.risk_aversion * wealth_new) : 0.0;
+    reward = is_terminal ? -(OUT_OF_LINE ? exp_out_of_line(-X.risk_aversion * wealth_new) : exp(-X.risk_aversion * wealth_new)) : 0.0;
   } else if (P.reward_kind != kRewPnl) {
     const double dt = t_next - t_now;
     const double qp = power(q_new, X.exponent);

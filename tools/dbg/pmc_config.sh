@@ -4,7 +4,10 @@
 set -u
 ONLY=$1; TAG=$2; OUT=gpurun_out/dbg; mkdir -p "$OUT"; ROOT=$(pwd); export TMPDIR=/tmp
 RES="$OUT/pmc_config_$TAG.txt"; echo "# $ONLY" > "$RES"
-for GROUP in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU_TRANS SQ_INSTS_VMEM" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE"; do
+# (one small group per pass; MBT_PMC_EXTRA="A B|C D" appends groups, e.g. the LDS counters)
+PMC_GROUPS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU_TRANS SQ_INSTS_VMEM" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE")
+if [ -n "${MBT_PMC_EXTRA:-}" ]; then IFS='|' read -ra MORE <<< "$MBT_PMC_EXTRA"; PMC_GROUPS+=("${MORE[@]}"); fi
+for GROUP in "${PMC_GROUPS[@]}"; do
   D=/tmp/prof_cfg_$$_$(echo $GROUP | tr ' ' '_' | cut -c1-40); rm -rf "$D"
   (cd /tmp && MBT_BENCH_ONLY="$ONLY" MBT_BENCH_STEPS=40 MBT_BENCH_WARMUP=10 timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d "$D" -- python "$ROOT/tests/perf/bench_configs.py" > /dev/null 2> "$D.err") || { echo "# group '$GROUP' failed: $(tail -1 $D.err)" >> "$RES"; continue; }
   F=$(find "$D" -name '*counter_collection.csv' | head -1)
