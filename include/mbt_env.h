@@ -670,6 +670,12 @@ int mbt_rng_fill_quad_host(int device, uint64_t seed, uint64_t trajectory_offset
 /* Raw Philox4x32-10 block function on the device: out[4] = philox(ctr[4], key[2]) (known-answer tests). */
 int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* MEASUREMENT: the write-only floor of a recording - one launch that writes `steps` time slices into device trajectory buffers laid out as
+ * for mbt_env_rollout_device (any may be NULL), with the rollout kernel's thread mapping and store instructions and no other work; enqueued
+ * on the environment's stream, so mbt_env_timer_* bracket it like a rollout.  For bench.py: floor and rollout timed in one process against
+ * the same buffers (16-byte observation rows only).  Touches nothing of the environment. */
+int mbt_env_record_floor_device(mbt_env* env, uint32_t steps, float* obs_traj, float* act_traj, float* rew_traj);
+
 /* ---- timing on the environment's stream (HIP events) ------------------------------------------- */
 int mbt_env_timer_begin(mbt_env* env);
 int mbt_env_timer_end(mbt_env* env, float* elapsed_ms); /* = stop + elapsed: synchronises */

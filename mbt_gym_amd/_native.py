@@ -235,6 +235,7 @@ SIGNATURES = {
     "mbt_env_release_staging": (C.c_int, [_ENV]),
     "mbt_env_policy_device": (C.c_int, [_ENV, C.POINTER(MbtPolicy)]),
     "mbt_env_padded_lanes": (C.c_uint64, [_ENV]),
+    "mbt_env_record_floor_device": (C.c_int, [_ENV, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mbt_env_set_noise_host": (C.c_int, [_ENV, _F, _F, _F]),
     "mbt_env_set_user_noise_host": (C.c_int, [_ENV, _F]),
     "mbt_env_action_ptr": (C.c_void_p, [_ENV]),

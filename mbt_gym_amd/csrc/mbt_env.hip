@@ -2639,6 +2639,18 @@ int mbt_env_policy_device(mbt_env* e, const mbt_policy* policy) {
   return MBT_OK;
 }
 
+int mbt_env_record_floor_device(mbt_env* e, uint32_t steps, float* obs_traj, float* act_traj, float* rew_traj) {
+  if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
+  if (e->speed || e->dim != 4) return fail(MBT_ERR_INVALID, "the recording floor is that of 16-byte observation rows (order-book dynamics without process columns)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  RESIDENT_STOP(e);
+  uint32_t dynamic_lds = 32u * 1024u;  // what a recording rollout is launched with (launch_rollout)
+  if (const char* v = std::getenv("MBT_ROLLOUT_DYNAMIC_LDS")) dynamic_lds = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
+  hipLaunchKernelGGL(mbt::record_floor_kernel, dim3(e->n_blocks), dim3(mbt::kBlockThreads), dynamic_lds, e->stream, obs_traj, act_traj, rew_traj, e->n_pad, steps, e->dim, e->act_dim);
+  HIP_TRY(hipGetLastError());
+  return MBT_OK;
+}
+
 uint64_t mbt_env_padded_lanes(mbt_env* e) { return e != nullptr ? e->n_pad : 0; }
 
 int mbt_env_rollout_device(mbt_env* e, const mbt_policy* policy, uint32_t max_steps, float* obs_traj, float* act_traj,

@@ -1725,6 +1725,7 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
   static_assert(!LEARNED || kBlockThreads == 256, "stage_mlp_weights copies with 256 threads");
   if (LEARNED && !LP->is_linear) stage_mlp_weights(LP->w, policy_lds + kMlpLdsWaveBytesPerBlock);  // (uniform branch: the barrier inside is reached by all or none)
 #endif
+  const bool recording = R.obs_traj != nullptr || R.act_traj != nullptr || R.rew_traj != nullptr;
   for (uint32_t k = 0; k < R.n_steps; ++k) {
     LaneNoise nz[2];
     if (!LEARNED) philox_pair_noise(pair, P.philox_step + k, P.key0, P.key1, nz[0], nz[1]);
@@ -1800,6 +1801,12 @@ __device__ __forceinline__ void rollout_body(const StepBuffers& B, const StepPar
       wave_clips += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(real[l] && (r.clipped_q | r.clipped_c))));
       last_reward[l] = r.reward;
       if (B.events != nullptr) last_events[l] = event_byte(r);
+      // (ONE scalar branch per lane and step in the returns-only rollout, which is bound by instruction issue, instead of three pointer
+      // tests: 1.08 -> 1.04 us per step at 2^18 lanes, profiles/r06_mb_rollout.txt.  What round 5 suspected of the RECORDED rollout at
+      // 2^18 lanes - six stores issued back to back stall a wave that has only one neighbour on its SIMD - was built and measured this
+      // round: the step's rows kept in registers and written one store after every third Philox round of the NEXT step, 1.32-1.36 ->
+      // 1.39-1.40 us per step.  Rejected; same file.)
+      if (!recording) continue;
       if (R.obs_traj != nullptr) {
         float* slice = R.obs_traj + static_cast<size_t>(k + 1) * n_pad * V::DIM;
         if (V::PRECISE) store_row_exact<V, kStoreRecord>(slice, lanes[l], core[l], lam[l], lo[l], t, P);
@@ -1902,6 +1909,29 @@ __global__ void captured_align_kernel(DeviceClock* clock) {
   if (clock->current != 0u) {
     clock->slot[0] = clock->slot[1];
     clock->current = 0u;
+  }
+}
+
+// MEASUREMENT (mbt_env_record_floor_device): the fused rollout's recording and nothing else - the same lane <-> thread mapping, the same
+// time-major slices, the same store instructions (kStoreRecord), 28 B per lane and step for D = 4, A = 2, no arithmetic worth the name -
+// so that bench.py can time the write-only floor of a recording in the SAME process, against the SAME buffers, as the rollout it compares
+// with it (the floor moves by +-15 % with where an allocation lands: a figure from another process is another allocation).
+__global__ __launch_bounds__(kBlockThreads) void record_floor_kernel(float* obs_traj, float* act_traj, float* rew_traj, uint32_t n_pad, uint32_t steps, int dim, int act_dim) {
+  const uint32_t lanes[2] = {blockIdx.x * kTileLanes + threadIdx.x, blockIdx.x * kTileLanes + threadIdx.x + kBlockThreads};
+  float4 row[2] = {make_float4(static_cast<float>(lanes[0]), 1.f, 0.f, 100.f), make_float4(static_cast<float>(lanes[1]), -1.f, 0.f, 100.f)};
+  for (uint32_t k = 0; k < steps; ++k) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      row[l].z = static_cast<float>(k);
+      row[l].x += 1.0f;
+      if (obs_traj != nullptr && dim == 4) store_as<kStoreRecord>(reinterpret_cast<float4*>(obs_traj + static_cast<size_t>(k + 1) * n_pad * 4) + lanes[l], row[l]);
+      if (act_traj != nullptr) {
+        float* dst = act_traj + static_cast<size_t>(k) * n_pad * act_dim;
+        if (act_dim == 2) store_as<kStoreRecord>(reinterpret_cast<float2*>(dst) + lanes[l], make_float2(row[l].w, row[l].x));
+        else store_as<kStoreRecord>(reinterpret_cast<float4*>(dst) + lanes[l], row[l]);
+      }
+      if (rew_traj != nullptr) store_as<kStoreRecord>(rew_traj + static_cast<size_t>(k) * n_pad + lanes[l], row[l].x);
+    }
   }
 }
 
