@@ -62,9 +62,9 @@ def default_prewarm_steps(lanes):
 
 
 # BASELINE.json configs[1..4] as the public plugin API builds them (sizes, parameters, credited bytes).
-# `kernel`: the template arguments of the step kernel the library picks (mbt_env.hip: pick_kernel) - arrival layout, dynamics,
-# Brownian, reward tier, normalised, injected noise, exogenous fill - to which the tier (precise_state) and the load policy
-# (STREAM beyond 320 MB per launch) are appended: the name a rocprofv3 kernel-stats row carries.
+# `kernel`: what decides the step kernel the library picks (mbt_env.hip: pick_kernel) - arrival layout (0 Poisson, 1 Hawkes), dynamics
+# (0 limit, 1 limit + market), plain Brownian midprice, reward weight (0 PnL, 1 quadratic penalties) - from which kernel_shape() forms the
+# kernel's list of named tags and kernel_name() the name a rocprofv3 kernel-stats row carries.
 WORKLOADS = {
     "cfg1": dict(label="cfg1 Avellaneda-Stoikov (BM, Poisson, exponential fills, PnL)", lanes=1 << 20, dim=4, act=2, kernel=(0, 0, True, 0)),
     "cfg2_cjmm": dict(label="cfg2 Cartea-Jaimungal-Penalva, CjMmCriterion(0.01, 0.001)", lanes=1 << 20, dim=4, act=2, kernel=(0, 0, True, 1)),
@@ -104,18 +104,33 @@ def tier_label(key, precise, lam32=False):
     return "float32"
 
 
-def kernel_name(key, precise, lanes, lam32=False):
+def kernel_shape(key, precise, lam32=False):
+    """The named tags of the step kernel the library picks for a workload (csrc/step_kernel.hpp: Variant<tags...>; the mapping from a
+    configuration is csrc/kernel_table.hpp: OrderBookShape), in the table's order - e.g. ["brownian", "pnl"] for BASELINE configs[1]."""
     arr, dyn, bm, rew = WORKLOADS[key]["kernel"]
+    tags = []
+    if arr == 1:
+        tags.append("hawkes" if (precise or lam32) else "hawkes_exact")  # (precise_state holds EVERY column exactly: the plain Hawkes layout)
+    if dyn == 1:
+        tags.append("limit_and_market")
+    if bm:
+        tags.append("brownian")
+    tags.append({0: "pnl", 1: "quadratic"}[rew])
+    if precise:
+        tags.append("precise")
+    return tags
+
+
+def kernel_name(key, precise, lanes, lam32=False):
+    """The name a rocprofv3 kernel-stats row carries for that kernel: step_kernel<Variant<tags...>, STREAM, MIRROR>."""
     # non-temporal loads once the lines a launch touches no longer fit the Infinity Cache: 16-byte rows beyond 300 MB DISTINCT (the state
     # is updated in place), other row widths beyond 640 MB moved (mbt_env.hip: tune_for_size)
     w = WORKLOADS[key]
     distinct = lanes * 4 * (w["dim"] + w["act"] + 1 + remainder_columns(key, precise, lam32))
     stream = distinct > (300 << 20) if w["dim"] == 4 else lanes * moved_bytes(key, precise, lam32) > (640 << 20)
-    b = lambda x: "true" if x else "false"  # noqa: E731
-    exact_lam = arr == 1 and not precise and not lam32  # Variant::EXACT_LAM, the last template argument
-    # step_kernel<Variant<...>, STREAM, MIRROR>: the mirror instantiation serves small batches over the host API only
-    return (f"mbt::step_kernel<mbt::Variant<{arr}, {dyn}, {b(bm)}, {rew}, false, false, false, {b(precise)}, false, false, false, false, 0, false, 0, {b(exact_lam)}>, "
-            f"{b(stream)}, false>")
+    shape = ", ".join("mbt::shape::" + tag for tag in kernel_shape(key, precise, lam32))
+    # (the mirror instantiation - the last argument - serves small batches over the host API only)
+    return f"mbt::step_kernel<mbt::Variant<{shape}>, {'true' if stream else 'false'}, false>"
 
 
 def build_env(n, offset, device, workload="cfg1", precise=False, lam32=False):

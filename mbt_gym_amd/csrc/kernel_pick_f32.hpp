@@ -9,7 +9,7 @@
 namespace mbt_table {
 
 template <int ARR, bool XL, int DYN, bool BM, int REW, bool NORM, bool INJECT>
-using OrderBookVariant = mbt::Variant<ARR, DYN, BM, REW, NORM, INJECT, false, false, false, false, false, false, 0, false, 0, XL>;
+using OrderBookVariant = OrderBookShape<ARR, XL, DYN, BM, REW, NORM, INJECT>;
 
 template <int ARR, bool XL, int DYN, bool BM, int REW, bool NORM>
 StepKernel pick_noise(bool inject, int mode) {

@@ -46,6 +46,25 @@ StepKernel pick_injected(int mode) {
   return (mode == kMirror || mode == kCaptured || mode == kCapturedStream) ? nullptr : mbt::step_kernel<V_INJECT>;
 }
 
+// ---- THE mapping from a configuration's values to a kernel's shape (step_kernel.hpp: Variant<tags...>) ---------------------------
+// The pick functions of csrc/kernels_*.hip branch over run-time values down to compile-time ones; this is where those become the list of
+// named tags a kernel is instantiated (and shown by a profiler) with.  ARR: mbt::kArrPoisson / kArrHawkes, XL: Hawkes intensities held
+// exactly; DYN: mbt::kDyn*; BM: plain Brownian midprice; REW: mbt::kReward*.
+template <int ARR, bool XL, int DYN, bool BM, int REW, bool NORM, bool INJECT, bool EXO = false, bool PRECISE = false>
+using OrderBookShape = mbt::shape::make<
+    mbt::shape::when<ARR == mbt::kArrHawkes && !XL, mbt::shape::hawkes>, mbt::shape::when<ARR == mbt::kArrHawkes && XL, mbt::shape::hawkes_exact>,
+    mbt::shape::when<DYN == mbt::kDynLimitAndMarket, mbt::shape::limit_and_market>, mbt::shape::when<DYN == mbt::kDynTouch, mbt::shape::touch>,
+    mbt::shape::when<BM, mbt::shape::brownian>, mbt::shape::when<REW == mbt::kRewardPnl, mbt::shape::pnl>, mbt::shape::when<REW == mbt::kRewardQuadratic, mbt::shape::quadratic>,
+    mbt::shape::when<NORM, mbt::shape::normalised>, mbt::shape::when<INJECT, mbt::shape::injected>, mbt::shape::when<EXO, mbt::shape::exogenous>,
+    mbt::shape::when<PRECISE, mbt::shape::precise>>;
+// ... and for trading-with-speed dynamics (speed_kernel.hpp: SpeedVariant<tags...>)
+template <class List> struct speed_variant_of;
+template <class... Tags> struct speed_variant_of<mbt::shape::tags<Tags...>> { using type = mbt::SpeedVariant<Tags...>; };
+template <bool STATE, bool NORM, bool INJECT, bool PRECISE = false, bool POW = true, bool HOST_IMPACT = false>
+using SpeedShape = typename speed_variant_of<typename mbt::shape::join_all<
+    mbt::shape::when<STATE, mbt::shape::impact_state>, mbt::shape::when<NORM, mbt::shape::normalised>, mbt::shape::when<INJECT, mbt::shape::injected>,
+    mbt::shape::when<PRECISE, mbt::shape::precise>, mbt::shape::when<POW, mbt::shape::powers>, mbt::shape::when<HOST_IMPACT, mbt::shape::host_impact>>::type>::type;
+
 // ---- predicates on a configuration that both the table and the C ABI use ------------------------------------------------
 // how heavy the reward is (Variant::REWARD)
 inline int reward_weight(const mbt_config& c) {

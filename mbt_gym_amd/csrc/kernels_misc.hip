@@ -5,7 +5,7 @@
 namespace mbt_table {
 namespace {
 template <int ARR, bool XL, int DYN, bool INJECT>
-using Exo = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, INJECT, true, false, false, false, false, false, 0, false, 0, XL>;
+using Exo = OrderBookShape<ARR, XL, DYN, false, mbt::kRewardGeneral, true, INJECT, true>;
 
 template <int ARR, bool XL, int DYN>
 StepKernel pick_exogenous(bool inject, int mode) {
@@ -28,8 +28,8 @@ RolloutKernel rpick_exogenous(bool market) {
 // coefficients, every reward); both with run-time normalisation flags.
 template <int ARR, bool XL, int DYN>
 LearnedRolloutKernel pick_learned_tier(bool brownian_pnl) {
-  using B = mbt::Variant<ARR, DYN, true, mbt::kRewardPnl, true, false, false, false, false, false, false, false, 0, false, 0, XL>;
-  using G = mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, false, false, false, false, false, false, 0, false, 0, XL>;
+  using B = OrderBookShape<ARR, XL, DYN, true, mbt::kRewardPnl, true, false>;
+  using G = OrderBookShape<ARR, XL, DYN, false, mbt::kRewardGeneral, true, false>;
   return brownian_pnl ? mbt::learned_rollout_kernel<B> : mbt::learned_rollout_kernel<G>;
 }
 template <int ARR, bool XL>

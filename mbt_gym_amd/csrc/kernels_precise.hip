@@ -12,13 +12,13 @@ namespace mbt_table {
 namespace {
 template <int ARR, int DYN, bool EXO>
 StepKernel pick_precise(bool inject, int mode) {
-  if (inject) return pick_injected<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>(mode);
-  return pick_mode<mbt::Variant<ARR, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>(mode);
+  if (inject) return pick_injected<OrderBookShape<ARR, false, DYN, false, mbt::kRewardGeneral, true, true, EXO, true>>(mode);
+  return pick_mode<OrderBookShape<ARR, false, DYN, false, mbt::kRewardGeneral, true, false, EXO, true>>(mode);
 }
 template <int ARR, int DYN, int REW>
 StepKernel pick_precise_special(bool brownian, int mode) {
-  using B = mbt::Variant<ARR, DYN, true, REW, false, false, false, true>;   // Brownian midprice (BASELINE configs 1, 2, 4)
-  using G = mbt::Variant<ARR, DYN, false, REW, false, false, false, true>;  // any other built-in midprice (config 3: OU)
+  using B = OrderBookShape<ARR, false, DYN, true, REW, false, false, false, true>;   // Brownian midprice (BASELINE configs 1, 2, 4)
+  using G = OrderBookShape<ARR, false, DYN, false, REW, false, false, false, true>;  // any other built-in midprice (config 3: OU)
   return brownian ? pick_mode<B>(mode) : pick_mode<G>(mode);
 }
 template <int ARR, int DYN>
@@ -39,12 +39,12 @@ template <int ARR>
 RolloutKernel rpick_precise(int dyn, bool exo) {
   switch (dyn) {
     case MBT_DYN_LIMIT:
-      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true, true>>
-                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
+      return exo ? mbt::rollout_kernel<OrderBookShape<ARR, false, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, true, true>>
+                 : mbt::rollout_kernel<OrderBookShape<ARR, false, mbt::kDynLimit, false, mbt::kRewardGeneral, true, false, false, true>>;
     case MBT_DYN_LIMIT_AND_MARKET:
-      return exo ? mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true, true>>
-                 : mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
-    default: return mbt::rollout_kernel<mbt::Variant<ARR, mbt::kDynTouch, false, mbt::kRewardGeneral, true, false, false, true>>;
+      return exo ? mbt::rollout_kernel<OrderBookShape<ARR, false, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, true, true>>
+                 : mbt::rollout_kernel<OrderBookShape<ARR, false, mbt::kDynLimitAndMarket, false, mbt::kRewardGeneral, true, false, false, true>>;
+    default: return mbt::rollout_kernel<OrderBookShape<ARR, false, mbt::kDynTouch, false, mbt::kRewardGeneral, true, false, false, true>>;
   }
 }
 }  // namespace

@@ -6,7 +6,7 @@
 namespace mbt_table {
 namespace {
 template <int ARR, bool XL, int DYN, bool BM, int REW, bool NORM>
-using V = mbt::Variant<ARR, DYN, BM, REW, NORM, false, false, false, false, false, false, false, 0, false, 0, XL>;
+using V = OrderBookShape<ARR, XL, DYN, BM, REW, NORM, false>;
 
 template <int ARR, bool XL, int DYN, bool BM>
 RolloutKernel rpick_rew(int rew, bool norm) {

@@ -20,8 +20,8 @@ StepKernel pick_speed_mode(bool inject, int mode) {
 }
 template <bool STATE, bool POW>
 StepKernel pick_speed_pow(bool norm, bool inject, int mode) {
-  return norm ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, false, POW>, mbt::SpeedVariant<STATE, true, true, false, POW>, STATE>(inject, mode)
-              : pick_speed_mode<mbt::SpeedVariant<STATE, false, false, false, POW>, mbt::SpeedVariant<STATE, false, true, false, POW>, STATE>(inject, mode);
+  return norm ? pick_speed_mode<SpeedShape<STATE, true, false, false, POW>, SpeedShape<STATE, true, true, false, POW>, STATE>(inject, mode)
+              : pick_speed_mode<SpeedShape<STATE, false, false, false, POW>, SpeedShape<STATE, false, true, false, POW>, STATE>(inject, mode);
 }
 template <bool STATE>
 StepKernel pick_speed(bool powers, bool norm, bool inject, int mode) {
@@ -30,17 +30,17 @@ StepKernel pick_speed(bool powers, bool norm, bool inject, int mode) {
 // (the precise_state tier of the speed family is the same kernel; POW as for the float32 tier)
 template <bool STATE>
 StepKernel pick_speed_precise(bool powers, bool inject, int mode) {
-  return powers ? pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true>, mbt::SpeedVariant<STATE, true, true, true, true>, STATE>(inject, mode)
-                : pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, false>, mbt::SpeedVariant<STATE, true, true, true, false>, STATE>(inject, mode);
+  return powers ? pick_speed_mode<SpeedShape<STATE, true, false, true, true>, SpeedShape<STATE, true, true, true, true>, STATE>(inject, mode)
+                : pick_speed_mode<SpeedShape<STATE, true, false, true, false>, SpeedShape<STATE, true, true, true, false>, STATE>(inject, mode);
 }
 // (a host-callback price impact model: the precise_state kernels with SpeedVariant::HOST_IMPACT, general reward form)
 template <bool STATE>
 StepKernel pick_speed_host_impact(bool inject, int mode) {
-  return pick_speed_mode<mbt::SpeedVariant<STATE, true, false, true, true, true>, mbt::SpeedVariant<STATE, true, true, true, true, true>, STATE>(inject, mode);
+  return pick_speed_mode<SpeedShape<STATE, true, false, true, true, true>, SpeedShape<STATE, true, true, true, true, true>, STATE>(inject, mode);
 }
 template <bool STATE, bool POW>
 RolloutKernel pick_speed_rollout(bool norm) {
-  return norm ? mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, true, false, false, POW>> : mbt::speed_rollout_kernel<mbt::SpeedVariant<STATE, false, false, false, POW>>;
+  return norm ? mbt::speed_rollout_kernel<SpeedShape<STATE, true, false, false, POW>> : mbt::speed_rollout_kernel<SpeedShape<STATE, false, false, false, POW>>;
 }
 }  // namespace
 
@@ -54,7 +54,7 @@ StepKernel pick_step_speed(const mbt_config& c, int mode) {
 RolloutKernel pick_rollout_speed(const mbt_config& c) {
   const bool norm = c.normalise_action != 0 || c.normalise_observation != 0;
   if (c.precise_state)
-    return impact_has_state(c) ? mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<true, true, false, true>> : mbt::speed_rollout_exact_kernel<mbt::SpeedVariant<false, true, false, true>>;
+    return impact_has_state(c) ? mbt::speed_rollout_exact_kernel<SpeedShape<true, true, false, true>> : mbt::speed_rollout_exact_kernel<SpeedShape<false, true, false, true>>;
   if (impact_has_state(c)) return speed_powers(c) ? pick_speed_rollout<true, true>(norm) : pick_speed_rollout<true, false>(norm);
   return speed_powers(c) ? pick_speed_rollout<false, true>(norm) : pick_speed_rollout<false, false>(norm);
 }

@@ -1437,8 +1437,28 @@ int jit_source(const mbt_config& c, const mbt_user_code& u, std::string& src) {
          // (a column the HOST advances - a host-callback arrival model's own state - passes through the kernel unchanged: "x0" / "x1")
          "  if (which == 0) { const double dt = " + owner_dt(0) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 0 ? (u.state_update[0] != nullptr && u.state_update[0][0] != 0 ? u.state_update[0] : "x0") : "0.0") + "); }\n"
          "  { const double dt = " + owner_dt(1) + "; (void)dt; return static_cast<double>(" + std::string(user_state > 1 ? (u.state_update[1] != nullptr && u.state_update[1][0] != 0 ? u.state_update[1] : "x1") : "0.0") + "); }\n}\n}  // namespace mbt\n";
-  src += "using V = mbt::Variant<" + std::to_string(arr) + ", " + std::to_string(dyn) + ", false, mbt::kRewardGeneral, true, " + (inject ? "true" : "false") +
-         ", " + (exogenous_fill(c) ? "true" : "false") + ", " + (c.precise_state ? "true" : "false") + ", " + (user_fill ? "true" : "false") + ", " + (user_reward ? "true" : "false") + ", " + (user_arrival ? "true" : "false") + ", " + (user_mid ? "true" : "false") + ", " + std::to_string(user_state) + ", " + (u.extra_normals ? "true" : "false") + ", " + std::to_string(host_mask) + ", " + (exact_intensities(c) ? "true" : "false") + ">;\n";
+  {  // the kernel's shape as its list of named tags (step_kernel.hpp: Variant) - the general tier: any midprice, every reward, normalisation flags at run time
+    std::string tags;
+    const auto tag = [&tags](bool on, const std::string& name) {
+      if (on) tags += (tags.empty() ? "" : ", ") + ("mbt::shape::" + name);
+    };
+    tag(arr == mbt::kArrHawkes && !exact_intensities(c), "hawkes");
+    tag(arr == mbt::kArrHawkes && exact_intensities(c), "hawkes_exact");
+    tag(dyn == mbt::kDynLimitAndMarket, "limit_and_market");
+    tag(dyn == mbt::kDynTouch, "touch");
+    tag(true, "normalised");
+    tag(inject, "injected");
+    tag(exogenous_fill(c), "exogenous");
+    tag(c.precise_state != 0, "precise");
+    tag(user_fill, "user_fill");
+    tag(user_reward, "user_reward");
+    tag(user_arrival, "user_arrival");
+    tag(user_mid, "user_mid");
+    tag(user_state != 0, "user_state<" + std::to_string(user_state) + ">");
+    tag(u.extra_normals != 0, "user_draws");
+    tag(host_mask != 0, "host<" + std::to_string(host_mask) + ">");
+    src += "using V = mbt::Variant<" + tags + ">;\n";
+  }
   src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false>(B, P); }\n";
   if (!inject)  // the small-batch host-API instantiation (step_kernel.hpp: signal_host)
     src += "extern \"C\" __global__ __launch_bounds__(256) void mbt_user_step_mirror(const mbt::StepBuffers B, const mbt::StepParams P) { mbt::step_body<V, false, true>(B, P); }\n";

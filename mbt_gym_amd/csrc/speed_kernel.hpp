@@ -23,26 +23,36 @@
 
 namespace mbt {
 
-template <bool HAS_IMPACT_STATE_, bool NORM_, bool INJECT_, bool PRECISE_ = false, bool POWERS_ = true, bool HOST_IMPACT_ = false>
+// The shape of a speed kernel, as a list of named tags like the order-book kernels' (step_kernel.hpp: Variant):
+// `SpeedVariant<shape::impact_state, shape::normalised, shape::precise>`.  kernels_speed.hip holds the mapping from a configuration.
+namespace shape {
+struct impact_state {};  // the price impact model owns a state column y: rows of D = 5
+struct powers {};        // the instantiation can raise to arbitrary powers (see POWERS below)
+struct host_impact {};   // a PriceImpactModel subclass that only has HOST code
+template <class T> constexpr bool known_speed = has<T, impact_state, normalised, injected, precise, powers, host_impact>;
+}  // namespace shape
+
+template <class... Tags>
 struct SpeedVariant {
-  static constexpr bool HAS_IMPACT_STATE = HAS_IMPACT_STATE_, NORM = NORM_, INJECT = INJECT_;
+  static_assert((shape::known_speed<Tags> && ... && true), "unknown shape tag of a speed kernel");
+  static constexpr bool HAS_IMPACT_STATE = shape::has<shape::impact_state, Tags...>, NORM = shape::has<shape::normalised, Tags...>, INJECT = shape::has<shape::injected, Tags...>;
+  // precise_state: [cash, inventory, midprice, impact state] held exactly as the reference's float64 values (the row's
+  // float32 + an int32 remainder each, step_kernel.hpp: exact_join) and stepped in double in the reference's operation order
+  static constexpr bool PRECISE = shape::has<shape::precise, Tags...>;
   // HOST_IMPACT: a PriceImpactModel subclass that only has HOST code (MBT_IMPACT_HOST / MBT_IMPACT_HOST_STATE): the (N) float64
   // impacts its get_impact(action) returned for this step are read from StepBuffers::host_fill_p, its state column (if it owns
   // one) passes through unchanged - ITS update() advances it on the host (mbt_env_set_host_state_columns).  precise_state only.
-  static constexpr bool HOST_IMPACT = HOST_IMPACT_;
-  static_assert(!HOST_IMPACT_ || PRECISE_, "host-computed price impacts are float64 values: the precise_state tier");
+  static constexpr bool HOST_IMPACT = shape::has<shape::host_impact, Tags...>;
+  static_assert(!HOST_IMPACT || PRECISE, "host-computed price impacts are float64 values: the precise_state tier");
   // POWERS: the instantiation can raise to arbitrary powers (a temporary impact with exponent != 1, IMP:55; an inventory
   // penalty with exponent != 2, RW:59-68; exponential utility).  Every reference configuration has exponent 1 / 2: the host
-  // picks the instantiation WITHOUT them then (mbt_env.hip: pick_speed) - four inlined powf bodies made the kernel 3300
+  // picks the instantiation WITHOUT them then (kernels_speed.hip) - four inlined powf bodies made the kernel 3300
   // instructions (20 KB of code for a 40-byte-per-lane copy), 740 without.
-  static constexpr bool POWERS = POWERS_;
-  // precise_state: [cash, inventory, midprice, impact state] held exactly as the reference's float64 values (the row's
-  // float32 + an int32 remainder each, step_kernel.hpp: exact_join) and stepped in double in the reference's operation order
-  static constexpr bool PRECISE = PRECISE_;
-  static constexpr int RES = PRECISE_ ? 4 : 0;
+  static constexpr bool POWERS = shape::has<shape::powers, Tags...>;
+  static constexpr int RES = PRECISE ? 4 : 0;
   static constexpr bool PENALISED = true;  // optimal-execution rewards are almost never plain PnL: one (general) variant
   static constexpr int REWARD = kRewardGeneral;
-  static constexpr int DIM = HAS_IMPACT_STATE_ ? 5 : 4;
+  static constexpr int DIM = HAS_IMPACT_STATE ? 5 : 4;
 };
 
 struct QuadNoise {

@@ -59,53 +59,108 @@ enum : int { kImpactTempPower = 0, kImpactTempPerm = 1, kImpactTempTransient = 2
 enum : int { kRewardPnl = 0, kRewardQuadratic = 1, kRewardGeneral = 2 };
 enum : int { kHostFill = 1, kHostArrival = 2, kHostReward = 4, kHostImpact = 8 /* speed kernels: SpeedVariant::HOST_IMPACT; host library only */ };
 
-template <int ARR_, int DYN_, bool BROWNIAN_, int REWARD_, bool NORM_, bool INJECT_, bool EXO_ = false, bool PRECISE_ = false,
-          bool USER_FILL_ = false, bool USER_REWARD_ = false, bool USER_ARRIVAL_ = false, bool USER_MID_ = false, int USER_STATE_ = 0,
-          bool USER_DRAWS_ = false, int HOST_ = 0, bool EXACT_LAM_ = false>
+// A kernel's shape is a LIST OF NAMED TAGS - `Variant<shape::brownian, shape::pnl>` is the Avellaneda-Stoikov kernel of BASELINE
+// configs[1], `Variant<shape::hawkes_exact, shape::normalised>` a Hawkes kernel with exact intensities and normalised spaces - not a
+// row of sixteen positional booleans: what is not named takes its default, the order of the tags does not matter to what is compiled, an
+// unknown tag does not compile, and the name a profiler prints for a kernel says what the kernel is.  (Rounds 1-5:
+// `Variant<1, 0, false, 0, false, false, false, false, false, false, false, false, 0, false, 0, true>` - one transposed `false` selected
+// another kernel silently.)  kernel_table.hpp holds the ONE mapping from a configuration's values to a shape (OrderBookShape).
+namespace shape {
+// arrivals (default: the Poisson layout - Poisson, PoissonNonLinear and user arrival expressions share it)
+struct hawkes {};        // two intensity columns, float32 (mbt_config::hawkes_float32_intensities)
+struct hawkes_exact {};  // ... held exactly: float32 rounding in the row + an int32 remainder beside it (the default Hawkes tier)
+// dynamics (default: limit orders)
+struct limit_and_market {};
+struct touch {};
+// midprice (default: any model, through run-time coefficients)
+struct brownian {};      // plain Brownian motion: the increment needs nothing from memory
+// how heavy the reward is (default: general - other exponents via powf, exponential utility)
+struct pnl {};           // plain PnL
+struct quadratic {};     // RunningInventoryPenalty / CjMmCriterion with exponent 2 (branch-free)
+struct normalised {};    // normalised actions and / or observations (TE:112-126)
+struct injected {};      // noise loaded from HBM instead of Philox (parity mode)
+struct exogenous {};     // ExogenousMmFillProbabilityModel: two more columns holding the exogenous best depths
+struct precise {};       // precise_state: the reference's float64 state, exactly
+// run-time compiled plugins (mbt_env_create_jit)
+struct user_fill {};
+struct user_reward {};
+struct user_arrival {};
+struct user_mid {};
+struct user_draws {};                  // the user's processes consume two more normals per lane and step
+template <int N> struct user_state {}; // state columns owned by user processes: 1 or 2
+template <int MASK> struct host {};    // host-callback plugins: kHostFill | kHostArrival | kHostReward
+
+template <class A, class B> struct same_tag { static constexpr bool value = false; };
+template <class A> struct same_tag<A, A> { static constexpr bool value = true; };
+template <class T, class... Tags> constexpr bool has = (same_tag<T, Tags>::value || ... || false);
+template <class T> struct columns_of { static constexpr int value = 0; };
+template <int N> struct columns_of<user_state<N>> { static constexpr int value = N; };
+template <class T> struct host_mask_of { static constexpr int value = 0; };
+template <int MASK> struct host_mask_of<host<MASK>> { static constexpr int value = MASK; };
+template <class T> constexpr bool known = has<T, hawkes, hawkes_exact, limit_and_market, touch, brownian, pnl, quadratic, normalised, injected, exogenous, precise, user_fill,
+                                              user_reward, user_arrival, user_mid, user_draws> || columns_of<T>::value != 0 || host_mask_of<T>::value != 0;
+
+// lists of tags, for code that assembles a shape from values (kernel_table.hpp): make<when<COND, tag>, ...> is the Variant of the tags whose
+// condition holds, in the order written
+template <class... Tags> struct tags {};
+template <bool COND, class T> struct when_impl { using type = tags<>; };
+template <class T> struct when_impl<true, T> { using type = tags<T>; };
+template <bool COND, class T> using when = typename when_impl<COND, T>::type;
+template <class A, class B> struct joined;
+template <class... A, class... B> struct joined<tags<A...>, tags<B...>> { using type = tags<A..., B...>; };
+template <class... Lists> struct join_all { using type = tags<>; };
+template <class First, class... Rest> struct join_all<First, Rest...> { using type = typename joined<First, typename join_all<Rest...>::type>::type; };
+}  // namespace shape
+
+template <class... Tags>
 struct Variant {
-  static constexpr int ARR = ARR_, DYN = DYN_;
-  static constexpr bool BROWNIAN = BROWNIAN_;  // plain Brownian midprice: the increment needs nothing from memory
+  static_assert((shape::known<Tags> && ... && true), "unknown shape tag");
+  template <class T> static constexpr bool has = shape::has<T, Tags...>;
+  static constexpr int ARR = (has<shape::hawkes> || has<shape::hawkes_exact>) ? kArrHawkes : kArrPoisson;
+  static constexpr int DYN = has<shape::limit_and_market> ? kDynLimitAndMarket : has<shape::touch> ? kDynTouch : kDynLimit;
+  static_assert(!(has<shape::hawkes> && has<shape::hawkes_exact>) && !(has<shape::limit_and_market> && has<shape::touch>) && !(has<shape::pnl> && has<shape::quadratic>),
+                "contradicting shape tags");
+  static constexpr bool BROWNIAN = has<shape::brownian>;  // plain Brownian midprice: the increment needs nothing from memory
   // how heavy the reward is: plain PnL | RunningInventoryPenalty / CjMmCriterion with exponent 2 (branch-free) |
   // everything else (other exponents via powf, exponential utility) - keeps the common kernels free of that code
-  static constexpr int REWARD = REWARD_;
-  static constexpr bool PENALISED = REWARD_ != kRewardPnl;
-  static constexpr bool NORM = NORM_;      // normalised actions and/or observations (TE:112-126)
-  static constexpr bool INJECT = INJECT_;  // noise loaded from HBM instead of Philox
+  static constexpr int REWARD = has<shape::pnl> ? kRewardPnl : has<shape::quadratic> ? kRewardQuadratic : kRewardGeneral;
+  static constexpr bool PENALISED = REWARD != kRewardPnl;
+  static constexpr bool NORM = has<shape::normalised>;  // normalised actions and/or observations (TE:112-126)
+  static constexpr bool INJECT = has<shape::injected>;  // noise loaded from HBM instead of Philox
   // ExogenousMmFillProbabilityModel (FILL:126-170): two more columns holding the exogenous best depths, which the
   // reference never advances (FILL:168-170) - the kernel does not load them, it writes the constants.  Instantiated
-  // only on the general tier (BROWNIAN false, kRewardGeneral, NORM true: each a superset of the specialised code).
-  static constexpr bool EXO = EXO_;
+  // only on the general tier (no brownian / pnl / quadratic tag, normalised: each a superset of the specialised code).
+  static constexpr bool EXO = has<shape::exogenous>;
   // precise_state (mbt_config): every real-valued state column is held EXACTLY as the reference's float64 value - the row
   // holds its float32 rounding (what the observation shows), a side buffer of int32 the rest (exact_join / exact_split) -
   // and the step is evaluated in double in the reference's own order of operations (lane_step_exact): state and rewards
-  // are the reference's float64 results, bit for bit, rounded once to float32 on the way out.  General tier only, like EXO.
-  static constexpr bool PRECISE = PRECISE_;
+  // are the reference's float64 results, bit for bit, rounded once to float32 on the way out.
+  static constexpr bool PRECISE = has<shape::precise>;
   // Exact Hawkes intensities in the float32 tier (mbt_config::hawkes_float32_intensities == 0, the default): ARR:110-123 keeps
   // lambda in float64 and decides `u < lambda dt` on it, so a float32 lambda decides ~1e-6 of lane-steps differently.  Here ONLY
   // the two intensity columns are held exactly (float32 rounding in the row + int32 remainder beside it, exact_join /
   // exact_split), the recursion and the threshold are evaluated in double in the reference's order; cash and midprice stay
   // float32 with the increment-form reward.  +16 B per env-step (76 instead of 60); arrivals, fills and inventory are then the
-  // reference's on the same draws in EVERY tier.  Meaningless (and off) under PRECISE, which holds every column exactly.
-  static constexpr bool EXACT_LAM = EXACT_LAM_ && !PRECISE_ && ARR_ == kArrHawkes;
-  static_assert(!EXACT_LAM_ || ARR_ == kArrHawkes, "exact intensities are a property of the Hawkes arrival model");
-  // residual columns: PRECISE [cash, midprice (, the two columns after it)]; EXACT_LAM [bid intensity, ask intensity]
-  static constexpr int RES = PRECISE_ ? ((ARR_ == kArrHawkes || USER_STATE_ != 0) ? 4 : 2) : (EXACT_LAM ? 2 : 0);
+  // reference's on the same draws in EVERY tier.  Meaningless (and off) under precise, which holds every column exactly.
+  static constexpr bool EXACT_LAM = has<shape::hawkes_exact> && !PRECISE;
   // User-defined plugins (mbt_env_create_jit): this header is compiled at RUN TIME (hiprtc) together with the user's
   // device expressions for FillProbabilityModel._get_fill_probabilities (FILL:22-34) and / or RewardFunction.calculate
   // (RW:8-17); general tier only.  Never instantiated in the ahead-of-time library.
-  static constexpr bool USER_FILL = USER_FILL_, USER_REWARD = USER_REWARD_;
-  static constexpr bool USER_MID = USER_MID_;  // MidpriceModel.update as an expression for S' - S (one column, one normal per step)
-  static constexpr bool USER_ARRIVAL = USER_ARRIVAL_;  // a stateless ArrivalModel.get_arrivals (ARR:27-29) as an expression of time
-  static_assert(!(USER_ARRIVAL_ && ARR_ == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (its state columns are USER_STATE)");
+  static constexpr bool USER_FILL = has<shape::user_fill>, USER_REWARD = has<shape::user_reward>;
+  static constexpr bool USER_MID = has<shape::user_mid>;  // MidpriceModel.update as an expression for S' - S (one column, one normal per step)
+  static constexpr bool USER_ARRIVAL = has<shape::user_arrival>;  // a stateless ArrivalModel.get_arrivals (ARR:27-29) as an expression of time
+  static_assert(!(USER_ARRIVAL && ARR == kArrHawkes), "a user arrival model replaces the arrival model: Poisson layout (its state columns are user_state)");
   // State columns OWNED by user-defined processes (SP:8-53: a subclass carries its own (N, d) state): 0, 1 or 2 columns
   // x0, x1 right after the midprice, in the reference's registry order (a second midprice factor first, then the arrival
   // model's columns, TE:303-318).  They live where the Hawkes intensities of the built-in model live (`lam`), are advanced
-  // by the user's state_update expressions, and may be read by the user's midprice and arrival expressions.  USER_DRAWS:
+  // by the user's state_update expressions, and may be read by the user's midprice and arrival expressions.  user_draws:
   // the user's processes consume two more standard normals per lane and step (a third Philox block per pair of lanes).
-  static constexpr int USER_STATE = USER_STATE_;
-  static constexpr bool USER_DRAWS = USER_DRAWS_;
-  static_assert(USER_STATE_ >= 0 && USER_STATE_ <= 2, "at most two user state columns");
-  static_assert(!(USER_STATE_ != 0 && (ARR_ == kArrHawkes || EXO_)), "user state columns take the place of the Hawkes intensities / exogenous depths");
+  static constexpr int USER_STATE = (shape::columns_of<Tags>::value + ... + 0);
+  static constexpr bool USER_DRAWS = has<shape::user_draws>;
+  static_assert(USER_STATE >= 0 && USER_STATE <= 2, "at most two user state columns");
+  static_assert(!(USER_STATE != 0 && (ARR == kArrHawkes || EXO)), "user state columns take the place of the Hawkes intensities / exogenous depths");
+  // residual columns: precise [cash, midprice (, the two columns after it)]; exact intensities [bid intensity, ask intensity]
+  static constexpr int RES = PRECISE ? ((ARR == kArrHawkes || USER_STATE != 0) ? 4 : 2) : (EXACT_LAM ? 2 : 0);
   // HOST-CALLBACK plugins (mbt_env_create_jit, no device expression): a subclass of the reference's plugin contract that only
   // has NumPy code (FILL:22-34 `_get_fill_probabilities`, ARR:27-29 `get_arrivals`, RW:10-13 `calculate`) keeps running on the
   // HOST, between launches; the kernel takes what the host computed for this step instead of evaluating a model -
@@ -114,14 +169,19 @@ struct Variant {
   //   kHostReward   the reward is calculate()'d on the host from the float64 states: the kernel reports 0 and the host's
   //                 values are filed afterwards (host_reward_kernel)
   // and everything else of the step (masking, cash / inventory, clip, midprice, Hawkes intensities, normalisation) stays here.
-  static constexpr int HOST = HOST_;
-  static constexpr bool HOST_FILL = (HOST_ & 1) != 0, HOST_ARRIVAL = (HOST_ & 2) != 0, HOST_REWARD = (HOST_ & 4) != 0;
-  static_assert(!(HOST_FILL && (USER_FILL_ || EXO_)) && !(HOST_ARRIVAL && (USER_ARRIVAL_ || ARR_ == kArrHawkes)) && !(HOST_REWARD && USER_REWARD_),
+  static constexpr int HOST = (shape::host_mask_of<Tags>::value | ... | 0);
+  static constexpr bool HOST_FILL = (HOST & 1) != 0, HOST_ARRIVAL = (HOST & 2) != 0, HOST_REWARD = (HOST & 4) != 0;
+  static_assert(!(HOST_FILL && (USER_FILL || EXO)) && !(HOST_ARRIVAL && (USER_ARRIVAL || ARR == kArrHawkes)) && !(HOST_REWARD && USER_REWARD),
                 "a plugin is either a built-in, a device expression or a host callback");
-  static constexpr int EXTRA = (ARR_ == kArrHawkes) ? 2 : USER_STATE_;  // columns between the midprice and the exogenous depths
+  static constexpr int EXTRA = (ARR == kArrHawkes) ? 2 : USER_STATE;  // columns between the midprice and the exogenous depths
   static constexpr int EXO_COL = 4 + EXTRA;
-  static constexpr int DIM = EXO_COL + (EXO_ ? 2 : 0);
+  static constexpr int DIM = EXO_COL + (EXO ? 2 : 0);
 };
+namespace shape {
+template <class List> struct variant_of;
+template <class... Tags> struct variant_of<tags<Tags...>> { using type = Variant<Tags...>; };
+template <class... Lists> using make = typename variant_of<typename join_all<Lists...>::type>::type;
+}  // namespace shape
 
 // Wave-uniform parameters of one step: passed by value (kernarg -> SGPRs).
 // What the precise_state tier computes with: the constructor arguments of the reference's classes as float64, kept

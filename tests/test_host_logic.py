@@ -449,3 +449,29 @@ def test_the_float32_tiers_clip_warning_fires_once_and_only_where_it_applies(no_
     with warnings.catch_warnings():
         warnings.simplefilter("error", Float32ClipWarning)
         assert exact._note_clip_count(5) is False  # exact there: nothing to announce
+
+
+def test_every_kernel_name_bench_derives_is_a_kernel_of_the_library():
+    """bench.py names its kernels from a workload's list of shape tags (bench.kernel_shape -> csrc/step_kernel.hpp: Variant<tags...>,
+    mapped in csrc/kernel_table.hpp: OrderBookShape): each name must be the demangled name of a kernel the built library holds - read from
+    the code objects' own metadata, no GPU - and the profiler's, so that `frac_rocprof` and the PMC ties cannot silently miss."""
+    import os
+    import sys
+    import tempfile
+
+    import bench
+
+    sys.path.insert(0, os.path.join(bench.ROOT, "tools", "dbg"))
+    import kernel_resources
+
+    import re
+
+    with tempfile.TemporaryDirectory() as work:
+        mangled = [k["name"] for obj in kernel_resources.code_objects(work) for k in kernel_resources.kernels(obj)]
+    names = {re.sub(r"^void ", "", name).split("(")[0] for name in kernel_resources.demangle(mangled)}
+    assert len(names) > 500
+    for key in bench.WORKLOADS:
+        for precise, lam32 in ((False, False), (True, False)) + (((False, True),) if key == "cfg3" else ()):
+            for lanes in (1 << 20, 1 << 26):  # default-policy loads | the non-temporal instantiation
+                assert bench.kernel_name(key, precise, lanes, lam32) in names, (key, precise, lam32, lanes)
+    assert bench.kernel_shape("cfg1", False) == ["brownian", "pnl"] and bench.kernel_shape("cfg3", False) == ["hawkes_exact", "pnl"]

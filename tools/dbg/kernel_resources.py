@@ -62,10 +62,9 @@ def waves_per_simd(vgpr, agpr):
     return max(1, min(8, 512 // max(regs, 8)))
 
 
-DEFAULT = ("step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, false,", "step_kernel<mbt::Variant<0, 0, true, 1, false, false, false, false,",
-           "step_kernel<mbt::Variant<1, 0, false, 0,", "step_kernel<mbt::Variant<0, 1, true, 0, false, false, false, false,",
-           "step_kernel<mbt::Variant<0, 0, true, 0, false, false, false, true,", "step_kernel<mbt::Variant<1, 0, false, 0, false, false, false, true,",
-           "speed_step_kernel<mbt::SpeedVariant<")
+DEFAULT = ("step_kernel<mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>", "step_kernel<mbt::Variant<mbt::shape::brownian, mbt::shape::quadratic>",
+           "step_kernel<mbt::Variant<mbt::shape::hawkes", "step_kernel<mbt::Variant<mbt::shape::limit_and_market, mbt::shape::brownian, mbt::shape::pnl>",
+           "step_kernel<mbt::Variant<mbt::shape::brownian, mbt::shape::pnl, mbt::shape::precise>", "speed_step_kernel<mbt::SpeedVariant<")
 
 
 def main():

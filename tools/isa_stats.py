@@ -3,7 +3,7 @@
 library (one per translation unit) and reports, per kernel whose demangled name matches the regular expression, the register
 budget (from the code object's metadata notes) and the instruction mix (from the disassembly).
 
-    python tools/isa_stats.py 'step_kernel<mbt::Variant<0, 0, true, 0, false, false' [--keep /tmp/isa]
+    python tools/isa_stats.py 'step_kernel<mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>' [--keep /tmp/isa]
 
 Used to check that a change to shared device code leaves the benchmarked instantiations alone (VGPRs, VALU count) and to
 count what a kernel issues per wave."""

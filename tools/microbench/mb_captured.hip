@@ -24,7 +24,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-using AS = mbt::Variant<0, 0, true, 0, false, false>;
+using AS = mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>;
 
 template <int SCHEME>
 __global__ __launch_bounds__(mbt::kBlockThreads) void kernel(const mbt::StepBuffers B, const mbt::StepParams P0, mbt::CapturedParams C, uint32_t parity) {

@@ -14,7 +14,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-using AS = mbt::Variant<0, 0, true, 0, false, false>;
+using AS = mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>;
 
 int run(int lg, uint32_t steps) {
   const uint32_t n = 1u << lg, n_pairs = n / 2, blocks = n_pairs / mbt::kBlockThreads;

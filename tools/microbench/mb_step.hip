@@ -166,9 +166,9 @@ int main(int argc, char** argv) {
   t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
                            hipLaunchKernelGGL((mbt::step_kernel<VARIANT>), dim3(blocks), dim3(mbt::kBlockThreads), 0, 0, B, P); }, iters); \
   printf("%-28s %8.2f us  %7.0f GB/s\n", LABEL, t, BYTES * n / t * 1e-3);
-  using AS = mbt::Variant<0, 0, true, 0, false, false>;
-  using ASI = mbt::Variant<0, 0, true, 0, false, true>;
-  using CJ = mbt::Variant<0, 0, true, 1, false, false>;
+  using AS = mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>;
+  using ASI = mbt::Variant<mbt::shape::brownian, mbt::shape::pnl, mbt::shape::injected>;
+  using CJ = mbt::Variant<mbt::shape::brownian, mbt::shape::quadratic>;
   RUN(AS, "step AS philox (44 B)", 44.0)
 #define RUNT(VARIANT, T, LABEL)                                                                                          \
   t = time_it([&](int i) { B.state_in = st[i & 1]; B.state_out = st[(i & 1) ^ 1]; P.philox_step = i;                   \
@@ -228,9 +228,9 @@ int main(int argc, char** argv) {
   }
   // where the Hawkes + OU kernel (BASELINE config 3) spends its time: each ingredient alone
   P.hawkes_base_bid = P.hawkes_base_ask = 10.f; P.hawkes_speed = 60.f; P.hawkes_jump = 40.f; P.ou_speed = 0.01f; P.ou_level = 100.f;
-  using OU = mbt::Variant<0, 0, false, 0, false, false>;
-  using HK = mbt::Variant<1, 0, true, 0, false, false>;
-  using HKOU = mbt::Variant<1, 0, false, 0, false, false>;
+  using OU = mbt::Variant<mbt::shape::pnl>;
+  using HK = mbt::Variant<mbt::shape::hawkes, mbt::shape::brownian, mbt::shape::pnl>;
+  using HKOU = mbt::Variant<mbt::shape::hawkes, mbt::shape::pnl>;
   RUN(OU, "step Poisson + OU (44 B)", 44.0)
   RUN(HK, "step Hawkes + BM (60 B)", 60.0)
   RUN(HKOU, "step Hawkes + OU (60 B)", 60.0)
