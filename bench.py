@@ -1077,7 +1077,11 @@ def main():
                 out["rollout"] = rollout_block(lib, gpu)
             except Exception as exc:  # noqa: BLE001
                 out["rollout"] = {"error": str(exc)}
-        if world == 1 and not args.no_device_loop:
+        if world == 1 and not args.no_device_loop and TRACED:
+            # (under a tracer the block would launch the headline's kernel at N = 1000 and 2^16 lanes and fold those launches into the
+            # kernel's row of the summary `roofline.frac_rocprof` is read from)
+            out["device_policy_loop"] = {"skipped": "a tracer is attached: the block's small-batch launches of the headline kernel would enter its row of the kernel statistics"}
+        elif world == 1 and not args.no_device_loop:
             # a policy that lives on the device writes `action_device`, the environment steps on the same stream - one Python
             # call per step (host clock) against a torch.cuda.graph of [policy, mbt_env_step_device_captured] x 50 (device clock)
             try:
