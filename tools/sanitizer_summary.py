@@ -16,6 +16,10 @@ def main(path):
     # a report starts at a line that names the sanitizer's verdict and runs to the next such line
     starts = [m.start() for m in re.finditer(r"^.*(ERROR: AddressSanitizer|WARNING: ThreadSanitizer|runtime error:|ERROR: LeakSanitizer)", text, flags=re.M)]
     reports = [text[a:b] for a, b in zip(starts, starts[1:] + [len(text)])]
+    # (the canary of tools/run_sanitizers.sh - mbt_exact_split handed a 2-byte heap block on purpose - proves the instrumentation is live;
+    # it is reported as such, not as a finding)
+    canary = [r for r in reports if "in mbt_exact_split" in r and "2-byte region" in r]
+    reports = [r for r in reports if r not in canary]
     ours = [r for r in reports if "libmbtenv" in r or "mbt_env.hip" in r]
     kinds = {}
     for r in reports:
@@ -23,7 +27,7 @@ def main(path):
         kind = re.sub(r"==\d+==|\(pc .*|0x[0-9a-f]+", "", head).strip()[:90]
         where = "libmbtenv" if r in ours else "outside libmbtenv"
         kinds[(where, kind)] = kinds.get((where, kind), 0) + 1
-    print(f"   reports: {len(reports)} in all, {len(ours)} with a frame in libmbtenv")
+    print(f"   reports: {len(reports)} in all, {len(ours)} with a frame in libmbtenv" + (f"  (+ the canary: {len(canary)} heap-buffer-overflow in mbt_exact_split, caught)" if canary else ""))
     for (where, kind), count in sorted(kinds.items()):
         print(f"     {count:4d} x [{where}] {kind}")
     for r in ours[:5]:
