@@ -112,16 +112,42 @@ def _refuse_overridden_builtin(part):
                 f"host-callback route), or state the formula as a device expression (DeviceExpression* classes) for the fast path.")
 
 
-def _is_a_no_op(function) -> bool:
-    """True for a Python function whose body does nothing (`pass`, `return None`, a docstring alone)."""
-    import dis
+def _no_op_code_of_this_interpreter():
+    """{number of constants: {bytecode}} of functions whose body does nothing, compiled by the RUNNING interpreter - so that what a no-op
+    looks like is never a list of opcode names kept by hand (rounds 4-5 disassembled the user's function and needed a fix for CPython
+    3.12's RETURN_CONST; the next release would have needed another)."""
+    def plain(self, *args, **kwargs):
+        pass
 
-    try:
-        ops = [ins for ins in dis.get_instructions(function) if ins.opname not in ("RESUME", "NOP")]
-    except TypeError:
+    def explicit(self, *args, **kwargs):
+        return None
+
+    def documented(self, *args, **kwargs):
+        """A docstring alone."""
+
+    def documented_explicit(self, *args, **kwargs):
+        """A docstring, then return None."""
+        return None
+
+    table = {}
+    for function in (plain, explicit, documented, documented_explicit):
+        code = function.__code__
+        table.setdefault(len(code.co_consts), set()).add(code.co_code)
+    return table
+
+
+_NO_OP_CODE = _no_op_code_of_this_interpreter()
+
+
+def _is_a_no_op(function) -> bool:
+    """True for a Python function whose body does nothing (`pass`, `return None`, a docstring alone): its bytecode is the bytecode this
+    interpreter compiles such a body to, and its constants are None (after an optional docstring).  Anything else - a C function, a
+    body that touches a name - is "not a no-op": the slower route, never a wrong one."""
+    code = getattr(function, "__code__", None)
+    if code is None or code.co_names or code.co_code not in _NO_OP_CODE.get(len(code.co_consts), ()):
         return False
-    names = [ins.opname for ins in ops]  # (CPython 3.12 folds the pair into RETURN_CONST; anything unrecognised: "not a no-op", the slower route)
-    return (names == ["LOAD_CONST", "RETURN_VALUE"] or names == ["RETURN_CONST"]) and ops[0].argval is None
+    consts = code.co_consts
+    return consts[-1] is None and (len(consts) == 1 or (len(consts) == 2 and isinstance(consts[0], str)))
 
 
 class TradingEnvironment(_EnvBase):

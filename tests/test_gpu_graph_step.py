@@ -370,3 +370,69 @@ def test_the_resident_kernel_lives_across_the_wrap_of_its_sequence_numbers(monke
         np.testing.assert_array_equal(rew, want[k][1], err_msg=f"step {k}")
     assert time.perf_counter() - t0 < 0.15, "a step waited for its 200 ms answer time-out: the kernel answered another sequence number"
     env.close()
+
+
+def test_graphs_of_any_length_replayed_in_any_order_with_single_calls_between_them():
+    """The clock has two slots and each captured launch carries the slot it reads (step_kernel.hpp: CapturedParams::parity); an align
+    kernel in front of every capture's first step - and of every call outside a capture - brings the current slot to 0.  So: a graph of
+    THREE steps (odd: it ends on the other slot), a graph of TWO, a graph of ONE and single calls, replayed in a scrambled order, take
+    exactly the steps the ordinary loop takes - episode ends (n_steps = 7 divides none of it) and their log included."""
+    hip = _Hip()
+    n = 3000
+    cfg = _cfg(n, n_steps=7, reward="cjmm", phi=0.01, alpha=0.001, initial_inventory=(-3, 4))
+    action = _actions(cfg, n)
+    env = make_env(cfg, noise="philox")
+    env.reset_device()
+    env.set_action_host(action)
+    stream = C.c_void_p()
+    hip.call("hipStreamCreate", C.byref(stream))
+    env.set_stream(stream.value)
+    env.device_clock_begin(auto_reset=True)
+    graphs = {}
+    for k in (3, 2, 1):
+        graph, executable = C.c_void_p(), C.c_void_p()
+        hip.call("hipStreamBeginCapture", stream, 0)
+        for _ in range(k):
+            env.step_device_captured()
+        hip.call("hipStreamEndCapture", stream, C.byref(graph))
+        hip.call("hipGraphInstantiate", C.byref(executable), graph, None, None, 0)
+        graphs[k] = (graph, executable)
+    order = [3, 3, 1, 0, 2, 3, 0, 0, 1, 1, 3, 2, 2, 0, 3, 1, 3, 3, 2, 0, 1, 3]  # 0 = a single call outside any capture
+    total = 0
+    for k in order:
+        if k == 0:
+            env.step_device_captured()
+            total += 1
+        else:
+            hip.call("hipGraphLaunch", graphs[k][1], stream)
+            total += k
+        assert env.device_clock_read()["steps"] == total  # (reading waits for the stream: every piece has run before the next is issued ...
+    for k in order:  # ... and once more without waiting in between: the pieces queue up behind each other on the stream)
+        if k == 0:
+            env.step_device_captured()
+            total += 1
+        else:
+            hip.call("hipGraphLaunch", graphs[k][1], stream)
+            total += k
+    now = env.device_clock_read()
+    assert (now["steps"], now["episodes"], now["episode_step"]) == (total, total // 7, total % 7)
+    env.device_clock_end()
+    got, got_log = _snapshot(env), _pop_all(env)
+    for graph, executable in graphs.values():
+        hip.call("hipGraphExecDestroy", executable)
+        hip.call("hipGraphDestroy", graph)
+    env.close()
+    hip.call("hipStreamDestroy", stream)
+
+    reference = make_env(cfg, noise="philox")
+    reference.reset_device()
+    reference.set_action_host(action)
+    assert reference.step_many_device(total, auto_reset=True) == (total, total // 7)
+    want, want_log = _snapshot(reference), _pop_all(reference)
+    reference.close()
+    for key in ("state", "obs", "reward"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    assert got["clock"] == want["clock"]
+    assert len(got_log) == len(want_log) == min(16, total // 7)
+    for x, y in zip(got_log, want_log):
+        np.testing.assert_array_equal(x, y)

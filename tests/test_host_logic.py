@@ -475,3 +475,38 @@ def test_every_kernel_name_bench_derives_is_a_kernel_of_the_library():
             for lanes in (1 << 20, 1 << 26):  # default-policy loads | the non-temporal instantiation
                 assert bench.kernel_name(key, precise, lanes, lam32) in names, (key, precise, lam32, lanes)
     assert bench.kernel_shape("cfg1", False) == ["brownian", "pnl"] and bench.kernel_shape("cfg3", False) == ["hawkes_exact", "pnl"]
+
+
+def test_a_do_nothing_update_is_recognised_without_a_list_of_opcode_names():
+    """The host-callback route skips `update()` bodies that do nothing (one host call per process and step saved).  What "does nothing"
+    looks like is compiled by the running interpreter (`_no_op_code_of_this_interpreter`), not spelled out opcode by opcode - the
+    version-specific list of rounds 4-5 needed a fix with CPython 3.12.  Anything unrecognised is "not a no-op": slower, never wrong."""
+    from mbt_gym_amd.gym.TradingEnvironment import _is_a_no_op
+
+    class Plugin:
+        def nothing(self, arrivals, fills, action, state=None):
+            pass
+
+        def nothing_said_twice(self, *args, **kwargs):
+            """A docstring."""
+            return None
+
+        def bare_return(self):
+            return
+
+        def returns_a_number(self):
+            return 5
+
+        def returns_a_string(self):
+            return "not a docstring"
+
+        def docstring_then_a_value(self):
+            """A docstring."""
+            return 1
+
+        def touches_state(self, x):
+            self.y = x
+
+    assert all(_is_a_no_op(getattr(Plugin, name)) for name in ("nothing", "nothing_said_twice", "bare_return"))
+    assert not any(_is_a_no_op(getattr(Plugin, name)) for name in ("returns_a_number", "returns_a_string", "docstring_then_a_value", "touches_state"))
+    assert not _is_a_no_op(len) and not _is_a_no_op(np.add)
