@@ -11,6 +11,8 @@ SRC = os.path.join(ROOT, "examples", "as_episode.c")
 EXE = os.path.join(ROOT, "examples", "as_episode")
 SHARDED_SRC = os.path.join(ROOT, "examples", "sharded_returns.c")
 SHARDED_EXE = os.path.join(ROOT, "examples", "sharded_returns")
+GRAPH_SRC = os.path.join(ROOT, "examples", "graph_steps.c")
+GRAPH_EXE = os.path.join(ROOT, "examples", "graph_steps")
 LIB_DIR = os.path.join(ROOT, "mbt_gym_amd")
 
 
@@ -20,13 +22,33 @@ def _compile(src=SRC, exe=EXE):
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
+def _compile_with_hip(src, exe):
+    """A C program that also calls the HIP runtime itself (stream capture): the runtime's C API header and library beside ours."""
+    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", src,
+           "-L" + LIB_DIR, "-lmbtenv", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
 def test_c_example_compiles_and_links_against_the_library():
     from mbt_gym_amd.build import build_native
 
     build_native()  # no-op when libmbtenv.so is newer than its sources
     _compile()
     _compile(SHARDED_SRC, SHARDED_EXE)
-    assert os.path.exists(EXE) and os.path.exists(SHARDED_EXE)
+    _compile_with_hip(GRAPH_SRC, GRAPH_EXE)
+    assert os.path.exists(EXE) and os.path.exists(SHARDED_EXE) and os.path.exists(GRAPH_EXE)
+
+
+@pytest.mark.gpu
+def test_c_example_of_the_graph_capturable_step_replays_a_hip_graph():
+    """examples/graph_steps.c: mbt_env_device_clock_begin, hipStreamBeginCapture, seven mbt_env_step_device_captured, hipStreamEndCapture, sixty
+    hipGraphLaunch - from plain C, no PyTorch in the process - against mbt_env_step_many_device on a twin: state, clock and episode log identical."""
+    _compile_with_hip(GRAPH_SRC, GRAPH_EXE)
+    out = subprocess.run([GRAPH_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[-1] == "state, clock and episode log identical", out.stdout
+    assert sum(ln.startswith("episode ") for ln in lines) == 2 and "420 steps = 60 replays of a 7-step graph, 2 episodes ended" in lines[-2]
 
 
 @pytest.mark.gpu
