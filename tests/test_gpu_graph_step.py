@@ -436,3 +436,54 @@ def test_graphs_of_any_length_replayed_in_any_order_with_single_calls_between_th
     assert len(got_log) == len(want_log) == min(16, total // 7)
     for x, y in zip(got_log, want_log):
         np.testing.assert_array_equal(x, y)
+
+
+FUZZ_SCALE = int(__import__("os").environ.get("MBT_FUZZ_SCALE", "1"))
+FUZZ_SEED = int(__import__("os").environ.get("MBT_FUZZ_SEED", "0"))
+
+
+@pytest.mark.parametrize("case", range(40 * FUZZ_SCALE))
+def test_random_configurations_step_the_same_from_the_devices_clock(case):
+    """Over the plugin space nobody picked by hand (tests/random_configs.py: random midprice / arrival / fill / dynamics / reward kinds and
+    parameters, late start times, tight limits, random initial inventories; order-book and trading-speed families; every third case in the
+    precise_state tier): a captured loop over two episode ends and three steps leaves the state, the float64 state, the rewards, the clock, the
+    clip count and the episode log of the ordinary loop.  MBT_FUZZ_SCALE / MBT_FUZZ_SEED turn it into a soak."""
+    from tests.random_configs import random_actions, random_config, random_speed_actions, random_speed_config
+
+    rng = np.random.default_rng(FUZZ_SEED + 61000 + case)
+    n = int(rng.choice([7, 600, 1500]))
+    speed = case % 4 == 3
+    cfg = random_speed_config(rng, n) if speed else random_config(rng, n)
+    cfg.n_steps = int(rng.choice([5, 9, 16]))
+    if cfg.arrival == "hawkes" and cfg.hawkes_speed * (cfg.arrival_step_size or cfg.terminal_time / cfg.n_steps) >= 1.0:
+        cfg.hawkes_speed = 0.5 * cfg.n_steps / cfg.terminal_time
+    precise = case % 3 == 2
+    action = (random_speed_actions if speed else random_actions)(rng, cfg, 1)[0]
+    steps = 2 * cfg.n_steps + 3
+    results = []
+    for route in ("host clock", "device clock"):
+        env = make_env(cfg, noise="philox", precise_state=precise)
+        env.track_lane_returns(True)
+        env.reset_device()
+        env.set_action_host(action)
+        first_done = None
+        if route == "host clock":
+            taken, ended = env.step_many_device(steps, auto_reset=True)
+        else:
+            env.device_clock_begin(auto_reset=True)
+            for _ in range(steps):
+                env.step_device_captured()
+            now = env.device_clock_read()
+            taken, ended = now["steps"], now["episodes"]
+            env.device_clock_end()
+        snap = _snapshot(env)
+        snap["state64"], snap["log"], snap["counts"] = env.state64.copy(), _pop_all(env), (taken, ended)
+        results.append(snap)
+        env.close()
+    a, b = results
+    assert a["counts"] == b["counts"] and a["clock"] == b["clock"] and a["clip_count"] == b["clip_count"], (case, a["counts"], b["counts"], a["clock"], b["clock"])
+    for key in ("state", "obs", "reward", "state64"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=f"case {case}: {key}")
+    assert len(a["log"]) == len(b["log"]) == a["counts"][1]
+    for x, y in zip(a["log"], b["log"]):
+        np.testing.assert_array_equal(x, y, err_msg=f"case {case}: episode log")
