@@ -1369,18 +1369,40 @@ __device__ __forceinline__ CapturedStep captured_prologue(clock_words_t w, const
 // threads l, l + 64, l + 128, l + 192 (four accumulators), the folds s = 128 and s = 64 are additions between its own accumulators,
 // the folds s = 32 ... 1 shuffles within the wave.  `zero`: the accumulators are cleared behind the reads (an automatic reset).
 __device__ __forceinline__ void captured_reduce_returns(double* wave_sums, uint32_t n_waves, float* lane_returns, uint32_t n, double out[3]) {
+  // (the wave sums are written by device-scope atomics of waves on every XCD and read here the same way - relaxed device-scope loads,
+  // EIGHT in flight per accumulator, added in index order; the per-lane returns are plain memory behind the caller's acquire fence)
   const uint32_t l = threadIdx.x & 63u;
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr uint32_t kAhead = 8;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    for (uint32_t i = l + 64u * v; i < n_waves; i += 256u) {
-      a[v] += __hip_atomic_load(wave_sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(wave_sums + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i0 = l + 64u * v; i0 < n_waves; i0 += 256u * kAhead) {
+      double x[kAhead];
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t i = i0 + 256u * k;
+        x[k] = i < n_waves ? __hip_atomic_load(wave_sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t i = i0 + 256u * k;
+        if (i < n_waves) {
+          a[v] += x[k];
+          __hip_atomic_store(wave_sums + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     if (lane_returns != nullptr)
-      for (uint32_t i = l + 64u * v; i < n; i += 256u) {
-        const float r = __hip_atomic_load(lane_returns + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b[v] += static_cast<double>(r) * r;
+      for (uint32_t i0 = l + 64u * v; i0 < n; i0 += 256u * kAhead) {
+        float r[kAhead];
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; ++k) {
+          const uint32_t i = i0 + 256u * k;
+          r[k] = i < n ? lane_returns[i] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; ++k)
+          if (i0 + 256u * k < n) b[v] += static_cast<double>(r[k]) * r[k];
       }
   }
   a[0] += a[2]; a[1] += a[3]; b[0] += b[2]; b[1] += b[3];  // s = 128
@@ -1399,22 +1421,29 @@ __device__ __forceinline__ void captured_reduce_returns(double* wave_sums, uint3
 __device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const StepParams& P, const CapturedParams& C, const CapturedStep s) {
   const bool episode_end = s.terminal && C.auto_reset != 0;
   if (__builtin_expect(episode_end, 0)) {
-    // this workgroup's own stores of the step are complete and visible to all its threads before any of its rows is rewritten
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // This workgroup's own stores of the step are complete and visible to all ITS threads before any of its rows is rewritten: a
+    // release / barrier / acquire at WORKGROUP scope (the stores have left for the L2 the workgroup shares; its L1 is dropped).  Not at
+    // device scope: that writes the whole L2 back, once per wave - 8192 waves x 3 fences made the episode-end launch 320 us at 2^20
+    // lanes (profiles/r06_graph_step.txt).  Nothing here is read by another workgroup of this launch - except the return accumulators, below.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t first = blockIdx.x * C.tile_lanes;
     float* state = B.state_out;
     if (C.terminal_obs != nullptr) {
       const float* shown = C.obs != nullptr ? C.obs : state;
       const size_t base = static_cast<size_t>(first) * C.dim, count = static_cast<size_t>(C.tile_lanes) * C.dim;
       for (size_t k = threadIdx.x; k < count; k += kBlockThreads) C.terminal_obs[base + k] = shown[base + k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
     }
     // (the running returns are cleared by the last workgroup, which needs them all for the sum of squares first)
     for (uint32_t i = first + threadIdx.x; i < first + C.tile_lanes; i += kBlockThreads) reset_lane(i, state, C.obs, nullptr, C.q0, C.row0, C.dim, P, B.resid);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // What the episode's filer (the workgroup dispatched last, possibly on another XCD) reads of this workgroup: its waves' return sums -
+    // device-scope atomics, coherent by themselves, which only have to be COMPLETE before the wave counts itself in (a workgroup-scope
+    // release is the wait for that) - and, when they are tracked, the per-lane returns, plain stores that do need the L2 written back.
+    if (B.lane_returns != nullptr) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
   }
   DeviceClock* clock = C.clock;
@@ -1461,7 +1490,7 @@ __device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const St
     for (uint32_t g = threadIdx.x; g < groups; g += 64u) __hip_atomic_store(C.counters + 16u * g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ... and, alone on the launch now, files the episode: its return sums into the log, the accumulators back to zero
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (B.lane_returns != nullptr) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the per-lane returns are plain memory: see above)
   double sums[3];
   captured_reduce_returns(B.wave_sums, C.n_waves, B.lane_returns, P.n, sums);
   if (B.lane_returns != nullptr)

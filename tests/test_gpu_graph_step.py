@@ -308,6 +308,11 @@ def test_torch_cuda_graph_of_policy_and_step_replays_the_eager_loop():
     torch.cuda.synchronize()
     now = env.device_clock_read()
     assert (now["steps"], now["episodes"]) == (k * replays, 2)
+    # the clock block itself, for device code that wants `done` or the step count without a host round trip (mbt_env_device_clock_ptr):
+    # eight int32 words laid out as struct mbt_device_clock
+    words = torch.as_tensor(env.device_clock_view, device="cuda").cpu().numpy()
+    assert (int(words[2]), int(words[3]), int(words[4]), int(words[5]), int(words[6])) == (now["episode_step"], now["philox_step"], now["steps"], now["episodes"], now["done"])
+    assert words[:2].view(np.float64)[0] == now["time"]
     env.device_clock_end()
     got = _snapshot(env)
     for key in ("state", "obs", "reward"):

@@ -33,7 +33,7 @@ def _env(n, device, normalised):
     from mbt_gym_amd.stochastic_processes.fill_probability_models import ExponentialFillFunction
     from mbt_gym_amd.stochastic_processes.midprice_models import BrownianMotionMidpriceModel
 
-    n_steps = 1000
+    n_steps = int(os.environ.get("MBT_DEVICE_LOOP_N_STEPS", "1000"))  # (a short episode makes the episode-end launches visible: tools/dbg/r06_captured_ab.py)
     dt = 1.0 / n_steps
     dynamics = LimitOrderModelDynamics(
         midprice_model=BrownianMotionMidpriceModel(volatility=2.0, initial_price=100, terminal_time=1.0, step_size=dt, num_trajectories=n),
