@@ -13,6 +13,12 @@ import numpy as np
 # MBT_LIBRARY_VARIANT=asan / tsan: the sanitizer build of the host side (mbt_gym_amd/build.py, MBT_SANITIZE; README "Sanitizers")
 _VARIANT = os.environ.get("MBT_LIBRARY_VARIANT", "").strip()
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"libmbtenv.{_VARIANT}.so" if _VARIANT else "libmbtenv.so")
+if _VARIANT and "MBT_EXTRA_HIPCC_FLAGS" not in os.environ:
+    # an experiment build (tools/dbg/build_variant.py) leaves the flags it was compiled with beside it: they are part of the source hash the
+    # staleness check below compares, so `MBT_LIBRARY_VARIANT=name` alone selects such a library
+    _flags = os.path.join(os.path.dirname(LIB_PATH), f"libmbtenv.{_VARIANT}.flags")
+    if os.path.exists(_flags):
+        os.environ["MBT_EXTRA_HIPCC_FLAGS"] = open(_flags).read().strip()
 ABI_VERSION = 8
 
 MID_BROWNIAN, MID_OU, MID_GBM, MID_BROWNIAN_JUMP, MID_OU_JUMP, MID_CONSTANT, MID_LINEAR_SDE, MID_USER, MID_HOST = 0, 1, 2, 3, 4, 5, 6, 7, 8

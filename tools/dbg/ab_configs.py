@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CHILD = r'''
 import os, sys, runpy
 sys.path.insert(0, %r)
-from mbt_gym_amd import _native
 v = os.environ.get("MBT_LIB_VARIANT", "")
-if v: _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "libmbtenv_" + v + ".so")
+if v: os.environ["MBT_LIBRARY_VARIANT"] = v  # (libmbtenv.<v>.so of tools/dbg/build_variant.py; read when the binding is imported)
+from mbt_gym_amd import _native
 sys.argv = ["bench_configs.py"]
 runpy.run_path(os.path.join(%r, "tests", "perf", "bench_configs.py"), run_name="__main__")
 ''' % (ROOT, ROOT)

@@ -11,9 +11,9 @@ CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
 import numpy as np
-from mbt_gym_amd import _native
 v = os.environ.get("MBT_LIB_VARIANT", "")
-if v: _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "libmbtenv_" + v + ".so")
+if v: os.environ["MBT_LIBRARY_VARIANT"] = v  # (libmbtenv.<v>.so of tools/dbg/build_variant.py; read when the binding is imported)
+from mbt_gym_amd import _native
 from mbt_gym_amd.gym.TradingEnvironment import TradingEnvironment
 from bench_policy import random_mlp, timed_rollouts
 n = 1 << 20

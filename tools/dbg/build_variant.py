@@ -3,7 +3,8 @@
 -> mbt_gym_amd/libmbtenv.NAME.so (same sources, extra preprocessor flags; every translation unit of mbt_gym_amd/build.py, compiled in
 parallel, objects cached by content + flags under build/).  A process loads it with
     MBT_LIBRARY_VARIANT=NAME MBT_EXTRA_HIPCC_FLAGS="-DMBT_EXP_X=1 ..." python ...
-(the flags are part of the source hash the binding checks), so two code variants can be timed back to back on the same box.  Never used by
+(or `MBT_LIBRARY_VARIANT=NAME` alone: the flags, which are part of the source hash the binding checks, are left beside the library in
+libmbtenv.NAME.flags), so two code variants can be timed back to back on the same box.  Never used by
 the package, the tests or bench.py."""
 import os
 import sys
@@ -15,4 +16,7 @@ os.environ["MBT_EXTRA_HIPCC_FLAGS"] = " ".join(extra)  # (read when mbt_gym_amd.
 os.environ["MBT_BUILD_VARIANT"] = name
 from mbt_gym_amd import build as b  # noqa: E402
 
-print(b.build_native())
+path = b.build_native()
+with open(path[:-len(".so")] + ".flags", "w") as f:  # (what `MBT_LIBRARY_VARIANT=NAME` needs to know to accept the library: _native.py)
+    f.write(" ".join(extra) + "\n")
+print(path)
