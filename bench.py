@@ -54,6 +54,32 @@ QUOTE = (0.7, 0.7)
 PREWARM_STEPS_AT_2_20 = 8192  # untimed, ~55 ms of launches: brings the clocks up before the warm-up the caller asked for
 
 
+class phase:
+    """A named range around a phase of the benchmark - roctx, through torch.cuda.nvtx (rocTX on ROCm builds): `rocprofv3 --marker-trace -- python
+    bench.py` shows which launches belong to the timed region, the warm-up, each block of the line.  Costs nothing when no tracer listens; never
+    inside the timed bracket itself (the range is pushed before the barrier and popped after the clock stopped)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        try:
+            import torch
+
+            torch.cuda.nvtx.range_push(self.name)
+            self.pushed = True
+        except Exception:  # noqa: BLE001 - a build without the marker library: ranges are an aid, not a requirement
+            self.pushed = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.pushed:
+            import torch
+
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def default_prewarm_steps(lanes):
     """The same ~55 ms at any size - and a function of the arguments alone: every rank takes EXACTLY the same number of
     steps, so every rank finishes the same number of episodes and enqueues the same number of return all-reduces (a
@@ -894,16 +920,18 @@ def main():
     prewarm, prewarm_target = 0, args.prewarm_steps if args.prewarm_steps >= 0 else default_prewarm_steps(n)
     with Watchdog(max(args.comm_timeout, 600.0), "warm-up steps (including the all-reduces of the episodes that end in them)", rank):
         t_warm = time.perf_counter()
-        while prewarm < prewarm_target:
-            prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
-            env.synchronize()
-        if args.warmup > 0:
-            env.step_many_device(args.warmup, auto_reset=True)
-        sync_all()
+        with phase("clock warm-up (untimed) + --warmup steps"):
+            while prewarm < prewarm_target:
+                prewarm += env.step_many_device(min(256, prewarm_target - prewarm), auto_reset=True)[0]
+                env.synchronize()
+            if args.warmup > 0:
+                env.step_many_device(args.warmup, auto_reset=True)
+            sync_all()
         warm_episodes = drain_log()
         seconds["warm_up_steps_and_their_collectives"] = time.perf_counter() - t_warm
 
-        wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
+        with phase(f"timed region: {args.steps} steps"):
+            wall, event_s, episodes = timed_steps(env, lib, args.steps, sync_all)
         episode_returns = drain_log()  # (the log keeps the newest 16 episodes)
     event_s_own = event_s  # (this rank's own; `event_s` becomes the slowest rank's below)
     launch_us_min = launch_us_max = event_s / args.steps * 1e6  # per-rank mean launch-to-launch time: a straggler shows here
@@ -1067,14 +1095,17 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_hbm_resident:
             try:
-                out["roofline"]["hbm_resident"] = hbm_resident_measurement(lib, gpu, reference)
+                with phase("block: hbm_resident (2^24 lanes)"):
+                    out["roofline"]["hbm_resident"] = hbm_resident_measurement(lib, gpu, reference)
             except Exception as exc:  # noqa: BLE001 - e.g. a smaller device: the headline stands on its own
                 out["roofline"]["hbm_resident"] = {"error": str(exc)}
         if world == 1 and not args.no_configs:
-            out["roofline"]["configs"] = configs_block(lib, gpu, reference)
+            with phase("block: roofline.configs (cfg2 / cfg3 / cfg4, precise_state)"):
+                out["roofline"]["configs"] = configs_block(lib, gpu, reference)
         if world == 1 and not args.no_rollout:
             try:
-                out["rollout"] = rollout_block(lib, gpu)
+                with phase("block: rollout (returns only, recorded + write-only floor)"):
+                    out["rollout"] = rollout_block(lib, gpu)
             except Exception as exc:  # noqa: BLE001
                 out["rollout"] = {"error": str(exc)}
         if world == 1 and not args.no_device_loop and TRACED:
@@ -1087,11 +1118,13 @@ def main():
             try:
                 from tools.bench_device_loop import device_policy_loop_block
 
-                out["device_policy_loop"] = device_policy_loop_block(gpu)
+                with phase("block: device_policy_loop (eager vs HIP graph)"):
+                    out["device_policy_loop"] = device_policy_loop_block(gpu)
             except Exception as exc:  # noqa: BLE001
                 out["device_policy_loop"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            with phase("block: cpu_baseline (NumPy port on the host cores; cfg0 on the GPU)"):
+                out["cpu_baseline"] = cpu_baseline()
             try:
                 out["cpu_baseline"]["configs0"]["gpu"] = gpu_cfg0_figures(gpu)
             except Exception as exc:  # noqa: BLE001
