@@ -322,6 +322,42 @@ def test_torch_cuda_graph_of_policy_and_step_replays_the_eager_loop():
     env.close()
 
 
+def test_episodes_that_end_in_the_mode_go_through_the_communicator():
+    """SURVEY 8e: one 24-byte all-reduce per episode.  In device-clock mode the launch that ends an episode files the sums on the device;
+    mbt_env_device_clock_end sends each of them through the environment's communicator (every rank replays the same graph, so every rank
+    files the same number) before it enters the episode log.  One RCCL rank here (RCCL refuses two ranks on one device): the collective is
+    enqueued on the environment's stream for every episode, and the log equals the host-clock loop's with the same communicator, to the bit."""
+    from mbt_gym_amd.distributed import RcclCommunicator
+
+    n = 4096
+    cfg = _cfg(n, n_steps=9)
+    action = _actions(cfg, n)
+    comm = RcclCommunicator(rank=0, world_size=1, device=0)
+    logs, clocks = [], []
+    for route in ("host clock", "device clock"):
+        env = make_env(cfg, noise="philox")
+        env.set_communicator(comm)
+        env.reset_device()
+        env.set_action_host(action)
+        if route == "host clock":
+            assert env.step_many_device(30, auto_reset=True) == (30, 3)
+        else:
+            env.device_clock_begin(auto_reset=True)
+            for _ in range(30):
+                env.step_device_captured()
+            env.device_clock_end()
+        logs.append(_pop_all(env))
+        clocks.append(env.clock)
+        env.set_communicator(None)
+        env.close()
+    assert clocks[0] == clocks[1]
+    assert len(logs[0]) == len(logs[1]) == 3
+    for x, y in zip(logs[0], logs[1]):
+        np.testing.assert_array_equal(x, y)
+        assert x[2] == n and np.isfinite(x[0])
+    comm.close()
+
+
 def test_what_the_mode_refuses():
     n = 1000
     cfg = _cfg(n)

@@ -1,10 +1,10 @@
-"""pytest plugin for tools/dbg/r06_asan_soak_repro.sh: where is a test that hangs?
+"""pytest plugin for tools/soak_watchdog.sh (tools/run_sanitizers.sh, tools/dbg/r06_asan_soak_repro.sh): where is a test that hangs?
 
 Every process (the xdist workers too) lets any process of the same user attach a debugger (prctl PR_SET_PTRACER_ANY: the watchdog's rocgdb is a
 sibling, not an ancestor) and arms faulthandler before each test: after MBT_HANG_DUMP_AFTER seconds (default 25) the Python stacks of all threads
 go to $MBT_HANG_DUMP_DIR/py_stack.<pid>.txt, the test's id in front, and the test carries on (the watchdog takes the native stacks and ends it).
 
-    PYTHONPATH=tools/dbg python -m pytest -p hang_dump_plugin ..."""
+    PYTHONPATH=tools python -m pytest -p hang_dump_plugin ..."""
 import ctypes
 import faulthandler
 import os

@@ -53,9 +53,22 @@ lib.mbt_exact_split(1.5, C.byref(hi), C.cast(small, C.POINTER(C.c_int32)))" > /d
   echo "== $variant ($sanitize): LD_PRELOAD=$runtime python -m pytest $TESTS $skip"
   LD_PRELOAD=$runtime timeout 1500 python -m pytest -m "gpu or not gpu" $TESTS $skip -q -p no:cacheprovider > "$OUT/${variant}_pytest.log" 2>&1
   echo "   pytest rc=$?: $(tail -1 "$OUT/${variant}_pytest.log")"
-  # the eight-process soak of round 5 (resident small-batch stepping: mailbox, spin flags, completion flags), shortened
-  LD_PRELOAD=$runtime MBT_RESIDENT_STEP=1 MBT_FUZZ_SCALE=2 MBT_FUZZ_SEED=3100000 timeout 900 python -m pytest tests/test_gpu_random_configs.py -q -n 8 -p no:cacheprovider > "$OUT/${variant}_soak.log" 2>&1
-  echo "   resident soak (8 processes) rc=$?: $(tail -1 "$OUT/${variant}_soak.log")"
+  # the eight-process soak of round 5 (resident small-batch stepping: mailbox, spin flags, completion flags), shortened - under a watchdog
+  # (tools/soak_watchdog.sh) that takes the stacks of a run that hangs and says what the stuck thread was doing.  Under ASan about one run
+  # in ten hangs INSIDE ROCm's ASan runtime (it quarantines device allocations, and recycling one from within ROCr's own allocator waits
+  # for a lock the thread already holds: profiles/r06_sanitizers.txt); such a run says nothing about libmbtenv and is repeated, anything
+  # else is reported as it is.  quarantine_size_mb=2048 (default 256) keeps the quarantine from filling up - and so from recycling - within a
+  # nine-second run: 0 hangs in 25 runs with it, 5 in 68 without (tools/dbg/r06_asan_soak_repro.sh).
+  local attempt rc_soak=98
+  for attempt in 1 2 3; do
+    ASAN_OPTIONS="$ASAN_OPTIONS:quarantine_size_mb=2048" LD_PRELOAD_FOR_PYTHON=$runtime MBT_RESIDENT_STEP=1 MBT_FUZZ_SCALE=2 MBT_FUZZ_SEED=$((3100000 + attempt - 1)) HANG_AFTER=90 bash tools/soak_watchdog.sh "$OUT" "${variant}_soak"
+    rc_soak=$?
+    [ $rc_soak -ne 98 ] && break
+    echo "   resident soak, attempt $attempt: $(cat "$OUT/${variant}_soak.verdict" 2>/dev/null | cut -c1-400)"
+    grep -q "not in libmbtenv" "$OUT/${variant}_soak.verdict" 2>/dev/null || break
+    cp "$OUT/${variant}_soak.verdict" "$OUT/${variant}_soak.attempt$attempt.verdict"
+  done
+  echo "   resident soak (8 processes) rc=$rc_soak: $(tail -1 "$OUT/${variant}_soak.log" | cut -c1-200)"
   cat "$OUT/${variant}_report".* > "$OUT/${variant}_reports.txt" 2>/dev/null
   python tools/sanitizer_summary.py "$OUT/${variant}_reports.txt" | tee "$OUT/${variant}_summary.txt"
 }
