@@ -583,6 +583,10 @@ int mbt_env_get_state_f64_host(mbt_env* env, double* state_host);
  * non-finite hi carry lo = 0).  Host-side restatements of the device functions, for bindings and tests. */
 void mbt_exact_split(double x, float* hi, int32_t* lo);
 double mbt_exact_join(float hi, int32_t lo);
+/* x ** p as the float32 tier's kernels evaluate it (IMP:55-56 `action ** exponent`, RW:59-68 `inventory ** exponent` for exponents other than
+ * 1 and 2; step_kernel.hpp: power_f32): NumPy's float64 power rounded to float32 once, to within 0.5001 ulp - n values on `device`, host arrays
+ * in and out.  For tests and for checking the tier's arithmetic; no environment needed. */
+int mbt_power_f32_device(int device, const float* x_host, double p, float* out_host, uint32_t n);
 /* Observation of the last reset/step as the API returns it ((N, D), normalised when configured, TE:112-118). */
 int mbt_env_get_obs_host(mbt_env* env, float* obs_host);
 /* Upload (N, A) actions into the buffer of mbt_env_action_ptr() (e.g. a fixed quote for step_device loops). */

@@ -253,6 +253,7 @@ SIGNATURES = {
     "mbt_env_get_state_host": (C.c_int, [_ENV, _F]),
     "mbt_env_get_state_f64_host": (C.c_int, [_ENV, C.POINTER(C.c_double)]),
     "mbt_exact_split": (None, [C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "mbt_power_f32_device": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_float), C.c_uint32]),
     "mbt_exact_join": (C.c_double, [C.c_float, C.c_int32]),
     "mbt_env_get_obs_host": (C.c_int, [_ENV, _F]),
     "mbt_env_set_action_host": (C.c_int, [_ENV, _F]),

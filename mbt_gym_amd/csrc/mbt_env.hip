@@ -2850,6 +2850,25 @@ void mbt_exact_split(double x, float* hi, int32_t* lo) {
 
 double mbt_exact_join(float hi, int32_t lo) { return exact_join_host(hi, lo); }
 
+int mbt_power_f32_device(int device, const float* x_host, double p, float* out_host, uint32_t n) {
+  if (x_host == nullptr || out_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
+  if (n == 0) return MBT_OK;
+  HIP_TRY(hipSetDevice(device));
+  float *x = nullptr, *out = nullptr;
+  HIP_TRY(hipMalloc(&x, size_t(n) * sizeof(float)));
+  hipError_t err = hipMalloc(&out, size_t(n) * sizeof(float));
+  if (err == hipSuccess) err = hipMemcpy(x, x_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(mbt::power_f32_kernel, dim3((n + mbt::kBlockThreads - 1) / mbt::kBlockThreads), dim3(mbt::kBlockThreads), 0, nullptr, x, p, out, n);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpy(out_host, out, size_t(n) * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(x);
+  (void)hipFree(out);
+  if (err != hipSuccess) return fail(MBT_ERR_HIP, "mbt_power_f32_device: %s", hipGetErrorString(err));
+  return MBT_OK;
+}
+
 int mbt_env_get_state_f64_host(mbt_env* e, double* state_host) {
   if (e == nullptr || state_host == nullptr) return fail(MBT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));

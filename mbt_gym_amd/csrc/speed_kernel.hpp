@@ -86,7 +86,7 @@ __device__ __forceinline__ SpeedResult speed_lane(const SpeedLane s, float a_raw
   if (V::NORM && P.norm_act) v = static_cast<float>((static_cast<double>(a_raw) + 1.0) * P.act_grad[0] + P.act_lo[0]);  // TE:124
   float impact, y_new = s.y;
   switch (P.impact_kind) {
-    case kImpactTempPower: impact = P.temp_coef * ((!V::POWERS || P.impact_exponent_is_one) ? v : powf(v, P.impact_exponent)); break;
+    case kImpactTempPower: impact = P.temp_coef * ((!V::POWERS || P.impact_exponent_is_one) ? v : power_f32(v, P.X.impact_exponent)); break;
     case kImpactTempPerm:
       impact = P.temp_coef * v + s.y;
       y_new = s.y + P.perm_coef * v * P.impact_dt;
@@ -270,6 +270,18 @@ __device__ __forceinline__ void speed_step_body(const StepBuffers& B, const Step
   constexpr bool kStaged = STAGED && V::DIM == 5 && !V::INJECT;
   static_assert(!(STAGED && STREAM), "the staged instantiation serves cache-resident sizes");
   static_assert(!(CAPTURED && (MIRROR || V::INJECT || V::HOST_IMPACT)), "a captured step has no host in its loop");
+  if (V::POWERS && !V::PRECISE) {
+    // A launch of this kernel is ONE round of waves (2^20 lanes: 4096 waves, four per SIMD, all resident at once), and with x ** p in it the vector
+    // pipe has ~530 instructions per wave to issue: at equal priority the four waves of a SIMD compute side by side, finish together and store
+    // together - the memory system idles while they compute and they idle while it stores.  Distinct instruction priorities make them finish
+    // one after the other, so that one wave's stores overlap the next one's arithmetic: 8.15 -> 7.74 us at 2^20 lanes.  Measured and NOT
+    // applied elsewhere (tools/dbg/r06_pow_variants.sh, profiles/r06_speed_variants.txt): the kernels without powers gain 0-1 %, precise_state
+    // loses 2.6 %, the order-book step kernel (eight waves per SIMD, bandwidth-bound) loses 8 %.
+    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;  // HW_REG_HW_ID bits 3:0: the wave's slot on its SIMD
+    if (slot == 0u) __builtin_amdgcn_s_setprio(3);
+    else if (slot == 1u) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 2u) __builtin_amdgcn_s_setprio(1);
+  }
   clock_words_t clock_words = {0u, 0u, 0u, 0u};
   if (CAPTURED) clock_words = captured_clock_issue(&C->clock->slot[C->parity]);
   StepParams P_step;  // (CAPTURED only: the kernel arguments with this step's clock filled in by captured_prologue, below)

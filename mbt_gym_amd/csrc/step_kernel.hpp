@@ -433,10 +433,65 @@ __device__ __attribute__((cold)) bool refine_fill_exogenous_f64(float u, float a
   return static_cast<double>(u) < (depth > best ? P.exo_base_f64 * exp(-P.kappa_f64 * (depth - best)) : 1.0);
 }
 
+// ---- x ** p for the float32 tier (IMP:55-56 `action ** exponent`; RW:59-68, :101-104, :133-137 `inventory ** exponent`) ------------
+// The library's powf is ~185 vector instructions a call, and the speed kernels call it for four lanes per thread: 1009 instructions per
+// wave against 271 without, the vector pipe 84 % busy, 0.56 of the HBM line (profiles/r06_speed_precise_pmc.json) - while a bare
+// exp2(p * log2(x)) on v_log_f32 / v_exp_f32 loses p * log2(x) * 2^-24 of relative accuracy (1e-6 at x = 100: the tier's whole reward
+// tolerance).  This form spends the chip's float64 rate instead (half the float32 rate on CDNA4) and is accurate to 0.5001 ulp - the
+// float64 power NumPy computes, rounded to float32 once (tools/microbench/pow_f32_model.py: 16 million arguments against long double):
+//   |x| = 2^k m, m in [sqrt(1/2), sqrt(2));  l0 = v_log_f32(m), good to ~2^-23;  d = m * 2^(-l0) - 1 in double (2^t: a degree-8
+//   polynomial, 1.5e-12 on |t| <= 0.52), so  log2(m) = l0 + d / ln 2  to ~1e-12 (d^2 < 1e-13);  y = p (k + log2 m);
+//   x^p = 2^rint(y) * 2^(y - rint(y)), the same polynomial, v_ldexp_f64, one conversion.  About 30 float64 + 10 float32 instructions.
+// Sign and zero as C's pow / NumPy's power have them (a negative base with an integral exponent keeps or loses its sign by the
+// exponent's parity, with any other exponent it is NaN; 0 ** p is 0, 1 or inf); subnormal, infinite and NaN bases and p == 0 go to the
+// library's pow out of line (pow_out_of_line below) - no configuration's actions or inventories are any of these.
+static __device__ __attribute__((noinline, cold)) double pow_out_of_line(double q, double p);
+__device__ __forceinline__ double exp2_on_half_unit(double t) {  // 2^t, |t| <= 0.52: Chebyshev interpolant of degree 8, relative error 1.5e-12
+  double r = 0x1.63e65bcaf94f0p-20;
+  r = __builtin_fma(r, t, 0x1.00f06b86a7b42p-16);
+  r = __builtin_fma(r, t, 0x1.43089c4c30d66p-13);
+  r = __builtin_fma(r, t, 0x1.5d87263a9a124p-10);
+  r = __builtin_fma(r, t, 0x1.3b2ab71ee8c18p-7);
+  r = __builtin_fma(r, t, 0x1.c6b08df2412e4p-5);
+  r = __builtin_fma(r, t, 0x1.ebfbdff821419p-3);
+  r = __builtin_fma(r, t, 0x1.62e42fef7972cp-1);
+  return __builtin_fma(r, t, 1.0);
+}
+__device__ __forceinline__ float power_f32(float x, double p) {
+  const float ax = __builtin_fabsf(x);
+  if (__builtin_expect(!(ax < __builtin_inff()) || (ax != 0.0f && ax < 1.17549435e-38f) || p == 0.0, 0))
+    return static_cast<float>(pow_out_of_line(static_cast<double>(x), p));
+  float m = __builtin_amdgcn_frexp_mantf(ax);  // [1/2, 1)
+  int k = __builtin_amdgcn_frexp_expf(ax);
+  if (m < 0.70710678f) {
+    m *= 2.0f;
+    k -= 1;
+  }
+  const float l0 = __builtin_amdgcn_logf(m);  // log2, |l0| <= 1/2
+  const double d = __builtin_fma(static_cast<double>(m), exp2_on_half_unit(-static_cast<double>(l0)), -1.0);
+  const double log2_m = __builtin_fma(d, 1.4426950408889634, static_cast<double>(l0));
+  double y = p * (static_cast<double>(k) + log2_m);
+  y = __builtin_fmin(__builtin_fmax(y, -2000.0), 2000.0);  // (far beyond float32 either way: ldexp saturates to 0 / inf)
+  const double whole = __builtin_rint(y);
+#ifndef MBT_EXP_POW_VEXP
+  const double magnitude = __builtin_ldexp(exp2_on_half_unit(y - whole), static_cast<int>(whole));
+#else  // EXPERIMENT (tools/dbg/r06_pow_variants.sh): the last stage on v_exp_f32 / v_ldexp_f32 - nine float64 instructions fewer per lane; measured 7.83
+       // instead of 8.18 us for the speed kernel, but 0.84 ulp and one result in sixteen not the correctly rounded one: the half ulp was kept
+  const float magnitude = __builtin_ldexpf(__builtin_amdgcn_exp2f(static_cast<float>(y - whole)), static_cast<int>(whole));
+#endif
+  float r = ax != 0.0f ? static_cast<float>(magnitude) : (p > 0.0 ? 0.0f : __builtin_inff());
+  if (__builtin_signbitf(x)) {  // (wave-uniform tests of the exponent; a lane-wise select of the result)
+    const bool integral = p == __builtin_rint(p);
+    const bool odd = integral && __builtin_fabs(p) < 0x1p53 && __builtin_rint(p * 0.5) * 2.0 != p;
+    r = integral ? (odd ? -r : r) : (ax != 0.0f ? __builtin_nanf("") : r);
+  }
+  return r;
+}
+
 // numpy `q ** p` (RW:101-104, RW:133-137) of up to three inventories at once; p == 2 in every reference
-// configuration.  The general case runs ONE inlined powf in a rolled loop over register selects (no arrays, so no
+// configuration.  The general case runs ONE inlined power_f32 in a rolled loop over register selects (no arrays, so no
 // scratch memory), which keeps it out of the instruction stream of the common path.
-__device__ __forceinline__ void inventory_powers(float a, float b, float c, float p, bool is_two, float& pa, float& pb, float& pc) {
+__device__ __forceinline__ void inventory_powers(float a, float b, float c, double p, bool is_two, float& pa, float& pb, float& pc) {
   if (__builtin_expect(is_two, 1)) {
     pa = a * a; pb = b * b; pc = c * c;
     return;
@@ -444,7 +499,7 @@ __device__ __forceinline__ void inventory_powers(float a, float b, float c, floa
   pa = pb = pc = 0.0f;
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {
-    const float y = powf(i == 0 ? a : (i == 1 ? b : c), p);
+    const float y = power_f32(i == 0 ? a : (i == 1 ? b : c), p);
     if (i == 0) pa = y; else if (i == 1) pb = y; else pc = y;
   }
 }
@@ -469,14 +524,14 @@ __device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_n
   } else if (P.reward_kind != kRewPnl) {
     float qp, qp_old, qp_init;
     const bool oe = P.reward_kind == kRewCjOe;  // needs q^(p-1) instead of q^p for the old inventory (RW:65)
-    inventory_powers(q_new, q_old, q_init, P.exponent, P.exponent_is_two != 0, qp, qp_old, qp_init);
+    inventory_powers(q_new, q_old, q_init, P.X.exponent, P.exponent_is_two != 0, qp, qp_old, qp_init);
     reward -= P.dt * P.phi * qp;
     if (P.reward_kind == kRewRunning) {
       reward -= is_terminal ? P.alpha * qp : 0.0f;
     } else if (!oe) {
       reward -= P.alpha * ((qp - qp_old) + P.dt_over_episode * qp_init);
     } else {  // the terminal term MULTIPLIES by the episode length in the reference (RW:67)
-      const float qpm1 = P.exponent_is_two ? q_old : powf(q_old, P.exponent - 1.0f);
+      const float qpm1 = P.exponent_is_two ? q_old : power_f32(q_old, P.X.exponent - 1.0);
       reward -= P.dt * P.alpha * (P.exponent * speed * qpm1 + qp_init * P.episode_length);
     }
   }
@@ -528,7 +583,7 @@ __device__ __forceinline__ double numpy_power(double q, double p) { return p == 
 // that advance several lanes per thread in double (the speed family's precise_state tier: four lanes, up to four pow() each - 47-59 KB
 // of code and 131-133 registers inlined, round 5) and take these paths only for exponents no reference configuration uses.  Same
 // code, same flags (-ffp-contract=off): the same bits as the inlined call.
-static __device__ __attribute__((noinline, cold)) double pow_out_of_line(double q, double p) { return pow(q, p); }
+static __device__ __attribute__((noinline, cold)) double pow_out_of_line(double q, double p) { return pow(q, p); }  // (declared above power_f32)
 static __device__ __attribute__((noinline, cold)) double exp_out_of_line(double x) { return exp(x); }
 __device__ __forceinline__ double numpy_power_out_of_line(double q, double p) { return p == 2.0 ? q * q : (p == 1.0 ? q : pow_out_of_line(q, p)); }
 
@@ -1999,6 +2054,12 @@ __global__ void captured_align_kernel(DeviceClock* clock) {
     clock->slot[0] = clock->slot[1];
     clock->current = 0u;
   }
+}
+
+// x ** p of the float32 tier on its own (mbt_power_f32_device): what tests measure power_f32's half-ulp claim on
+__global__ __launch_bounds__(kBlockThreads) void power_f32_kernel(const float* x, double p, float* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i < n) out[i] = power_f32(x[i], p);
 }
 
 // MEASUREMENT (mbt_env_record_floor_device): the fused rollout's recording and nothing else - the same lane <-> thread mapping, the same

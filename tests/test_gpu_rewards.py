@@ -161,3 +161,33 @@ def test_the_clip_cash_fixture_raises_the_float32_tiers_clip_warning_at_its_next
                 warnings.simplefilter("error", Float32ClipWarning)
                 env.reset()  # once per environment
         env.close()
+
+
+@pytest.mark.parametrize("p", [0.5, 0.6, 1.5, 2.5, 3.0, 4.0, -1.3])
+def test_the_float32_tiers_power_is_the_float64_power_rounded_once(p):
+    """mbt_power_f32_device = step_kernel.hpp: power_f32, the `x ** p` of the float32 kernels for exponents other than 1 and 2 (IMP:55-56
+    `action ** exponent`; RW:59-68, :101-104, :133-137 `inventory ** exponent`): within 0.5002 float32 ulp of NumPy's float64 power over six
+    decades of magnitude, both signs (a negative base keeps NumPy's rule: its sign by the exponent's parity, NaN for a fractional exponent),
+    zeros, and - through the library's pow, out of line - subnormal, infinite and NaN bases."""
+    import ctypes as C
+
+    from mbt_gym_amd import _native
+
+    lib = _native.load_library()
+    rng = np.random.default_rng(int(abs(p) * 100))
+    x = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), size=1 << 20)).astype(np.float32)
+    x[::3] *= -1.0
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-41, -1e-41, np.inf, -np.inf, np.nan, np.float32(1.17549435e-38), np.float32(3.4e38)], dtype=np.float32)
+    x = np.concatenate([special, x])
+    got = np.empty_like(x)
+    _native.check(lib.mbt_power_f32_device(0, x.ctypes.data_as(C.POINTER(C.c_float)), p, got.ctypes.data_as(C.POINTER(C.c_float)), len(x)))
+    with np.errstate(all="ignore"):
+        exact = np.power(x.astype(np.longdouble), np.longdouble(p))
+        want = exact.astype(np.float32)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.signbit(got[~np.isnan(want)]), np.signbit(want[~np.isnan(want)]))
+    finite = np.isfinite(want) & (np.abs(want) >= np.float32(1.17549435e-38))  # (float32 subnormal results: one subnormal ulp, below)
+    ulps = np.abs(got[finite].astype(np.longdouble) - exact[finite]) / np.spacing(np.abs(want[finite]))
+    assert float(ulps.max()) < 0.5002, (p, float(ulps.max()))
+    rest = ~finite & ~np.isnan(want)
+    np.testing.assert_allclose(got[rest], want[rest], rtol=0, atol=1.5e-45)  # 0, inf, and subnormal results to one subnormal ulp

@@ -510,3 +510,19 @@ def test_a_do_nothing_update_is_recognised_without_a_list_of_opcode_names():
     assert all(_is_a_no_op(getattr(Plugin, name)) for name in ("nothing", "nothing_said_twice", "bare_return"))
     assert not any(_is_a_no_op(getattr(Plugin, name)) for name in ("returns_a_number", "returns_a_string", "docstring_then_a_value", "touches_state"))
     assert not _is_a_no_op(len) and not _is_a_no_op(np.add)
+
+
+def test_the_power_polynomial_in_the_header_gives_half_ulp_powers():
+    """step_kernel.hpp: power_f32 (x ** p of the float32 tier: IMP:55-56, RW:59-68 for exponents other than 1 and 2).  The arithmetic is
+    modelled in NumPy from the constants IN THE HEADER (tools/microbench/pow_f32_model.py), with a float32 log2 that is deliberately two ulps
+    sloppy, and compared with long double: the float64 power rounded once, to 0.5002 ulp.  The device function itself against the same
+    reference: tests/test_gpu_rewards.py."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pow_f32_model", os.path.join(root, "tools", "microbench", "pow_f32_model.py"))
+    model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model)
+    for p, worst, differing in model.check(200_000):
+        assert worst < 0.5002 and differing < 2e-4, (p, worst, differing)

@@ -35,6 +35,10 @@ python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.stderr"; stamp "bench 
 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_args.json" 2>> "$OUT/bench.stderr"; stamp "bench driver args rc=$?"
 rm -rf /tmp/prof_ungated && (cd /tmp && MBT_BENCH_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ungated -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-resident --no-configs --no-rollout --no-device-loop > "$ROOT/$OUT/${TAG}_bench_under_rocprof_ungated.json" 2>> "$ROOT/$OUT/rocprof_main.stderr")
 find /tmp/prof_ungated -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_bench_kernel_stats_ungated.csv"; stamp "kernel stats of bench.py (ungated, for comparison)"
+# which launches belong to which phase of bench.py: its roctx ranges (bench.py: class phase) beside the kernel trace, at the driver's arguments
+rm -rf /tmp/prof_marker && (cd /tmp && rocprofv3 --marker-trace --kernel-trace -d /tmp/prof_marker -o bench -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>> "$ROOT/$OUT/rocprof_main.stderr")
+find /tmp/prof_marker -name 'bench_results.db' | head -1 | xargs -I{} python tools/marker_trace_summary.py {} | cut -c1-220 > "$OUT/${TAG}_bench_marker_trace.txt"; stamp "marker trace of bench.py"
+cp "$OUT/${TAG}_bench_marker_trace.txt" profiles/
 
 profile() {  # profile <name> <bench args...>: kernel trace + stats, then the two PMC passes
   local name=$1; shift
