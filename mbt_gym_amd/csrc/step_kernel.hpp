@@ -490,16 +490,19 @@ __device__ __forceinline__ float power_f32(float x, double p) {
 
 // numpy `q ** p` (RW:101-104, RW:133-137) of up to three inventories at once; p == 2 in every reference
 // configuration.  The general case runs ONE inlined power_f32 in a rolled loop over register selects (no arrays, so no
-// scratch memory), which keeps it out of the instruction stream of the common path.
-__device__ __forceinline__ void inventory_powers(float a, float b, float c, double p, bool is_two, float& pa, float& pb, float& pc) {
+// scratch memory), which keeps it out of the instruction stream of the common path, and only for the inventories the reward
+// reads (`need`: bit 0 a, bit 1 b, bit 2 c - wave-uniform: a running penalty reads one of them, not three); b is raised to `p_b`
+// (CjOe: the old inventory to p - 1, RW:65).
+__device__ __forceinline__ void inventory_powers(float a, float b, float c, double p, double p_b, bool is_two, uint32_t need, float& pa, float& pb, float& pc) {
   if (__builtin_expect(is_two, 1)) {
-    pa = a * a; pb = b * b; pc = c * c;
+    pa = a * a; pb = p_b == 2.0 ? b * b : b; pc = c * c;
     return;
   }
   pa = pb = pc = 0.0f;
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {
-    const float y = power_f32(i == 0 ? a : (i == 1 ? b : c), p);
+    if (((need >> i) & 1u) == 0u) continue;
+    const float y = power_f32(i == 0 ? a : (i == 1 ? b : c), i == 1 ? p_b : p);
     if (i == 0) pa = y; else if (i == 1) pb = y; else pc = y;
   }
 }
@@ -524,15 +527,15 @@ __device__ __forceinline__ float finish_reward(float pnl, float q_old, float q_n
   } else if (P.reward_kind != kRewPnl) {
     float qp, qp_old, qp_init;
     const bool oe = P.reward_kind == kRewCjOe;  // needs q^(p-1) instead of q^p for the old inventory (RW:65)
-    inventory_powers(q_new, q_old, q_init, P.X.exponent, P.exponent_is_two != 0, qp, qp_old, qp_init);
+    // RW:133-137 reads q' ** p alone, RW:101-108 all three, RW:59-68 q' and q0 to p and q to p - 1
+    inventory_powers(q_new, q_old, q_init, P.X.exponent, oe ? P.X.exponent - 1.0 : P.X.exponent, P.exponent_is_two != 0, P.reward_kind == kRewRunning ? 1u : 7u, qp, qp_old, qp_init);
     reward -= P.dt * P.phi * qp;
     if (P.reward_kind == kRewRunning) {
       reward -= is_terminal ? P.alpha * qp : 0.0f;
     } else if (!oe) {
       reward -= P.alpha * ((qp - qp_old) + P.dt_over_episode * qp_init);
     } else {  // the terminal term MULTIPLIES by the episode length in the reference (RW:67)
-      const float qpm1 = P.exponent_is_two ? q_old : power_f32(q_old, P.X.exponent - 1.0);
-      reward -= P.dt * P.alpha * (P.exponent * speed * qpm1 + qp_init * P.episode_length);
+      reward -= P.dt * P.alpha * (P.exponent * speed * qp_old + qp_init * P.episode_length);  // (qp_old: q ** (p - 1) here)
     }
   }
   return reward * P.reward_scale;

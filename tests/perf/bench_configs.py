@@ -26,6 +26,9 @@ CASES = {
     "speed power impact, PnL 2^20 (D=4,A=1,40B)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.0, reward="pnl", initial_inventory=10), 20, [0.5]),
     "default normalised 2^20 (60B incl. obs)": (dict(midprice="bm", arrival="poisson", intensity=(100.0, 100.0), reward="pnl", normalise_action_space=True, normalise_observation_space=True, max_inventory=10000), 20, [-0.5, -0.5]),
     "speed power impact ^1.5, running penalty 2^20 (40B, the instantiation with powers: power_f32)": (dict(midprice="bm", arrival="none", dynamics="speed", impact="temp_power", temporary_impact=0.03, impact_exponent=1.5, reward="running", phi=0.01, alpha=0.05, initial_inventory=10), 20, [0.5]),
+    # the order-book kernels with the general reward (exponential utility; inventory exponents other than 2 through power_f32): no reference configuration
+    "AS + exponential utility 2^20 (44B, the general-reward kernel)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="exp_utility", risk_aversion=0.1), 20, [0.7, 0.7]),
+    "CJP running, inventory exponent 1.5 2^20 (44B, the general-reward kernel: power_f32)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="running", phi=0.01, alpha=0.001, inventory_exponent=1.5, max_inventory=100, initial_inventory=50), 20, [0.7, 0.7]),
     # precise_state: the reference's float64 state (float32 row + int32 remainders: +8 B per remainder column and env-step), float64 arithmetic
     "cfg1 AS 2^20, precise_state (60B)": (dict(midprice="bm", arrival="poisson", intensity=(140.0, 140.0), reward="pnl"), 20, [0.7, 0.7], dict(precise_state=True)),
     "cfg3 Hawkes+OU 2^22, precise_state (92B)": (dict(midprice="ou", ou_level=100.0, ou_speed=0.01, arrival="hawkes", intensity=(10.0, 10.0), reward="pnl"), 22, [0.7, 0.7], dict(precise_state=True)),
