@@ -502,7 +502,7 @@ __device__ __forceinline__ void inventory_powers(float a, float b, float c, doub
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {
     if (((need >> i) & 1u) == 0u) continue;
-    const float y = power_f32(i == 0 ? a : (i == 1 ? b : c), i == 1 ? p_b : p);
+    const float y = power_f32(i == 0 ? a : (i == 1 ? b : c), i == 1 ? p_b : p);  // (as a call, out of line: 8.97 -> 9.93 us for the exponent-1.5 case, -1 % elsewhere)
     if (i == 0) pa = y; else if (i == 1) pb = y; else pc = y;
   }
 }
