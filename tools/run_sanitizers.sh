@@ -52,7 +52,7 @@ lib.mbt_exact_split(1.5, C.byref(hi), C.cast(small, C.POINTER(C.c_int32)))" > /d
   fi
   echo "== $variant ($sanitize): LD_PRELOAD=$runtime python -m pytest $TESTS $skip"
   LD_PRELOAD=$runtime timeout 1500 python -m pytest -m "gpu or not gpu" $TESTS $skip -q -p no:cacheprovider > "$OUT/${variant}_pytest.log" 2>&1
-  echo "   pytest rc=$?: $(tail -1 "$OUT/${variant}_pytest.log")"
+  echo "   pytest rc=$?: $(grep -E " passed| failed| error" "$OUT/${variant}_pytest.log" | tail -1)"
   # the eight-process soak of round 5 (resident small-batch stepping: mailbox, spin flags, completion flags), shortened - under a watchdog
   # (tools/soak_watchdog.sh) that takes the stacks of a run that hangs and says what the stuck thread was doing.  Under ASan about one run
   # in ten hangs INSIDE ROCm's ASan runtime (it quarantines device allocations, and recycling one from within ROCr's own allocator waits
