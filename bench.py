@@ -41,6 +41,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# (ranks of one node share device memory handles through dmabuf only on this driver: RCCL's set-up fails with "hipIpcGetMemHandle: invalid
+# argument" otherwise.  Exported on the boxes this runs on; kept here for a launcher that starts the ranks from a cleaner environment.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 

@@ -48,6 +48,7 @@ FAMILIES = {
     "precise_hawkes_normalised": (dict(normalise_observation_space=True, **HAWKES), dict(precise_state=True)),
     "clip_cash": (dict(max_cash=3.0, initial_cash=0.0), dict()),
     "speed_temp_power": (dict(impact="temp_power", **SPEED), dict()),
+    "speed_cubic_impact_and_quartic_penalty": (dict(impact="temp_power", impact_exponent=3.0, inventory_exponent=4.0, **SPEED), dict()),  # the instantiation with powers (power_f32, wave priorities)
     "speed_transient_state": (dict(impact="temp_transient", **SPEED), dict()),
     "speed_precise_state": (dict(impact="temp_perm", **SPEED), dict(precise_state=True)),
     "user_power_law_fill": (dict(fill="user_power_law", fill_scale=1.25, fill_power=1.5), dict()),
