@@ -199,69 +199,87 @@ struct PreciseParams {
   double temp_coef, impact_exponent, perm_coef, trans_coef, resilience, kernel_coef, impact_dt, speed_dt;
 };
 
+// LAYOUT (round 6).  Kernel arguments are read with scalar loads from a segment that is fresh memory at every launch, and a
+// launch pays for every distinct 64-byte line of it the kernel must have before its first vector load: the same 40-byte-per-lane
+// kernel takes 5.9 us reading one line of a 1.3 KB block, 6.1 reading two to four, 6.45 reading eight
+// (tools/microbench/mb_lanes_per_thread.hip).  The benchmark kernel read parameters from five lines of this struct (fields in
+// the order five rounds added them); they are now grouped BY WHO READS THEM, the lightest kernels' first, one group per 64 bytes:
+// two lines for the benchmark kernel (tools/dbg/kernarg_loads.py lists what a kernel reads, from its disassembly).  In the
+// kernels the gain is a fraction of the micro-benchmark's - medians of eight alternating processes (tools/dbg/ab_variants.sh,
+// profiles/r06_kernarg_layout.txt): Avellaneda-Stoikov 6.62 -> 6.56 us, CJP 6.79 -> 6.64, Hawkes float32 36.65 -> 36.24,
+// precise_state AS 9.86 -> 9.51; limit + market 16.6 -> 16.7 and speed precise_state 13.68 -> 13.81 the other way.  Measured and not taken: the
+// struct 64-byte aligned (the segment then is, too: the benchmark kernel +0.1 us), the pointers of StepBuffers regrouped the
+// same way (one 64-byte load of eight pointers: the benchmark kernel -0.15 us in some processes and +0.15 in others, CJP +0.1).
+// Keep it that way: a new field goes into the group of the kernels that read it, or to the end.
 struct StepParams {
+  // ---- line 0: every kernel (lanes, generator, clock) + Brownian midprice + Poisson arrival thresholds --------------------
   uint32_t n;            // lanes of this shard
   uint32_t n_pairs;      // padded lanes / 2 (a whole number of 512-lane tiles for order-book dynamics)
   uint64_t pair_offset;  // global pair index of local pair 0
   uint32_t key0, key1;   // Philox key (seed)
   uint32_t philox_step;  // Philox counter word 2
   int32_t is_terminal;   // this step ends the episode (TE:218-220), decided on the host
-  int32_t reserved_pad;
   float t_next;          // time written into the next state (TE:216)
   float dt;              // terminal_time / n_steps (TE:49): the clock and the reward penalties
   // midprice (each process scales with ITS OWN step size, SP:21; the environment never synchronises them)
-  float mid_add, mid_mul;  // midprice model as coefficients, see midprice_increment()
   float drift_dt;        // mu * dt_mid                  (MID:63, MID:98)
   float vol_sqrt_dt;     // sigma * sqrt(dt_mid)         (MID:64, MID:100-102, MID:143)
-  float ou_speed, ou_level;
-  float jump_size;       // MID:226, MID:269
-  // arrivals
-  float arr_thr_bid, arr_thr_ask;  // Poisson: smallest float32 >= lambda*dt_arr (ARR:56) or 1-exp(-lambda*dt_arr) (ARR:83)
-  // the same thresholds on the generator's 32-bit word w (u = (w >> 8) * 2^-24):  u < thr  <=>  (w >> 8) < K, K = ceil(thr * 2^24)
+  // Poisson thresholds on the generator's 32-bit word w (u = (w >> 8) * 2^-24):  u < thr  <=>  (w >> 8) < K, K = ceil(thr * 2^24)
   // <=>  w < (K << 8) - no shift, no conversion, no multiply.  K = 2^24 (a probability of one) does not fit: the word is then
   // 0xFFFFFFFF and arr_always_* says that every draw arrives.
   uint32_t arr_thr_w_bid, arr_thr_w_ask;
   int32_t arr_always_bid, arr_always_ask;
-  double arr_dt_f64;               // Hawkes: threshold lambda_lane * dt_arr in double (ARR:123)
-  float arr_dt;
-  float hawkes_base_bid, hawkes_base_ask, hawkes_speed, hawkes_jump;
-  // fills
-  float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)  (exogenous-depth model)
+  // ---- line 1: fills, clip, reward scale; the quadratic inventory penalties --------------------------------------------------
   float fill_depth_per_log2;  // -ln(2) / kappa: the depth threshold is log2(u) times this
   float fill_band_abs;        // 2e-7 / kappa
   double kappa_f64;
-  float exo_depth[2], exo_base;          // exogenous best depths (bid, ask) and base fill probability (FILL:159-163)
-  double exo_depth_f64[2], exo_base_f64;
-  // dynamics
-  float half_spread;
   float q_max, c_max;
-  // reward
+  float reward_scale;     // TE:128-129
+  float half_spread;
   float alpha_running, alpha_cjmm;  // kRewardQuadratic: alpha routed to the terminal (RW:135-137) or the spread (RW:102-108) term
   float quad_new, quad_init;        // kRewardQuadratic: dt phi + alpha_cjmm, and alpha_cjmm dt / (T - t_start) (set by reset)
+  float dt_over_episode;  // CjMm: dt / (T - t_start)    (RW:106)
+  float q_init_scalar;    // CjMm: initial inventory when it is the same for every lane
   int32_t reward_kind;
   int32_t exponent_is_two;
-  float phi, alpha, exponent;
-  float risk_aversion;    // ExponentialUtility (RW:150)
-  float episode_length;   // CjOe: T - t_start (RW:73-74)
-  // trading-with-speed dynamics and price impact (MD:262-267, IMP:34-179)
+  // ---- line 2: the other midprice models, Hawkes arrivals, normalisation flags and the action's affine map -----------------
+  float mid_add, mid_mul;  // midprice model as coefficients, see midprice_increment()
+  float ou_speed, ou_level;
+  float jump_size;       // MID:226, MID:269
+  float arr_dt;
+  double arr_dt_f64;               // Hawkes: threshold lambda_lane * dt_arr in double (ARR:123)
+  float hawkes_base_bid, hawkes_base_ask, hawkes_speed, hawkes_jump;
+  // normalisation (TE:112-126); gradients are float32 like the reference's Box bounds
+  int32_t norm_act, norm_obs;
+  float arr_thr_bid, arr_thr_ask;  // Poisson: smallest float32 >= lambda*dt_arr (ARR:56) or 1-exp(-lambda*dt_arr) (ARR:83) - injected uniforms compare with these
+  // ---- line 3: trading-with-speed dynamics and price impact (MD:262-267, IMP:34-179), the general reward ----------------------
   int32_t impact_kind;
   int32_t impact_exponent_is_one;
   float speed_dt;         // the MIDPRICE model's step size (MD:265)
   float impact_dt;        // the impact model's own step size (IMP:75)
   float temp_coef, impact_exponent, perm_coef, trans_coef, resilience, kernel_coef;
-  float dt_over_episode;  // CjMm: dt / (T - t_start)    (RW:106)
-  float q_init_scalar;    // CjMm: initial inventory when it is the same for every lane
-  float reward_scale;     // TE:128-129
-  // normalisation (TE:112-126); gradients are float32 like the reference's Box bounds
-  int32_t norm_act, norm_obs;
+  float phi, alpha, exponent;
+  float risk_aversion;    // ExponentialUtility (RW:150)
+  float episode_length;   // CjOe: T - t_start (RW:73-74)
+  int32_t reserved_pad;
+  // ---- lines 4-5: the Box bounds of normalised spaces --------------------------------------------------------------------------
   float act_lo[4], act_grad[4];
   float obs_lo[8], obs_grad[8];
-  PreciseParams X;
-  double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8], user_state_p[8];  // parameters of the user's device expressions (mbt_user_code)
-  double mid_dt_f64;  // the midprice model's own step size (SP:21), for a user midprice expression
+  // ---- the exogenous-depth fill model ----------------------------------------------------------------------------------------
+  float exo_depth[2], exo_base;          // exogenous best depths (bid, ask) and base fill probability (FILL:159-163)
+  float kappa_log2e_neg;  // -kappa * log2(e): p = 2^(kappa_log2e_neg * depth)  (exogenous-depth model)
+  double exo_depth_f64[2], exo_base_f64;
+  // ---- precise_state: its two clocks, then the reference's constructor arguments in double ---------------------------------
   double t_now;  // the clock BEFORE this step (TE:216 accumulates it in double on the host): what a user arrival model sees
   double t_next_f64;  // ... and after it: the precise_state tier's TIME column and the `dt` of its rewards (RW:99, RW:131)
+  double mid_dt_f64;  // the midprice model's own step size (SP:21), for a user midprice expression
+  PreciseParams X;
+  double user_fill_p[8], user_reward_p[8], user_arrival_p[8], user_mid_p[8], user_state_p[8];  // parameters of the user's device expressions (mbt_user_code)
 };
+
+static_assert(__builtin_offsetof(StepParams, fill_depth_per_log2) == 64 && __builtin_offsetof(StepParams, mid_add) == 128 && __builtin_offsetof(StepParams, impact_kind) == 192 &&
+                  __builtin_offsetof(StepParams, act_lo) == 256 && __builtin_offsetof(StepParams, exo_depth) == 352,
+              "StepParams: one group of readers per 64-byte line (see LAYOUT above)");
 
 // what the user's process expressions may read beyond their own arguments: the user state columns before the step and the
 // two extra normals of the step (zero when the configuration has none)
@@ -292,7 +310,7 @@ __device__ double mbt_user_state_next(int which, double S, double t, double dt_m
                                       double fills_ask, const UserProcessState& u, const double* p);
 #endif
 
-struct StepBuffers {
+struct StepBuffers {  // (field order: as it grew; regrouping the pointers by reader was measured and not taken - profiles/r06_kernarg_layout.txt)
   const float* state_in;   // (n_pad, D) row-major
   float* state_out;
   const float* action;     // (n_pad, A)
