@@ -32,9 +32,19 @@ __global__ __launch_bounds__(256) void kernel_big(float4* state, const float* ac
   for (int l = 0; l < 4; ++l) { row[l] = state[lane + l * 256u]; act[l] = action[lane + l * 256u]; }
   // sixteen parameters from all over the block, as the production kernels read theirs
   float c = 0.0f;
+  if (MODE == 3) {  // the same sixteen, read through the kernarg segment pointer AFTER the vector loads were issued (the compiler hoists plain argument
+                    // reads above everything and waits for them before the first vector load): a scheduling barrier + the pointer passed through an empty asm
+    typedef const float __attribute__((address_space(4))) * kernarg_floats_t;
+    __builtin_amdgcn_sched_barrier(0);
+    kernarg_floats_t late = (kernarg_floats_t)(__builtin_amdgcn_kernarg_segment_ptr()) + 32 / 4;  // `big` sits behind three pointers and a word
+    asm volatile("" : "+s"(late));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c += late[k * 20 + 3];
+  } else {
 #pragma unroll
   for (int k = 0; k < 16; ++k)  // MODE >= 10: sixteen reads spread over (MODE - 10) 64-byte lines of the by-value block
     c += MODE == 0 ? big.f[k * 20 + 3] : (MODE == 1 ? big.f[k] : (MODE == 2 ? resident->f[k * 20 + 3] : big.f[(k % (MODE - 10)) * 16 + k / (MODE - 10)]));
+  }
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
     float x = act[l] * 0.001f + c, acc = row[l].x;
@@ -139,6 +149,7 @@ int main(int argc, char** argv) {
   printf("                the same block by value, sixteen read from its first 64 bytes:         work 16: %.2f   work 64: %.2f\n", run_big<1, 16>(state, action, reward, n, iters), run_big<1, 64>(state, action, reward, n, iters));
   printf("                by value, sixteen reads over 2 / 4 / 8 / 16 adjacent 64-byte lines (work 16):  %.2f / %.2f / %.2f / %.2f\n", run_big<12, 16>(state, action, reward, n, iters),
          run_big<14, 16>(state, action, reward, n, iters), run_big<18, 16>(state, action, reward, n, iters), run_big<26, 16>(state, action, reward, n, iters));
+  printf("                by value, the sixteen from all over it read AFTER the vector loads were issued:  work 16: %.2f   work 64: %.2f\n", run_big<3, 16>(state, action, reward, n, iters), run_big<3, 64>(state, action, reward, n, iters));
   printf("                the block resident in device memory behind a pointer, sixteen read:    work 16: %.2f   work 64: %.2f\n", run_big<2, 16>(state, action, reward, n, iters), run_big<2, 64>(state, action, reward, n, iters));
   return 0;
 }
