@@ -1579,27 +1579,6 @@ __device__ __forceinline__ void captured_epilogue(const StepBuffers& B, const St
   }
 }
 
-// The step kernels' parameters, read from the kernel-argument segment AFTER the launch's vector loads were issued.  Left to itself the
-// compiler hoists every argument read to the top of the kernel and waits for all of them before the first vector load - and a launch
-// pays for each 64-byte line of its arguments it waits for there (StepParams: LAYOUT).  Behind a scheduling barrier, through the
-// segment's own pointer passed through an empty asm (so that nothing read through it can move above this point), the same reads fly
-// with the vector loads: tools/microbench/mb_lanes_per_thread.hip, 6.39 -> 5.98 us for sixteen values from all over a 1.3 KB block.
-// Only for kernels whose signature is (StepBuffers, StepParams) and that take the parameters as the host wrote them.
-#ifdef MBT_EXP_LATE_PARAMS
-constexpr bool kLateParams = true;
-#else
-constexpr bool kLateParams = false;
-#endif
-constexpr size_t kParamsKernargOffset = (sizeof(StepBuffers) + alignof(StepParams) - 1) / alignof(StepParams) * alignof(StepParams);
-__device__ __forceinline__ const StepParams* params_in_the_kernarg_segment() {
-  typedef const char __attribute__((address_space(4))) * segment_t;
-  typedef const StepParams __attribute__((address_space(4))) * params_t;
-  __builtin_amdgcn_sched_barrier(0);
-  params_t late = (params_t)((segment_t)__builtin_amdgcn_kernarg_segment_ptr() + kParamsKernargOffset);
-  asm volatile("; parameters are read below this line" : "+s"(late));
-  return (const StepParams*)late;
-}
-
 // STREAM: the state / action loads carry the non-temporal bit.  Chosen by the host (mbt_env.hip: tune_for_size) when one
 // launch's working set exceeds the Infinity Cache - nothing read now is still cached at the next step, so it should not
 // displace lines on its way in: 128.3 -> 118.7 us for the 44-byte copy kernel at 2^24 lanes (profiles/r01_microbench.txt) -
@@ -1612,7 +1591,7 @@ __device__ __forceinline__ const StepParams* params_in_the_kernarg_segment() {
 // small-batch kernel walks several tiles per workgroup and step)
 // CAPTURED: the graph-capturable instantiation - the step's clock comes from device memory (`C`, see above), `P_in` holds what
 // does not change from step to step; `captured` receives the step's clock for captured_epilogue.
-template <class V, bool STREAM = false, bool MIRROR = false, bool CAPTURED = false, bool LATE = false>
+template <class V, bool STREAM = false, bool MIRROR = false, bool CAPTURED = false>
 __device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams& P_in, const uint32_t tile, const CapturedParams* C = nullptr,
                                           CapturedStep* captured = nullptr) {
   static_assert(!(STREAM && MIRROR), "streaming loads are for launches beyond the Infinity Cache, the mirror for small batches");
@@ -1627,10 +1606,10 @@ __device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams
     P_step = P_in;
     *captured = captured_prologue(clock_words, *C, P_step);
   }
-  static_assert(!(LATE && CAPTURED), "a captured step fills its clock into a copy of the parameters");
-  const StepParams* params = CAPTURED ? &P_step : &P_in;
-  if (LATE) params = params_in_the_kernarg_segment();
-  const StepParams& P = *params;
+  // (Reading the parameters from the kernel-argument segment only HERE, behind the loads - a scheduling barrier and the segment's pointer
+  // passed through an empty asm: 6.39 -> 5.98 us in the micro-benchmark - makes every kernel slower, AS 6.63 -> 6.86 us: the generator
+  // below needs its key and counters at once, and its ~120 instructions are what hides the loads.  profiles/r06_kernarg_layout.txt.)
+  const StepParams& P = CAPTURED ? P_step : P_in;
   const uint64_t pair = P.pair_offset + tile * kBlockThreads + threadIdx.x;
   LaneNoise nz0, nz1;
   LaneDraw d0, d1;
@@ -1686,7 +1665,7 @@ __device__ __forceinline__ void step_tile(const StepBuffers& B, const StepParams
 
 template <class V, bool STREAM = false, bool MIRROR = false>
 __device__ __forceinline__ void step_body(const StepBuffers& B, const StepParams& P) {
-  step_tile<V, STREAM, MIRROR, false, kLateParams>(B, P, blockIdx.x);
+  step_tile<V, STREAM, MIRROR>(B, P, blockIdx.x);
   if (MIRROR) signal_host(B);
 }
 
