@@ -44,6 +44,7 @@ if ROOT not in sys.path:
 # (ranks of one node share device memory handles through dmabuf only on this driver: RCCL's set-up fails with "hipIpcGetMemHandle: invalid
 # argument" otherwise.  Exported on the boxes this runs on; kept here for a launcher that starts the ranks from a cleaner environment.)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # (this stack's default; with kernel arguments in host memory every launch waits 1.2-3 us longer: profiles/r06_kernarg_layout.txt)
 
 import numpy as np  # noqa: E402
 

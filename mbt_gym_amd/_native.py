@@ -10,6 +10,11 @@ import time
 
 import numpy as np
 
+# Kernel arguments in device memory: this ROCm stack's default, spelled out for one whose default differs - and only if the HIP runtime has not
+# started yet and the user has not said otherwise.  With the arguments in host memory every step kernel waits 1.2-3 us longer for its 1.3 KB of
+# them (profiles/r06_kernarg_layout.txt).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 # MBT_LIBRARY_VARIANT=asan / tsan: the sanitizer build of the host side (mbt_gym_amd/build.py, MBT_SANITIZE; README "Sanitizers")
 _VARIANT = os.environ.get("MBT_LIBRARY_VARIANT", "").strip()
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"libmbtenv.{_VARIANT}.so" if _VARIANT else "libmbtenv.so")
