@@ -681,9 +681,6 @@ int mbt_philox4x32_10_host(int device, const uint32_t ctr[4], const uint32_t key
 int mbt_env_record_floor_device(mbt_env* env, uint32_t steps, float* obs_traj, float* act_traj, float* rew_traj);
 
 /* ---- timing on the environment's stream (HIP events) ------------------------------------------- */
-/* The opening event.  If a step launch follows (mbt_env_step_device / _step_many_device), the event is recorded again directly in front of
- * the first one: on an idle stream an event's time is the moment it was enqueued, and the caller's way from this call to its first launch
- * would otherwise count as kernel time (0.1-0.2 us per launch of a 20-launch interval).  Other work (rollouts) is timed from this call. */
 int mbt_env_timer_begin(mbt_env* env);
 int mbt_env_timer_end(mbt_env* env, float* elapsed_ms); /* = stop + elapsed: synchronises */
 /* The same in two halves, for a caller whose own clock brackets the work: `stop` only records the closing event (no

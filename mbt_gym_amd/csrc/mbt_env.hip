@@ -214,7 +214,6 @@ struct mbt_env {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  bool timer_armed = false;        // mbt_env_timer_begin: the opening event is recorded AGAIN in front of the next step launch (launch_step)
   hipEvent_t ev_sums = nullptr;   // mbt_env_return_sums_begin / _end
   double* h_sums = nullptr;       // pinned: [sum of rewards, sum of squared per-lane returns]
   bool sums_pending = false;
@@ -726,10 +725,6 @@ int launch_step(mbt_env* e, const float* action_dev, int32_t* done, bool mirror 
   P.t_now = e->time;
   P.t_next_f64 = t_next;
 
-  if (e->timer_armed) {  // the timed interval opens HERE, in front of the first launch behind mbt_env_timer_begin: on an idle stream an event's time
-    e->timer_armed = false;  // is the moment it was enqueued, and the caller's way from that call to this launch (two binding calls) is not kernel time
-    HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
-  }
   mbt::StepBuffers B;
   std::memset(&B, 0, sizeof B);
   B.state_in = e->state[e->cur];
@@ -3197,7 +3192,6 @@ int mbt_env_timer_begin(mbt_env* e) {
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
   HIP_TRY(hipEventRecord(e->ev_begin, e->stream));
-  e->timer_armed = true;  // (see launch_step: what the caller does between this call and its first step is not the kernels' time)
   return MBT_OK;
 }
 
@@ -3205,7 +3199,6 @@ int mbt_env_timer_stop(mbt_env* e) {
   if (e == nullptr) return fail(MBT_ERR_INVALID, "null env");
   HIP_TRY(hipSetDevice(e->cfg.device));
   RESIDENT_STOP(e);
-  e->timer_armed = false;
   HIP_TRY(hipEventRecord(e->ev_end, e->stream));
   return MBT_OK;
 }
