@@ -526,3 +526,26 @@ def test_the_power_polynomial_in_the_header_gives_half_ulp_powers():
     spec.loader.exec_module(model)
     for p, worst, differing in model.check(200_000):
         assert worst < 0.5002 and differing < 2e-4, (p, worst, differing)
+
+
+def test_the_benchmark_kernel_needs_few_lines_of_its_arguments():
+    """step_kernel.hpp, "LAYOUT": a launch pays for every 64-byte line of its ~1.3 KB of by-value arguments that it reads (profiles/r06_kernarg_layout.txt),
+    so StepParams is grouped by reader.  From the disassembly of the built library (tools/dbg/kernarg_loads.py, no GPU): the benchmark kernel reads its
+    parameters from TWO lines' worth of StepParams (offsets 200-295 of the segment, behind the 200 bytes of StepBuffers) and about 150 bytes in all - a field
+    added in the wrong place (or the old order back) shows here."""
+    import importlib.util
+    import os
+    import shutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("c++filt") is None or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the ROCm LLVM tools")
+    spec = importlib.util.spec_from_file_location("kernarg_loads", os.path.join(root, "tools", "dbg", "kernarg_loads.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    reads = tool.kernarg_reads("mbt::step_kernel<mbt::Variant<mbt::shape::brownian, mbt::shape::pnl>, false, false>")
+    assert len(reads) == 1, list(reads)
+    (loads, lines), = reads.values()
+    params = [(off, width) for off, width in loads if off >= 200]
+    assert params and min(off for off, _ in params) == 200 and max(off + width for off, width in params) <= 200 + 128, loads
+    assert sum(width for _, width in loads) <= 160 and len(lines) <= 4, (loads, lines)

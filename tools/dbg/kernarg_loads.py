@@ -17,8 +17,11 @@ import isa_stats  # noqa: E402
 WIDTH = {"dword": 4, "dwordx2": 8, "dwordx4": 16, "dwordx8": 32, "dwordx16": 64}
 
 
-def main(pattern, keep="/tmp/isa"):
+def kernarg_reads(pattern, keep=None):
+    """{demangled kernel name: (sorted [(offset, bytes)], sorted [64-byte line])} for the kernels whose name contains `pattern`."""
+    keep = keep or os.path.join(ROOT, "build", "isa")
     os.makedirs(keep, exist_ok=True)
+    out = {}
     for co in isa_stats.code_objects(keep):
         meta = isa_stats.kernel_metadata(co)
         names = isa_stats.demangle(list(meta))
@@ -31,9 +34,14 @@ def main(pattern, keep="/tmp/isa"):
                 m = re.match(r"\s+s_load_(dword(?:x\d+)?)\s+\S+,\s*s\[0:1\],\s*(0x[0-9a-f]+|\d+)", line)
                 if m:
                     loads.append((int(m.group(2), 0), WIDTH[m.group(1)]))
-            lines = sorted({b // 64 for off, w in loads for b in range(off, off + w)})
-            print(f"{pretty}\n   {len(loads)} loads from the kernarg segment, {sum(w for _, w in loads)} bytes, {len(lines)} distinct 64-byte lines: {lines}")
-            print("   offsets: " + ", ".join(f"{off}+{w}" for off, w in sorted(loads)))
+            out[pretty] = (sorted(loads), sorted({b // 64 for off, w in loads for b in range(off, off + w)}))
+    return out
+
+
+def main(pattern):
+    for pretty, (loads, lines) in kernarg_reads(pattern).items():
+        print(f"{pretty}\n   {len(loads)} loads from the kernarg segment, {sum(w for _, w in loads)} bytes, {len(lines)} distinct 64-byte lines: {lines}")
+        print("   offsets: " + ", ".join(f"{off}+{w}" for off, w in loads))
 
 
 if __name__ == "__main__":
